@@ -1,0 +1,318 @@
+"""Generate tests/golden/*.npz by running the REFERENCE (imported on CPU from
+/root/reference with the stub recipe in oracle/ref_import.py) on seeded inputs,
+and check the oracle restatement against it while doing so.
+
+Container-only: run ``python -m oracle.make_golden`` from the repo root.  The
+fixtures are data (inputs + the reference's outputs); no reference source is
+stored.  Weights are regenerated on both sides from ``seeded_state_dict(cfg, seed)``
+(a SHA-256 of the weight blob is stored to detect RNG drift).
+"""
+import hashlib
+import math
+import os
+import sys
+
+import numpy as np
+import torch
+
+from oracle import ncsnpp_ref as NR
+from oracle import sde_ref as SR
+from oracle import frontend_ref as FR
+from oracle.ref_import import import_reference
+
+OUT = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden")
+
+TINY = {
+    # name: (cfg kwargs, spatial shape)
+    "tiny4": (dict(nf=8, input_channels=4), (32, 64)),
+    "tiny6": (dict(nf=8, input_channels=6), (32, 64)),
+    "tiny2d": (dict(nf=8, input_channels=2, discriminative=True), (32, 64)),
+    "tinyattn": (dict(nf=16, ch_mult=(1, 1, 2, 2), num_res_blocks=2, attn_resolutions=(8,),
+                      image_size=32, input_channels=4), (32, 64)),
+}
+
+
+def sd_hash(sd):
+    h = hashlib.sha256()
+    for k in sorted(sd):
+        h.update(k.encode())
+        h.update(sd[k].detach().contiguous().numpy().tobytes())
+    return h.hexdigest()
+
+
+def rel_l2(a, b):
+    a, b = torch.as_tensor(a), torch.as_tensor(b)
+    return float((a - b).abs().pow(2).sum().sqrt() / (b.abs().pow(2).sum().sqrt() + 1e-30))
+
+
+def c2np(x):
+    return x.detach().numpy()
+
+
+def ref_backbone(ref, cfg: NR.NCSNppConfig, sd):
+    kw = dict(nf=cfg.nf, ch_mult=cfg.ch_mult, num_res_blocks=cfg.num_res_blocks,
+              attn_resolutions=cfg.attn_resolutions, image_size=cfg.image_size,
+              input_channels=cfg.input_channels, discriminative=cfg.discriminative)
+    net = ref["ncsnpp"].NCSNpp(**kw)
+    missing, unexpected = net.load_state_dict(sd, strict=True)
+    net.eval()
+    return net
+
+
+def check(name, got, want, tol):
+    e = rel_l2(got, want)
+    status = "ok" if e <= tol else "FAIL"
+    print(f"  [{status}] oracle vs reference  {name}: rel-L2 {e:.3e} (tol {tol:g})")
+    if e > tol:
+        raise SystemExit(f"oracle disagrees with the reference on {name}")
+    return e
+
+
+def main():
+    os.makedirs(OUT, exist_ok=True)
+    torch.set_num_threads(8)
+    torch.manual_seed(0)
+    ref = import_reference()
+    L, UD = ref["layerspp"], ref["updown"]
+    g = torch.Generator().manual_seed(1234)
+
+    # ---------------- F1: per-op ----------------
+    print("F1 per-op")
+    f1 = {}
+    x = torch.randn(2, 5, 8, 12, generator=g)
+    up_ref, dn_ref = UD.upsample_2d(x, [1, 3, 3, 1], factor=2), UD.downsample_2d(x, [1, 3, 3, 1], factor=2)
+    check("fir_up2", NR.fir_up2(x), up_ref, 1e-6)
+    check("fir_down2", NR.fir_down2(x), dn_ref, 1e-6)
+    f1.update(fir_x=x.numpy(), fir_up=up_ref.numpy(), fir_down=dn_ref.numpy())
+    for C in (8, 128, 384):
+        xx = torch.randn(2, C, 8, 16, generator=g) * 1.5 + 0.3
+        w, b = 1 + 0.1 * torch.randn(C, generator=g), 0.1 * torch.randn(C, generator=g)
+        gn = torch.nn.GroupNorm(min(C // 4, 32), C, eps=1e-6)
+        gn.weight.data, gn.bias.data = w, b
+        y_ref = torch.nn.SiLU()(gn(xx)).detach()
+        check(f"gn_silu C={C}", NR.silu(NR.group_norm(xx, w, b)), y_ref, 1e-6)
+        f1.update({f"gn{C}_x": xx.numpy(), f"gn{C}_w": w.numpy(), f"gn{C}_b": b.numpy(), f"gn{C}_y": y_ref.numpy()})
+    # attention block
+    C = 16
+    blk = L.AttnBlockpp(channels=C, skip_rescale=True, init_scale=0.)
+    sd = {k: (torch.randn(v.shape, generator=g) * (0.3 if "NIN" in k and k.endswith("W") else 0.1)
+              + (1.0 if "GroupNorm_0.weight" in k else 0.0)) for k, v in blk.state_dict().items()}
+    blk.load_state_dict(sd)
+    xa = torch.randn(2, C, 4, 8, generator=g)
+    ya = blk(xa).detach()
+    check("attnblock", NR.attnblock(NR._SD(sd), xa), ya, 1e-5)
+    f1.update(attn_x=xa.numpy(), attn_y=ya.numpy(), **{"attn_" + k: v.numpy() for k, v in sd.items()})
+    # resnet blocks plain / up / down
+    for tag, kw in (("plain", {}), ("up", dict(up=True)), ("down", dict(down=True)), ("widen", dict(out_ch=24))):
+        blk = L.ResnetBlockBigGANpp(act=torch.nn.SiLU(), in_ch=16, temb_dim=32, dropout=0., fir=True,
+                                    fir_kernel=[1, 3, 3, 1], init_scale=0., skip_rescale=True, **kw)
+        sd = {k: torch.randn(v.shape, generator=g) * 0.15 + (1.0 if "GroupNorm" in k and k.endswith("weight") else 0.0)
+              for k, v in blk.state_dict().items()}
+        blk.load_state_dict(sd)
+        blk.eval()
+        xr, te = torch.randn(2, 16, 8, 16, generator=g), torch.randn(2, 32, generator=g)
+        yr = blk(xr, te).detach()
+        check(f"resblock {tag}", NR.resblock(NR._SD(sd), xr, te, up=kw.get("up", False), down=kw.get("down", False)), yr, 1e-5)
+        f1.update({f"res_{tag}_x": xr.numpy(), f"res_{tag}_temb": te.numpy(), f"res_{tag}_y": yr.numpy(),
+                   **{f"res_{tag}_" + k: v.numpy() for k, v in sd.items()}})
+    np.savez_compressed(os.path.join(OUT, "f1_ops.npz"), **f1)
+
+    # ---------------- F2: tiny nets ----------------
+    print("F2 tiny nets")
+    f2 = {}
+    t = torch.tensor([0.9, 0.05])
+    for name, (ckw, (F_, T_)) in TINY.items():
+        cfg = NR.NCSNppConfig(**ckw)
+        sd = NR.seeded_state_dict(cfg, seed=7)
+        net = ref_backbone(ref, cfg, sd)
+        xin = torch.randn(2, cfg.in_ch // 2, F_, T_, dtype=torch.complex64, generator=g) * 0.5
+        with torch.no_grad():
+            y_ref = net(xin, None if cfg.discriminative else t)
+            y_or = NR.ncsnpp_forward(sd, cfg, xin, t)
+        check(f"{name} forward", y_or, y_ref, 2e-5)
+        f2.update({f"{name}_x": c2np(xin), f"{name}_y": c2np(y_ref), f"{name}_sdhash": np.array(sd_hash(sd))})
+    f2["t"] = t.numpy()
+    np.savez_compressed(os.path.join(OUT, "f2_tiny_nets.npz"), **f2)
+
+    # ---------------- F3: full-width net ----------------
+    print("F3 full-width nets (this takes a minute)")
+    f3 = {}
+    for name, ckw, shape in (("ncsnpp4", dict(input_channels=4), (256, 64)),
+                             ("ncsnpp6", dict(input_channels=6), (64, 64)),
+                             ("ncsnpp2d", dict(input_channels=2, discriminative=True), (64, 64)),
+                             ("large4", dict(**NR.NAMED_CONFIGS["ncsnpplarge"], input_channels=4), (256, 64))):
+        cfg = NR.NCSNppConfig(**ckw)
+        sd = NR.seeded_state_dict(cfg, seed=11)
+        net = ref_backbone(ref, cfg, sd)
+        nparam = sum(v.numel() for k, v in sd.items())
+        xin = torch.randn(1, cfg.in_ch // 2, *shape, dtype=torch.complex64, generator=g) * 0.5
+        tt = torch.tensor([0.37])
+        with torch.no_grad():
+            y_ref = net(xin, None if cfg.discriminative else tt)
+            y_or = NR.ncsnpp_forward(sd, cfg, xin, tt)
+        print(f"  {name}: {nparam/1e6:.3f} M params")
+        check(f"{name} forward", y_or, y_ref, 5e-5)
+        f3.update({f"{name}_x": c2np(xin), f"{name}_y": c2np(y_ref), f"{name}_sdhash": np.array(sd_hash(sd)),
+                   f"{name}_nparam": np.array(nparam)})
+    f3["t"] = np.array([0.37], dtype=np.float32)
+    np.savez_compressed(os.path.join(OUT, "f3_full_nets.npz"), **f3)
+
+    # ---------------- F4: SDE scalars + sampler traces ----------------
+    print("F4 SDE / sampler")
+    f4 = {}
+    rs = ref["sdes"].OUVESDE(theta=1.5, sigma_min=0.05, sigma_max=0.5, N=30)
+    osde = SR.OUVE(1.5, 0.05, 0.5, N=30)
+    tt = torch.tensor([1.0, 0.5, 0.03])
+    std_ref = rs._std(tt)
+    assert torch.equal(std_ref, osde.std(tt))
+    xx = torch.randn(3, 1, 4, 4, dtype=torch.complex64, generator=g)
+    yy = torch.randn(3, 1, 4, 4, dtype=torch.complex64, generator=g)
+    f_ref, G_ref = rs.discretize(xx, tt, yy)
+    f_or, G_or = osde.discretize(xx, tt, yy)
+    assert torch.equal(f_ref, f_or) and torch.equal(G_ref, G_or)
+    f4.update(t=tt.numpy(), std=std_ref.numpy(), disc_x=c2np(xx), disc_y=c2np(yy), disc_f=c2np(f_ref), disc_G=G_ref.numpy())
+
+    def analytic_score(x, t, y):
+        return -(x - y) / (rs._std(t)[:, None, None, None] ** 2 + 0.1)
+
+    def run_ref_sampler(score_fn, y, N, predictor, corrector, steps, snr, noises, conditioning=None):
+        it = iter(noises)
+        orig = torch.randn_like
+        torch.randn_like = lambda x, *a, **k: next(it).to(x.dtype)
+        try:
+            sde = ref["sdes"].OUVESDE(theta=1.5, sigma_min=0.05, sigma_max=0.5, N=N)
+            sampler = ref["sampling"].get_pc_sampler(predictor, corrector, sde=sde, score_fn=score_fn, y=y,
+                                                     eps=0.03, snr=snr, corrector_steps=steps,
+                                                     conditioning=conditioning)
+            return sampler()
+        finally:
+            torch.randn_like = orig
+
+    ysam = torch.randn(2, 1, 8, 16, dtype=torch.complex64, generator=g) * 0.3
+    for tag, (N, pred, corr, steps) in dict(ald2=(7, "reverse_diffusion", "ald", 2),
+                                             lang=(5, "reverse_diffusion", "langevin", 1),
+                                             em=(6, "euler_maruyama", "none", 1),
+                                             none=(4, "reverse_diffusion", "none", 1)).items():
+        ndraw = 1 + N * ((0 if corr == "none" else steps) + 1)
+        noises = [SR.complex_randn(ysam.shape, g) for _ in range(ndraw)]
+        x_ref, nfe_ref = run_ref_sampler(analytic_score, ysam, N, pred, corr, steps, 0.5, noises)
+        it = iter(noises)
+        x_or, nfe_or = SR.pc_sample(SR.OUVE(1.5, 0.05, 0.5, N=N), analytic_score, ysam, lambda: next(it),
+                                    predictor=pred, corrector=corr, corrector_steps=steps, snr=0.5)
+        assert nfe_ref == nfe_or, (nfe_ref, nfe_or)
+        bit = torch.equal(x_ref, x_or)
+        print(f"  sampler {tag}: nfe {nfe_ref}, bit-exact vs reference: {bit}, rel {rel_l2(x_or, x_ref):.2e}")
+        assert rel_l2(x_or, x_ref) < 1e-6
+        f4.update({f"{tag}_noise": np.stack([c2np(n) for n in noises]), f"{tag}_out": c2np(x_ref), f"{tag}_nfe": np.array(nfe_ref)})
+    f4["sam_y"] = c2np(ysam)
+
+    # sampler with a tiny net as score function (ScoreModel.forward = -dnn(cat[x,y], t), model.py:127-132)
+    cfg = NR.NCSNppConfig(**TINY["tiny4"][0])
+    sd = NR.seeded_state_dict(cfg, seed=7)
+    net = ref_backbone(ref, cfg, sd)
+    ynet = torch.randn(2, 1, 32, 64, dtype=torch.complex64, generator=g) * 0.3
+    N, steps = 3, 1
+    noises = [SR.complex_randn(ynet.shape, g) for _ in range(1 + N * (steps + 1))]
+    with torch.no_grad():
+        x_ref, nfe = run_ref_sampler(lambda x, t, y: -net(torch.cat([x, y], 1), t), ynet, N, "reverse_diffusion", "ald", steps, 0.5, noises)
+        it = iter(noises)
+        x_or, _ = SR.pc_sample(SR.OUVE(1.5, 0.05, 0.5, N=N), lambda x, t, y: -NR.ncsnpp_forward(sd, cfg, torch.cat([x, y], 1), t),
+                               ynet, lambda: next(it), corrector_steps=steps, snr=0.5)
+    check("sampler tiny4 net", x_or, x_ref, 1e-4)
+    f4.update(net_y=c2np(ynet), net_noise=np.stack([c2np(n) for n in noises]), net_out=c2np(x_ref), net_nfe=np.array(nfe))
+    np.savez_compressed(os.path.join(OUT, "f4_sampler.npz"), **f4)
+
+    # ---------------- F5: front/back end ----------------
+    print("F5 front/back end")
+    f5 = {}
+    for Lsig in (8000, 64000):
+        for fac in (0.15, 0.33):
+            dm = ref["data_module"].SpecsDataModule(spec_factor=fac, spec_abs_exponent=0.5, gpu=False)
+            y = torch.randn(1, Lsig, generator=torch.Generator().manual_seed(1234 + Lsig)) * 0.1
+            nf_ = y.abs().max().item()
+            Y_ref = ref["other"].pad_spec(torch.unsqueeze(dm.spec_fwd(dm.stft(y / nf_)), 0))
+            Y_or, nf_or, _ = FR.wav_to_spec(y, fac, 0.5)
+            assert torch.equal(Y_ref, Y_or) and nf_ == nf_or
+            w_ref = dm.istft(dm.spec_back(Y_ref.squeeze()), Lsig)
+            w_or = FR.istft(FR.spec_back(Y_or.squeeze(), fac, 0.5), Lsig)
+            assert torch.equal(w_ref, w_or)
+            key = f"L{Lsig}_f{int(fac*100)}"
+            if Lsig == 8000:
+                f5.update({f"{key}_y": y.numpy(), f"{key}_Y": c2np(Y_ref), f"{key}_wav": w_ref.numpy()})
+            else:   # keep the big one small: a frame slice + the tail of the waveform
+                f5.update({f"{key}_Yslice": c2np(Y_ref[..., 245:262]), f"{key}_wavtail": w_ref[..., -512:].numpy(),
+                           f"{key}_wavhead": w_ref[..., :512].numpy()})
+            print(f"  {key}: frames {Y_ref.shape[-1]}, istft rel err vs y/nf {rel_l2(w_ref[..., :Lsig-200], (y/nf_)[..., :Lsig-200]):.2e}")
+    np.savez_compressed(os.path.join(OUT, "f5_frontend.npz"), **f5)
+
+    # ---------------- F6: end-to-end enhance ----------------
+    print("F6 enhance() wav -> wav")
+    f6 = {}
+    M = ref["model"]
+    DM = ref["data_module"].SpecsDataModule
+    ywav = torch.randn(1, 8000, generator=torch.Generator().manual_seed(99)) * 0.1
+    common = dict(sde="ouve", data_module_cls=DM, theta=1.5, sigma_min=0.05, sigma_max=0.5,
+                  spec_factor=0.15, spec_abs_exponent=0.5, nf=8)
+    # score-only
+    m = M.ScoreModel(backbone="ncsnpp", **common)
+    cfg = NR.NCSNppConfig(nf=8, input_channels=4)
+    sd = NR.seeded_state_dict(cfg, seed=21)
+    m.dnn.load_state_dict(sd)
+    m.eval(no_ema=True)
+    N, steps = 3, 1
+    Ysh = FR.wav_to_spec(ywav)[0].shape
+    noises = [SR.complex_randn(Ysh, g) for _ in range(1 + N * (steps + 1))]
+    it = iter(noises)
+    orig = torch.randn_like
+    torch.randn_like = lambda x, *a, **k: next(it).to(x.dtype)
+    try:
+        with torch.no_grad():
+            xh_ref = m.enhance(ywav.clone(), N=N, corrector="ald", corrector_steps=steps, snr=0.5)
+    finally:
+        torch.randn_like = orig
+    Y, nfac, T0 = FR.wav_to_spec(ywav)
+    it = iter(noises)
+    with torch.no_grad():
+        samp, _ = SR.pc_sample(SR.OUVE(1.5, 0.05, 0.5, N=N),
+                               lambda x, t, y: -NR.ncsnpp_forward(sd, cfg, torch.cat([x, y], 1), t),
+                               Y, lambda: next(it), corrector_steps=steps, snr=0.5)
+    xh_or = FR.spec_to_wav(samp, nfac, T0)
+    check("enhance score-only", xh_or, xh_ref, 1e-4)
+    f6.update(wav_in=ywav.numpy(), so_noise=np.stack([c2np(n) for n in noises]), so_out=xh_ref.numpy())
+    # StoRM, the three conditioning variants (model.py:743-750)
+    for cond in ("both", "noisy", "post_denoiser"):
+        m = M.StochasticRegenerationModel(backbone_denoiser="ncsnpp", backbone_score="ncsnpp", condition=cond, **dict(common))
+        cfg_d = NR.NCSNppConfig(nf=8, input_channels=2, discriminative=True)
+        cfg_s = NR.NCSNppConfig(nf=8, input_channels=6 if cond == "both" else 4)
+        sd_d, sd_s = NR.seeded_state_dict(cfg_d, seed=31), NR.seeded_state_dict(cfg_s, seed=32)
+        m.denoiser_net.load_state_dict(sd_d)
+        m.score_net.load_state_dict(sd_s)
+        m.eval(no_ema=True)
+        N = 3
+        noises = [SR.complex_randn(Ysh, g) for _ in range(1 + N)]
+        it = iter(noises)
+        torch.randn_like = lambda x, *a, **k: next(it).to(x.dtype)
+        try:
+            with torch.no_grad():
+                xh_ref = m.enhance(ywav.clone(), N=N, corrector="none", snr=0.5)
+        finally:
+            torch.randn_like = orig
+        with torch.no_grad():
+            Yd = NR.ncsnpp_forward(sd_d, cfg_d, Y, None)
+            condl = dict(both=[Y, Yd], noisy=[Y], post_denoiser=[Yd])[cond]
+            it = iter(noises)
+            samp, _ = SR.pc_sample(SR.OUVE(1.5, 0.05, 0.5, N=N),
+                                   lambda x, t, y: -NR.ncsnpp_forward(sd_s, cfg_s, torch.cat([x] + condl, 1), t),
+                                   Yd, lambda: next(it), corrector="none", snr=0.5)
+        xh_or = FR.spec_to_wav(samp, nfac, T0)
+        check(f"enhance storm/{cond}", xh_or, xh_ref, 1e-4)
+        f6.update({f"storm_{cond}_noise": np.stack([c2np(n) for n in noises]), f"storm_{cond}_out": xh_ref.numpy()})
+    np.savez_compressed(os.path.join(OUT, "f6_enhance.npz"), **f6)
+
+    for fn in sorted(os.listdir(OUT)):
+        print(f"  {fn}: {os.path.getsize(os.path.join(OUT, fn))/1024:.0f} KiB")
+    print("golden fixtures written to", OUT)
+
+
+if __name__ == "__main__":
+    main()
