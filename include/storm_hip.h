@@ -1,0 +1,241 @@
+/*
+ * libstorm_hip — C ABI of the MI355X-native (gfx950) StoRM reverse-SDE sampling engine.
+ *
+ * Drop-in boundary for the hot path  ScoreModel.enhance -> get_pc_sampler ->
+ * predictor/corrector -> OUVE SDE -> NCSN++ forward  (+ STFT/iSTFT front/back end).
+ * The reference (sp-uhh/storm) has no FFI for this path except one pybind op
+ * (sgmse/backbones/ncsnpp_utils/op/upfirdn2d.cpp:12-22); its extension points are
+ * Python.  Each entry point below therefore names the reference
+ * Python/ATen/CUDA interface it replaces (file:line relative to the reference root).
+ *
+ * Conventions
+ *  - every function returns 0 (STORM_OK) or a negative error code; the message is
+ *    available from storm_last_error() (thread-local);
+ *  - nothing allocates: the caller owns every buffer (activations, packed weights,
+ *    workspace); all pointers are DEVICE pointers unless a parameter says "host";
+ *  - kernels are enqueued on the given HIP stream (pass torch's current stream),
+ *    no host synchronisation inside (mirrors upfirdn2d_kernel.cu:213-215);
+ *  - activations are NHWC ("[B][F][T][C]", C a multiple of 8) in fp32 or bf16
+ *    (dtype argument); the complex spectrogram [B,1,F,T] complex64 of the reference
+ *    is bit-identical to NHWC fp32 with C=2 (re, im interleaved);
+ *  - thread-compatible: calls from different host threads must use different streams
+ *    and buffers.
+ */
+#ifndef STORM_HIP_H
+#define STORM_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef void* storm_stream_t;              /* hipStream_t */
+
+enum { STORM_OK = 0, STORM_ERR_INVALID = -1, STORM_ERR_HIP = -2, STORM_ERR_UNSUPPORTED = -3 };
+enum { STORM_F32 = 0, STORM_BF16 = 1 };    /* activation / operand dtype */
+
+const char* storm_last_error(void);
+int storm_abi_version(void);
+/* device name / CU count of the current device, for logs; host out-buffers */
+int storm_device_info(char* name, int name_len, int* n_cu, size_t* hbm_bytes);
+
+/* ------------------------------------------------------------------------------------------
+ * Weight repacking (device -> device).  Replaces nothing in the reference: it is the
+ * engine's own weight layout, built once per model from the reference's state_dict tensors.
+ *   conv:   src fp32 [Cout][Cin][KH][KW] (nn.Conv2d.weight, layers.py:100-126)
+ *           -> dst [KH*KW][CoutP][CinP] (ci contiguous), zero padded
+ *   matrix: src fp32 [rows][cols]; transpose!=0 reads src as [cols][rows]
+ *           (layers.NIN.W is [Cin][Cout], layers.py:548-557) -> dst [CoutP][CinP]
+ * ------------------------------------------------------------------------------------------ */
+int storm_pack_conv_weight(const float* src, void* dst, int Cout, int Cin, int ntaps,
+                           int CoutP, int CinP, int dtype, storm_stream_t s);
+int storm_pack_matrix(const float* src, void* dst, int Cout, int Cin, int transpose,
+                      int CoutP, int CinP, int dtype, storm_stream_t s);
+
+/* ------------------------------------------------------------------------------------------
+ * Implicit-GEMM convolution on the matrix cores (MFMA 32x32x16 bf16 / 32x32x2 f32).
+ * Replaces nn.Conv2d 3x3/1x1 (layers.py:100-126, called from layerspp.py:225-235,260,266,269,
+ * ncsnpp.py:183,240,252,108), layers.NIN (layers.py:548-557) and the attention einsums
+ * (layerspp.py:82,86) — all are "NT" contractions  out[pix][co] = sum_k X[pix][k] W[co][k].
+ *
+ * Up to two K-segments accumulate into the same output tile (e.g. Conv_1 3x3 over h plus the
+ * Conv_2 1x1 shortcut over x of a BigGAN block, layerspp.py:266-274); a segment may read the
+ * channel-concatenation of two tensors (torch.cat([h, hs.pop()], 1), ncsnpp.py:381).
+ * Epilogue: out = (acc + bias[co] + tbias[b][co] + skip[pix][co]) * scale.
+ * ------------------------------------------------------------------------------------------ */
+typedef struct storm_conv_seg {
+    const void* src_a;          /* NHWC [B][H][W][Ca]                                   */
+    const void* src_b;          /* optional second tensor [B][H][W][Cb] (concat) or NULL  */
+    int Ca, Cb;
+    long long bstride_a;        /* elements between batches of src_a (H*W*Ca)             */
+    long long bstride_b;
+    const void* w;              /* packed [ntaps][w_rows_padded][CinP]                    */
+    int CinP;                   /* row stride of w (elements)                             */
+    int w_rows;                 /* rows of w that may be read (>= Cout valid)             */
+    int ntaps;                  /* 9 (3x3, pad 1) or 1                                    */
+    long long w_bstride;        /* elements between per-batch weight matrices, 0 = shared */
+    long long w_tapstride;      /* elements between taps of w                             */
+} storm_conv_seg;
+
+typedef struct storm_conv_args {
+    storm_conv_seg seg[2];
+    int nseg;
+    int B, H, W;                /* 1x1-only calls may pass H=1, W=npix                    */
+    void* out;                  /* NHWC [B][H][W][outC]                                   */
+    int outC;                   /* channel count of out (multiple of 8)                   */
+    int Cout;                   /* valid output channels (<= outC); the rest are written 0+skip */
+    long long out_bstride;
+    const float* bias;          /* [Cout] or NULL                                         */
+    const float* tbias;         /* [B][tbias_stride] per-batch per-channel bias or NULL   */
+    int tbias_stride;
+    const void* skip;           /* NHWC like out (same dtype as activations) or NULL      */
+    long long skip_bstride;
+    float scale;
+    int out_f32;                /* !=0: write fp32 whatever the operand dtype (scores)    */
+    int dtype;                  /* STORM_F32 / STORM_BF16 operands + activations          */
+} storm_conv_args;
+
+int storm_conv(const storm_conv_args* a, storm_stream_t s);
+
+/* ------------------------------------------------------------------------------------------
+ * GroupNorm(min(C/4,32) groups, eps) [+ SiLU] [+ FIR x2 up / down of BOTH the activated and
+ * the raw tensor].  Replaces nn.GroupNorm(eps=1e-6) + nn.SiLU (layerspp.py:219,231,243,264;
+ * ncsnpp.py:238,250,392,406; layerspp.py:67,77) and, fused, upsample_2d/downsample_2d on h
+ * and x inside ResnetBlockBigGANpp.forward (layerspp.py:245-255).
+ * The input may be the channel concat of two tensors.  stats: [B][G][2] doubles (sum, sumsq),
+ * must be zero before storm_gn_stats.
+ * ------------------------------------------------------------------------------------------ */
+int storm_gn_stats(const void* xa, int Ca, const void* xb, int Cb, int B, int HW,
+                   int groups, double* stats, int dtype, storm_stream_t s);
+/* resample: 0 none, 1 FIR up x2, 2 FIR down x2.  out_act gets act(GN(x)) (resampled),
+ * out_raw (may be NULL; required non-NULL only if wanted) gets the resampled raw concat. */
+int storm_gn_apply(const void* xa, int Ca, const void* xb, int Cb, int B, int H, int W,
+                   int groups, const double* stats, const float* gamma, const float* beta,
+                   float eps, int silu, int resample, void* out_act, void* out_raw,
+                   int dtype, storm_stream_t s);
+
+/* FIR resampling with taps [1,3,3,1] (zero boundary), optional "+ add" on the output.
+ * Replaces upsample_2d / downsample_2d -> upfirdn2d (up_or_down_sampling.py:195-257,
+ * op/upfirdn2d.py:145-156, op/upfirdn2d_kernel.cu:107-207 modes 3 and 5).               */
+int storm_fir_up2(const void* x, const void* add, void* out, int B, int H, int W, int C,
+                  int dtype, storm_stream_t s);
+int storm_fir_down2(const void* x, void* out, int B, int H, int W, int C,
+                    int dtype, storm_stream_t s);
+
+/* Row softmax of fp32 scores [rows][L] -> probabilities (activation dtype).
+ * Replaces F.softmax(w, dim=-1) in AttnBlockpp.forward (layerspp.py:84).                 */
+int storm_softmax_rows(const float* scores, void* probs, long long rows, int L,
+                       int dtype, storm_stream_t s);
+
+/* ------------------------------------------------------------------------------------------
+ * Network input / time embedding / output head.
+ * ------------------------------------------------------------------------------------------ */
+/* complex [B,F,T] tensors (n_in of them) -> NHWC [B][F][T][8] = 2*(re,im..)-1, zero padded.
+ * Replaces the real/imag channel packing + "x = 2x - 1" (ncsnpp.py:289-296, 321-323).     */
+int storm_pack_input(const float* const* cplx_in /* host array of n_in device ptrs */, int n_in,
+                     void* out, int B, int F, int T, int dtype, storm_stream_t s);
+/* t[B] -> act_temb[B][4nf] = SiLU(Linear2(SiLU(Linear1(GFP(log t)))))
+ * Replaces GaussianFourierProjection + the 2-layer MLP (layerspp.py:39-41, ncsnpp.py:298-317)
+ * plus the SiLU that every block applies to temb (layerspp.py:263).                        */
+int storm_time_embedding(const float* t, const float* gfp_W, const float* W1, const float* b1,
+                         const float* W2, const float* b2, float* act_temb, int B, int nf,
+                         storm_stream_t s);
+/* out[B][N] = W[N][K] . act_temb[b] + bias[N]  — all blocks' Dense_0 at once (layerspp.py:262-263) */
+int storm_dense(const float* x, const float* W, const float* bias, float* out, int B, int N, int K,
+                storm_stream_t s);
+/* pyramid NHWC [B][F][T][8] -> complex [B,F,T]:  sign * (W[2][cin] . (p / t_b) + b)
+ * Replaces "h / used_sigmas", output_layer and view_as_complex (ncsnpp.py:441-449) and the
+ * negation in ScoreModel.forward (model.py:131-132) when negate!=0.                        */
+int storm_output_head(const void* pyr, const float* t /* NULL: no division */, const float* W,
+                      const float* bias, int cin, float* out_cplx, int B, int F, int T,
+                      int negate, int dtype, storm_stream_t s);
+
+/* ------------------------------------------------------------------------------------------
+ * OUVE SDE steps on the complex64 state [B, n] (n = F*T complex per batch item).
+ * Replace OUVESDE.prior_sampling/_std/sde, SDE.discretize, RSDE.discretize (sdes.py:73-90,
+ * 147-157, 200-237), ReverseDiffusionPredictor / EulerMaruyamaPredictor.update_fn
+ * (predictors.py:46-69), AnnealedLangevinDynamics / LangevinCorrector.update_fn
+ * (correctors.py:45-93).  z == NULL: standard complex normal noise (variance 1/2 per
+ * component, like torch.randn_like on a complex tensor) is generated in-kernel with
+ * Philox4x32-10 from (seed, offset).
+ * ------------------------------------------------------------------------------------------ */
+typedef struct storm_ouve { float theta, sigma_min, sigma_max; int N; } storm_ouve;
+
+int storm_ouve_prior(const float* y, const float* z, float* x, int B, long long n, storm_ouve p,
+                     uint64_t seed, uint64_t offset, storm_stream_t s);
+int storm_ouve_ald_step(float* x, float* x_mean, const float* score, const float* z, const float* t,
+                        int B, long long n, storm_ouve p, float snr,
+                        uint64_t seed, uint64_t offset, storm_stream_t s);
+/* predictor: kind 0 = reverse_diffusion, 1 = euler_maruyama; noise_free!=0 skips "+ G z" */
+int storm_ouve_predictor_step(float* x, float* x_mean, const float* score, const float* y,
+                              const float* z, const float* t, int B, long long n, storm_ouve p,
+                              int kind, int noise_free, uint64_t seed, uint64_t offset,
+                              storm_stream_t s);
+/* per-batch L2 norms of complex tensors: out[b] = ||v_b||  (correctors.py:53-54) */
+int storm_batch_l2norm(const float* v, float* out, int B, long long n, storm_stream_t s);
+/* Langevin corrector step; z must be given or generated beforehand (its norm is needed):
+ * step = 2 (snr * mean_b||z_b|| / mean_b||score_b||)^2 from the two [B] norm arrays.      */
+int storm_langevin_step(float* x, float* x_mean, const float* score, const float* z,
+                        const float* score_norms, const float* z_norms, int B, long long n,
+                        float snr, storm_stream_t s);
+/* fills z[B*n] complex with standard complex normal noise (Philox) */
+int storm_complex_randn(float* z, long long n_complex, uint64_t seed, uint64_t offset,
+                        storm_stream_t s);
+
+/* ------------------------------------------------------------------------------------------
+ * Spectral front / back end.  Replace torch.stft / torch.istft as called by
+ * SpecsDataModule.stft/istft (data_module.py:195-223: n_fft, hop, periodic Hann, center=True,
+ * reflect padding), spec_fwd / spec_back (data_module.py:182-193), pad_spec (util/other.py:
+ * 102-109) and the peak normalisation in enhance() (model.py:282-284, 302).
+ * ------------------------------------------------------------------------------------------ */
+/* peak[b] = max |wav[b][:]|  (model.py:283) */
+int storm_peak_abs(const float* wav, float* peak, int B, long long L, long long stride,
+                   storm_stream_t s);
+/* wav [B][L] (row stride `stride`) -> spec complex [B][F][Tpad]; frames >= n_frames are zero.
+ * spec = spec_fwd(stft(wav / peak[b])); peak may be NULL (no normalisation).
+ * twiddle: fp32 [n_fft][2] = (cos, sin)(2 pi k / n_fft); window: fp32 [n_fft].            */
+int storm_stft(const float* wav, const float* peak, float* spec, const float* window,
+               const float* twiddle, int B, long long L, long long stride, int n_fft, int hop,
+               int n_frames, int Tpad, float spec_factor, float spec_abs_exponent,
+               storm_stream_t s);
+/* spec complex [B][F][T] (ALL T frames are inverted, as to_audio does, model.py:258-259,301)
+ * -> wav [B][L] = istft(spec_back(spec), length=L) * peak[b].
+ * frames: workspace fp32 [B][T][n_fft].                                                    */
+int storm_istft(const float* spec, const float* peak, float* wav, float* frames,
+                const float* window, const float* twiddle, int B, int T, long long L,
+                long long stride, int n_fft, int hop, float spec_factor, float spec_abs_exponent,
+                storm_stream_t s);
+
+/* ------------------------------------------------------------------------------------------
+ * Program interpreter: runs a whole NCSN++ forward (or any op list) with one host call.
+ * The op list is planned on the host side (storm_amd/backbones/plan.py) once per
+ * (model, B, F, T, dtype); pointers are offsets into the caller-owned buffers in `bufs`.
+ * Replaces the Python op-by-op dispatch of NCSNpp.forward (ncsnpp.py:281-450).
+ * ------------------------------------------------------------------------------------------ */
+enum {
+    STORM_OP_MEMSET = 0, STORM_OP_PACK_INPUT = 1, STORM_OP_TEMB = 2, STORM_OP_DENSE = 3,
+    STORM_OP_CONV = 4, STORM_OP_GN_STATS = 5, STORM_OP_GN_APPLY = 6, STORM_OP_FIR_UP = 7,
+    STORM_OP_FIR_DOWN = 8, STORM_OP_SOFTMAX = 9, STORM_OP_OUTPUT_HEAD = 10
+};
+#define STORM_OP_NPTR 12
+#define STORM_OP_NINT 24
+#define STORM_OP_NFLT 4
+typedef struct storm_ref { int32_t buf; int32_t pad_; int64_t off; } storm_ref; /* buf<0: NULL; byte offset */
+typedef struct storm_op {
+    int32_t code;
+    int32_t pad_;
+    storm_ref p[STORM_OP_NPTR];
+    int64_t i[STORM_OP_NINT];
+    float f[STORM_OP_NFLT];
+} storm_op;
+
+/* ops: host array; bufs: host array of n_bufs device base pointers.                       */
+int storm_program_run(const storm_op* ops, int n_ops, void* const* bufs, int n_bufs, int dtype,
+                      storm_stream_t s);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* STORM_HIP_H */

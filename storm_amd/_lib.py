@@ -1,0 +1,156 @@
+"""ctypes binding to libstorm_hip.so (the C ABI declared in include/storm_hip.h).
+
+The product path has no CPU fallback: importing an op without the built library, or
+handing it a tensor that is not on a HIP device, raises.  (CPU tests load the lane-accurate
+host simulation of the same kernel sources through ``_load_for_tests`` — test infrastructure,
+see tests/sim/.)
+"""
+import ctypes as C
+import os
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "csrc", "libstorm_hip.so")
+
+F32, BF16 = 0, 1
+_TORCH2DT = {torch.float32: F32, torch.bfloat16: BF16}
+_DT2TORCH = {F32: torch.float32, BF16: torch.bfloat16}
+
+OP_NPTR, OP_NINT, OP_NFLT = 12, 24, 4
+
+
+class StormError(RuntimeError):
+    pass
+
+
+class ConvSeg(C.Structure):
+    _fields_ = [("src_a", C.c_void_p), ("src_b", C.c_void_p), ("Ca", C.c_int), ("Cb", C.c_int),
+                ("bstride_a", C.c_longlong), ("bstride_b", C.c_longlong), ("w", C.c_void_p),
+                ("CinP", C.c_int), ("w_rows", C.c_int), ("ntaps", C.c_int),
+                ("w_bstride", C.c_longlong), ("w_tapstride", C.c_longlong)]
+
+
+class ConvArgs(C.Structure):
+    _fields_ = [("seg", ConvSeg * 2), ("nseg", C.c_int), ("B", C.c_int), ("H", C.c_int), ("W", C.c_int),
+                ("out", C.c_void_p), ("outC", C.c_int), ("Cout", C.c_int), ("out_bstride", C.c_longlong),
+                ("bias", C.c_void_p), ("tbias", C.c_void_p), ("tbias_stride", C.c_int),
+                ("skip", C.c_void_p), ("skip_bstride", C.c_longlong), ("scale", C.c_float),
+                ("out_f32", C.c_int), ("dtype", C.c_int)]
+
+
+class Ouve(C.Structure):
+    _fields_ = [("theta", C.c_float), ("sigma_min", C.c_float), ("sigma_max", C.c_float), ("N", C.c_int)]
+
+
+class Ref(C.Structure):
+    _fields_ = [("buf", C.c_int32), ("pad_", C.c_int32), ("off", C.c_int64)]
+
+
+class Op(C.Structure):
+    _fields_ = [("code", C.c_int32), ("pad_", C.c_int32), ("p", Ref * OP_NPTR),
+                ("i", C.c_int64 * OP_NINT), ("f", C.c_float * OP_NFLT)]
+
+
+_vp, _i, _ll, _f, _u64 = C.c_void_p, C.c_int, C.c_longlong, C.c_float, C.c_uint64
+_SIGNATURES = {
+    "storm_abi_version": ([], C.c_int),
+    "storm_device_info": ([C.c_char_p, _i, C.POINTER(C.c_int), C.POINTER(C.c_size_t)], C.c_int),
+    "storm_pack_conv_weight": ([_vp, _vp, _i, _i, _i, _i, _i, _i, _vp], C.c_int),
+    "storm_pack_matrix": ([_vp, _vp, _i, _i, _i, _i, _i, _i, _vp], C.c_int),
+    "storm_conv": ([C.POINTER(ConvArgs), _vp], C.c_int),
+    "storm_gn_stats": ([_vp, _i, _vp, _i, _i, _i, _i, _vp, _i, _vp], C.c_int),
+    "storm_gn_apply": ([_vp, _i, _vp, _i, _i, _i, _i, _i, _vp, _vp, _vp, _f, _i, _i, _vp, _vp, _i, _vp], C.c_int),
+    "storm_fir_up2": ([_vp, _vp, _vp, _i, _i, _i, _i, _i, _vp], C.c_int),
+    "storm_fir_down2": ([_vp, _vp, _i, _i, _i, _i, _i, _vp], C.c_int),
+    "storm_softmax_rows": ([_vp, _vp, _ll, _i, _i, _vp], C.c_int),
+    "storm_pack_input": ([C.POINTER(_vp), _i, _vp, _i, _i, _i, _i, _vp], C.c_int),
+    "storm_time_embedding": ([_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _vp], C.c_int),
+    "storm_dense": ([_vp, _vp, _vp, _vp, _i, _i, _i, _vp], C.c_int),
+    "storm_output_head": ([_vp, _vp, _vp, _vp, _i, _vp, _i, _i, _i, _i, _i, _vp], C.c_int),
+    "storm_ouve_prior": ([_vp, _vp, _vp, _i, _ll, Ouve, _u64, _u64, _vp], C.c_int),
+    "storm_ouve_ald_step": ([_vp, _vp, _vp, _vp, _vp, _i, _ll, Ouve, _f, _u64, _u64, _vp], C.c_int),
+    "storm_ouve_predictor_step": ([_vp, _vp, _vp, _vp, _vp, _vp, _i, _ll, Ouve, _i, _i, _u64, _u64, _vp], C.c_int),
+    "storm_batch_l2norm": ([_vp, _vp, _i, _ll, _vp], C.c_int),
+    "storm_langevin_step": ([_vp, _vp, _vp, _vp, _vp, _vp, _i, _ll, _f, _vp], C.c_int),
+    "storm_complex_randn": ([_vp, _ll, _u64, _u64, _vp], C.c_int),
+    "storm_peak_abs": ([_vp, _vp, _i, _ll, _ll, _vp], C.c_int),
+    "storm_stft": ([_vp, _vp, _vp, _vp, _vp, _i, _ll, _ll, _i, _i, _i, _i, _f, _f, _vp], C.c_int),
+    "storm_istft": ([_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _ll, _ll, _i, _i, _f, _f, _vp], C.c_int),
+    "storm_program_run": ([C.POINTER(Op), _i, C.POINTER(_vp), _i, _i, _vp], C.c_int),
+}
+EXPORTS = ["storm_last_error"] + list(_SIGNATURES)
+
+_lib = None
+_sim = False
+
+
+def _bind(path):
+    lib = C.CDLL(path)
+    lib.storm_last_error.restype = C.c_char_p
+    lib.storm_last_error.argtypes = []
+    for name, (args, res) in _SIGNATURES.items():
+        fn = getattr(lib, name)
+        fn.argtypes, fn.restype = args, res
+    return lib
+
+
+def lib():
+    """The loaded library; raises if libstorm_hip.so has not been built."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise StormError(
+                f"{LIB_PATH} not found: build the HIP extension first "
+                "(python -c 'import __graft_entry__ as g; g.build()' or python -m storm_amd.build). "
+                "storm_amd has no CPU fallback.")
+        _lib = _bind(LIB_PATH)
+    return _lib
+
+
+def _load_for_tests(path, sim):
+    """TEST HOOK: bind another build of the same C ABI (the host simulation)."""
+    global _lib, _sim
+    _lib = _bind(path)
+    _sim = bool(sim)
+    return _lib
+
+
+def is_sim():
+    return _sim
+
+
+def check(rc, what=""):
+    if rc != 0:
+        raise StormError(f"{what} failed ({rc}): {lib().storm_last_error().decode()}")
+
+
+def dt(t_or_dtype):
+    d = t_or_dtype.dtype if isinstance(t_or_dtype, torch.Tensor) else t_or_dtype
+    try:
+        return _TORCH2DT[d]
+    except KeyError:
+        raise StormError(f"unsupported activation dtype {d}")
+
+
+def torch_dtype(code):
+    return _DT2TORCH[code]
+
+
+def ptr(t, allow_none=True):
+    """Raw device pointer of a contiguous tensor (None -> NULL)."""
+    if t is None:
+        if allow_none:
+            return None
+        raise StormError("null tensor")
+    if not t.is_contiguous():
+        raise StormError("tensor must be contiguous")
+    if not _sim and not t.is_cuda:
+        raise StormError("storm_amd ops run on the GPU only: got a CPU tensor (there is no CPU fallback)")
+    return t.data_ptr()
+
+
+def stream():
+    if _sim:
+        return None
+    return torch.cuda.current_stream().cuda_stream

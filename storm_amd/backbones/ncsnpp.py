@@ -1,0 +1,303 @@
+"""NCSN++ score network on the HIP engine.
+
+Drop-in for the reference backbone plugin (sgmse/backbones/ncsnpp.py:36-450): same registry
+names, constructor keywords, ``state_dict`` key names/shapes (``all_modules.<i>.<Layer>.<param>``,
+``output_layer.*``) and ``forward(x: complex64[B,C,F,T], time_cond: float32[B]) ->
+complex64[B,1,F,T]`` contract.  The modules below only HOLD parameters; ``forward`` plans the
+whole network once per (B, F, T, dtype) (plan.py) and runs it with one ``storm_program_run``
+call.  There is no PyTorch/CPU execution path.
+"""
+import math
+
+import numpy as np
+import torch
+import torch.nn as nn
+
+from .. import _lib as L
+from .plan import (BUF_IN0, BUF_OUT, BUF_PARAMS, BUF_T, BUF_WS, N_BUFS, NCSNppConfig, ParamLayout, Program,
+                   module_list)
+from .shared import BackboneRegistry
+import ctypes as C
+
+
+def _default_init(shape, scale=1.0):
+    """DDPM / JAX variance_scaling(scale, 'fan_avg', 'uniform') (layers.py:52-91)."""
+    scale = 1e-10 if scale == 0 else scale
+    receptive = np.prod(shape) / shape[0] / shape[1]
+    fan_in, fan_out = shape[1] * receptive, shape[0] * receptive
+    variance = scale / ((fan_in + fan_out) / 2)
+    return (torch.rand(*shape) * 2.0 - 1.0) * np.sqrt(3 * variance)
+
+
+def _conv(i, o, k, init_scale=1.0):
+    c = nn.Conv2d(i, o, k, padding=k // 2)
+    c.weight.data = _default_init(c.weight.shape, init_scale)
+    nn.init.zeros_(c.bias)
+    return c
+
+
+def _dense(i, o):
+    d = nn.Linear(i, o)
+    d.weight.data = _default_init(d.weight.shape)
+    nn.init.zeros_(d.bias)
+    return d
+
+
+def _gn(c):
+    return nn.GroupNorm(num_groups=min(c // 4, 32), num_channels=c, eps=1e-6)
+
+
+class _Holder(nn.Module):
+    """Parameter container; the engine reads the parameters, nothing is executed here."""
+
+    def forward(self, *a, **k):
+        raise RuntimeError("parameter holder: run the enclosing NCSNpp, not its sub-modules")
+
+
+class GaussianFourierProjection(_Holder):
+    def __init__(self, embedding_size, scale):
+        super().__init__()
+        self.W = nn.Parameter(torch.randn(embedding_size) * scale, requires_grad=False)
+
+
+class NIN(_Holder):
+    def __init__(self, c, init_scale=0.1):
+        super().__init__()
+        self.W = nn.Parameter(_default_init((c, c), init_scale))
+        self.b = nn.Parameter(torch.zeros(c))
+
+
+class AttnBlockpp(_Holder):
+    def __init__(self, c, init_scale=0.0):
+        super().__init__()
+        self.GroupNorm_0 = _gn(c)
+        self.NIN_0, self.NIN_1, self.NIN_2 = NIN(c), NIN(c), NIN(c)
+        self.NIN_3 = NIN(c, init_scale)
+
+
+class ResnetBlockBigGANpp(_Holder):
+    def __init__(self, i, o, temb_dim, resample, init_scale=0.0):
+        super().__init__()
+        self.GroupNorm_0 = _gn(i)
+        self.Conv_0 = _conv(i, o, 3)
+        self.Dense_0 = _dense(temb_dim, o)
+        self.GroupNorm_1 = _gn(o)
+        self.Conv_1 = _conv(o, o, 3, init_scale)
+        if i != o or resample:
+            self.Conv_2 = _conv(i, o, 1)
+
+
+class Combine(_Holder):
+    def __init__(self, i, o):
+        super().__init__()
+        self.Conv_0 = _conv(i, o, 1)
+
+
+@BackboneRegistry.register("ncsnpp")
+class NCSNpp(nn.Module):
+    """NCSN++ (27.8 M parameters with the defaults)."""
+
+    def __init__(self, scale_by_sigma=True, nonlinearity="swish", nf=128, ch_mult=(1, 2, 2, 2), num_res_blocks=1,
+                 attn_resolutions=(0,), resamp_with_conv=True, conditional=True, fir=True, fir_kernel=(1, 3, 3, 1),
+                 skip_rescale=True, resblock_type="biggan", progressive="output_skip", progressive_input="input_skip",
+                 progressive_combine="sum", init_scale=0.0, fourier_scale=16, image_size=256, embedding_type="fourier",
+                 input_channels=4, spatial_channels=1, dropout=0.0, centered=False, discriminative=False, **kwargs):
+        super().__init__()
+        unsupported = []
+        if nonlinearity != "swish": unsupported.append(f"nonlinearity={nonlinearity}")
+        if not fir or list(fir_kernel) != [1, 3, 3, 1]: unsupported.append("fir / fir_kernel")
+        if not skip_rescale: unsupported.append("skip_rescale=False")
+        if resblock_type.lower() != "biggan": unsupported.append(f"resblock_type={resblock_type}")
+        if progressive.lower() != "output_skip": unsupported.append(f"progressive={progressive}")
+        if progressive_input.lower() != "input_skip": unsupported.append(f"progressive_input={progressive_input}")
+        if progressive_combine.lower() != "sum": unsupported.append(f"progressive_combine={progressive_combine}")
+        if embedding_type.lower() != "fourier": unsupported.append(f"embedding_type={embedding_type}")
+        if spatial_channels != 1: unsupported.append(f"spatial_channels={spatial_channels}")
+        if dropout != 0.0: unsupported.append("dropout (inference engine)")
+        if centered: unsupported.append("centered=True")
+        if not discriminative and (not conditional or not scale_by_sigma):
+            unsupported.append("conditional / scale_by_sigma = False on a score network")
+        if unsupported:
+            raise NotImplementedError("storm_amd NCSNpp covers the StoRM hot-path configuration only; unsupported: "
+                                      + ", ".join(unsupported))
+        self.FORCE_STFT_OUT = False
+        if discriminative:
+            print("Running NCSN++ as discriminative backbone")
+            input_channels = 2
+        if nf % 8:
+            raise NotImplementedError("nf must be a multiple of 8 (NHWC channel octets)")
+        self.cfg = NCSNppConfig(nf=nf, ch_mult=tuple(ch_mult), num_res_blocks=num_res_blocks,
+                                attn_resolutions=tuple(attn_resolutions), image_size=image_size,
+                                input_channels=input_channels, discriminative=discriminative,
+                                fourier_scale=float(fourier_scale))
+        self.nf, self.discriminative, self.input_channels = nf, discriminative, input_channels
+        self.spatial_channels = 1
+        total = self.cfg.total_channels
+        self.output_layer = nn.Conv2d(total, 2, 1)
+        mods = []
+        for kind, p in module_list(self.cfg):
+            if kind == "gfp":
+                mods.append(GaussianFourierProjection(p["n"], fourier_scale))
+            elif kind == "linear":
+                mods.append(_dense(p["i"], p["o"]))
+            elif kind == "conv3":
+                first = p["i"] == total and p["o"] == nf and len(mods) <= 3
+                mods.append(_conv(p["i"], p["o"], 3, 1.0 if first else init_scale))
+            elif kind == "res":
+                mods.append(ResnetBlockBigGANpp(p["i"], p["o"], 4 * nf, p["resample"], init_scale))
+            elif kind == "combine":
+                mods.append(Combine(p["i"], p["o"]))
+            elif kind == "attn":
+                mods.append(AttnBlockpp(p["c"], init_scale))
+            elif kind == "gn":
+                mods.append(_gn(p["c"]))
+        self.all_modules = nn.ModuleList(mods)
+        self.compute_dtype = torch.float32
+        self.negate_output = False        # ScoreModel folds the "score = -dnn(...)" sign into the output head
+        self._arena = {}                  # dtype code -> (ParamLayout, arena tensor, params version)
+        self._programs = {}               # (B, F, T, dtype, negate) -> (Program, workspace)
+        self._param_version = 0
+        self.register_load_state_dict_post_hook(lambda m, keys: m.invalidate())
+
+    @staticmethod
+    def add_argparse_args(parser):
+        return parser
+
+    # ---- engine state ----------------------------------------------------------------------
+    def set_compute_dtype(self, dtype):
+        """torch.float32 (exact fp32 MFMA, parity path) or torch.bfloat16 (bf16 MFMA operands and
+        activations, fp32 accumulation / statistics / SDE state)."""
+        L.dt(dtype)
+        self.compute_dtype = dtype
+        return self
+
+    def invalidate(self):
+        """Call after changing parameters in place (e.g. EMA swap): re-packs the weight arena lazily."""
+        self._param_version += 1
+
+    def _apply(self, fn, *a, **k):
+        self.invalidate()
+        self._programs.clear()
+        return super()._apply(fn, *a, **k)
+
+    def _get_arena(self, dtype_code, device):
+        ent = self._arena.get(dtype_code)
+        if ent is not None and ent[2] == self._param_version and ent[1].device == device:
+            return ent[0], ent[1]
+        layout = ent[0] if ent is not None else ParamLayout(self.cfg, dtype_code)
+        arena = torch.zeros(layout.size, dtype=torch.uint8, device=device)
+        sd = {k: v.detach().to(device=device, dtype=torch.float32).contiguous() for k, v in self.state_dict().items()}
+        base = arena.data_ptr() if not L.is_sim() else arena.data_ptr()
+        lib, st = L.lib(), L.stream()
+        keep = []
+        for e in layout.entries.values():
+            dst = base + e.offset
+            if e.kind == "conv":
+                w = sd[e.sources[0]]
+                Cout, Cin, taps = w.shape[0], w.shape[1], w.shape[2] * w.shape[3]
+                L.check(lib.storm_pack_conv_weight(L.ptr(w), dst, Cout, Cin, taps, e.shape[1], e.shape[2], dtype_code, st),
+                        "storm_pack_conv_weight")
+            elif e.kind == "nin":
+                w = sd[e.sources[0]]                      # [Cin][Cout]
+                L.check(lib.storm_pack_matrix(L.ptr(w), dst, w.shape[1], w.shape[0], 1, e.shape[1], e.shape[2], dtype_code, st),
+                        "storm_pack_matrix")
+            else:
+                if e.kind == "f32":
+                    src = sd[e.sources[0]].reshape(-1)
+                elif e.kind == "f32sum":
+                    src = sd[e.sources[0]] + sd[e.sources[1]]
+                elif e.kind == "dense_w":
+                    src = torch.cat([sd[s] for s in e.sources], 0).reshape(-1)
+                elif e.kind == "dense_b":
+                    src = torch.cat([sd[s] for s in e.sources], 0)
+                else:
+                    raise AssertionError(e.kind)
+                assert src.numel() * 4 == e.nbytes, (e.key, src.shape, e.nbytes)
+                arena[e.offset:e.offset + e.nbytes].copy_(src.contiguous().view(torch.uint8))
+            keep.append(e)
+        if not L.is_sim():
+            torch.cuda.current_stream().synchronize()    # sd temporaries die with this scope
+        self._arena[dtype_code] = (layout, arena, self._param_version)
+        return layout, arena
+
+    def _get_program(self, B, F, T, dtype_code, device):
+        key = (B, F, T, dtype_code, bool(self.negate_output))
+        ent = self._programs.get(key)
+        if ent is None:
+            layout, _ = self._get_arena(dtype_code, device)
+            prog = Program(self.cfg, layout, B, F, T)
+            prog.ops[-1].i[4] = int(self.negate_output)
+            prog.op_array = (L.Op * len(prog.ops))(*prog.ops)
+            ws = torch.empty(prog.ws_bytes, dtype=torch.uint8, device=device)
+            ent = (prog, ws)
+            self._programs[key] = ent
+        return ent
+
+    def workspace_bytes(self, B, F, T, dtype=None):
+        code = L.dt(dtype or self.compute_dtype)
+        return Program(self.cfg, ParamLayout(self.cfg, code), B, F, T).ws_bytes
+
+    # ---- forward ---------------------------------------------------------------------------
+    def forward(self, x, time_cond=None):
+        """x: complex64 [B, input_channels/2, F, T] (x, y[, y_denoised]); time_cond: float32 [B]."""
+        if not x.is_complex():
+            raise TypeError("NCSNpp expects a complex spectrogram batch [B, C, F, T]")
+        B, Cc, F, T = x.shape
+        if 2 * Cc != self.cfg.total_channels:
+            raise ValueError(f"expected {self.cfg.total_channels // 2} complex input channels, got {Cc}")
+        ins = [x[:, c].contiguous() for c in range(Cc)]
+        return self.forward_parts(ins, time_cond)
+
+    def forward_parts(self, ins, time_cond=None):
+        """Same as forward() but takes the complex channels as separate contiguous [B,F,T] tensors
+        (avoids materialising torch.cat([x, y], 1) every score evaluation)."""
+        x0 = ins[0]
+        B, F, T = x0.shape
+        dev = x0.device
+        code = L.dt(self.compute_dtype)
+        _, arena = self._get_arena(code, dev)
+        prog, ws = self._get_program(B, F, T, code, dev)
+        out = torch.empty((B, 1, F, T), dtype=torch.complex64, device=dev)
+        bufs = (C.c_void_p * N_BUFS)()
+        bufs[BUF_WS], bufs[BUF_PARAMS] = L.ptr(ws), L.ptr(arena)
+        for j, t_in in enumerate(ins):
+            if t_in.dtype != torch.complex64 or t_in.shape != x0.shape:
+                raise TypeError("inputs must be complex64 tensors of identical shape")
+            bufs[BUF_IN0 + j] = L.ptr(torch.view_as_real(t_in))
+        if self.cfg.conditional:
+            if time_cond is None:
+                raise ValueError("time_cond is required for a score network")
+            tc = time_cond.to(device=dev, dtype=torch.float32).contiguous()
+            if tc.shape != (B,):
+                raise ValueError(f"time_cond must have shape [{B}]")
+            bufs[BUF_T] = L.ptr(tc)
+        bufs[BUF_OUT] = L.ptr(torch.view_as_real(out))
+        L.check(L.lib().storm_program_run(prog.op_array, len(prog.ops), bufs, N_BUFS, code, L.stream()),
+                "storm_program_run")
+        return out
+
+
+@BackboneRegistry.register("ncsnpplarge")
+class NCSNppLarge(NCSNpp):
+    """~65.6 M parameters (ncsnpp.py:460-470)."""
+
+    def __init__(self, **kwargs):
+        for k in ("nf", "ch_mult", "num_res_blocks", "attn_resolutions"):
+            kwargs.pop(k, None)
+        super().__init__(nf=128, ch_mult=(1, 1, 2, 2, 2, 2, 2), num_res_blocks=2, attn_resolutions=(16,), **kwargs)
+
+
+@BackboneRegistry.register("ncsnpp12M")
+class NCSNpp12M(NCSNpp):
+    def __init__(self, **kwargs):
+        for k in ("nf", "ch_mult", "num_res_blocks", "attn_resolutions"):
+            kwargs.pop(k, None)
+        super().__init__(nf=96, ch_mult=(1, 2, 2, 1), num_res_blocks=1, attn_resolutions=(0,), **kwargs)
+
+
+@BackboneRegistry.register("ncsnpp6M")
+class NCSNpp6M(NCSNpp):
+    def __init__(self, **kwargs):
+        for k in ("nf", "ch_mult", "num_res_blocks", "attn_resolutions"):
+            kwargs.pop(k, None)
+        super().__init__(nf=96, ch_mult=(1, 1, 1, 1), num_res_blocks=1, attn_resolutions=(0,), **kwargs)

@@ -1,0 +1,564 @@
+"""Host-side planner: turns an NCSN++ configuration into (a) a packed parameter arena layout
+and (b) an op program for ``storm_program_run`` (one C-ABI call per score evaluation).
+
+It mirrors the module enumeration of the reference ``NCSNpp.__init__`` / ``forward``
+(sgmse/backbones/ncsnpp.py:153-273, 281-450) for the configuration family of the hot path
+(BigGAN blocks, FIR resampling, output_skip / input_skip pyramids, Fourier embedding) but
+emits fused ops: GN-stats / GN-apply+SiLU(+FIR of h and x) / conv3x3(+temb bias) /
+conv3x3 + 1x1 shortcut + residual rescale in one kernel, concat-free skip connections,
+attention as three MFMA GEMMs + a wave64 row softmax.
+"""
+import ctypes as C
+import math
+from dataclasses import dataclass, field
+from typing import Dict, List, Optional, Tuple
+
+from .. import _lib as L
+
+# op codes (include/storm_hip.h)
+OP_MEMSET, OP_PACK_INPUT, OP_TEMB, OP_DENSE, OP_CONV, OP_GN_STATS, OP_GN_APPLY, OP_FIR_UP, OP_FIR_DOWN, \
+    OP_SOFTMAX, OP_OUTPUT_HEAD = range(11)
+
+# buffer slots of storm_program_run
+BUF_WS, BUF_PARAMS, BUF_IN0, BUF_IN1, BUF_IN2, BUF_T, BUF_OUT = range(7)
+N_BUFS = 7
+
+ALIGN = 256
+
+
+def _up(x, m):
+    return (x + m - 1) // m * m
+
+
+@dataclass(frozen=True)
+class NCSNppConfig:
+    """Graph-shaping hyper-parameters (ncsnpp.py:40-65)."""
+    nf: int = 128
+    ch_mult: Tuple[int, ...] = (1, 2, 2, 2)
+    num_res_blocks: int = 1
+    attn_resolutions: Tuple[int, ...] = (0,)
+    image_size: int = 256
+    input_channels: int = 4
+    discriminative: bool = False
+    fourier_scale: float = 16.0
+
+    @property
+    def conditional(self):
+        return not self.discriminative
+
+    @property
+    def total_channels(self):
+        return 2 if self.discriminative else self.input_channels
+
+
+def module_list(cfg: NCSNppConfig):
+    """``all_modules`` in registration order: list of (kind, params).  kind in
+    {gfp, linear, conv3, res, combine, attn, gn}.  Same order as ncsnpp.py:153-273."""
+    nf, nres, total = cfg.nf, len(cfg.ch_mult), cfg.total_channels
+    all_res = [cfg.image_size // (2 ** i) for i in range(nres)]
+    mods = [("gfp", dict(n=nf))]
+    if cfg.conditional:
+        mods += [("linear", dict(i=2 * nf, o=4 * nf)), ("linear", dict(i=4 * nf, o=4 * nf))]
+    mods.append(("conv3", dict(i=total, o=nf)))
+    hs_c, in_ch = [nf], nf
+    for lvl in range(nres):
+        for _ in range(cfg.num_res_blocks):
+            out_ch = nf * cfg.ch_mult[lvl]
+            mods.append(("res", dict(i=in_ch, o=out_ch, resample=False)))
+            in_ch = out_ch
+            if all_res[lvl] in cfg.attn_resolutions:
+                mods.append(("attn", dict(c=in_ch)))
+            hs_c.append(in_ch)
+        if lvl != nres - 1:
+            mods.append(("res", dict(i=in_ch, o=in_ch, resample=True)))
+            mods.append(("combine", dict(i=total, o=in_ch)))
+            hs_c.append(in_ch)
+    in_ch = hs_c[-1]
+    mods += [("res", dict(i=in_ch, o=in_ch, resample=False)), ("attn", dict(c=in_ch)),
+             ("res", dict(i=in_ch, o=in_ch, resample=False))]
+    for lvl in reversed(range(nres)):
+        for _ in range(cfg.num_res_blocks + 1):
+            out_ch = nf * cfg.ch_mult[lvl]
+            mods.append(("res", dict(i=in_ch + hs_c.pop(), o=out_ch, resample=False)))
+            in_ch = out_ch
+        if all_res[lvl] in cfg.attn_resolutions:
+            mods.append(("attn", dict(c=in_ch)))
+        mods.append(("gn", dict(c=in_ch)))
+        mods.append(("conv3", dict(i=in_ch, o=total)))
+        if lvl != 0:
+            mods.append(("res", dict(i=in_ch, o=in_ch, resample=True)))
+    assert not hs_c
+    return mods
+
+
+def state_dict_shapes(cfg: NCSNppConfig):
+    """name -> shape of every tensor in the reference state_dict."""
+    total = cfg.total_channels
+    shapes = {"output_layer.weight": (2, total, 1, 1), "output_layer.bias": (2,)}
+    for idx, (kind, p) in enumerate(module_list(cfg)):
+        k = f"all_modules.{idx}."
+        if kind == "gfp":
+            shapes[k + "W"] = (p["n"],)
+        elif kind == "linear":
+            shapes[k + "weight"] = (p["o"], p["i"]); shapes[k + "bias"] = (p["o"],)
+        elif kind == "conv3":
+            shapes[k + "weight"] = (p["o"], p["i"], 3, 3); shapes[k + "bias"] = (p["o"],)
+        elif kind == "gn":
+            shapes[k + "weight"] = (p["c"],); shapes[k + "bias"] = (p["c"],)
+        elif kind == "combine":
+            shapes[k + "Conv_0.weight"] = (p["o"], p["i"], 1, 1); shapes[k + "Conv_0.bias"] = (p["o"],)
+        elif kind == "attn":
+            c = p["c"]
+            shapes[k + "GroupNorm_0.weight"] = (c,); shapes[k + "GroupNorm_0.bias"] = (c,)
+            for j in range(4):
+                shapes[k + f"NIN_{j}.W"] = (c, c); shapes[k + f"NIN_{j}.b"] = (c,)
+        elif kind == "res":
+            i, o = p["i"], p["o"]
+            shapes[k + "GroupNorm_0.weight"] = (i,); shapes[k + "GroupNorm_0.bias"] = (i,)
+            shapes[k + "Conv_0.weight"] = (o, i, 3, 3); shapes[k + "Conv_0.bias"] = (o,)
+            shapes[k + "Dense_0.weight"] = (o, 4 * cfg.nf); shapes[k + "Dense_0.bias"] = (o,)
+            shapes[k + "GroupNorm_1.weight"] = (o,); shapes[k + "GroupNorm_1.bias"] = (o,)
+            shapes[k + "Conv_1.weight"] = (o, o, 3, 3); shapes[k + "Conv_1.bias"] = (o,)
+            if i != o or p["resample"]:
+                shapes[k + "Conv_2.weight"] = (o, i, 1, 1); shapes[k + "Conv_2.bias"] = (o,)
+    return shapes
+
+
+# ------------------------------------------------------------------------------------------
+# Parameter arena
+# ------------------------------------------------------------------------------------------
+@dataclass
+class ParamEntry:
+    key: str                 # arena key
+    kind: str                # conv | nin | f32 | f32sum | dense_w | dense_b
+    sources: Tuple[str, ...]  # state_dict names
+    shape: Tuple[int, ...]   # packed shape
+    offset: int = 0
+    nbytes: int = 0
+
+
+class ParamLayout:
+    """Byte layout of the packed parameter arena for (cfg, dtype)."""
+
+    def __init__(self, cfg: NCSNppConfig, dtype_code: int):
+        self.cfg, self.dtype = cfg, dtype_code
+        self.esize = 2 if dtype_code == L.BF16 else 4
+        self.per16 = 16 // self.esize
+        self.entries: Dict[str, ParamEntry] = {}
+        self.size = 0
+        self.dense_rows = 0          # total rows of the concatenated Dense_0 matrix
+        self.dense_off: Dict[int, int] = {}   # module idx -> row offset
+        self._build()
+
+    def _add(self, key, kind, sources, shape, esize):
+        n = esize
+        for s in shape:
+            n *= s
+        e = ParamEntry(key, kind, tuple(sources), tuple(shape), self.size, n)
+        self.entries[key] = e
+        self.size = _up(self.size + n, ALIGN)
+        return e
+
+    def conv(self, name, Cout, Cin, taps):
+        CoutP, CinP = _up(Cout, 32), _up(Cin, 2 * self.per16)
+        return self._add(name, "conv", [name], (taps, CoutP, CinP), self.esize)
+
+    def nin(self, name, Cc):
+        return self._add(name, "nin", [name], (1, _up(Cc, 32), Cc), self.esize)
+
+    def f32(self, name, shape):
+        return self._add(name, "f32", [name], shape, 4)
+
+    def _build(self):
+        cfg = self.cfg
+        total = cfg.total_channels
+        self.f32("output_layer.weight", (2, total))
+        self.f32("output_layer.bias", (2,))
+        dense_srcs = []
+        for idx, (kind, p) in enumerate(module_list(cfg)):
+            k = f"all_modules.{idx}."
+            if kind == "gfp":
+                self.f32(k + "W", (p["n"],))
+            elif kind == "linear":
+                self.f32(k + "weight", (p["o"], p["i"])); self.f32(k + "bias", (p["o"],))
+            elif kind == "conv3":
+                self.conv(k + "weight", p["o"], p["i"], 9); self.f32(k + "bias", (p["o"],))
+            elif kind == "gn":
+                self.f32(k + "weight", (p["c"],)); self.f32(k + "bias", (p["c"],))
+            elif kind == "combine":
+                self.conv(k + "Conv_0.weight", p["o"], p["i"], 1); self.f32(k + "Conv_0.bias", (p["o"],))
+            elif kind == "attn":
+                c = p["c"]
+                self.f32(k + "GroupNorm_0.weight", (c,)); self.f32(k + "GroupNorm_0.bias", (c,))
+                for j in range(4):
+                    self.nin(k + f"NIN_{j}.W", c); self.f32(k + f"NIN_{j}.b", (c,))
+            elif kind == "res":
+                i, o = p["i"], p["o"]
+                self.f32(k + "GroupNorm_0.weight", (i,)); self.f32(k + "GroupNorm_0.bias", (i,))
+                self.conv(k + "Conv_0.weight", o, i, 9); self.f32(k + "Conv_0.bias", (o,))
+                self.f32(k + "GroupNorm_1.weight", (o,)); self.f32(k + "GroupNorm_1.bias", (o,))
+                self.conv(k + "Conv_1.weight", o, o, 9)
+                if i != o or p["resample"]:
+                    self.conv(k + "Conv_2.weight", o, i, 1)
+                    self._add(k + "bias12", "f32sum", [k + "Conv_1.bias", k + "Conv_2.bias"], (o,), 4)
+                else:
+                    self.f32(k + "Conv_1.bias", (o,))
+                if cfg.conditional:
+                    self.dense_off[idx] = self.dense_rows
+                    self.dense_rows += o
+                    dense_srcs.append(k + "Dense_0")
+        if cfg.conditional:
+            self._add("dense.weight", "dense_w", [s + ".weight" for s in dense_srcs], (self.dense_rows, 4 * cfg.nf), 4)
+            self._add("dense.bias", "dense_b", [s + ".bias" for s in dense_srcs], (self.dense_rows,), 4)
+
+    def off(self, key):
+        return self.entries[key].offset
+
+
+# ------------------------------------------------------------------------------------------
+# Program builder
+# ------------------------------------------------------------------------------------------
+class _Arena:
+    """First-fit offset allocator with coalescing free list (activations are reused aggressively:
+    a 4-s batch-16 forward peaks at a few GB instead of the ~60 GB a bump allocator would take)."""
+
+    def __init__(self):
+        self.free: List[List[int]] = []     # [off, size]
+        self.top = 0
+        self.live: Dict[int, int] = {}
+
+    def alloc(self, nbytes):
+        n = _up(max(nbytes, 1), ALIGN)
+        for k, (off, size) in enumerate(self.free):
+            if size >= n:
+                if size == n:
+                    self.free.pop(k)
+                else:
+                    self.free[k] = [off + n, size - n]
+                self.live[off] = n
+                return off
+        # extend: merge with a trailing free block if it touches the top
+        if self.free and self.free[-1][0] + self.free[-1][1] == self.top:
+            off, size = self.free.pop()
+            self.top = off + n
+        else:
+            off = self.top
+            self.top += n
+        self.live[off] = n
+        return off
+
+    def release(self, off):
+        n = self.live.pop(off)
+        self.free.append([off, n])
+        self.free.sort()
+        merged = []
+        for o, s in self.free:
+            if merged and merged[-1][0] + merged[-1][1] == o:
+                merged[-1][1] += s
+            else:
+                merged.append([o, s])
+        self.free = merged
+
+
+@dataclass
+class Act:
+    """An NHWC activation living in the workspace."""
+    off: int
+    H: int
+    W: int
+    C: int
+    external: Optional[int] = None     # buffer slot if not in the workspace
+
+
+class Program:
+    def __init__(self, cfg: NCSNppConfig, layout: ParamLayout, B: int, F: int, T: int):
+        self.cfg, self.layout, self.B, self.F, self.T = cfg, layout, B, F, T
+        self.dtype = layout.dtype
+        self.esize = layout.esize
+        self.ops: List[L.Op] = []
+        self.arena = _Arena()
+        self.n_in = cfg.total_channels // 2
+        nlev = len(cfg.ch_mult)
+        if F % (1 << (nlev - 1)) or T % (1 << (nlev - 1)):
+            raise ValueError(f"spectrogram {F}x{T} must be divisible by {1 << (nlev - 1)}")
+        self.flops = 0
+        self._build()
+        self.ws_bytes = self.arena.top
+        self.op_array = (L.Op * len(self.ops))(*self.ops)
+
+    # ---- helpers -------------------------------------------------------------------------
+    def _op(self, code):
+        op = L.Op()
+        op.code = code
+        for j in range(L.OP_NPTR):
+            op.p[j].buf = -1
+        self.ops.append(op)
+        return op
+
+    @staticmethod
+    def _ref(op, j, buf, off):
+        op.p[j].buf, op.p[j].off = buf, off
+
+    def _ws(self, op, j, act_or_off):
+        off = act_or_off.off if isinstance(act_or_off, Act) else act_or_off
+        self._ref(op, j, BUF_WS, off)
+
+    def _par(self, op, j, key):
+        self._ref(op, j, BUF_PARAMS, self.layout.off(key))
+
+    def new_act(self, H, W, Cc, esize=None):
+        n = self.B * H * W * Cc * (esize or self.esize)
+        return Act(self.arena.alloc(n), H, W, Cc)
+
+    def free(self, a: Act):
+        self.arena.release(a.off)
+
+    def new_stats(self, G):
+        off = self.stats_cursor
+        self.stats_cursor += _up(self.B * G * 2 * 8, ALIGN)
+        assert self.stats_cursor <= self.stats_off + self.stats_bytes
+        return off
+
+    # ---- op emitters -----------------------------------------------------------------------
+    def gn(self, xa: Act, xb: Optional[Act], wkey, bkey, silu=True, resample=0):
+        Cc = xa.C + (xb.C if xb else 0)
+        G = min(Cc // 4, 32)
+        st = self.new_stats(G)
+        op = self._op(OP_GN_STATS)
+        self._ws(op, 0, xa)
+        if xb:
+            self._ws(op, 1, xb)
+        self._ws(op, 2, st)
+        op.i[0], op.i[1], op.i[2], op.i[3], op.i[4] = xa.C, (xb.C if xb else 0), self.B, xa.H * xa.W, G
+        OH, OW = (2 * xa.H, 2 * xa.W) if resample == 1 else ((xa.H // 2, xa.W // 2) if resample == 2 else (xa.H, xa.W))
+        out = self.new_act(OH, OW, Cc)
+        raw = self.new_act(OH, OW, Cc) if resample else None
+        op = self._op(OP_GN_APPLY)
+        self._ws(op, 0, xa)
+        if xb:
+            self._ws(op, 1, xb)
+        self._ws(op, 2, st)
+        self._par(op, 3, wkey)
+        self._par(op, 4, bkey)
+        self._ws(op, 5, out)
+        if raw:
+            self._ws(op, 6, raw)
+        op.i[0], op.i[1], op.i[2], op.i[3], op.i[4], op.i[5] = xa.C, (xb.C if xb else 0), self.B, xa.H, xa.W, G
+        op.i[6], op.i[7] = int(silu), resample
+        op.f[0] = 1e-6
+        return out, raw
+
+    def conv(self, segs, Cout, H, W, outC=None, bias_key=None, tbias=None, skip: Optional[Act] = None, scale=1.0,
+             out_f32=False, out_bstride=-1, src0_bstride=-1):
+        """segs: list of dict(a=Act|(buf,off,C), b=Act|None, w=('par',key)|('ws',off), CinP, rows, taps,
+        w_bstride, w_tapstride)."""
+        outC = outC or _up(Cout, 8)
+        out = self.new_act(H, W, outC, 4 if out_f32 else None)
+        op = self._op(OP_CONV)
+        op.i[0], op.i[1], op.i[2], op.i[3], op.i[4], op.i[5] = len(segs), self.B, H, W, outC, Cout
+        op.i[7] = int(out_f32)
+        for g, s in enumerate(segs):
+            a = s["a"]
+            if isinstance(a, Act):
+                self._ws(op, 3 * g, a)
+                Ca = a.C
+            else:
+                self._ref(op, 3 * g, a[0], a[1])
+                Ca = a[2]
+            Cb = 0
+            if s.get("b") is not None:
+                self._ws(op, 3 * g + 1, s["b"])
+                Cb = s["b"].C
+            kindw, wv = s["w"]
+            if kindw == "par":
+                self._par(op, 3 * g + 2, wv)
+            else:
+                self._ws(op, 3 * g + 2, wv)
+            q = 8 + 7 * g
+            op.i[q], op.i[q + 1], op.i[q + 2], op.i[q + 3], op.i[q + 4] = Ca, Cb, s["CinP"], s["rows"], s["taps"]
+            op.i[q + 5], op.i[q + 6] = s.get("w_bstride", 0), s.get("w_tapstride", s["CinP"] * s["rows"])
+            self.flops += 2 * self.B * H * W * Cout * (Ca + Cb) * s["taps"]
+        op.i[22], op.i[23] = src0_bstride, out_bstride
+        self._ws(op, 6, out)
+        if bias_key:
+            self._par(op, 7, bias_key)
+        if tbias is not None:
+            self._ref(op, 8, BUF_WS, tbias[0])
+            op.i[6] = tbias[1]
+        if skip is not None:
+            assert skip.C == outC and skip.H == H and skip.W == W
+            self._ws(op, 9, skip)
+        op.f[0] = scale
+        return out
+
+    def wseg(self, a, key, taps, b=None):
+        e = self.layout.entries[key]
+        return dict(a=a, b=b, w=("par", key), CinP=e.shape[2], rows=e.shape[1], taps=taps)
+
+    # ---- blocks ----------------------------------------------------------------------------
+    def resblock(self, idx, p, xa: Act, xb: Optional[Act] = None, resample=0):
+        """ResnetBlockBigGANpp.forward (layerspp.py:242-274) as 6-7 fused ops."""
+        k = f"all_modules.{idx}."
+        o = p["o"]
+        a, xr = self.gn(xa, xb, k + "GroupNorm_0.weight", k + "GroupNorm_0.bias", True, resample)
+        tb = None
+        if self.cfg.conditional:
+            tb = (self.dense_out + 4 * self.layout.dense_off[idx], self.layout.dense_rows)
+        u = self.conv([self.wseg(a, k + "Conv_0.weight", 9)], o, a.H, a.W, bias_key=k + "Conv_0.bias", tbias=tb)
+        self.free(a)
+        a2, _ = self.gn(u, None, k + "GroupNorm_1.weight", k + "GroupNorm_1.bias", True, 0)
+        self.free(u)
+        inv = 1.0 / math.sqrt(2.0)
+        if (k + "Conv_2.weight") in self.layout.entries:
+            if xr is not None:
+                s2 = self.wseg(xr, k + "Conv_2.weight", 1)
+            else:
+                s2 = self.wseg(xa, k + "Conv_2.weight", 1, b=xb)
+            out = self.conv([self.wseg(a2, k + "Conv_1.weight", 9), s2], o, a2.H, a2.W, bias_key=k + "bias12", scale=inv)
+        else:
+            assert xb is None and xr is None and xa.C == o
+            out = self.conv([self.wseg(a2, k + "Conv_1.weight", 9)], o, a2.H, a2.W, bias_key=k + "Conv_1.bias",
+                            skip=xa, scale=inv)
+        self.free(a2)
+        if xr is not None:
+            self.free(xr)
+        return out
+
+    def attnblock(self, idx, p, x: Act):
+        """AttnBlockpp.forward (layerspp.py:75-91): GN -> q,k,v (NIN) -> softmax(q k^T / sqrt C) v -> NIN_3 -> skip."""
+        k = f"all_modules.{idx}."
+        Cc, Lp = p["c"], x.H * x.W
+        if Lp % 8:
+            raise ValueError("attention needs H*W % 8 == 0")
+        h, _ = self.gn(x, None, k + "GroupNorm_0.weight", k + "GroupNorm_0.bias", silu=False)
+        hl = Act(h.off, 1, Lp, Cc)
+        q = self.conv([self.wseg(hl, k + "NIN_0.W", 1)], Cc, 1, Lp, bias_key=k + "NIN_0.b")
+        kk = self.conv([self.wseg(hl, k + "NIN_1.W", 1)], Cc, 1, Lp, bias_key=k + "NIN_1.b")
+        # v^T[c][j] = sum_c' Wv^T[c][c'] h[j][c']: the packed NIN_2 matrix is the "pixel" operand, h the weights.
+        e2 = self.layout.entries[k + "NIN_2.W"]
+        vT = self.conv([dict(a=(BUF_PARAMS, e2.offset, Cc), w=("ws", h.off), CinP=Cc, rows=Lp, taps=1,
+                             w_bstride=Lp * Cc)], Lp, 1, Cc, outC=Lp, src0_bstride=0)
+        self.free(h)
+        S = self.conv([dict(a=q, w=("ws", kk.off), CinP=Cc, rows=Lp, taps=1, w_bstride=Lp * Cc)], Lp, 1, Lp, outC=Lp,
+                      scale=float(int(Cc) ** (-0.5)), out_f32=True)
+        self.free(q); self.free(kk)
+        P = self.new_act(1, Lp, Lp)
+        op = self._op(OP_SOFTMAX)
+        self._ws(op, 0, S); self._ws(op, 1, P)
+        op.i[0], op.i[1] = self.B * Lp, Lp
+        self.free(S)
+        # h = P v (+ b_v: rows of P sum to one, so the NIN_2 bias passes through unchanged)
+        o = self.conv([dict(a=P, w=("ws", vT.off), CinP=Lp, rows=Cc, taps=1, w_bstride=Cc * Lp)], Cc, 1, Lp,
+                      bias_key=k + "NIN_2.b")
+        self.free(P); self.free(vT)
+        xl = Act(x.off, 1, Lp, Cc)
+        out = self.conv([self.wseg(o, k + "NIN_3.W", 1)], Cc, 1, Lp, bias_key=k + "NIN_3.b", skip=xl,
+                        scale=1.0 / math.sqrt(2.0))
+        self.free(o)
+        return Act(out.off, x.H, x.W, Cc)
+
+    # ---- whole network ---------------------------------------------------------------------
+    def _build(self):
+        cfg, B, F, T = self.cfg, self.B, self.F, self.T
+        mods = module_list(cfg)
+        nres, total = len(cfg.ch_mult), cfg.total_channels
+        # statistics arena: every GroupNorm gets its own [B][G][2] fp64 slot, zeroed by one memset
+        n_gn = sum({"res": 2, "attn": 1, "gn": 1}.get(kind, 0) for kind, _ in mods)
+        self.stats_bytes = n_gn * _up(B * 32 * 2 * 8, ALIGN)
+        self.stats_off = self.arena.alloc(self.stats_bytes)
+        self.stats_cursor = self.stats_off
+        op = self._op(OP_MEMSET)
+        self._ws(op, 0, self.stats_off)
+        op.i[0] = self.stats_bytes
+
+        x0 = self.new_act(F, T, 8)
+        op = self._op(OP_PACK_INPUT)
+        for j in range(self.n_in):
+            self._ref(op, j, BUF_IN0 + j, 0)
+        self._ws(op, 3, x0)
+        op.i[0], op.i[1], op.i[2], op.i[3] = self.n_in, B, F, T
+
+        midx = 1
+        if cfg.conditional:
+            temb = self.arena.alloc(B * 4 * cfg.nf * 4)
+            op = self._op(OP_TEMB)
+            self._ref(op, 0, BUF_T, 0)
+            self._par(op, 1, "all_modules.0.W")
+            self._par(op, 2, "all_modules.1.weight"); self._par(op, 3, "all_modules.1.bias")
+            self._par(op, 4, "all_modules.2.weight"); self._par(op, 5, "all_modules.2.bias")
+            self._ws(op, 6, temb)
+            op.i[0], op.i[1] = B, cfg.nf
+            self.dense_out = self.arena.alloc(B * self.layout.dense_rows * 4)
+            op = self._op(OP_DENSE)
+            self._ws(op, 0, temb); self._par(op, 1, "dense.weight"); self._par(op, 2, "dense.bias")
+            self._ws(op, 3, self.dense_out)
+            op.i[0], op.i[1], op.i[2] = B, self.layout.dense_rows, 4 * cfg.nf
+            midx = 3
+
+        ip = x0
+        k = f"all_modules.{midx}."
+        hs = [self.conv([self.wseg(x0, k + "weight", 9)], cfg.nf, F, T, bias_key=k + "bias")]
+        midx += 1
+        for lvl in range(nres):
+            for _ in range(cfg.num_res_blocks):
+                h = self.resblock(midx, mods[midx][1], hs[-1]); midx += 1
+                if h.H in cfg.attn_resolutions:                     # ncsnpp.py:338 (frequency axis)
+                    h2 = self.attnblock(midx, mods[midx][1], h); midx += 1
+                    self.free(h); h = h2
+                hs.append(h)
+            if lvl != nres - 1:
+                h = self.resblock(midx, mods[midx][1], hs[-1], resample=2); midx += 1
+                ipd = self.new_act(ip.H // 2, ip.W // 2, 8)
+                op = self._op(OP_FIR_DOWN)
+                self._ws(op, 0, ip); self._ws(op, 1, ipd)
+                op.i[0], op.i[1], op.i[2], op.i[3] = B, ip.H, ip.W, 8
+                self.free(ip); ip = ipd
+                kk = f"all_modules.{midx}."                          # Combine (layerspp.py:52-57), method 'sum'
+                hc = self.conv([self.wseg(ip, kk + "Conv_0.weight", 1)], h.C, h.H, h.W, bias_key=kk + "Conv_0.bias", skip=h)
+                midx += 1
+                self.free(h)
+                hs.append(hc)
+        self.free(ip)
+        h = hs[-1]
+        h1 = self.resblock(midx, mods[midx][1], h); midx += 1
+        h2 = self.attnblock(midx, mods[midx][1], h1); midx += 1
+        self.free(h1)
+        h = self.resblock(midx, mods[midx][1], h2); midx += 1
+        self.free(h2)
+        pyramid = None
+        for lvl in reversed(range(nres)):
+            for _ in range(cfg.num_res_blocks + 1):
+                skip = hs.pop()
+                hn = self.resblock(midx, mods[midx][1], h, skip); midx += 1
+                self.free(h); self.free(skip)
+                h = hn
+            if h.H in cfg.attn_resolutions:                          # ncsnpp.py:385
+                hn = self.attnblock(midx, mods[midx][1], h); midx += 1
+                self.free(h); h = hn
+            kg, kc = f"all_modules.{midx}.", f"all_modules.{midx + 1}."
+            a, _ = self.gn(h, None, kg + "weight", kg + "bias", True, 0)
+            ph = self.conv([self.wseg(a, kc + "weight", 9)], total, h.H, h.W, outC=8, bias_key=kc + "bias")
+            midx += 2
+            self.free(a)
+            if pyramid is None:
+                pyramid = ph
+            else:
+                pn = self.new_act(h.H, h.W, 8)
+                op = self._op(OP_FIR_UP)
+                self._ws(op, 0, pyramid); self._ws(op, 1, ph); self._ws(op, 2, pn)
+                op.i[0], op.i[1], op.i[2], op.i[3] = B, pyramid.H, pyramid.W, 8
+                self.free(pyramid); self.free(ph)
+                pyramid = pn
+            if lvl != 0:
+                hn = self.resblock(midx, mods[midx][1], h, resample=1); midx += 1
+                self.free(h); h = hn
+        assert not hs and midx == len(mods)
+        self.free(h)
+        op = self._op(OP_OUTPUT_HEAD)
+        self._ws(op, 0, pyramid)
+        if cfg.conditional:
+            self._ref(op, 1, BUF_T, 0)
+        self._par(op, 2, "output_layer.weight"); self._par(op, 3, "output_layer.bias")
+        self._ref(op, 4, BUF_OUT, 0)
+        op.i[0], op.i[1], op.i[2], op.i[3], op.i[4] = total, B, F, T, 0
+        self.free(pyramid)

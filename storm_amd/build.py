@@ -1,0 +1,61 @@
+"""Build libstorm_hip.so in-tree with hipcc for gfx950 (cross-compiles without a GPU).
+
+    python -m storm_amd.build [--force]
+"""
+import os
+import subprocess
+import sys
+from concurrent.futures import ThreadPoolExecutor
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, "csrc")
+OUT = os.path.join(CSRC, "libstorm_hip.so")
+SOURCES = ["abi", "conv_igemm", "norm_resample", "elementwise", "sde", "spectral", "program"]
+HEADERS = [os.path.join(CSRC, "common.h"), os.path.join(CSRC, "conv_index.h"),
+           os.path.join(os.path.dirname(HERE), "include", "storm_hip.h")]
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off"]
+
+
+def hipcc():
+    for c in (os.environ.get("HIPCC"), "/opt/rocm/bin/hipcc", "hipcc"):
+        if c and (os.path.isabs(c) and os.path.exists(c) or not os.path.isabs(c)):
+            return c
+    raise RuntimeError("hipcc not found")
+
+
+def up_to_date():
+    if not os.path.exists(OUT):
+        return False
+    t = os.path.getmtime(OUT)
+    deps = [os.path.join(CSRC, s + ".hip") for s in SOURCES] + HEADERS
+    return all(os.path.getmtime(d) <= t for d in deps)
+
+
+def build(force=False, verbose=False):
+    if not force and up_to_date():
+        return OUT
+    cc = hipcc()
+    bdir = os.path.join(CSRC, "build")
+    os.makedirs(bdir, exist_ok=True)
+
+    def compile_one(s):
+        src, obj = os.path.join(CSRC, s + ".hip"), os.path.join(bdir, s + ".o")
+        cmd = [cc] + FLAGS + ["-c", src, "-o", obj]
+        r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)
+        if r.returncode != 0:
+            raise RuntimeError(f"hipcc failed on {s}.hip:\n{r.stdout.decode()}")
+        if verbose and r.stdout:
+            sys.stderr.write(r.stdout.decode())
+        return obj
+
+    with ThreadPoolExecutor(max_workers=4) as ex:
+        objs = list(ex.map(compile_one, SOURCES))
+    r = subprocess.run([cc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", OUT] + objs,
+                       stdout=subprocess.PIPE, stderr=subprocess.STDOUT)
+    if r.returncode != 0:
+        raise RuntimeError(f"link failed:\n{r.stdout.decode()}")
+    return OUT
+
+
+if __name__ == "__main__":
+    print(build(force="--force" in sys.argv, verbose=True))

@@ -1,0 +1,101 @@
+// Shared device/host helpers for libstorm_hip (gfx950 / CDNA4 only).
+#pragma once
+#ifdef STORM_HOST_SIM
+#include "hip_host_shim.h"   // tests/sim: lane-accurate CPU simulation (test infrastructure)
+#else
+#include <hip/hip_runtime.h>
+#endif
+#include <stdint.h>
+#include "../../include/storm_hip.h"
+
+namespace storm {
+
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+
+struct bf16_t { uint16_t v; };   // storage type for bf16 activations / weights
+
+// ---- error reporting (storm_last_error) ----
+void set_error(const char* fmt, ...);
+#define STORM_CHECK(cond, ...) do { if (!(cond)) { storm::set_error(__VA_ARGS__); return STORM_ERR_INVALID; } } while (0)
+#define STORM_HIP(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) { \
+    storm::set_error("%s failed: %s", #expr, hipGetErrorString(e_)); return STORM_ERR_HIP; } } while (0)
+#define STORM_LAUNCH_CHECK() STORM_HIP(hipGetLastError())
+
+// ---- bf16 <-> f32 (round-to-nearest-even, NaN quieted) ----
+__host__ __device__ inline uint16_t f32_to_bf16_bits(float f) {
+    union { float f; uint32_t u; } c; c.f = f;
+    uint32_t u = c.u;
+    if ((u & 0x7fffffffu) > 0x7f800000u) return (uint16_t)((u >> 16) | 0x0040u);
+    u += 0x7fffu + ((u >> 16) & 1u);
+    return (uint16_t)(u >> 16);
+}
+__host__ __device__ inline float bf16_bits_to_f32(uint16_t h) {
+    union { float f; uint32_t u; } c; c.u = ((uint32_t)h) << 16;
+    return c.f;
+}
+
+template <typename T> struct Elem;
+template <> struct Elem<float> {
+    static constexpr int PER16 = 4;                 // elements per 16-byte slot
+    static constexpr int DT = STORM_F32;
+};
+template <> struct Elem<bf16_t> {
+    static constexpr int PER16 = 8;
+    static constexpr int DT = STORM_BF16;
+};
+
+// Load / store 8 consecutive elements as fp32 (addresses 16-B aligned for bf16, 32-B for f32).
+__device__ inline void load8(const float* p, float (&v)[8]) {
+    const float4 a = *reinterpret_cast<const float4*>(p);
+    const float4 b = *reinterpret_cast<const float4*>(p + 4);
+    v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w;
+}
+__device__ inline void load8(const bf16_t* p, float (&v)[8]) {
+    const uint4 r = *reinterpret_cast<const uint4*>(p);
+    const uint32_t w[4] = {r.x, r.y, r.z, r.w};
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        v[2 * i] = __uint_as_float(w[i] << 16);
+        v[2 * i + 1] = __uint_as_float(w[i] & 0xffff0000u);
+    }
+}
+__device__ inline void store8(float* p, const float (&v)[8]) {
+    *reinterpret_cast<float4*>(p) = make_float4(v[0], v[1], v[2], v[3]);
+    *reinterpret_cast<float4*>(p + 4) = make_float4(v[4], v[5], v[6], v[7]);
+}
+__device__ inline void store8(bf16_t* p, const float (&v)[8]) {
+    uint32_t w[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+        w[i] = (uint32_t)f32_to_bf16_bits(v[2 * i]) | ((uint32_t)f32_to_bf16_bits(v[2 * i + 1]) << 16);
+    *reinterpret_cast<uint4*>(p) = make_uint4(w[0], w[1], w[2], w[3]);
+}
+__device__ inline float to_f32(float x) { return x; }
+__device__ inline float to_f32(bf16_t x) { return bf16_bits_to_f32(x.v); }
+__device__ inline void from_f32(float& d, float x) { d = x; }
+__device__ inline void from_f32(bf16_t& d, float x) { d.v = f32_to_bf16_bits(x); }
+
+__device__ inline float silu_f(float x) { return x / (1.0f + expf(-x)); }
+
+// wave64 all-reduce (sum / max) through DPP-lowered shuffles
+__device__ inline float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+__device__ inline float wave_max(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+    return v;
+}
+__device__ inline double wave_sum_d(double v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+
+inline int cdiv(long long a, long long b) { return (int)((a + b - 1) / b); }
+
+}  // namespace storm

@@ -1,0 +1,274 @@
+// GroupNorm (+SiLU) and FIR x2 resampling on NHWC activations — the HBM-bound family.
+//
+// Replaces nn.GroupNorm(eps=1e-6)+nn.SiLU and upsample_2d/downsample_2d (upfirdn2d CUDA
+// kernel modes 3/5) of the reference; see include/storm_hip.h for the file:line map.
+// Design: every thread owns a fixed octet of channels (16 B bf16 / 32 B fp32 per access,
+// a pixel's channels are contiguous so a wave reads whole 128-B lines), statistics are
+// reduced per thread in fp32 over <=256 pixels, then in fp64 across threads / workgroups
+// (one fp64 atomicAdd per (batch, group) per workgroup).  The resampling variants fuse
+// GN-apply + SiLU + FIR of BOTH the activated and the raw tensor (BigGAN block) in one pass.
+#include "common.h"
+
+namespace storm {
+
+constexpr int GN_MAX_C = 1024;
+
+struct GnGeom { int C8, PL, NT; };
+static inline GnGeom gn_geom(int C) {
+    GnGeom g; g.C8 = C / 8; g.PL = 256 / g.C8; if (g.PL < 1) g.PL = 1; g.NT = g.C8 * g.PL; return g;
+}
+
+template <typename T>
+__device__ __forceinline__ void load_cat8(const T* xa, int Ca, const T* xb, int Cb, long long pix, int c,
+                                          float (&v)[8]) {
+    if (c < Ca) load8(xa + pix * Ca + c, v);
+    else load8(xb + pix * Cb + (c - Ca), v);
+}
+
+template <typename T>
+__global__ void gn_stats_kernel(const T* __restrict__ xa, int Ca, const T* __restrict__ xb, int Cb,
+                                int HW, int G, double* __restrict__ stats, int ppb, int C8, int PL) {
+    __shared__ float red[256 * 16];
+    __shared__ double chs[GN_MAX_C * 2];
+    const int C = Ca + Cb, b = blockIdx.y, tid = threadIdx.x;
+    const int oct = tid % C8, pl = tid / C8, c = oct * 8;
+    const long long base = (long long)b * HW;
+    const int p0 = blockIdx.x * ppb, p1 = min(HW, p0 + ppb);
+    float s[8], ss[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { s[e] = 0.f; ss[e] = 0.f; }
+    for (int p = p0 + pl; p < p1; p += PL) {
+        float v[8];
+        load_cat8(xa, Ca, xb, Cb, base + p, c, v);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { s[e] += v[e]; ss[e] = fmaf(v[e], v[e], ss[e]); }
+    }
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { red[tid * 16 + e] = s[e]; red[tid * 16 + 8 + e] = ss[e]; }
+    __syncthreads();
+    if (tid < C8) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            double a = 0.0, q = 0.0;
+            for (int k = 0; k < PL; ++k) { a += (double)red[(k * C8 + tid) * 16 + e]; q += (double)red[(k * C8 + tid) * 16 + 8 + e]; }
+            chs[(tid * 8 + e) * 2] = a; chs[(tid * 8 + e) * 2 + 1] = q;
+        }
+    }
+    __syncthreads();
+    const int gs = C / G;
+    for (int g = tid; g < G; g += blockDim.x) {
+        double a = 0.0, q = 0.0;
+        for (int k = 0; k < gs; ++k) { a += chs[(g * gs + k) * 2]; q += chs[(g * gs + k) * 2 + 1]; }
+        atomicAdd(&stats[((long long)b * G + g) * 2], a);
+        atomicAdd(&stats[((long long)b * G + g) * 2 + 1], q);
+    }
+}
+
+// FIR taps: down: k = [1,3,3,1]/8 per axis over input 2o-1..2o+2; up: out[2i+a] = 3/4 x[i] + 1/4 x[i -/+ 1].
+struct GnParams { float mean[8], a[8], beta[8]; };
+
+template <typename T, bool ACT_PATH>
+__device__ __forceinline__ void fetch8(const T* xa, int Ca, const T* xb, int Cb, long long base, int H, int W,
+                                       int iy, int ix, int c, const GnParams& gp, int silu, float w, float (&acc)[8]) {
+    if (iy < 0 || iy >= H || ix < 0 || ix >= W) return;       // zero boundary
+    float v[8];
+    load_cat8(xa, Ca, xb, Cb, base + (long long)iy * W + ix, c, v);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        float y = v[e];
+        if (ACT_PATH) {
+            y = (y - gp.mean[e]) * gp.a[e] + gp.beta[e];
+            if (silu) y = silu_f(y);
+        }
+        acc[e] = fmaf(w, y, acc[e]);
+    }
+}
+
+// Returns the (optionally GN+SiLU transformed) FIR-resampled octet at output pixel (oy, ox).
+template <typename T, int RESAMPLE, bool ACT_PATH>
+__device__ __forceinline__ void gather8(const T* xa, int Ca, const T* xb, int Cb, long long base, int H, int W,
+                                        int oy, int ox, int c, const GnParams& gp, int silu, float (&out)[8]) {
+#pragma unroll
+    for (int e = 0; e < 8; ++e) out[e] = 0.f;
+    if (RESAMPLE == 0) {
+        fetch8<T, ACT_PATH>(xa, Ca, xb, Cb, base, H, W, oy, ox, c, gp, silu, 1.0f, out);
+    } else if (RESAMPLE == 1) {          // up x2
+        const int iy = oy >> 1, ix = ox >> 1;
+        const int ny = (oy & 1) ? iy + 1 : iy - 1, nx = (ox & 1) ? ix + 1 : ix - 1;
+        fetch8<T, ACT_PATH>(xa, Ca, xb, Cb, base, H, W, iy, ix, c, gp, silu, 0.5625f, out);
+        fetch8<T, ACT_PATH>(xa, Ca, xb, Cb, base, H, W, iy, nx, c, gp, silu, 0.1875f, out);
+        fetch8<T, ACT_PATH>(xa, Ca, xb, Cb, base, H, W, ny, ix, c, gp, silu, 0.1875f, out);
+        fetch8<T, ACT_PATH>(xa, Ca, xb, Cb, base, H, W, ny, nx, c, gp, silu, 0.0625f, out);
+    } else {                              // down x2
+        const float k[4] = {0.125f, 0.375f, 0.375f, 0.125f};
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                fetch8<T, ACT_PATH>(xa, Ca, xb, Cb, base, H, W, 2 * oy - 1 + i, 2 * ox - 1 + j, c, gp, silu, k[i] * k[j], out);
+    }
+}
+
+template <typename T, int RESAMPLE>
+__global__ void gn_apply_kernel(const T* __restrict__ xa, int Ca, const T* __restrict__ xb, int Cb,
+                                int H, int W, int G, const double* __restrict__ stats,
+                                const float* __restrict__ gamma, const float* __restrict__ beta, float eps,
+                                int silu, T* __restrict__ out_act, T* __restrict__ out_raw,
+                                int ppb, int C8, int PL) {
+    const int C = Ca + Cb, b = blockIdx.y, tid = threadIdx.x;
+    const int oct = tid % C8, pl = tid / C8, c = oct * 8;
+    const int OH = RESAMPLE == 1 ? 2 * H : (RESAMPLE == 2 ? H / 2 : H);
+    const int OW = RESAMPLE == 1 ? 2 * W : (RESAMPLE == 2 ? W / 2 : W);
+    const int gs = C / G;
+    const double n = (double)gs * H * W;
+    GnParams gp;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        const int g = (c + e) / gs;
+        const double m = stats[((long long)b * G + g) * 2] / n;
+        double var = stats[((long long)b * G + g) * 2 + 1] / n - m * m;
+        if (var < 0.0) var = 0.0;
+        const float rstd = (float)(1.0 / sqrt(var + (double)eps));
+        gp.mean[e] = (float)m;
+        gp.a[e] = rstd * gamma[c + e];
+        gp.beta[e] = beta[c + e];
+    }
+    const long long ibase = (long long)b * H * W, obase = (long long)b * OH * OW;
+    const int OHW = OH * OW;
+    const int p0 = blockIdx.x * ppb, p1 = min(OHW, p0 + ppb);
+    for (int p = p0 + pl; p < p1; p += PL) {
+        const int oy = p / OW, ox = p - oy * OW;
+        float v[8];
+        gather8<T, RESAMPLE, true>(xa, Ca, xb, Cb, ibase, H, W, oy, ox, c, gp, silu, v);
+        store8(out_act + (obase + p) * C + c, v);
+        if (RESAMPLE != 0 && out_raw != nullptr) {
+            gather8<T, RESAMPLE, false>(xa, Ca, xb, Cb, ibase, H, W, oy, ox, c, gp, 0, v);
+            store8(out_raw + (obase + p) * C + c, v);
+        }
+    }
+}
+
+template <typename T, int RESAMPLE>
+__global__ void fir_kernel(const T* __restrict__ x, const T* __restrict__ add, T* __restrict__ out,
+                           int H, int W, int C, int ppb, int C8, int PL) {
+    const int b = blockIdx.y, tid = threadIdx.x;
+    const int oct = tid % C8, pl = tid / C8, c = oct * 8;
+    const int OH = RESAMPLE == 1 ? 2 * H : H / 2, OW = RESAMPLE == 1 ? 2 * W : W / 2;
+    const long long ibase = (long long)b * H * W, obase = (long long)b * OH * OW;
+    const int OHW = OH * OW;
+    const int p0 = blockIdx.x * ppb, p1 = min(OHW, p0 + ppb);
+    GnParams gp;   // unused (raw path)
+    for (int p = p0 + pl; p < p1; p += PL) {
+        const int oy = p / OW, ox = p - oy * OW;
+        float v[8];
+        gather8<T, RESAMPLE, false>(x, C, (const T*)nullptr, 0, ibase, H, W, oy, ox, c, gp, 0, v);
+        if (add != nullptr) {
+            float a[8];
+            load8(add + (obase + p) * C + c, a);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] += a[e];
+        }
+        store8(out + (obase + p) * C + c, v);
+    }
+}
+
+template <typename T>
+static int gn_stats_t(const void* xa, int Ca, const void* xb, int Cb, int B, int HW, int G, double* stats,
+                      hipStream_t st) {
+    const GnGeom g = gn_geom(Ca + Cb);
+    const int per_thread = 256;
+    int ppb = g.PL * per_thread;
+    const int nblk = cdiv(HW, ppb);
+    hipLaunchKernelGGL((gn_stats_kernel<T>), dim3(nblk, B), dim3(g.NT), 0, st, (const T*)xa, Ca, (const T*)xb, Cb,
+                       HW, G, stats, ppb, g.C8, g.PL);
+    STORM_LAUNCH_CHECK();
+    return STORM_OK;
+}
+
+template <typename T, int R>
+static int gn_apply_t(const void* xa, int Ca, const void* xb, int Cb, int B, int H, int W, int G,
+                      const double* stats, const float* gamma, const float* beta, float eps, int silu,
+                      void* out_act, void* out_raw, hipStream_t st) {
+    const GnGeom g = gn_geom(Ca + Cb);
+    const int OHW = (R == 1 ? 4 : 1) * H * W / (R == 2 ? 4 : 1);
+    int ppb = g.PL * 64;
+    const int nblk = cdiv(OHW, ppb);
+    hipLaunchKernelGGL((gn_apply_kernel<T, R>), dim3(nblk, B), dim3(g.NT), 0, st, (const T*)xa, Ca, (const T*)xb,
+                       Cb, H, W, G, stats, gamma, beta, eps, silu, (T*)out_act, (T*)out_raw, ppb, g.C8, g.PL);
+    STORM_LAUNCH_CHECK();
+    return STORM_OK;
+}
+
+template <typename T, int R>
+static int fir_t(const void* x, const void* add, void* out, int B, int H, int W, int C, hipStream_t st) {
+    const GnGeom g = gn_geom(C);
+    const int OHW = R == 1 ? 4 * H * W : H * W / 4;
+    int ppb = g.PL * 64;
+    const int nblk = cdiv(OHW, ppb);
+    hipLaunchKernelGGL((fir_kernel<T, R>), dim3(nblk, B), dim3(g.NT), 0, st, (const T*)x, (const T*)add, (T*)out,
+                       H, W, C, ppb, g.C8, g.PL);
+    STORM_LAUNCH_CHECK();
+    return STORM_OK;
+}
+
+}  // namespace storm
+
+using namespace storm;
+
+static int check_c(const char* who, int Ca, int Cb, int groups) {
+    const int C = Ca + Cb;
+    STORM_CHECK(Ca > 0 && Ca % 8 == 0 && Cb >= 0 && Cb % 8 == 0, "%s: channels must be multiples of 8 (Ca=%d Cb=%d)", who, Ca, Cb);
+    STORM_CHECK(C <= GN_MAX_C, "%s: C=%d > %d unsupported", who, C, GN_MAX_C);
+    STORM_CHECK(groups > 0 && C % groups == 0, "%s: C=%d not divisible by groups=%d", who, C, groups);
+    return STORM_OK;
+}
+
+extern "C" int storm_gn_stats(const void* xa, int Ca, const void* xb, int Cb, int B, int HW, int groups,
+                              double* stats, int dtype, storm_stream_t s) {
+    if (int e = check_c("storm_gn_stats", Ca, Cb, groups)) return e;
+    STORM_CHECK(xa && stats && B > 0 && HW > 0, "storm_gn_stats: bad arguments");
+    STORM_CHECK((Cb == 0) == (xb == nullptr), "storm_gn_stats: xb / Cb mismatch");
+    hipStream_t st = (hipStream_t)s;
+    if (dtype == STORM_BF16) return gn_stats_t<bf16_t>(xa, Ca, xb, Cb, B, HW, groups, stats, st);
+    if (dtype == STORM_F32) return gn_stats_t<float>(xa, Ca, xb, Cb, B, HW, groups, stats, st);
+    STORM_CHECK(false, "storm_gn_stats: dtype %d", dtype);
+}
+
+extern "C" int storm_gn_apply(const void* xa, int Ca, const void* xb, int Cb, int B, int H, int W, int groups,
+                              const double* stats, const float* gamma, const float* beta, float eps, int silu,
+                              int resample, void* out_act, void* out_raw, int dtype, storm_stream_t s) {
+    if (int e = check_c("storm_gn_apply", Ca, Cb, groups)) return e;
+    STORM_CHECK(xa && stats && gamma && beta && out_act, "storm_gn_apply: null pointer");
+    STORM_CHECK((Cb == 0) == (xb == nullptr), "storm_gn_apply: xb / Cb mismatch");
+    STORM_CHECK(resample >= 0 && resample <= 2, "storm_gn_apply: resample=%d", resample);
+    STORM_CHECK(resample != 2 || (H % 2 == 0 && W % 2 == 0), "storm_gn_apply: FIR down needs even H, W");
+    hipStream_t st = (hipStream_t)s;
+#define STORM_GN_DISPATCH(T)                                                                                   \
+    switch (resample) {                                                                                        \
+        case 0: return gn_apply_t<T, 0>(xa, Ca, xb, Cb, B, H, W, groups, stats, gamma, beta, eps, silu, out_act, out_raw, st); \
+        case 1: return gn_apply_t<T, 1>(xa, Ca, xb, Cb, B, H, W, groups, stats, gamma, beta, eps, silu, out_act, out_raw, st); \
+        default: return gn_apply_t<T, 2>(xa, Ca, xb, Cb, B, H, W, groups, stats, gamma, beta, eps, silu, out_act, out_raw, st); \
+    }
+    if (dtype == STORM_BF16) { STORM_GN_DISPATCH(bf16_t) }
+    if (dtype == STORM_F32) { STORM_GN_DISPATCH(float) }
+#undef STORM_GN_DISPATCH
+    STORM_CHECK(false, "storm_gn_apply: dtype %d", dtype);
+}
+
+extern "C" int storm_fir_up2(const void* x, const void* add, void* out, int B, int H, int W, int C, int dtype,
+                             storm_stream_t s) {
+    STORM_CHECK(x && out && C > 0 && C % 8 == 0 && C <= GN_MAX_C, "storm_fir_up2: bad arguments (C=%d)", C);
+    hipStream_t st = (hipStream_t)s;
+    if (dtype == STORM_BF16) return fir_t<bf16_t, 1>(x, add, out, B, H, W, C, st);
+    if (dtype == STORM_F32) return fir_t<float, 1>(x, add, out, B, H, W, C, st);
+    STORM_CHECK(false, "storm_fir_up2: dtype %d", dtype);
+}
+
+extern "C" int storm_fir_down2(const void* x, void* out, int B, int H, int W, int C, int dtype, storm_stream_t s) {
+    STORM_CHECK(x && out && C > 0 && C % 8 == 0 && C <= GN_MAX_C, "storm_fir_down2: bad arguments (C=%d)", C);
+    STORM_CHECK(H % 2 == 0 && W % 2 == 0, "storm_fir_down2: needs even H, W");
+    hipStream_t st = (hipStream_t)s;
+    if (dtype == STORM_BF16) return fir_t<bf16_t, 2>(x, nullptr, out, B, H, W, C, st);
+    if (dtype == STORM_F32) return fir_t<float, 2>(x, nullptr, out, B, H, W, C, st);
+    STORM_CHECK(false, "storm_fir_down2: dtype %d", dtype);
+}

@@ -1,0 +1,94 @@
+// Program interpreter: executes a host-planned op list (one NCSN++ forward) with a single
+// C-ABI call, so the ~300 kernel launches of a score evaluation cost no Python dispatch.
+// Field conventions are mirrored by storm_amd/backbones/plan.py (class Op).
+#include <cstring>
+#include "common.h"
+
+using namespace storm;
+
+static inline void* resolve(const storm_ref& r, void* const* bufs, int n_bufs, bool& ok) {
+    if (r.buf < 0) return nullptr;
+    if (r.buf >= n_bufs || bufs[r.buf] == nullptr) { ok = false; return nullptr; }
+    return static_cast<char*>(bufs[r.buf]) + r.off;
+}
+
+extern "C" int storm_program_run(const storm_op* ops, int n_ops, void* const* bufs, int n_bufs, int dtype,
+                                 storm_stream_t s) {
+    STORM_CHECK(ops && bufs && n_ops >= 0, "storm_program_run: bad arguments");
+    hipStream_t st = (hipStream_t)s;
+    for (int k = 0; k < n_ops; ++k) {
+        const storm_op& op = ops[k];
+        bool ok = true;
+        void* p[STORM_OP_NPTR];
+        for (int j = 0; j < STORM_OP_NPTR; ++j) p[j] = resolve(op.p[j], bufs, n_bufs, ok);
+        STORM_CHECK(ok, "storm_program_run: op %d (code %d) references a missing buffer", k, op.code);
+        const int64_t* i = op.i;
+        int rc = STORM_OK;
+        switch (op.code) {
+            case STORM_OP_MEMSET:
+                STORM_HIP(hipMemsetAsync(p[0], 0, (size_t)i[0], st));
+                break;
+            case STORM_OP_PACK_INPUT: {
+                const float* in[3] = {(const float*)p[0], (const float*)p[1], (const float*)p[2]};
+                rc = storm_pack_input(in, (int)i[0], p[3], (int)i[1], (int)i[2], (int)i[3], dtype, s);
+                break;
+            }
+            case STORM_OP_TEMB:
+                rc = storm_time_embedding((const float*)p[0], (const float*)p[1], (const float*)p[2], (const float*)p[3],
+                                          (const float*)p[4], (const float*)p[5], (float*)p[6], (int)i[0], (int)i[1], s);
+                break;
+            case STORM_OP_DENSE:
+                rc = storm_dense((const float*)p[0], (const float*)p[1], (const float*)p[2], (float*)p[3], (int)i[0],
+                                 (int)i[1], (int)i[2], s);
+                break;
+            case STORM_OP_CONV: {
+                storm_conv_args a;
+                memset(&a, 0, sizeof(a));
+                a.nseg = (int)i[0]; a.B = (int)i[1]; a.H = (int)i[2]; a.W = (int)i[3];
+                a.outC = (int)i[4]; a.Cout = (int)i[5]; a.tbias_stride = (int)i[6]; a.out_f32 = (int)i[7];
+                const long long hw = (long long)a.H * a.W;
+                for (int g = 0; g < 2; ++g) {
+                    storm_conv_seg& sgm = a.seg[g];
+                    const int64_t* q = i + 8 + 7 * g;
+                    sgm.src_a = p[3 * g]; sgm.src_b = p[3 * g + 1]; sgm.w = p[3 * g + 2];
+                    sgm.Ca = (int)q[0]; sgm.Cb = (int)q[1]; sgm.CinP = (int)q[2]; sgm.w_rows = (int)q[3];
+                    sgm.ntaps = (int)q[4]; sgm.w_bstride = q[5]; sgm.w_tapstride = q[6];
+                    sgm.bstride_a = hw * sgm.Ca; sgm.bstride_b = hw * sgm.Cb;
+                }
+                if (i[22] >= 0) a.seg[0].bstride_a = i[22];
+                a.out = p[6]; a.bias = (const float*)p[7]; a.tbias = (const float*)p[8]; a.skip = p[9];
+                a.out_bstride = i[23] >= 0 ? i[23] : hw * a.outC;
+                a.skip_bstride = hw * a.outC;
+                a.scale = op.f[0];
+                a.dtype = dtype;
+                rc = storm_conv(&a, s);
+                break;
+            }
+            case STORM_OP_GN_STATS:
+                rc = storm_gn_stats(p[0], (int)i[0], p[1], (int)i[1], (int)i[2], (int)i[3], (int)i[4], (double*)p[2], dtype, s);
+                break;
+            case STORM_OP_GN_APPLY:
+                rc = storm_gn_apply(p[0], (int)i[0], p[1], (int)i[1], (int)i[2], (int)i[3], (int)i[4], (int)i[5],
+                                    (const double*)p[2], (const float*)p[3], (const float*)p[4], op.f[0], (int)i[6],
+                                    (int)i[7], p[5], p[6], dtype, s);
+                break;
+            case STORM_OP_FIR_UP:
+                rc = storm_fir_up2(p[0], p[1], p[2], (int)i[0], (int)i[1], (int)i[2], (int)i[3], dtype, s);
+                break;
+            case STORM_OP_FIR_DOWN:
+                rc = storm_fir_down2(p[0], p[1], (int)i[0], (int)i[1], (int)i[2], (int)i[3], dtype, s);
+                break;
+            case STORM_OP_SOFTMAX:
+                rc = storm_softmax_rows((const float*)p[0], p[1], (long long)i[0], (int)i[1], dtype, s);
+                break;
+            case STORM_OP_OUTPUT_HEAD:
+                rc = storm_output_head(p[0], (const float*)p[1], (const float*)p[2], (const float*)p[3], (int)i[0],
+                                       (float*)p[4], (int)i[1], (int)i[2], (int)i[3], (int)i[4], dtype, s);
+                break;
+            default:
+                STORM_CHECK(false, "storm_program_run: op %d has unknown code %d", k, op.code);
+        }
+        if (rc != STORM_OK) return rc;
+    }
+    return STORM_OK;
+}

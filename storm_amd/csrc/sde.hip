@@ -1,0 +1,211 @@
+// OUVE SDE steps of the predictor-corrector sampler on the complex64 state.
+// Reference map in include/storm_hip.h.  One fused elementwise kernel per update rule; the
+// per-batch coefficients (std(t), g(t), step sizes) are computed in-kernel from t[b] in fp64
+// and rounded once, the state update follows the reference's fp32 op order.  Noise is either
+// injected (parity runs) or generated in-kernel with Philox4x32-10 + Box-Muller.
+#include "common.h"
+
+namespace storm {
+
+// ---- Philox4x32-10 --------------------------------------------------------------------------
+__device__ inline void philox_round(uint32_t (&c)[4], uint32_t k0, uint32_t k1) {
+    const uint64_t p0 = (uint64_t)0xD2511F53u * c[0], p1 = (uint64_t)0xCD9E8D57u * c[2];
+    const uint32_t hi0 = (uint32_t)(p0 >> 32), lo0 = (uint32_t)p0, hi1 = (uint32_t)(p1 >> 32), lo1 = (uint32_t)p1;
+    c[0] = hi1 ^ c[1] ^ k0; c[1] = lo1; c[2] = hi0 ^ c[3] ^ k1; c[3] = lo0;
+}
+__device__ inline void philox4x32(uint64_t seed, uint64_t idx, uint64_t offset, uint32_t (&c)[4]) {
+    uint32_t k0 = (uint32_t)seed, k1 = (uint32_t)(seed >> 32);
+    c[0] = (uint32_t)idx; c[1] = (uint32_t)(idx >> 32); c[2] = (uint32_t)offset; c[3] = (uint32_t)(offset >> 32);
+#pragma unroll
+    for (int r = 0; r < 10; ++r) { philox_round(c, k0, k1); k0 += 0x9E3779B9u; k1 += 0xBB67AE85u; }
+}
+// standard complex normal: re, im ~ N(0, 1/2) independent (torch.randn_like on complex64)
+__device__ inline float2 complex_normal(uint64_t seed, uint64_t idx, uint64_t offset) {
+    uint32_t c[4];
+    philox4x32(seed, idx, offset, c);
+    const float u1 = ((float)(c[0] >> 8) + 0.5f) * (1.0f / 16777216.0f);     // (0,1)
+    const float u2 = ((float)(c[1] >> 8) + 0.5f) * (1.0f / 16777216.0f);
+    const float r = sqrtf(-logf(u1));                                         // sqrt(-2 ln u / 2)
+    float sn, cs;
+    sincosf(6.28318530717958647692f * u2, &sn, &cs);
+    return make_float2(r * cs, r * sn);
+}
+__device__ inline float2 get_noise(const float* z, long long i, uint64_t seed, uint64_t offset) {
+    return z ? reinterpret_cast<const float2*>(z)[i] : complex_normal(seed, (uint64_t)i, offset);
+}
+
+// ---- OUVE coefficient helpers (sdes.py:200-231), fp64 then rounded ---------------------------
+struct Ouve { double theta, smin, smax, logsig; int N; };
+__device__ inline Ouve make_ouve(storm_ouve p) {
+    Ouve o; o.theta = p.theta; o.smin = p.sigma_min; o.smax = p.sigma_max; o.logsig = log(o.smax / o.smin); o.N = p.N;
+    return o;
+}
+__device__ inline float ouve_std(const Ouve& o, double t) {
+    const double v = o.smin * o.smin * exp(-2.0 * o.theta * t) * (exp(2.0 * (o.theta + o.logsig) * t) - 1.0) * o.logsig /
+                     (o.theta + o.logsig);
+    return (float)sqrt(v);
+}
+__device__ inline float ouve_g(const Ouve& o, double t) {
+    return (float)(o.smin * pow(o.smax / o.smin, t) * sqrt(2.0 * o.logsig));
+}
+
+__global__ void ouve_prior_kernel(const float* __restrict__ y, const float* __restrict__ z, float* __restrict__ x,
+                                  long long n, storm_ouve p, uint64_t seed, uint64_t offset) {
+    const int b = blockIdx.y;
+    const float std1 = ouve_std(make_ouve(p), 1.0);
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+        const long long k = (long long)b * n + i;
+        const float2 yy = reinterpret_cast<const float2*>(y)[k];
+        const float2 zz = get_noise(z, k, seed, offset);
+        reinterpret_cast<float2*>(x)[k] = make_float2(yy.x + zz.x * std1, yy.y + zz.y * std1);
+    }
+}
+
+__global__ void ouve_ald_kernel(float* __restrict__ x, float* __restrict__ x_mean, const float* __restrict__ score,
+                                const float* __restrict__ z, const float* __restrict__ t, long long n, storm_ouve p,
+                                float snr, uint64_t seed, uint64_t offset) {
+    const int b = blockIdx.y;
+    const float std = ouve_std(make_ouve(p), (double)t[b]);
+    const float sstd = snr * std;
+    const float step = sstd * sstd * 2.0f;                 // correctors.py:87
+    const float nscale = sqrtf(step * 2.0f);               // correctors.py:91
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+        const long long k = (long long)b * n + i;
+        const float2 xx = reinterpret_cast<const float2*>(x)[k];
+        const float2 s = reinterpret_cast<const float2*>(score)[k];
+        const float2 zz = get_noise(z, k, seed, offset);
+        const float2 xm = make_float2(xx.x + step * s.x, xx.y + step * s.y);
+        if (x_mean) reinterpret_cast<float2*>(x_mean)[k] = xm;
+        reinterpret_cast<float2*>(x)[k] = make_float2(xm.x + zz.x * nscale, xm.y + zz.y * nscale);
+    }
+}
+
+__global__ void ouve_predictor_kernel(float* __restrict__ x, float* __restrict__ x_mean, const float* __restrict__ score,
+                                      const float* __restrict__ y, const float* __restrict__ z,
+                                      const float* __restrict__ t, long long n, storm_ouve p, int kind,
+                                      int noise_free, uint64_t seed, uint64_t offset) {
+    const int b = blockIdx.y;
+    const Ouve o = make_ouve(p);
+    const float g = ouve_g(o, (double)t[b]);
+    const float theta = p.theta;
+    const float dt = (float)(1.0 / o.N);
+    const float sqdt = sqrtf(dt);
+    const float G = g * sqdt;                 // sdes.py:89 (also g * sqrt(-dt) for euler_maruyama)
+    const float G2 = kind == 0 ? G * G : g * g;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+        const long long k = (long long)b * n + i;
+        const float2 xx = reinterpret_cast<const float2*>(x)[k];
+        const float2 yy = reinterpret_cast<const float2*>(y)[k];
+        const float2 s = reinterpret_cast<const float2*>(score)[k];
+        float2 xm;
+        if (kind == 0) {
+            // reverse diffusion: f = theta (y - x) dt; rev_f = f - G^2 s; x_mean = x - rev_f   (sdes.py:86-90,147-157)
+            const float fx = (theta * (yy.x - xx.x)) * dt, fy = (theta * (yy.y - xx.y)) * dt;
+            const float rx = fx - G2 * s.x, ry = fy - G2 * s.y;
+            xm = make_float2(xx.x - rx, xx.y - ry);
+        } else {
+            // Euler-Maruyama: x_mean = x + (theta (y - x) - g^2 s) * (-1/N)                    (predictors.py:46-54)
+            const float dx = theta * (yy.x - xx.x) + (-G2) * s.x, dy = theta * (yy.y - xx.y) + (-G2) * s.y;
+            xm = make_float2(xx.x + dx * (-dt), xx.y + dy * (-dt));
+        }
+        if (x_mean) reinterpret_cast<float2*>(x_mean)[k] = xm;
+        if (noise_free) {
+            reinterpret_cast<float2*>(x)[k] = xm;
+        } else {
+            const float2 zz = get_noise(z, k, seed, offset);
+            reinterpret_cast<float2*>(x)[k] = make_float2(xm.x + G * zz.x, xm.y + G * zz.y);
+        }
+    }
+}
+
+__global__ void batch_l2norm_kernel(const float* __restrict__ v, float* __restrict__ out, long long n2) {
+    // one workgroup per batch item; n2 = number of floats per item
+    __shared__ double red[4];
+    const int b = blockIdx.x;
+    const float* p = v + (long long)b * n2;
+    double acc = 0.0;
+    for (long long i = threadIdx.x; i < n2; i += blockDim.x) { const double a = p[i]; acc += a * a; }
+    acc = wave_sum_d(acc);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) out[b] = (float)sqrt(red[0] + red[1] + red[2] + red[3]);
+}
+
+__global__ void langevin_kernel(float* __restrict__ x, float* __restrict__ x_mean, const float* __restrict__ score,
+                                const float* __restrict__ z, const float* __restrict__ snorm,
+                                const float* __restrict__ znorm, int B, long long total, float snr) {
+    float gs = 0.f, gz = 0.f;
+    for (int b = 0; b < B; ++b) { gs += snorm[b]; gz += znorm[b]; }
+    gs /= (float)B; gz /= (float)B;
+    const float r = snr * gz / gs;
+    const float step = r * r * 2.0f;                       // correctors.py:55
+    const float nscale = sqrtf(step * 2.0f);
+    for (long long k = (long long)blockIdx.x * blockDim.x + threadIdx.x; k < total; k += (long long)gridDim.x * blockDim.x) {
+        const float2 xx = reinterpret_cast<const float2*>(x)[k];
+        const float2 s = reinterpret_cast<const float2*>(score)[k];
+        const float2 zz = reinterpret_cast<const float2*>(z)[k];
+        const float2 xm = make_float2(xx.x + step * s.x, xx.y + step * s.y);
+        if (x_mean) reinterpret_cast<float2*>(x_mean)[k] = xm;
+        reinterpret_cast<float2*>(x)[k] = make_float2(xm.x + zz.x * nscale, xm.y + zz.y * nscale);
+    }
+}
+
+__global__ void complex_randn_kernel(float* __restrict__ z, long long n, uint64_t seed, uint64_t offset) {
+    for (long long k = (long long)blockIdx.x * blockDim.x + threadIdx.x; k < n; k += (long long)gridDim.x * blockDim.x)
+        reinterpret_cast<float2*>(z)[k] = complex_normal(seed, (uint64_t)k, offset);
+}
+
+static inline int ew_blocks(long long n) { long long b = (n + 255) / 256; return (int)(b > 2048 ? 2048 : (b < 1 ? 1 : b)); }
+
+}  // namespace storm
+
+using namespace storm;
+
+extern "C" int storm_ouve_prior(const float* y, const float* z, float* x, int B, long long n, storm_ouve p,
+                                uint64_t seed, uint64_t offset, storm_stream_t s) {
+    STORM_CHECK(y && x && B > 0 && n > 0, "storm_ouve_prior: bad arguments");
+    hipLaunchKernelGGL(ouve_prior_kernel, dim3(ew_blocks(n), B), dim3(256), 0, (hipStream_t)s, y, z, x, n, p, seed, offset);
+    STORM_LAUNCH_CHECK();
+    return STORM_OK;
+}
+
+extern "C" int storm_ouve_ald_step(float* x, float* x_mean, const float* score, const float* z, const float* t, int B,
+                                   long long n, storm_ouve p, float snr, uint64_t seed, uint64_t offset,
+                                   storm_stream_t s) {
+    STORM_CHECK(x && score && t && B > 0 && n > 0, "storm_ouve_ald_step: bad arguments");
+    hipLaunchKernelGGL(ouve_ald_kernel, dim3(ew_blocks(n), B), dim3(256), 0, (hipStream_t)s, x, x_mean, score, z, t, n, p, snr, seed, offset);
+    STORM_LAUNCH_CHECK();
+    return STORM_OK;
+}
+
+extern "C" int storm_ouve_predictor_step(float* x, float* x_mean, const float* score, const float* y, const float* z,
+                                         const float* t, int B, long long n, storm_ouve p, int kind, int noise_free,
+                                         uint64_t seed, uint64_t offset, storm_stream_t s) {
+    STORM_CHECK(x && score && y && t && B > 0 && n > 0 && p.N > 0, "storm_ouve_predictor_step: bad arguments");
+    STORM_CHECK(kind == 0 || kind == 1, "storm_ouve_predictor_step: kind=%d", kind);
+    hipLaunchKernelGGL(ouve_predictor_kernel, dim3(ew_blocks(n), B), dim3(256), 0, (hipStream_t)s, x, x_mean, score, y, z, t, n, p, kind, noise_free, seed, offset);
+    STORM_LAUNCH_CHECK();
+    return STORM_OK;
+}
+
+extern "C" int storm_batch_l2norm(const float* v, float* out, int B, long long n, storm_stream_t s) {
+    STORM_CHECK(v && out && B > 0 && n > 0, "storm_batch_l2norm: bad arguments");
+    hipLaunchKernelGGL(batch_l2norm_kernel, dim3(B), dim3(256), 0, (hipStream_t)s, v, out, 2 * n);
+    STORM_LAUNCH_CHECK();
+    return STORM_OK;
+}
+
+extern "C" int storm_langevin_step(float* x, float* x_mean, const float* score, const float* z, const float* score_norms,
+                                   const float* z_norms, int B, long long n, float snr, storm_stream_t s) {
+    STORM_CHECK(x && score && z && score_norms && z_norms && B > 0 && n > 0, "storm_langevin_step: bad arguments");
+    hipLaunchKernelGGL(langevin_kernel, dim3(ew_blocks(n * B)), dim3(256), 0, (hipStream_t)s, x, x_mean, score, z, score_norms, z_norms, B, n * B, snr);
+    STORM_LAUNCH_CHECK();
+    return STORM_OK;
+}
+
+extern "C" int storm_complex_randn(float* z, long long n_complex, uint64_t seed, uint64_t offset, storm_stream_t s) {
+    STORM_CHECK(z && n_complex > 0, "storm_complex_randn: bad arguments");
+    hipLaunchKernelGGL(complex_randn_kernel, dim3(ew_blocks(n_complex)), dim3(256), 0, (hipStream_t)s, z, n_complex, seed, offset);
+    STORM_LAUNCH_CHECK();
+    return STORM_OK;
+}

@@ -1,0 +1,289 @@
+"""Tensor-level wrappers over the C ABI (one function per entry point of include/storm_hip.h).
+
+Activations are NHWC tensors ``[B, H, W, C]`` (C % 8 == 0) in float32 or bfloat16; complex
+spectrograms are complex64 ``[B, F, T]``.  These wrappers only marshal pointers/shapes and
+enqueue on torch's current HIP stream; all compute happens in libstorm_hip.
+"""
+import ctypes as C
+import math
+
+import torch
+
+from . import _lib as L
+
+
+def _alloc(shape, dtype, like):
+    return torch.empty(shape, dtype=dtype, device=like.device)
+
+
+def round_up(x, m):
+    return (x + m - 1) // m * m
+
+
+# ---------------------------------------------------------------- weights -----------------
+def pack_conv_weight(w, dtype, cout_pad=32):
+    """nn.Conv2d weight [Cout, Cin, kh, kw] fp32 -> packed [taps][CoutP][CinP]."""
+    Cout, Cin, kh, kw = w.shape
+    ntaps = kh * kw
+    per16 = 8 if dtype == torch.bfloat16 else 4
+    CoutP, CinP = round_up(Cout, cout_pad), round_up(Cin, per16 * 2)
+    w = w.contiguous().float()
+    out = _alloc((ntaps, CoutP, CinP), dtype, w)
+    L.check(L.lib().storm_pack_conv_weight(L.ptr(w), L.ptr(out), Cout, Cin, ntaps, CoutP, CinP, L.dt(dtype), L.stream()),
+            "storm_pack_conv_weight")
+    return out
+
+
+def pack_matrix(w, dtype, transpose=False, cout_pad=32):
+    """[Cout][Cin] fp32 (or [Cin][Cout] with transpose=True, e.g. NIN.W) -> packed [CoutP][CinP]."""
+    w = w.contiguous().float()
+    Cin, Cout = (w.shape[0], w.shape[1]) if transpose else (w.shape[1], w.shape[0])
+    per16 = 8 if dtype == torch.bfloat16 else 4
+    CoutP, CinP = round_up(Cout, cout_pad), round_up(Cin, per16 * 2)
+    out = _alloc((1, CoutP, CinP), dtype, w)
+    L.check(L.lib().storm_pack_matrix(L.ptr(w), L.ptr(out), Cout, Cin, int(transpose), CoutP, CinP, L.dt(dtype), L.stream()),
+            "storm_pack_matrix")
+    return out
+
+
+# ---------------------------------------------------------------- conv / gemm -------------
+class Seg:
+    """One K-segment of storm_conv: activations (optionally the channel concat of two tensors)
+    and packed weights [ntaps][rows][CinP] (or a per-batch activation used as the weight matrix)."""
+
+    def __init__(self, src_a, w, ntaps, src_b=None, w_batched=False, src_bstride=None):
+        self.src_a, self.src_b, self.w, self.ntaps = src_a, src_b, w, ntaps
+        self.w_batched, self.src_bstride = w_batched, src_bstride
+
+
+def conv(segs, Cout, out=None, outC=None, bias=None, tbias=None, skip=None, scale=1.0, out_f32=False,
+         B=None, H=None, W=None):
+    """out[b,h,w,co] = (sum_seg conv(seg) + bias + tbias[b] + skip) * scale   (storm_conv)."""
+    x = segs[0].src_a
+    if B is None:
+        B, H, W = x.shape[0], x.shape[1], x.shape[2]
+    dtype = x.dtype
+    outC = outC if outC is not None else round_up(Cout, 8)
+    if out is None:
+        out = _alloc((B, H, W, outC), torch.float32 if out_f32 else dtype, x)
+    a = L.ConvArgs()
+    a.nseg = len(segs)
+    for k, s in enumerate(segs):
+        g = a.seg[k]
+        g.src_a, g.Ca = L.ptr(s.src_a), s.src_a.shape[-1]
+        g.bstride_a = s.src_bstride if s.src_bstride is not None else H * W * g.Ca
+        if s.src_b is not None:
+            g.src_b, g.Cb = L.ptr(s.src_b), s.src_b.shape[-1]
+            g.bstride_b = H * W * g.Cb
+        g.w, g.ntaps = L.ptr(s.w), s.ntaps
+        g.CinP, g.w_rows = s.w.shape[-1], s.w.shape[-2]
+        g.w_tapstride = s.w.shape[-1] * s.w.shape[-2]
+        g.w_bstride = s.w.shape[-1] * s.w.shape[-2] if s.w_batched else 0
+    a.B, a.H, a.W = B, H, W
+    a.out, a.outC, a.Cout, a.out_bstride = L.ptr(out), outC, Cout, H * W * outC
+    a.bias = L.ptr(bias)
+    if tbias is not None:
+        a.tbias, a.tbias_stride = L.ptr(tbias), tbias.stride(0)
+    if skip is not None:
+        a.skip, a.skip_bstride = L.ptr(skip), H * W * outC
+    a.scale, a.out_f32, a.dtype = scale, int(out_f32), L.dt(dtype)
+    L.check(L.lib().storm_conv(C.byref(a), L.stream()), "storm_conv")
+    return out
+
+
+# ---------------------------------------------------------------- norm / resample ---------
+def gn_groups(C):
+    return min(C // 4, 32)
+
+
+def gn_stats(xa, xb=None):
+    B, H, W, Ca = xa.shape
+    Cb = xb.shape[-1] if xb is not None else 0
+    G = gn_groups(Ca + Cb)
+    stats = torch.zeros((B, G, 2), dtype=torch.float64, device=xa.device)
+    L.check(L.lib().storm_gn_stats(L.ptr(xa), Ca, L.ptr(xb), Cb, B, H * W, G, L.ptr(stats), L.dt(xa), L.stream()),
+            "storm_gn_stats")
+    return stats
+
+
+def gn_apply(xa, stats, gamma, beta, xb=None, silu=True, resample=0, eps=1e-6, want_raw=True):
+    B, H, W, Ca = xa.shape
+    Cb = xb.shape[-1] if xb is not None else 0
+    Ctot = Ca + Cb
+    OH, OW = (2 * H, 2 * W) if resample == 1 else ((H // 2, W // 2) if resample == 2 else (H, W))
+    out = _alloc((B, OH, OW, Ctot), xa.dtype, xa)
+    raw = _alloc((B, OH, OW, Ctot), xa.dtype, xa) if (resample and want_raw) else None
+    L.check(L.lib().storm_gn_apply(L.ptr(xa), Ca, L.ptr(xb), Cb, B, H, W, stats.shape[1], L.ptr(stats),
+                                   L.ptr(gamma), L.ptr(beta), eps, int(silu), resample, L.ptr(out), L.ptr(raw),
+                                   L.dt(xa), L.stream()), "storm_gn_apply")
+    return (out, raw) if resample else out
+
+
+def fir_up2(x, add=None):
+    B, H, W, Cc = x.shape
+    out = _alloc((B, 2 * H, 2 * W, Cc), x.dtype, x)
+    L.check(L.lib().storm_fir_up2(L.ptr(x), L.ptr(add), L.ptr(out), B, H, W, Cc, L.dt(x), L.stream()), "storm_fir_up2")
+    return out
+
+
+def fir_down2(x):
+    B, H, W, Cc = x.shape
+    out = _alloc((B, H // 2, W // 2, Cc), x.dtype, x)
+    L.check(L.lib().storm_fir_down2(L.ptr(x), L.ptr(out), B, H, W, Cc, L.dt(x), L.stream()), "storm_fir_down2")
+    return out
+
+
+def softmax_rows(scores, dtype):
+    rows, Lr = scores.numel() // scores.shape[-1], scores.shape[-1]
+    out = _alloc(scores.shape, dtype, scores)
+    L.check(L.lib().storm_softmax_rows(L.ptr(scores), L.ptr(out), rows, Lr, L.dt(dtype), L.stream()), "storm_softmax_rows")
+    return out
+
+
+# ---------------------------------------------------------------- network head/tail -------
+def pack_input(cplx, dtype):
+    """list of complex64 [B,F,T] -> NHWC [B,F,T,8] holding 2*(re,im)-1."""
+    B, F, T = cplx[0].shape
+    views = [torch.view_as_real(c.contiguous()) for c in cplx]
+    arr = (C.c_void_p * len(views))(*[L.ptr(v) for v in views])
+    out = _alloc((B, F, T, 8), dtype, views[0])
+    L.check(L.lib().storm_pack_input(arr, len(views), L.ptr(out), B, F, T, L.dt(dtype), L.stream()), "storm_pack_input")
+    return out
+
+
+def time_embedding(t, gfp_W, W1, b1, W2, b2):
+    B, nf = t.shape[0], gfp_W.shape[0]
+    out = _alloc((B, 4 * nf), torch.float32, t)
+    L.check(L.lib().storm_time_embedding(L.ptr(t), L.ptr(gfp_W), L.ptr(W1), L.ptr(b1), L.ptr(W2), L.ptr(b2),
+                                         L.ptr(out), B, nf, L.stream()), "storm_time_embedding")
+    return out
+
+
+def dense(x, W, bias):
+    B, K = x.shape
+    N = W.shape[0]
+    out = _alloc((B, N), torch.float32, x)
+    L.check(L.lib().storm_dense(L.ptr(x), L.ptr(W), L.ptr(bias), L.ptr(out), B, N, K, L.stream()), "storm_dense")
+    return out
+
+
+def output_head(pyr, t, W, bias, negate):
+    B, F, T, _ = pyr.shape
+    cin = W.shape[1]
+    out = torch.empty((B, F, T), dtype=torch.complex64, device=pyr.device)
+    W2 = W.reshape(2, cin).contiguous()
+    L.check(L.lib().storm_output_head(L.ptr(pyr), L.ptr(t), L.ptr(W2), L.ptr(bias), cin,
+                                      L.ptr(torch.view_as_real(out)), B, F, T, int(negate), L.dt(pyr), L.stream()),
+            "storm_output_head")
+    return out
+
+
+# ---------------------------------------------------------------- SDE steps ---------------
+def _ouve(sde):
+    return L.Ouve(float(sde.theta), float(sde.sigma_min), float(sde.sigma_max), int(sde.N))
+
+
+def _r(z):
+    return None if z is None else torch.view_as_real(z)
+
+
+def _n_per_batch(x):
+    return x.numel() // x.shape[0]
+
+
+def ouve_prior(sde, y, z=None, seed=0, offset=0):
+    x = torch.empty_like(y)
+    L.check(L.lib().storm_ouve_prior(L.ptr(_r(y)), L.ptr(_r(z)), L.ptr(_r(x)), y.shape[0], _n_per_batch(y), _ouve(sde),
+                                     seed, offset, L.stream()), "storm_ouve_prior")
+    return x
+
+
+def ouve_ald_step(sde, x, score, t, snr, z=None, seed=0, offset=0):
+    """In place on x; returns (x, x_mean)."""
+    xm = torch.empty_like(x)
+    L.check(L.lib().storm_ouve_ald_step(L.ptr(_r(x)), L.ptr(_r(xm)), L.ptr(_r(score)), L.ptr(_r(z)), L.ptr(t),
+                                        x.shape[0], _n_per_batch(x), _ouve(sde), float(snr), seed, offset, L.stream()),
+            "storm_ouve_ald_step")
+    return x, xm
+
+
+def ouve_predictor_step(sde, x, score, y, t, kind=0, z=None, noise_free=False, seed=0, offset=0):
+    xm = torch.empty_like(x)
+    L.check(L.lib().storm_ouve_predictor_step(L.ptr(_r(x)), L.ptr(_r(xm)), L.ptr(_r(score)), L.ptr(_r(y)), L.ptr(_r(z)),
+                                              L.ptr(t), x.shape[0], _n_per_batch(x), _ouve(sde), kind, int(noise_free),
+                                              seed, offset, L.stream()), "storm_ouve_predictor_step")
+    return x, xm
+
+
+def batch_l2norm(v):
+    out = _alloc((v.shape[0],), torch.float32, v)
+    L.check(L.lib().storm_batch_l2norm(L.ptr(_r(v)), L.ptr(out), v.shape[0], _n_per_batch(v), L.stream()), "storm_batch_l2norm")
+    return out
+
+
+def langevin_step(x, score, z, snr):
+    xm = torch.empty_like(x)
+    sn, zn = batch_l2norm(score), batch_l2norm(z)
+    L.check(L.lib().storm_langevin_step(L.ptr(_r(x)), L.ptr(_r(xm)), L.ptr(_r(score)), L.ptr(_r(z)), L.ptr(sn), L.ptr(zn),
+                                        x.shape[0], _n_per_batch(x), float(snr), L.stream()), "storm_langevin_step")
+    return x, xm
+
+
+def complex_randn(shape, device, seed, offset):
+    z = torch.empty(shape, dtype=torch.complex64, device=device)
+    L.check(L.lib().storm_complex_randn(L.ptr(_r(z)), z.numel(), seed, offset, L.stream()), "storm_complex_randn")
+    return z
+
+
+# ---------------------------------------------------------------- spectral ----------------
+_tables = {}
+
+
+def dft_tables(n_fft, device, window="hann"):
+    """(window [n_fft], twiddle [n_fft,2] = (cos, sin)(2 pi k / n_fft)) on `device`, cached."""
+    key = (n_fft, str(device), window)
+    if key not in _tables:
+        if window == "hann":
+            w = torch.hann_window(n_fft, periodic=True)
+        elif window == "sqrthann":
+            w = torch.sqrt(torch.hann_window(n_fft, periodic=True))
+        else:
+            raise NotImplementedError(f"Window type {window} not implemented!")
+        k = torch.arange(n_fft, dtype=torch.float64) * (2.0 * math.pi / n_fft)
+        tw = torch.stack([torch.cos(k), torch.sin(k)], dim=1).float().contiguous()
+        _tables[key] = (w.to(device).contiguous(), tw.to(device))
+    return _tables[key]
+
+
+def peak_abs(wav):
+    B, Lw = wav.shape
+    out = _alloc((B,), torch.float32, wav)
+    L.check(L.lib().storm_peak_abs(L.ptr(wav), L.ptr(out), B, Lw, wav.stride(0), L.stream()), "storm_peak_abs")
+    return out
+
+
+def stft(wav, peak=None, n_fft=510, hop=128, spec_factor=1.0, spec_abs_exponent=1.0, pad_to=1, window="hann"):
+    """wav [B, L] fp32 -> complex64 [B, n_fft/2+1, Tpad] = spec_fwd(stft(wav / peak)), zero padded
+    in T to a multiple of `pad_to`."""
+    B, Lw = wav.shape
+    n_frames = 1 + Lw // hop
+    Tpad = round_up(n_frames, pad_to)
+    win, tw = dft_tables(n_fft, wav.device, window)
+    spec = torch.empty((B, n_fft // 2 + 1, Tpad), dtype=torch.complex64, device=wav.device)
+    L.check(L.lib().storm_stft(L.ptr(wav), L.ptr(peak), L.ptr(_r(spec)), L.ptr(win), L.ptr(tw), B, Lw, wav.stride(0),
+                               n_fft, hop, n_frames, Tpad, float(spec_factor), float(spec_abs_exponent), L.stream()),
+            "storm_stft")
+    return spec
+
+
+def istft(spec, length, peak=None, n_fft=510, hop=128, spec_factor=1.0, spec_abs_exponent=1.0, window="hann"):
+    """complex64 [B, F, T] -> wav [B, length] = istft(spec_back(spec)) * peak."""
+    B, F, T = spec.shape
+    spec = spec.contiguous()
+    win, tw = dft_tables(n_fft, spec.device, window)
+    wav = torch.empty((B, length), dtype=torch.float32, device=spec.device)
+    frames = torch.empty((B, T, n_fft), dtype=torch.float32, device=spec.device)
+    L.check(L.lib().storm_istft(L.ptr(_r(spec)), L.ptr(peak), L.ptr(wav), L.ptr(frames), L.ptr(win), L.ptr(tw), B, T,
+                                length, wav.stride(0), n_fft, hop, float(spec_factor), float(spec_abs_exponent),
+                                L.stream()), "storm_istft")
+    return wav

@@ -1,0 +1,43 @@
+"""TEST INFRASTRUCTURE: build tests/sim/libstorm_sim.so — the kernel sources of storm_amd/csrc
+compiled for the HOST with the fiber shim (hip_host_shim.h), exporting the same C ABI as
+libstorm_hip.so but operating on host memory.  Used only by CPU tests to exercise kernel index
+math / launch code without a GPU."""
+import os
+import subprocess
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+CSRC = os.path.join(ROOT, "storm_amd", "csrc")
+OUT = os.path.join(HERE, "libstorm_sim.so")
+CXX = os.environ.get("STORM_SIM_CXX", "/opt/rocm/lib/llvm/bin/clang++")
+SOURCES = ["abi", "conv_igemm", "norm_resample", "elementwise", "sde", "spectral", "program"]
+
+
+def build(force=False):
+    srcs = [os.path.join(CSRC, s + ".hip") for s in SOURCES] + [os.path.join(HERE, "simrt.cpp")]
+    deps = srcs + [os.path.join(CSRC, "common.h"), os.path.join(CSRC, "conv_index.h"),
+                   os.path.join(HERE, "hip_host_shim.h"), os.path.join(ROOT, "include", "storm_hip.h")]
+    if not force and os.path.exists(OUT) and all(os.path.getmtime(OUT) >= os.path.getmtime(d) for d in deps):
+        return OUT
+    objs = []
+    bdir = os.path.join(HERE, "build")
+    os.makedirs(bdir, exist_ok=True)
+    procs = []
+    for s in srcs:
+        o = os.path.join(bdir, os.path.basename(s) + ".o")
+        objs.append(o)
+        cmd = [CXX, "-x", "c++", "-std=c++17", "-O2", "-g", "-fPIC", "-DSTORM_HOST_SIM", "-I", HERE, "-I", CSRC,
+               "-Wno-unknown-attributes", "-Wno-unknown-pragmas", "-Wno-pass-failed", "-c", s, "-o", o]
+        procs.append((s, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)))
+    for s, p in procs:
+        out, _ = p.communicate()
+        if p.returncode != 0:
+            sys.stderr.write(out.decode())
+            raise RuntimeError(f"sim build failed for {s}")
+    subprocess.check_call([CXX, "-shared", "-fPIC", "-o", OUT] + objs + ["-lpthread"])
+    return OUT
+
+
+if __name__ == "__main__":
+    print(build(force="--force" in sys.argv))
