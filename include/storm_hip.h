@@ -190,6 +190,10 @@ int storm_complex_randn(float* z, long long n_complex, uint64_t seed, uint64_t o
  * reflect padding), spec_fwd / spec_back (data_module.py:182-193), pad_spec (util/other.py:
  * 102-109) and the peak normalisation in enhance() (model.py:282-284, 302).
  * ------------------------------------------------------------------------------------------ */
+/* out = spec_fwd(in) (inverse==0) or spec_back(in) (inverse!=0) on n complex64 values
+ * (data_module.py:182-193): |z|^e e^{j angle z} * factor  /  its inverse.                  */
+int storm_spec_transform(const float* in, float* out, long long n_complex, float spec_factor,
+                         float spec_abs_exponent, int inverse, storm_stream_t s);
 /* peak[b] = max |wav[b][:]|  (model.py:283) */
 int storm_peak_abs(const float* wav, float* peak, int B, long long L, long long stride,
                    storm_stream_t s);

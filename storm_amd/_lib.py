@@ -74,6 +74,7 @@ _SIGNATURES = {
     "storm_batch_l2norm": ([_vp, _vp, _i, _ll, _vp], C.c_int),
     "storm_langevin_step": ([_vp, _vp, _vp, _vp, _vp, _vp, _i, _ll, _f, _vp], C.c_int),
     "storm_complex_randn": ([_vp, _ll, _u64, _u64, _vp], C.c_int),
+    "storm_spec_transform": ([_vp, _vp, _ll, _f, _f, _i, _vp], C.c_int),
     "storm_peak_abs": ([_vp, _vp, _i, _ll, _ll, _vp], C.c_int),
     "storm_stft": ([_vp, _vp, _vp, _vp, _vp, _i, _ll, _ll, _i, _i, _i, _i, _f, _f, _vp], C.c_int),
     "storm_istft": ([_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _ll, _ll, _i, _i, _f, _f, _vp], C.c_int),
@@ -145,6 +146,15 @@ def ptr(t, allow_none=True):
         raise StormError("null tensor")
     if not t.is_contiguous():
         raise StormError("tensor must be contiguous")
+    if not _sim and not t.is_cuda:
+        raise StormError("storm_amd ops run on the GPU only: got a CPU tensor (there is no CPU fallback)")
+    return t.data_ptr()
+
+
+def ptr_rows(t):
+    """Pointer of a 2-D tensor whose rows are contiguous (row stride may exceed the row length)."""
+    if t.dim() != 2 or t.stride(1) != 1:
+        raise StormError("expected a row-contiguous 2-D tensor")
     if not _sim and not t.is_cuda:
         raise StormError("storm_amd ops run on the GPU only: got a CPU tensor (there is no CPU fallback)")
     return t.data_ptr()

@@ -120,9 +120,35 @@ __global__ void istft_ola_kernel(const float* __restrict__ frames, const float* 
     wav[(long long)b * stride + n] = v;
 }
 
+// standalone spec_fwd / spec_back on a complex tensor (data_module.py:182-193)
+__global__ void spec_transform_kernel(const float* __restrict__ in, float* __restrict__ out, long long n,
+                                      float factor, float expo, int inverse) {
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+        float2 z = reinterpret_cast<const float2*>(in)[i];
+        if (inverse) { z.x /= factor; z.y /= factor; }
+        if (expo != 1.0f) {
+            const float mag = sqrtf(z.x * z.x + z.y * z.y);
+            const float sc = mag > 0.f ? powf(mag, (inverse ? 1.0f / expo : expo) - 1.0f) : 0.f;
+            z.x *= sc; z.y *= sc;
+        }
+        if (!inverse) { z.x *= factor; z.y *= factor; }
+        reinterpret_cast<float2*>(out)[i] = z;
+    }
+}
+
 }  // namespace storm
 
 using namespace storm;
+
+extern "C" int storm_spec_transform(const float* in, float* out, long long n_complex, float spec_factor,
+                                    float spec_abs_exponent, int inverse, storm_stream_t s) {
+    STORM_CHECK(in && out && n_complex > 0 && spec_factor != 0.f && spec_abs_exponent != 0.f, "storm_spec_transform: bad arguments");
+    long long nb = (n_complex + 255) / 256; if (nb > 4096) nb = 4096;
+    hipLaunchKernelGGL(spec_transform_kernel, dim3((unsigned)nb), dim3(256), 0, (hipStream_t)s, in, out, n_complex,
+                       spec_factor, spec_abs_exponent, inverse);
+    STORM_LAUNCH_CHECK();
+    return STORM_OK;
+}
 
 extern "C" int storm_peak_abs(const float* wav, float* peak, int B, long long L, long long stride, storm_stream_t s) {
     STORM_CHECK(wav && peak && B > 0 && L > 0, "storm_peak_abs: bad arguments");

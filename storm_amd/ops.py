@@ -83,7 +83,7 @@ def conv(segs, Cout, out=None, outC=None, bias=None, tbias=None, skip=None, scal
     a.out, a.outC, a.Cout, a.out_bstride = L.ptr(out), outC, Cout, H * W * outC
     a.bias = L.ptr(bias)
     if tbias is not None:
-        a.tbias, a.tbias_stride = L.ptr(tbias), tbias.stride(0)
+        a.tbias, a.tbias_stride = L.ptr_rows(tbias), tbias.stride(0)
     if skip is not None:
         a.skip, a.skip_bstride = L.ptr(skip), H * W * outC
     a.scale, a.out_f32, a.dtype = scale, int(out_f32), L.dt(dtype)
@@ -253,6 +253,15 @@ def dft_tables(n_fft, device, window="hann"):
         tw = torch.stack([torch.cos(k), torch.sin(k)], dim=1).float().contiguous()
         _tables[key] = (w.to(device).contiguous(), tw.to(device))
     return _tables[key]
+
+
+def spec_transform(spec, spec_factor, spec_abs_exponent, inverse):
+    """spec_fwd (inverse=False) / spec_back (inverse=True) on a complex64 tensor."""
+    spec = spec.contiguous()
+    out = torch.empty_like(spec)
+    L.check(L.lib().storm_spec_transform(L.ptr(_r(spec)), L.ptr(_r(out)), spec.numel(), float(spec_factor),
+                                         float(spec_abs_exponent), int(inverse), L.stream()), "storm_spec_transform")
+    return out
 
 
 def peak_abs(wav):

@@ -1,0 +1,280 @@
+"""Per-op parity: every C-ABI entry point against the oracle / plain torch fp32 on the same
+seeded inputs.  Runs on the host simulation (CPU suite) and on the MI355X (-m gpu)."""
+import math
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from oracle import frontend_ref as FR
+from oracle import ncsnpp_ref as NR
+from oracle import sde_ref as SR
+from tests.backend import dev, nchw, nhwc, tol  # noqa: F401
+from tests.util import rel_l2
+
+DTYPES = [torch.float32, torch.bfloat16]
+
+
+def q(x, dtype):
+    """quantise a reference input the way the engine sees it"""
+    return x.to(dtype).float()
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("shape", [(2, 16, 24, 10, 40, 3), (1, 72, 136, 9, 33, 3), (2, 8, 4, 8, 32, 3),
+                                   (1, 40, 40, 5, 7, 1), (1, 128, 128, 16, 64, 3)])
+def test_conv(dev, dtype, shape):
+    from storm_amd import ops
+    B, Cin, Cout, H, W, k = shape
+    if dev.type == "cpu" and Cin * Cout > 72 * 136:
+        pytest.skip("large case: GPU only")
+    g = torch.Generator().manual_seed(1)
+    x = torch.randn(B, Cin, H, W, generator=g)
+    w = torch.randn(Cout, Cin, k, k, generator=g) * 0.2
+    b = torch.randn(Cout, generator=g)
+    xq = nhwc(x).to(dtype).to(dev)
+    wp = ops.pack_conv_weight(w.to(dev), dtype)
+    y = ops.conv([ops.Seg(xq, wp, k * k)], Cout, bias=b.to(dev)).float().cpu()
+    ref = F.conv2d(q(x, dtype), q(w, dtype), b, padding=k // 2)
+    assert rel_l2(nchw(y)[:, :Cout], ref) < tol(dtype, 2e-6, 6e-3)
+    if y.shape[-1] > Cout:
+        assert float(y[..., Cout:].abs().max()) == 0.0
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_conv_fused_block_tail(dev, dtype):
+    """Conv_1 3x3 over h + Conv_2 1x1 over cat[xa, xb] + bias + temb bias, rescaled (layerspp.py:266-274)."""
+    from storm_amd import ops
+    g = torch.Generator().manual_seed(2)
+    B, H, W, Ca, Cb, Co = 2, 9, 35, 24, 16, 40
+    h = torch.randn(B, Co, H, W, generator=g)
+    xa, xb = torch.randn(B, Ca, H, W, generator=g), torch.randn(B, Cb, H, W, generator=g)
+    w1 = torch.randn(Co, Co, 3, 3, generator=g) * 0.1
+    w2 = torch.randn(Co, Ca + Cb, 1, 1, generator=g) * 0.2
+    bias, tb = torch.randn(Co, generator=g), torch.randn(B, 64, generator=g)
+    segs = [ops.Seg(nhwc(h).to(dtype).to(dev), ops.pack_conv_weight(w1.to(dev), dtype), 9),
+            ops.Seg(nhwc(xa).to(dtype).to(dev), ops.pack_conv_weight(w2.to(dev), dtype), 1, src_b=nhwc(xb).to(dtype).to(dev))]
+    tbd = tb.to(dev)
+    y = ops.conv(segs, Co, bias=bias.to(dev), tbias=tbd[:, 8:], scale=1 / math.sqrt(2)).float().cpu()
+    ref = (F.conv2d(q(h, dtype), q(w1, dtype), padding=1) + F.conv2d(q(torch.cat([xa, xb], 1), dtype), q(w2, dtype))
+           + bias[None, :, None, None] + tb[:, 8:8 + Co, None, None]) / math.sqrt(2)
+    assert rel_l2(nchw(y), ref) < tol(dtype, 2e-6, 6e-3)
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_conv_skip_and_batched_weights(dev, dtype):
+    """identity skip epilogue, and per-batch 'weights' = an activation (attention q k^T), fp32 scores out."""
+    from storm_amd import ops
+    g = torch.Generator().manual_seed(3)
+    B, Lq, Cc = 2, 40, 24
+    qq, kk = torch.randn(B, Lq, Cc, generator=g), torch.randn(B, Lq, Cc, generator=g)
+    qd, kd = qq.to(dtype).to(dev).view(B, 1, Lq, Cc), kk.to(dtype).to(dev).view(B, 1, Lq, Cc)
+    S = ops.conv([ops.Seg(qd, kd.view(B, Lq, Cc), 1, w_batched=True)], Lq, outC=Lq, scale=0.5, out_f32=True)
+    assert S.dtype == torch.float32
+    ref = torch.einsum("bic,bjc->bij", q(qq, dtype), q(kk, dtype)) * 0.5
+    assert rel_l2(S.cpu().view(B, Lq, Lq), ref) < 2e-6
+    x = torch.randn(B, 16, 6, 9, generator=g)
+    w = torch.randn(16, 16, 3, 3, generator=g) * 0.2
+    xd = nhwc(x).to(dtype).to(dev)
+    y = ops.conv([ops.Seg(xd, ops.pack_conv_weight(w.to(dev), dtype), 9)], 16, skip=xd, scale=2.0).float().cpu()
+    ref = (F.conv2d(q(x, dtype), q(w, dtype), padding=1) + q(x, dtype)) * 2.0
+    assert rel_l2(nchw(y), ref) < tol(dtype, 2e-6, 6e-3)
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("C,Cb", [(8, 0), (128, 0), (256, 128), (24, 16)])
+def test_groupnorm_silu(dev, dtype, C, Cb):
+    from storm_amd import ops
+    g = torch.Generator().manual_seed(4)
+    B, H, W = 2, 8, 16
+    x = torch.randn(B, C + Cb, H, W, generator=g) * 1.5 + 0.3
+    gam, bet = 1 + 0.1 * torch.randn(C + Cb, generator=g), 0.1 * torch.randn(C + Cb, generator=g)
+    xa = nhwc(x[:, :C]).to(dtype).to(dev)
+    xb = nhwc(x[:, C:]).to(dtype).to(dev) if Cb else None
+    st = ops.gn_stats(xa, xb)
+    y = ops.gn_apply(xa, st, gam.to(dev), bet.to(dev), xb=xb, silu=True).float().cpu()
+    ref = NR.silu(NR.group_norm(q(x, dtype), gam, bet))
+    assert rel_l2(nchw(y), ref) < tol(dtype, 2e-6, 5e-3)
+    y2 = ops.gn_apply(xa, st, gam.to(dev), bet.to(dev), xb=xb, silu=False).float().cpu()
+    assert rel_l2(nchw(y2), NR.group_norm(q(x, dtype), gam, bet)) < tol(dtype, 2e-6, 5e-3)
+
+
+def test_groupnorm_golden(dev, golden):
+    """the reference's own GroupNorm+SiLU outputs (tests/golden/f1_ops.npz)"""
+    from storm_amd import ops
+    g = golden["f1_ops"]
+    for C in (8, 128, 384):
+        x = torch.from_numpy(g[f"gn{C}_x"])
+        xa = nhwc(x).to(dev)
+        st = ops.gn_stats(xa)
+        y = ops.gn_apply(xa, st, torch.from_numpy(g[f"gn{C}_w"]).to(dev), torch.from_numpy(g[f"gn{C}_b"]).to(dev))
+        assert rel_l2(nchw(y.cpu()), g[f"gn{C}_y"]) < 2e-6
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("resample", [1, 2])
+def test_groupnorm_fir_fused(dev, dtype, resample):
+    """h = FIR(SiLU(GN(x))) and x = FIR(x) of a BigGAN up/down block in one pass (layerspp.py:243-255)."""
+    from storm_amd import ops
+    g = torch.Generator().manual_seed(5)
+    B, C, H, W = 2, 24, 6, 10
+    x = torch.randn(B, C, H, W, generator=g)
+    gam, bet = 1 + 0.1 * torch.randn(C, generator=g), 0.1 * torch.randn(C, generator=g)
+    xa = nhwc(x).to(dtype).to(dev)
+    st = ops.gn_stats(xa)
+    act, raw = ops.gn_apply(xa, st, gam.to(dev), bet.to(dev), resample=resample)
+    fir = NR.fir_up2 if resample == 1 else NR.fir_down2
+    assert rel_l2(nchw(act.float().cpu()), fir(NR.silu(NR.group_norm(q(x, dtype), gam, bet)))) < tol(dtype, 2e-6, 5e-3)
+    assert rel_l2(nchw(raw.float().cpu()), fir(q(x, dtype))) < tol(dtype, 2e-6, 5e-3)
+
+
+def test_fir_golden(dev, golden):
+    from storm_amd import ops
+    g = golden["f1_ops"]
+    x = torch.from_numpy(g["fir_x"])                       # [2,5,8,12]: pad channels to 8
+    xp = torch.cat([x, torch.zeros(2, 3, 8, 12)], 1)
+    up = ops.fir_up2(nhwc(xp).to(dev)).cpu()
+    dn = ops.fir_down2(nhwc(xp).to(dev)).cpu()
+    assert rel_l2(nchw(up)[:, :5], g["fir_up"]) < 1e-6
+    assert rel_l2(nchw(dn)[:, :5], g["fir_down"]) < 1e-6
+    add = torch.randn(2, 8, 16, 24)
+    up2 = ops.fir_up2(nhwc(xp).to(dev), add=nhwc(add).to(dev)).cpu()
+    assert rel_l2(nchw(up2)[:, :5], torch.from_numpy(g["fir_up"]) + add[:, :5]) < 1e-6
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_softmax_rows(dev, dtype):
+    from storm_amd import ops
+    g = torch.Generator().manual_seed(6)
+    s = torch.randn(3, 5, 200, generator=g) * 4
+    s[0, 0, 7] = 60.0                                         # a spike: stable max subtraction
+    p = ops.softmax_rows(s.to(dev), dtype).float().cpu()
+    assert rel_l2(p, F.softmax(s, -1)) < tol(dtype, 1e-6, 4e-3)
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_pack_input_and_output_head(dev, dtype):
+    from storm_amd import ops
+    g = torch.Generator().manual_seed(7)
+    B, Fq, T = 2, 8, 16
+    zs = [torch.randn(B, Fq, T, dtype=torch.complex64, generator=g) for _ in range(3)]
+    x = ops.pack_input([z.to(dev) for z in zs], dtype).float().cpu()
+    ref = 2 * torch.stack([c for z in zs for c in (z.real, z.imag)], -1) - 1
+    assert rel_l2(x[..., :6], q(ref, dtype)) < 1e-7 and float(x[..., 6:].abs().max()) == 0
+    pyr = torch.randn(B, Fq, T, 8, generator=g)
+    Wt, b, t = torch.randn(2, 6, 1, 1, generator=g), torch.randn(2, generator=g), torch.tensor([0.8, 0.05])
+    out = ops.output_head(pyr.to(dtype).to(dev), t.to(dev), Wt.to(dev), b.to(dev), negate=True).cpu()
+    h = q(pyr, dtype)[..., :6] / t[:, None, None, None]
+    r = -(torch.einsum("bftc,oc->bfto", h, Wt.view(2, 6)) + b)
+    assert rel_l2(torch.view_as_real(out), r) < 2e-6
+    out2 = ops.output_head(pyr.to(dtype).to(dev), None, Wt.to(dev), b.to(dev), negate=False).cpu()
+    r2 = torch.einsum("bftc,oc->bfto", q(pyr, dtype)[..., :6], Wt.view(2, 6)) + b
+    assert rel_l2(torch.view_as_real(out2), r2) < 2e-6
+
+
+def test_time_embedding_and_dense(dev):
+    from storm_amd import ops
+    g = torch.Generator().manual_seed(8)
+    nf = 16
+    sd = {"0.W": torch.randn(nf, generator=g) * 16, "1.weight": torch.randn(4 * nf, 2 * nf, generator=g) * 0.2,
+          "1.bias": torch.randn(4 * nf, generator=g) * 0.1, "2.weight": torch.randn(4 * nf, 4 * nf, generator=g) * 0.2,
+          "2.bias": torch.randn(4 * nf, generator=g) * 0.1}
+    t = torch.tensor([1.0, 0.5, 0.03])
+    d = {k: v.to(dev) for k, v in sd.items()}
+    at = ops.time_embedding(t.to(dev), d["0.W"], d["1.weight"], d["1.bias"], d["2.weight"], d["2.bias"])
+    ref = NR.silu(NR.time_embedding(NR._SD(sd), None, t))
+    assert rel_l2(at.cpu(), ref) < 2e-5
+    Wd, bd = torch.randn(37, 4 * nf, generator=g) * 0.2, torch.randn(37, generator=g)
+    o = ops.dense(at, Wd.to(dev), bd.to(dev)).cpu()
+    assert rel_l2(o, F.linear(at.cpu(), Wd, bd)) < 2e-6
+
+
+# ---------------------------------------------------------------- SDE steps ---------------
+def _sde():
+    return SR.OUVE(1.5, 0.05, 0.5, N=30)
+
+
+def test_sde_steps_vs_oracle(dev):
+    from storm_amd import ops
+    g = torch.Generator().manual_seed(9)
+    sh = (3, 1, 8, 16)
+    x, y, s, z = [torch.randn(sh, dtype=torch.complex64, generator=g) * 0.5 for _ in range(4)]
+    t = torch.tensor([1.0, 0.5, 0.03])
+    sde = _sde()
+    score = lambda *_: s
+    # prior
+    xp = ops.ouve_prior(sde, y.to(dev), z=z.to(dev)).cpu()
+    assert rel_l2(xp, sde.prior(y, z)) < 2e-7
+    # ALD corrector
+    xa, xm = ops.ouve_ald_step(sde, x.clone().to(dev), s.to(dev), t.to(dev), 0.5, z=z.to(dev))
+    r, rm = SR.ald_step(sde, score, x, t, y, z, 0.5)
+    assert rel_l2(xa.cpu(), r) < 3e-7 and rel_l2(xm.cpu(), rm) < 3e-7
+    # reverse diffusion / euler-maruyama predictors
+    for kind, fn in ((0, SR.revdiff_step), (1, SR.euler_maruyama_step)):
+        xa, xm = ops.ouve_predictor_step(sde, x.clone().to(dev), s.to(dev), y.to(dev), t.to(dev), kind=kind, z=z.to(dev))
+        r, rm = fn(sde, score, x, t, y, z)
+        assert rel_l2(xa.cpu(), r) < 3e-7 and rel_l2(xm.cpu(), rm) < 3e-7
+    xa, xm = ops.ouve_predictor_step(sde, x.clone().to(dev), s.to(dev), y.to(dev), t.to(dev), kind=0, noise_free=True)
+    assert torch.equal(xa.cpu(), xm.cpu()) and rel_l2(xm.cpu(), SR.revdiff_step(sde, score, x, t, y, z)[1]) < 3e-7
+    # langevin (batch-mean norms)
+    xa, xm = ops.langevin_step(x.clone().to(dev), s.to(dev), z.to(dev), 0.5)
+    r, rm = SR.langevin_step(sde, score, x, t, y, z, 0.5)
+    assert rel_l2(xa.cpu(), r) < 3e-6 and rel_l2(xm.cpu(), rm) < 3e-6
+
+
+def test_complex_randn_statistics(dev):
+    from storm_amd import ops
+    n = 1 << 16
+    z = ops.complex_randn((n,), dev, seed=1234, offset=0).cpu()
+    z2 = ops.complex_randn((n,), dev, seed=1234, offset=0).cpu()
+    z3 = ops.complex_randn((n,), dev, seed=1234, offset=1).cpu()
+    assert torch.equal(z, z2) and not torch.equal(z, z3)            # counter based: reproducible
+    for comp in (z.real, z.imag):                                    # N(0, 1/2) per component
+        assert abs(float(comp.mean())) < 0.01 and abs(float(comp.var()) - 0.5) < 0.01
+    assert abs(float((z.real * z.imag).mean())) < 0.01
+    kurt = float((z.real ** 4).mean() / (z.real ** 2).mean() ** 2)
+    assert abs(kurt - 3.0) < 0.1
+    # in-kernel noise path of a step == explicit noise with the same (seed, offset)
+    sde = _sde()
+    y = torch.zeros(2, 1, 8, 16, dtype=torch.complex64)
+    zz = ops.complex_randn(y.shape, dev, seed=5, offset=3)
+    a = ops.ouve_prior(sde, y.to(dev), z=None, seed=5, offset=3).cpu()
+    b = ops.ouve_prior(sde, y.to(dev), z=zz).cpu()
+    assert torch.equal(a, b)
+
+
+# ---------------------------------------------------------------- spectral ----------------
+@pytest.mark.parametrize("fac", [0.15, 0.33])
+def test_stft_istft_golden(dev, golden, fac):
+    from storm_amd import ops
+    g = golden["f5_frontend"]
+    key = f"L8000_f{int(fac * 100)}"
+    y = torch.from_numpy(g[f"{key}_y"])                                # [1, 8000]
+    yd = y.to(dev)
+    peak = ops.peak_abs(yd)
+    assert float(peak.cpu()) == float(y.abs().max())
+    Y = ops.stft(yd, peak, spec_factor=fac, spec_abs_exponent=0.5, pad_to=64)
+    assert Y.shape == (1, 256, 64)
+    assert rel_l2(Y.cpu(), torch.from_numpy(g[f"{key}_Y"])[0]) < 5e-6
+    w = ops.istft(torch.from_numpy(g[f"{key}_Y"])[0].to(dev), 8000, None, spec_factor=fac, spec_abs_exponent=0.5)
+    assert rel_l2(w.cpu(), g[f"{key}_wav"]) < 5e-6
+
+
+def test_stft_batched_ragged_vs_oracle(dev):
+    """batched front end == per-utterance reference calls; odd length, exponent 1 path"""
+    from storm_amd import ops
+    g = torch.Generator().manual_seed(11)
+    y = torch.randn(3, 5003, generator=g) * 0.1
+    Y = ops.stft(y.to(dev), None, spec_factor=1.0, spec_abs_exponent=1.0).cpu()
+    ref = FR.stft(y)
+    assert Y.shape == ref.shape and rel_l2(Y, ref) < 5e-6
+    peak = ops.peak_abs(y.to(dev))
+    Y2 = ops.stft(y.to(dev), peak, spec_factor=0.15, spec_abs_exponent=0.5, pad_to=64)
+    for b in range(3):
+        Yb, nf, T0 = FR.wav_to_spec(y[b:b + 1])
+        assert rel_l2(Y2[b].cpu(), Yb[0, 0]) < 5e-6
+    w = ops.istft(Y2, 5003, peak, spec_factor=0.15, spec_abs_exponent=0.5).cpu()
+    for b in range(3):
+        Yb, nf, T0 = FR.wav_to_spec(y[b:b + 1])
+        assert rel_l2(w[b], FR.spec_to_wav(Yb, nf, T0)) < 5e-6
