@@ -124,9 +124,10 @@ int storm_fir_up2(const void* x, const void* add, void* out, int B, int H, int W
 int storm_fir_down2(const void* x, void* out, int B, int H, int W, int C,
                     int dtype, storm_stream_t s);
 
-/* Row softmax of fp32 scores [rows][L] -> probabilities (activation dtype).
+/* Row softmax of fp32 scores [rows][ld] (first L columns valid) -> probabilities (activation
+ * dtype, same row stride, padding columns written as 0).
  * Replaces F.softmax(w, dim=-1) in AttnBlockpp.forward (layerspp.py:84).                 */
-int storm_softmax_rows(const float* scores, void* probs, long long rows, int L,
+int storm_softmax_rows(const float* scores, void* probs, long long rows, int L, int ld,
                        int dtype, storm_stream_t s);
 
 /* ------------------------------------------------------------------------------------------
@@ -238,6 +239,10 @@ typedef struct storm_op {
 /* ops: host array; bufs: host array of n_bufs device base pointers.                       */
 int storm_program_run(const storm_op* ops, int n_ops, void* const* bufs, int n_bufs, int dtype,
                       storm_stream_t s);
+/* Same, but brackets every op with HIP events on stream `s`, synchronises, and writes the
+ * elapsed milliseconds of each op to the HOST array ms[n_ops] (bench.py's roofline leg).    */
+int storm_program_run_timed(const storm_op* ops, int n_ops, void* const* bufs, int n_bufs,
+                            int dtype, storm_stream_t s, float* ms);
 
 #ifdef __cplusplus
 }

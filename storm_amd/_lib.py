@@ -63,7 +63,7 @@ _SIGNATURES = {
     "storm_gn_apply": ([_vp, _i, _vp, _i, _i, _i, _i, _i, _vp, _vp, _vp, _f, _i, _i, _vp, _vp, _i, _vp], C.c_int),
     "storm_fir_up2": ([_vp, _vp, _vp, _i, _i, _i, _i, _i, _vp], C.c_int),
     "storm_fir_down2": ([_vp, _vp, _i, _i, _i, _i, _i, _vp], C.c_int),
-    "storm_softmax_rows": ([_vp, _vp, _ll, _i, _i, _vp], C.c_int),
+    "storm_softmax_rows": ([_vp, _vp, _ll, _i, _i, _i, _vp], C.c_int),
     "storm_pack_input": ([C.POINTER(_vp), _i, _vp, _i, _i, _i, _i, _vp], C.c_int),
     "storm_time_embedding": ([_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _vp], C.c_int),
     "storm_dense": ([_vp, _vp, _vp, _vp, _i, _i, _i, _vp], C.c_int),
@@ -79,6 +79,7 @@ _SIGNATURES = {
     "storm_stft": ([_vp, _vp, _vp, _vp, _vp, _i, _ll, _ll, _i, _i, _i, _i, _f, _f, _vp], C.c_int),
     "storm_istft": ([_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _ll, _ll, _i, _i, _f, _f, _vp], C.c_int),
     "storm_program_run": ([C.POINTER(Op), _i, C.POINTER(_vp), _i, _i, _vp], C.c_int),
+    "storm_program_run_timed": ([C.POINTER(Op), _i, C.POINTER(_vp), _i, _i, _vp, C.POINTER(C.c_float)], C.c_int),
 }
 EXPORTS = ["storm_last_error"] + list(_SIGNATURES)
 

@@ -428,8 +428,7 @@ class Program:
         """AttnBlockpp.forward (layerspp.py:75-91): GN -> q,k,v (NIN) -> softmax(q k^T / sqrt C) v -> NIN_3 -> skip."""
         k = f"all_modules.{idx}."
         Cc, Lp = p["c"], x.H * x.W
-        if Lp % 8:
-            raise ValueError("attention needs H*W % 8 == 0")
+        Lp8 = _up(Lp, 8)                 # row padding of the [L][L] score / probability / v^T matrices
         h, _ = self.gn(x, None, k + "GroupNorm_0.weight", k + "GroupNorm_0.bias", silu=False)
         hl = Act(h.off, 1, Lp, Cc)
         q = self.conv([self.wseg(hl, k + "NIN_0.W", 1)], Cc, 1, Lp, bias_key=k + "NIN_0.b")
@@ -437,18 +436,18 @@ class Program:
         # v^T[c][j] = sum_c' Wv^T[c][c'] h[j][c']: the packed NIN_2 matrix is the "pixel" operand, h the weights.
         e2 = self.layout.entries[k + "NIN_2.W"]
         vT = self.conv([dict(a=(BUF_PARAMS, e2.offset, Cc), w=("ws", h.off), CinP=Cc, rows=Lp, taps=1,
-                             w_bstride=Lp * Cc)], Lp, 1, Cc, outC=Lp, src0_bstride=0)
+                             w_bstride=Lp * Cc)], Lp, 1, Cc, outC=Lp8, src0_bstride=0)
         self.free(h)
-        S = self.conv([dict(a=q, w=("ws", kk.off), CinP=Cc, rows=Lp, taps=1, w_bstride=Lp * Cc)], Lp, 1, Lp, outC=Lp,
+        S = self.conv([dict(a=q, w=("ws", kk.off), CinP=Cc, rows=Lp, taps=1, w_bstride=Lp * Cc)], Lp, 1, Lp, outC=Lp8,
                       scale=float(int(Cc) ** (-0.5)), out_f32=True)
         self.free(q); self.free(kk)
-        P = self.new_act(1, Lp, Lp)
+        P = self.new_act(1, Lp, Lp8)
         op = self._op(OP_SOFTMAX)
         self._ws(op, 0, S); self._ws(op, 1, P)
-        op.i[0], op.i[1] = self.B * Lp, Lp
+        op.i[0], op.i[1], op.i[2] = self.B * Lp, Lp, Lp8
         self.free(S)
         # h = P v (+ b_v: rows of P sum to one, so the NIN_2 bias passes through unchanged)
-        o = self.conv([dict(a=P, w=("ws", vT.off), CinP=Lp, rows=Cc, taps=1, w_bstride=Cc * Lp)], Cc, 1, Lp,
+        o = self.conv([dict(a=P, w=("ws", vT.off), CinP=Lp8, rows=Cc, taps=1, w_bstride=Cc * Lp8)], Cc, 1, Lp,
                       bias_key=k + "NIN_2.b")
         self.free(P); self.free(vT)
         xl = Act(x.off, 1, Lp, Cc)

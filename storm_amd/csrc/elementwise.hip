@@ -76,11 +76,11 @@ __global__ void dense_kernel(const float* __restrict__ x, const float* __restric
 
 // ---- row softmax: one wave per row, wave64 reductions -------------------------------------
 template <typename T>
-__global__ void softmax_rows_kernel(const float* __restrict__ s, T* __restrict__ p, long long rows, int L) {
+__global__ void softmax_rows_kernel(const float* __restrict__ s, T* __restrict__ p, long long rows, int L, int ld) {
     const int lane = threadIdx.x & 63;
     const long long row = (long long)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
     if (row >= rows) return;
-    const float* x = s + row * L;
+    const float* x = s + row * ld;
     float m = -INFINITY;
     for (int k = lane; k < L; k += 64) m = fmaxf(m, x[k]);
     m = wave_max(m);
@@ -88,8 +88,9 @@ __global__ void softmax_rows_kernel(const float* __restrict__ s, T* __restrict__
     for (int k = lane; k < L; k += 64) sum += expf(x[k] - m);
     sum = wave_sum(sum);
     const float inv = 1.0f / sum;
-    T* o = p + row * L;
+    T* o = p + row * ld;
     for (int k = lane; k < L; k += 64) from_f32(o[k], expf(x[k] - m) * inv);
+    for (int k = L + lane; k < ld; k += 64) from_f32(o[k], 0.0f);       // zero the row padding
 }
 
 // ---- output head --------------------------------------------------------------------------
@@ -150,13 +151,13 @@ extern "C" int storm_dense(const float* x, const float* W, const float* bias, fl
     return STORM_OK;
 }
 
-extern "C" int storm_softmax_rows(const float* scores, void* probs, long long rows, int L, int dtype,
+extern "C" int storm_softmax_rows(const float* scores, void* probs, long long rows, int L, int ld, int dtype,
                                   storm_stream_t s) {
-    STORM_CHECK(scores && probs && rows > 0 && L > 0, "storm_softmax_rows: bad arguments");
+    STORM_CHECK(scores && probs && rows > 0 && L > 0 && ld >= L, "storm_softmax_rows: bad arguments");
     const int nb = cdiv(rows, 4);
     hipStream_t st = (hipStream_t)s;
-    if (dtype == STORM_BF16) hipLaunchKernelGGL((softmax_rows_kernel<bf16_t>), dim3(nb), dim3(256), 0, st, scores, (bf16_t*)probs, rows, L);
-    else if (dtype == STORM_F32) hipLaunchKernelGGL((softmax_rows_kernel<float>), dim3(nb), dim3(256), 0, st, scores, (float*)probs, rows, L);
+    if (dtype == STORM_BF16) hipLaunchKernelGGL((softmax_rows_kernel<bf16_t>), dim3(nb), dim3(256), 0, st, scores, (bf16_t*)probs, rows, L, ld);
+    else if (dtype == STORM_F32) hipLaunchKernelGGL((softmax_rows_kernel<float>), dim3(nb), dim3(256), 0, st, scores, (float*)probs, rows, L, ld);
     else STORM_CHECK(false, "storm_softmax_rows: dtype %d", dtype);
     STORM_LAUNCH_CHECK();
     return STORM_OK;

@@ -12,11 +12,12 @@ static inline void* resolve(const storm_ref& r, void* const* bufs, int n_bufs, b
     return static_cast<char*>(bufs[r.buf]) + r.off;
 }
 
-extern "C" int storm_program_run(const storm_op* ops, int n_ops, void* const* bufs, int n_bufs, int dtype,
-                                 storm_stream_t s) {
+static int run_ops(const storm_op* ops, int n_ops, void* const* bufs, int n_bufs, int dtype, storm_stream_t s,
+                   hipEvent_t* ev) {
     STORM_CHECK(ops && bufs && n_ops >= 0, "storm_program_run: bad arguments");
     hipStream_t st = (hipStream_t)s;
     for (int k = 0; k < n_ops; ++k) {
+        if (ev) STORM_HIP(hipEventRecord(ev[k], st));
         const storm_op& op = ops[k];
         bool ok = true;
         void* p[STORM_OP_NPTR];
@@ -79,7 +80,7 @@ extern "C" int storm_program_run(const storm_op* ops, int n_ops, void* const* bu
                 rc = storm_fir_down2(p[0], p[1], (int)i[0], (int)i[1], (int)i[2], (int)i[3], dtype, s);
                 break;
             case STORM_OP_SOFTMAX:
-                rc = storm_softmax_rows((const float*)p[0], p[1], (long long)i[0], (int)i[1], dtype, s);
+                rc = storm_softmax_rows((const float*)p[0], p[1], (long long)i[0], (int)i[1], (int)i[2], dtype, s);
                 break;
             case STORM_OP_OUTPUT_HEAD:
                 rc = storm_output_head(p[0], (const float*)p[1], (const float*)p[2], (const float*)p[3], (int)i[0],
@@ -90,5 +91,30 @@ extern "C" int storm_program_run(const storm_op* ops, int n_ops, void* const* bu
         }
         if (rc != STORM_OK) return rc;
     }
+    if (ev) STORM_HIP(hipEventRecord(ev[n_ops], st));
     return STORM_OK;
+}
+
+extern "C" int storm_program_run(const storm_op* ops, int n_ops, void* const* bufs, int n_bufs, int dtype,
+                                 storm_stream_t s) {
+    return run_ops(ops, n_ops, bufs, n_bufs, dtype, s, nullptr);
+}
+
+// Profiling variant: brackets every op with HIP events ON THE LAUNCH STREAM and returns the
+// elapsed milliseconds per op (host array ms[n_ops]); synchronises the stream at the end.
+extern "C" int storm_program_run_timed(const storm_op* ops, int n_ops, void* const* bufs, int n_bufs, int dtype,
+                                       storm_stream_t s, float* ms) {
+    STORM_CHECK(ms != nullptr && n_ops > 0, "storm_program_run_timed: bad arguments");
+    hipEvent_t* ev = new hipEvent_t[n_ops + 1];
+    int created = 0, rc = STORM_OK;
+    for (; created <= n_ops; ++created)
+        if (hipEventCreate(&ev[created]) != hipSuccess) { storm::set_error("hipEventCreate failed"); rc = STORM_ERR_HIP; break; }
+    if (rc == STORM_OK) rc = run_ops(ops, n_ops, bufs, n_bufs, dtype, s, ev);
+    if (rc == STORM_OK && hipEventSynchronize(ev[n_ops]) != hipSuccess) { storm::set_error("hipEventSynchronize failed"); rc = STORM_ERR_HIP; }
+    if (rc == STORM_OK)
+        for (int k = 0; k < n_ops; ++k)
+            if (hipEventElapsedTime(&ms[k], ev[k], ev[k + 1]) != hipSuccess) { storm::set_error("hipEventElapsedTime failed"); rc = STORM_ERR_HIP; break; }
+    for (int k = 0; k < created; ++k) hipEventDestroy(ev[k]);
+    delete[] ev;
+    return rc;
 }

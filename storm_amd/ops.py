@@ -133,10 +133,12 @@ def fir_down2(x):
     return out
 
 
-def softmax_rows(scores, dtype):
-    rows, Lr = scores.numel() // scores.shape[-1], scores.shape[-1]
+def softmax_rows(scores, dtype, valid=None):
+    """softmax over the first `valid` columns of each row (the rest is row padding, written as 0)."""
+    ld = scores.shape[-1]
+    rows, Lr = scores.numel() // ld, (valid if valid is not None else ld)
     out = _alloc(scores.shape, dtype, scores)
-    L.check(L.lib().storm_softmax_rows(L.ptr(scores), L.ptr(out), rows, Lr, L.dt(dtype), L.stream()), "storm_softmax_rows")
+    L.check(L.lib().storm_softmax_rows(L.ptr(scores), L.ptr(out), rows, Lr, ld, L.dt(dtype), L.stream()), "storm_softmax_rows")
     return out
 
 

@@ -138,5 +138,11 @@ inline hipError_t hipGetDevice(int* d) { *d = 0; return hipSuccess; }
 inline hipError_t hipGetDeviceProperties(hipDeviceProp_t* p, int) {
     strcpy(p->gcnArchName, "host-sim"); p->multiProcessorCount = 0; p->totalGlobalMem = 0; return hipSuccess;
 }
+typedef int hipEvent_t;
+inline hipError_t hipEventCreate(hipEvent_t* e) { *e = 0; return hipSuccess; }
+inline hipError_t hipEventDestroy(hipEvent_t) { return hipSuccess; }
+inline hipError_t hipEventRecord(hipEvent_t, hipStream_t) { return hipSuccess; }
+inline hipError_t hipEventSynchronize(hipEvent_t) { return hipSuccess; }
+inline hipError_t hipEventElapsedTime(float* ms, hipEvent_t, hipEvent_t) { *ms = 0.f; return hipSuccess; }
 #define hipLaunchKernelGGL(kern, grid, block, lds, stream, ...) \
     simrt::launch((grid), (block), (size_t)(lds), [=]() { (kern)(__VA_ARGS__); })
