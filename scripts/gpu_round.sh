@@ -9,7 +9,7 @@ timeout 1200 python -m pytest tests -m gpu -q --tb=short > gpurun_out/pytest_gpu
 tail -3 gpurun_out/pytest_gpu_$TAG.log
 timeout 900 python bench.py --ops-json gpurun_out/ops_$TAG.json > gpurun_out/bench_$TAG.json 2> gpurun_out/bench_$TAG.err
 cat gpurun_out/bench_$TAG.json; tail -3 gpurun_out/bench_$TAG.err
-timeout 900 rocprofv3 --kernel-trace --stats -d gpurun_out/prof_$TAG -o trace -- python bench.py --steps 1 --warmup 0 --no-cpu-baseline > gpurun_out/prof_bench_$TAG.json 2> gpurun_out/prof_$TAG.err
+timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_$TAG -o trace -- python bench.py --steps 1 --warmup 0 --no-cpu-baseline > gpurun_out/prof_bench_$TAG.json 2> gpurun_out/prof_$TAG.err
 cat gpurun_out/prof_bench_$TAG.json
 find gpurun_out/prof_$TAG -name "*stats*" | head
 f=$(find gpurun_out/prof_$TAG -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && head -12 "$f"

@@ -20,6 +20,7 @@
 //     skip / bias reads) are 16-32 B per lane, full 128-B lines per 4-8 lanes.
 //   * bf16 operands: v_mfma_f32_32x32x16_bf16 (fp32 accumulate).  fp32 operands:
 //     v_mfma_f32_32x32x2_f32 (exact fp32, used by the parity path).
+#include <cstring>
 #include "common.h"
 #include "conv_index.h"
 
@@ -59,13 +60,28 @@ struct ConvCfg {
     static_assert(BN * 8 % THREADS == 0, "");
 };
 
-struct SegInfo {           // per-segment scalars derived once per block
-    int Cin, nchunks, ntaps;
+// Kernel-side view of storm_conv_args: the K dimension as up to four single-source "runs"
+// (a segment reading cat[xa, xb] becomes two runs), so the inner loops never select a source per
+// element and every run field is a scalar loaded once per run.
+struct ConvRun {
+    const void* src; const void* w;
+    long long src_bstride, w_bstride, w_tapstride;
+    int C;          // channel stride of src
+    int c0, cn;     // channels [c0, c0+cn) of src ...
+    int wc0;        // ... multiply weight columns [wc0, wc0+cn)
+    int CinP, w_rows, ntaps, pad_;
+};
+struct ConvParams {
+    ConvRun run[4];
+    int nruns, B, H, W;
+    void* out; int outC, Cout; long long out_bstride;
+    const float* bias; const float* tbias; int tbias_stride, out_f32;
+    const void* skip; long long skip_bstride; float scale; int pad_;
 };
 
 template <typename T, int TAPS, int WM, int WAVES_M>
 __global__ __launch_bounds__(256, 2)
-void conv_igemm_kernel(const storm_conv_args a, const int n_ct, const int tiles_per_xcd,
+void conv_igemm_kernel(const ConvParams a, const int n_ct, const int tiles_per_xcd,
                        const int ntiles, const int tiles_x, const int tiles_per_img) {
     typedef ConvCfg<TAPS, WM, WAVES_M> Cfg;
     typedef typename Mma<T>::Frag Frag;
@@ -91,15 +107,6 @@ void conv_igemm_kernel(const storm_conv_args a, const int n_ct, const int tiles_
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave % WAVES_M, wn = wave / WAVES_M;
 
-    SegInfo si[2];
-#pragma unroll
-    for (int s = 0; s < 2; ++s) {
-        si[s].Cin = a.seg[s].Ca + a.seg[s].Cb;
-        si[s].nchunks = (si[s].Cin + KC - 1) / KC;
-        si[s].ntaps = a.seg[s].ntaps;
-    }
-    const int nseg = a.nseg;
-
     f32x16 acc[WM][WN];
 #pragma unroll
     for (int mi = 0; mi < WM; ++mi)
@@ -108,20 +115,18 @@ void conv_igemm_kernel(const storm_conv_args a, const int n_ct, const int tiles_
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[mi][ni][r] = 0.0f;
 
-    // ---- loaders -------------------------------------------------------------------------
+    // ---- loaders (all arguments wave-uniform scalars) -----------------------------------------
     uint4 wreg[Cfg::WU];
-    auto load_w = [&](int sg, int ch, int tp) {
-        const storm_conv_seg& S = a.seg[sg];
-        const T* wbase = reinterpret_cast<const T*>(S.w) + (long long)b * S.w_bstride +
-                         (long long)tp * S.w_tapstride;
+    auto load_w = [&](const T* wbase, int CinP, int w_rows, int kbeg, int klim) {
+        // weight tile rows cout0.., columns [kbeg, kbeg + KC) of a row of the current run (klim = row end)
 #pragma unroll
         for (int i = 0; i < Cfg::WU; ++i) {
             const int u = tid + i * THREADS;
             const int row = u >> 3, slot = u & 7;
-            const int co = cout0 + row, c = ch * KC + slot * PER16;
+            const int co = cout0 + row, c = kbeg + slot * PER16;
             uint4 v = make_uint4(0u, 0u, 0u, 0u);
-            if (co < S.w_rows && c < S.CinP)
-                v = *reinterpret_cast<const uint4*>(wbase + (long long)co * S.CinP + c);
+            if (co < w_rows && c < klim)
+                v = *reinterpret_cast<const uint4*>(wbase + (long long)co * CinP + c);
             wreg[i] = v;
         }
     };
@@ -133,95 +138,109 @@ void conv_igemm_kernel(const storm_conv_args a, const int n_ct, const int tiles_
             *reinterpret_cast<uint4*>(dst + lds_off(u >> 3, u & 7)) = wreg[i];
         }
     };
-    auto load_patch = [&](int sg, int ch) {
-        const storm_conv_seg& S = a.seg[sg];
-        const T* pa = reinterpret_cast<const T*>(S.src_a) + (long long)b * S.bstride_a;
-        const T* pb = reinterpret_cast<const T*>(S.src_b) + (long long)b * S.bstride_b;
-        const int Ca = S.Ca, Cb = S.Cb, Cin = Ca + Cb;
-        uint4 preg[Cfg::PU];
+    auto load_patch = [&](const T* src, int C, int cbeg, int cvalid) {
+        // channels [cbeg, cbeg + cvalid) of the haloed tile -> LDS; everything else zero
+        // two half-batches keep the staging registers at ~6 x 16 B per thread
+        constexpr int HALF = (Cfg::PU + 1) / 2;
 #pragma unroll
-        for (int i = 0; i < Cfg::PU; ++i) {
-            const int u = tid + i * THREADS;
-            const int p = u >> 3, slot = u & 7;
-            const int c = ch * KC + slot * PER16;
-            long long pix;
-            bool ok = (u < Cfg::NPIX * 8) && (c < Cin);
-            if (TAPS == 9) {
-                const int py = p / PW, px = p - py * PW;
-                const int gy = ty0 + py - 1, gx = tx0 + px - 1;
-                ok = ok && gy >= 0 && gy < a.H && gx >= 0 && gx < a.W;
-                pix = (long long)gy * a.W + gx;
-            } else {
-                pix = lin0 + p;
-                ok = ok && pix < npix;
-            }
-            uint4 v = make_uint4(0u, 0u, 0u, 0u);
-            if (ok) {
-                const T* src = (c < Ca) ? (pa + pix * Ca + c) : (pb + pix * Cb + (c - Ca));
-                v = *reinterpret_cast<const uint4*>(src);
-            }
-            preg[i] = v;
-        }
+        for (int h0 = 0; h0 < Cfg::PU; h0 += HALF) {
+            uint4 preg[HALF];
 #pragma unroll
-        for (int i = 0; i < Cfg::PU; ++i) {
-            const int u = tid + i * THREADS;
-            if (u < Cfg::NPIX * 8) *reinterpret_cast<uint4*>(patch + lds_off(u >> 3, u & 7)) = preg[i];
+            for (int k = 0; k < HALF; ++k) {
+                const int u = tid + (h0 + k) * THREADS;
+                const int p = u >> 3, slot = u & 7;
+                long long pix;
+                bool ok = (h0 + k < Cfg::PU) && (u < Cfg::NPIX * 8) && (slot * PER16 < cvalid);
+                if (TAPS == 9) {
+                    const int py = p / PW, px = p - py * PW;
+                    const int gy = ty0 + py - 1, gx = tx0 + px - 1;
+                    ok = ok && gy >= 0 && gy < a.H && gx >= 0 && gx < a.W;
+                    pix = (long long)gy * a.W + gx;
+                } else {
+                    pix = lin0 + p;
+                    ok = ok && pix < npix;
+                }
+                uint4 v = make_uint4(0u, 0u, 0u, 0u);
+                if (ok) v = *reinterpret_cast<const uint4*>(src + pix * C + cbeg + slot * PER16);
+                preg[k] = v;
+            }
+#pragma unroll
+            for (int k = 0; k < HALF; ++k) {
+                const int u = tid + (h0 + k) * THREADS;
+                if (h0 + k < Cfg::PU && u < Cfg::NPIX * 8)
+                    *reinterpret_cast<uint4*>(patch + lds_off(u >> 3, u & 7)) = preg[k];
+            }
         }
     };
 
-    // ---- main loop over (segment, K-chunk, tap) steps -------------------------------------
-    int sg = 0, ch = 0, tp = 0, step = 0;
-    load_w(0, 0, 0);
-    store_w(0);
-    while (sg < nseg) {
-        if (tp == 0) {
-            __syncthreads();                 // every wave finished reading the previous patch
-            load_patch(sg, ch);
-        }
-        // next step's coordinates
-        int nsg = sg, nch = ch, ntp = tp + 1;
-        if (ntp == si[sg].ntaps) { ntp = 0; ++nch; if (nch == si[sg].nchunks) { nch = 0; ++nsg; } }
-        const bool has_next = nsg < nseg;
-        if (has_next) load_w(nsg, nch, ntp);      // global loads fly during the MFMAs below
-        __syncthreads();                          // patch + wbuf[step&1] visible
+    // per-lane fragment rows (tap independent parts)
+    int arow[WM];
+#pragma unroll
+    for (int mi = 0; mi < WM; ++mi) arow[mi] = (wm * WM + mi) * 32 + (lane & 31);
 
-        {
-            const char* wb = wbuf + (step & 1) * Cfg::WBUF_BYTES;
-            int dy = 0, dx = 0;
-            if (TAPS == 9) {
-                if (si[sg].ntaps == 9) { dy = tp / 3; dx = tp - dy * 3; } else { dy = 1; dx = 1; }
-            }
-            const int rem = si[sg].Cin - ch * KC;
-            const int nk = rem >= KC ? 4 : (rem + KG - 1) / KG;
-            int prow[WN], arow[WM];
+    auto compute = [&](const char* wb, int dy, int dx, int nk) {
+        int prow[WN];
 #pragma unroll
-            for (int ni = 0; ni < WN; ++ni) prow[ni] = patch_pixel<TAPS>(lane, wn * WN + ni, dy, dx);
+        for (int ni = 0; ni < WN; ++ni) prow[ni] = patch_pixel<TAPS>(lane, wn * WN + ni, dy, dx);
+        auto kgroup = [&](int j) {
+            const int slot = frag_slot(lane, j);
+            Frag fa[WM], fb[WN];
 #pragma unroll
-            for (int mi = 0; mi < WM; ++mi) arow[mi] = (wm * WM + mi) * 32 + (lane & 31);
-            auto kgroup = [&](int j) {
-                const int slot = frag_slot(lane, j);
-                Frag fa[WM], fb[WN];
+            for (int mi = 0; mi < WM; ++mi) fa[mi] = *reinterpret_cast<const Frag*>(wb + lds_off(arow[mi], slot));
 #pragma unroll
-                for (int mi = 0; mi < WM; ++mi)
-                    fa[mi] = *reinterpret_cast<const Frag*>(wb + lds_off(arow[mi], slot));
+            for (int ni = 0; ni < WN; ++ni) fb[ni] = *reinterpret_cast<const Frag*>(patch + lds_off(prow[ni], slot));
 #pragma unroll
-                for (int ni = 0; ni < WN; ++ni)
-                    fb[ni] = *reinterpret_cast<const Frag*>(patch + lds_off(prow[ni], slot));
+            for (int mi = 0; mi < WM; ++mi)
 #pragma unroll
-                for (int mi = 0; mi < WM; ++mi)
-#pragma unroll
-                    for (int ni = 0; ni < WN; ++ni) Mma<T>::run(fa[mi], fb[ni], acc[mi][ni]);
-            };
-            if (nk == 4) {
-#pragma unroll
-                for (int j = 0; j < 4; ++j) kgroup(j);
-            } else {
+                for (int ni = 0; ni < WN; ++ni) Mma<T>::run(fa[mi], fb[ni], acc[mi][ni]);
+        };
+        // one rolled loop (a second, unrolled copy makes the register allocator keep two homes for the
+        // 128 accumulator registers and shuffle / spill them at the join)
 #pragma unroll 1
-                for (int j = 0; j < nk; ++j) kgroup(j);
+        for (int j = 0; j < nk; ++j) kgroup(j);
+    };
+
+    // ---- main loop: runs x K-chunks x taps ------------------------------------------------------
+    int step = 0;
+    {
+        const ConvRun& R0 = a.run[0];
+        load_w(reinterpret_cast<const T*>(R0.w) + (long long)b * R0.w_bstride + R0.wc0, R0.CinP, R0.w_rows, 0, R0.CinP - R0.wc0);
+        store_w(0);
+    }
+    const int nruns = a.nruns;
+    for (int r = 0; r < nruns; ++r) {
+        const ConvRun& R = a.run[r];
+        const T* const src = reinterpret_cast<const T*>(R.src) + (long long)b * R.src_bstride;
+        const T* const w = reinterpret_cast<const T*>(R.w) + (long long)b * R.w_bstride + R.wc0;
+        const int C = R.C, c0 = R.c0, cn = R.cn, CinP = R.CinP, w_rows = R.w_rows, ntaps = R.ntaps;
+        const long long w_tapstride = R.w_tapstride;
+        const int klim = CinP - R.wc0;
+        const int nch = (cn + KC - 1) / KC;
+        const bool has_nr = r + 1 < nruns;
+        const ConvRun& NR = a.run[has_nr ? r + 1 : r];
+        for (int ch = 0; ch < nch; ++ch) {
+            const int cvalid = min(KC, cn - ch * KC);
+            __syncthreads();                       // every wave finished reading the previous patch
+            load_patch(src, C, c0 + ch * KC, cvalid);
+            const int nk = (cvalid + KG - 1) / KG;
+            for (int tp = 0; tp < ntaps; ++tp) {
+                // prefetch the next step's weight tile into registers (flies during the MFMAs below)
+                bool has_next = true;
+                if (tp + 1 < ntaps) load_w(w + (long long)(tp + 1) * w_tapstride, CinP, w_rows, ch * KC, klim);
+                else if (ch + 1 < nch) load_w(w, CinP, w_rows, (ch + 1) * KC, klim);
+                else if (has_nr) load_w(reinterpret_cast<const T*>(NR.w) + (long long)b * NR.w_bstride + NR.wc0, NR.CinP,
+                                        NR.w_rows, 0, NR.CinP - NR.wc0);
+                else has_next = false;
+                __syncthreads();                   // patch + wbuf[step&1] visible
+                int dy = 0, dx = 0;
+                if (TAPS == 9) {
+                    if (ntaps == 9) { dy = tp / 3; dx = tp - dy * 3; } else { dy = 1; dx = 1; }
+                }
+                compute(wbuf + (step & 1) * Cfg::WBUF_BYTES, dy, dx, nk);
+                if (has_next) store_w((step + 1) & 1);   // that buffer was last read in step-1 (barrier passed)
+                ++step;
             }
         }
-        if (has_next) store_w((step + 1) & 1);    // that buffer was last read in step-1 (barrier passed)
-        sg = nsg; ch = nch; tp = ntp; ++step;
     }
 
     // ---- epilogue: LDS transpose -> (bias, temb bias, skip, scale) -> wide stores ---------
@@ -263,14 +282,23 @@ void conv_igemm_kernel(const storm_conv_args a, const int n_ct, const int tiles_
             }
             const int co = cout0 + wm * WM * 32 + c8 * 8;
             if (ok && co < a.outC) {
+                if (co + 8 <= a.Cout) {               // fast path: 8 aligned floats per source
+                    if (a.bias) { float bb[8]; load8(a.bias + co, bb);
 #pragma unroll
-                for (int e = 0; e < 8; ++e) {
-                    float add = 0.0f;
-                    if (co + e < a.Cout) {
-                        if (a.bias) add += a.bias[co + e];
-                        if (a.tbias) add += a.tbias[(long long)b * a.tbias_stride + co + e];
+                        for (int e = 0; e < 8; ++e) v[e] += bb[e]; }
+                    if (a.tbias) { float bb[8]; load8(a.tbias + (long long)b * a.tbias_stride + co, bb);
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) v[e] += bb[e]; }
+                } else {
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) {
+                        float add = 0.0f;
+                        if (co + e < a.Cout) {
+                            if (a.bias) add += a.bias[co + e];
+                            if (a.tbias) add += a.tbias[(long long)b * a.tbias_stride + co + e];
+                        }
+                        v[e] += add;
                     }
-                    v[e] += add;
                 }
                 if (a.skip) {
                     float sk[8];
@@ -287,6 +315,31 @@ void conv_igemm_kernel(const storm_conv_args a, const int n_ct, const int tiles_
         }
         if (pass + 1 < WN / 2) __syncthreads();
     }
+}
+
+static ConvParams make_params(const storm_conv_args& a) {
+    ConvParams p;
+    memset(&p, 0, sizeof(p));
+    int n = 0;
+    for (int s = 0; s < a.nseg; ++s) {
+        const storm_conv_seg& g = a.seg[s];
+        for (int part = 0; part < 2; ++part) {
+            if (part == 1 && g.Cb == 0) break;
+            ConvRun& r = p.run[n++];
+            r.src = part == 0 ? g.src_a : g.src_b;
+            r.src_bstride = part == 0 ? g.bstride_a : g.bstride_b;
+            r.C = part == 0 ? g.Ca : g.Cb;
+            r.c0 = 0; r.cn = r.C;
+            r.wc0 = part == 0 ? 0 : g.Ca;
+            r.w = g.w; r.w_bstride = g.w_bstride; r.w_tapstride = g.w_tapstride;
+            r.CinP = g.CinP; r.w_rows = g.w_rows; r.ntaps = g.ntaps;
+        }
+    }
+    p.nruns = n; p.B = a.B; p.H = a.H; p.W = a.W;
+    p.out = a.out; p.outC = a.outC; p.Cout = a.Cout; p.out_bstride = a.out_bstride;
+    p.bias = a.bias; p.tbias = a.tbias; p.tbias_stride = a.tbias_stride; p.out_f32 = a.out_f32;
+    p.skip = a.skip; p.skip_bstride = a.skip_bstride; p.scale = a.scale;
+    return p;
 }
 
 template <typename T, int TAPS, int WM, int WAVES_M>
@@ -311,7 +364,8 @@ static int launch_conv(const storm_conv_args& a, hipStream_t st) {
     const int tiles_per_xcd = cdiv(ntiles, 8);
     const long long grid = 8LL * tiles_per_xcd * n_ct;
     STORM_CHECK(grid > 0 && grid < (1LL << 31), "storm_conv: grid %lld out of range", grid);
-    hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(THREADS), Cfg::LDS_BYTES, st, a, n_ct,
+    const ConvParams prm = make_params(a);
+    hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(THREADS), Cfg::LDS_BYTES, st, prm, n_ct,
                        tiles_per_xcd, (int)ntiles, tiles_x, tiles_per_img);
     STORM_LAUNCH_CHECK();
     return STORM_OK;

@@ -18,6 +18,15 @@ static inline GnGeom gn_geom(int C) {
     GnGeom g; g.C8 = C / 8; g.PL = 256 / g.C8; if (g.PL < 1) g.PL = 1; g.NT = g.C8 * g.PL; return g;
 }
 
+// Pixels each thread walks: aim at >= ~4096 workgroups so small feature maps are not latency bound
+// (a thread that loops 256 dependent loads takes ~80 us whatever the tensor size).
+static inline int pixels_per_thread(long long total_pixels, int PL, int max_per_thread) {
+    long long per = total_pixels / ((long long)PL * 4096);
+    if (per < 2) per = 2;
+    if (per > max_per_thread) per = max_per_thread;
+    return (int)per;
+}
+
 template <typename T>
 __device__ __forceinline__ void load_cat8(const T* xa, int Ca, const T* xb, int Cb, long long pix, int c,
                                           float (&v)[8]) {
@@ -148,6 +157,117 @@ __global__ void gn_apply_kernel(const T* __restrict__ xa, int Ca, const T* __res
     }
 }
 
+// Fused GN-apply + SiLU + FIR x2 (up or down) of BOTH the activated and the raw tensor, LDS tiled:
+// a workgroup stages a 10x18-pixel input tile (8x16 core + 1-pixel halo) of one 128-byte channel
+// group, applying the normalisation + SiLU ONCE per input element, then filters from LDS.
+// Output tile: 4x8 pixels (down) / 16x32 pixels (up).
+constexpr int RS_IH = 10, RS_IW = 18, RS_NPIX = RS_IH * RS_IW;
+template <typename T, int RESAMPLE>
+__global__ __launch_bounds__(256)
+void gn_apply_resample_kernel(const T* __restrict__ xa, int Ca, const T* __restrict__ xb, int Cb,
+                              int H, int W, int G, const double* __restrict__ stats,
+                              const float* __restrict__ gamma, const float* __restrict__ beta, float eps,
+                              int silu, T* __restrict__ out_act, T* __restrict__ out_raw, int tiles_x, int tiles_y) {
+    constexpr int PER16 = Elem<T>::PER16;           // elements per 16-byte slot
+    constexpr int CG = 8 * PER16;                   // channels per workgroup (128 B per pixel)
+    __shared__ __attribute__((aligned(16))) char tile[2 * RS_NPIX * 128];
+    char* const t_act = tile;
+    char* const t_raw = tile + RS_NPIX * 128;
+    const int C = Ca + Cb, b = blockIdx.y, tid = threadIdx.x;
+    int bid = blockIdx.x;
+    const int tx = bid % tiles_x; bid /= tiles_x;
+    const int ty = bid % tiles_y; const int cg = bid / tiles_y;
+    const int slot = tid & 7;
+    const int c = cg * CG + slot * PER16;           // first channel of this thread's 16-byte slot
+    const bool cvalid = c < C;
+    const int OH = RESAMPLE == 1 ? 2 * H : H / 2, OW = RESAMPLE == 1 ? 2 * W : W / 2;
+    const int iy0 = ty * 8 - 1, ix0 = tx * 16 - 1;  // input tile origin (core starts at ty*8, tx*16)
+    // per-thread GN parameters of its PER16 channels
+    float pm[PER16], pa[PER16], pb[PER16];
+    const int gs = C / G;
+    const double n = (double)gs * H * W;
+#pragma unroll
+    for (int e = 0; e < PER16; ++e) {
+        pm[e] = 0.f; pa[e] = 0.f; pb[e] = 0.f;
+        if (cvalid) {
+            const int g = (c + e) / gs;
+            const double m = stats[((long long)b * G + g) * 2] / n;
+            double var = stats[((long long)b * G + g) * 2 + 1] / n - m * m;
+            if (var < 0.0) var = 0.0;
+            pm[e] = (float)m;
+            pa[e] = (float)(1.0 / sqrt(var + (double)eps)) * gamma[c + e];
+            pb[e] = beta[c + e];
+        }
+    }
+    const long long ibase = (long long)b * H * W;
+    // ---- stage: raw + activated input tile -> LDS (zeros outside the image) ----
+    for (int u = tid; u < RS_NPIX * 8; u += 256) {
+        const int p = u >> 3;                        // (u & 7) == slot because 256 % 8 == 0
+        const int py = p / RS_IW, px = p - py * RS_IW;
+        const int iy = iy0 + py, ix = ix0 + px;
+        alignas(16) T raw[PER16];
+        alignas(16) T act[PER16];
+        const bool ok = cvalid && iy >= 0 && iy < H && ix >= 0 && ix < W;
+        if (ok) {
+            const long long pix = ibase + (long long)iy * W + ix;
+            const T* src = (c < Ca) ? (xa + pix * Ca + c) : (xb + pix * Cb + (c - Ca));
+            *reinterpret_cast<uint4*>(raw) = *reinterpret_cast<const uint4*>(src);
+#pragma unroll
+            for (int e = 0; e < PER16; ++e) {
+                float y = (to_f32(raw[e]) - pm[e]) * pa[e] + pb[e];
+                if (silu) y = silu_f(y);
+                from_f32(act[e], y);
+            }
+        } else {
+            *reinterpret_cast<uint4*>(raw) = make_uint4(0u, 0u, 0u, 0u);
+            *reinterpret_cast<uint4*>(act) = make_uint4(0u, 0u, 0u, 0u);
+        }
+        *reinterpret_cast<uint4*>(t_raw + p * 128 + slot * 16) = *reinterpret_cast<const uint4*>(raw);
+        *reinterpret_cast<uint4*>(t_act + p * 128 + slot * 16) = *reinterpret_cast<const uint4*>(act);
+    }
+    __syncthreads();
+    if (!cvalid) return;
+    // ---- filter from LDS ----
+    constexpr int TOH = RESAMPLE == 1 ? 16 : 4, TOW = RESAMPLE == 1 ? 32 : 8;
+    const long long obase = (long long)b * OH * OW;
+    for (int u = tid; u < TOH * TOW * 8; u += 256) {
+        const int q = u >> 3;
+        const int oy_l = q / TOW, ox_l = q - oy_l * TOW;
+        const int oy = ty * TOH + oy_l, ox = tx * TOW + ox_l;
+        if (oy >= OH || ox >= OW) continue;
+        float va[PER16], vr[PER16];
+#pragma unroll
+        for (int e = 0; e < PER16; ++e) { va[e] = 0.f; vr[e] = 0.f; }
+        auto tap = [&](int py, int px, float wgt) {
+            alignas(16) T ra[PER16];
+            alignas(16) T rr[PER16];
+            *reinterpret_cast<uint4*>(ra) = *reinterpret_cast<const uint4*>(t_act + (py * RS_IW + px) * 128 + slot * 16);
+            *reinterpret_cast<uint4*>(rr) = *reinterpret_cast<const uint4*>(t_raw + (py * RS_IW + px) * 128 + slot * 16);
+#pragma unroll
+            for (int e = 0; e < PER16; ++e) { va[e] = fmaf(wgt, to_f32(ra[e]), va[e]); vr[e] = fmaf(wgt, to_f32(rr[e]), vr[e]); }
+        };
+        if (RESAMPLE == 1) {
+            // input pixel (oy>>1, ox>>1) sits at tile coords (+1, +1) relative to the core origin
+            const int py = (oy_l >> 1) + 1, px = (ox_l >> 1) + 1;
+            const int ny = (oy_l & 1) ? py + 1 : py - 1, nx = (ox_l & 1) ? px + 1 : px - 1;
+            tap(py, px, 0.5625f); tap(py, nx, 0.1875f); tap(ny, px, 0.1875f); tap(ny, nx, 0.0625f);
+        } else {
+            const float k[4] = {0.125f, 0.375f, 0.375f, 0.125f};
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) tap(2 * oy_l + i, 2 * ox_l + j, k[i] * k[j]);
+        }
+        alignas(16) T oa[PER16];
+        alignas(16) T orr[PER16];
+#pragma unroll
+        for (int e = 0; e < PER16; ++e) { from_f32(oa[e], va[e]); from_f32(orr[e], vr[e]); }
+        const long long o = (obase + (long long)oy * OW + ox) * C + c;
+        *reinterpret_cast<uint4*>(out_act + o) = *reinterpret_cast<const uint4*>(oa);
+        if (out_raw) *reinterpret_cast<uint4*>(out_raw + o) = *reinterpret_cast<const uint4*>(orr);
+    }
+}
+
 template <typename T, int RESAMPLE>
 __global__ void fir_kernel(const T* __restrict__ x, const T* __restrict__ add, T* __restrict__ out,
                            int H, int W, int C, int ppb, int C8, int PL) {
@@ -176,7 +296,7 @@ template <typename T>
 static int gn_stats_t(const void* xa, int Ca, const void* xb, int Cb, int B, int HW, int G, double* stats,
                       hipStream_t st) {
     const GnGeom g = gn_geom(Ca + Cb);
-    const int per_thread = 256;
+    const int per_thread = pixels_per_thread((long long)B * HW, g.PL, 256);
     int ppb = g.PL * per_thread;
     const int nblk = cdiv(HW, ppb);
     hipLaunchKernelGGL((gn_stats_kernel<T>), dim3(nblk, B), dim3(g.NT), 0, st, (const T*)xa, Ca, (const T*)xb, Cb,
@@ -190,10 +310,20 @@ static int gn_apply_t(const void* xa, int Ca, const void* xb, int Cb, int B, int
                       const double* stats, const float* gamma, const float* beta, float eps, int silu,
                       void* out_act, void* out_raw, hipStream_t st) {
     const GnGeom g = gn_geom(Ca + Cb);
-    const int OHW = (R == 1 ? 4 : 1) * H * W / (R == 2 ? 4 : 1);
-    int ppb = g.PL * 64;
+    if (R != 0) {
+        constexpr int CG = 8 * Elem<T>::PER16;
+        const int tiles_x = cdiv(W, 16), tiles_y = cdiv(H, 8), ncg = cdiv(Ca + Cb, CG);
+        hipLaunchKernelGGL((gn_apply_resample_kernel<T, R == 0 ? 1 : R>), dim3(tiles_x * tiles_y * ncg, B), dim3(256), 0, st,
+                           (const T*)xa, Ca, (const T*)xb, Cb, H, W, G, stats, gamma, beta, eps, silu, (T*)out_act,
+                           (T*)out_raw, tiles_x, tiles_y);
+        STORM_LAUNCH_CHECK();
+        return STORM_OK;
+    }
+    const int OHW = H * W;
+    const int per_thread = pixels_per_thread((long long)B * OHW, g.PL, 32);
+    int ppb = g.PL * per_thread;
     const int nblk = cdiv(OHW, ppb);
-    hipLaunchKernelGGL((gn_apply_kernel<T, R>), dim3(nblk, B), dim3(g.NT), 0, st, (const T*)xa, Ca, (const T*)xb,
+    hipLaunchKernelGGL((gn_apply_kernel<T, 0>), dim3(nblk, B), dim3(g.NT), 0, st, (const T*)xa, Ca, (const T*)xb,
                        Cb, H, W, G, stats, gamma, beta, eps, silu, (T*)out_act, (T*)out_raw, ppb, g.C8, g.PL);
     STORM_LAUNCH_CHECK();
     return STORM_OK;
@@ -203,7 +333,7 @@ template <typename T, int R>
 static int fir_t(const void* x, const void* add, void* out, int B, int H, int W, int C, hipStream_t st) {
     const GnGeom g = gn_geom(C);
     const int OHW = R == 1 ? 4 * H * W : H * W / 4;
-    int ppb = g.PL * 64;
+    int ppb = g.PL * pixels_per_thread((long long)B * OHW, g.PL, 32);
     const int nblk = cdiv(OHW, ppb);
     hipLaunchKernelGGL((fir_kernel<T, R>), dim3(nblk, B), dim3(g.NT), 0, st, (const T*)x, (const T*)add, (T*)out,
                        H, W, C, ppb, g.C8, g.PL);

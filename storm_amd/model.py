@@ -136,10 +136,6 @@ class _Base(nn.Module):
         ckpt = load_checkpoint_file(checkpoint_path, map_location)
         hp = dict(ckpt.get("hyper_parameters", {}))
         hp.update(overrides)
-        extra = hp.pop("kwargs", None)
-        if isinstance(extra, dict):
-            for k, v in extra.items():
-                hp.setdefault(k, v)
         if not isinstance(hp.get("data_module_cls"), type):
             hp["data_module_cls"] = SpecsDataModule
         model = cls(**hp)

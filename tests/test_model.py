@@ -1,0 +1,99 @@
+"""End-to-end enhance() wav -> wav against the reference's outputs (tests/golden/f6_enhance.npz),
+the checkpoint reader / EMA swap, and batched == per-utterance."""
+import os
+
+import pytest
+import torch
+
+from oracle import ncsnpp_ref as NR
+from tests.backend import dev  # noqa: F401
+from tests.util import rel_l2
+
+T = torch.from_numpy
+COMMON = dict(sde="ouve", theta=1.5, sigma_min=0.05, sigma_max=0.5, spec_factor=0.15, spec_abs_exponent=0.5, nf=8)
+
+
+def score_model(dev, seed=21):
+    from storm_amd.model import ScoreModel
+    m = ScoreModel(backbone="ncsnpp", **dict(COMMON))
+    m.dnn.load_state_dict(NR.seeded_state_dict(NR.NCSNppConfig(nf=8, input_channels=4), seed=seed))
+    m._error_loading_ema = True
+    return m.eval().to(dev)
+
+
+def test_enhance_score_only(dev, golden):
+    g = golden["f6_enhance"]
+    m = score_model(dev)
+    it = iter(T(g["so_noise"]))
+    x = m.enhance(T(g["wav_in"]), N=3, corrector="ald", corrector_steps=1, snr=0.5, noise_fn=lambda: next(it))
+    assert x.shape == (8000,) and x.device.type == "cpu"
+    assert rel_l2(x, g["so_out"]) < 1e-3
+
+
+@pytest.mark.parametrize("cond", ["both", "noisy", "post_denoiser"])
+def test_enhance_storm(dev, golden, cond):
+    from storm_amd.model import StochasticRegenerationModel
+    g = golden["f6_enhance"]
+    m = StochasticRegenerationModel(backbone_denoiser="ncsnpp", backbone_score="ncsnpp", condition=cond, **dict(COMMON))
+    m.denoiser_net.load_state_dict(NR.seeded_state_dict(NR.NCSNppConfig(nf=8, input_channels=2, discriminative=True), seed=31))
+    m.score_net.load_state_dict(NR.seeded_state_dict(NR.NCSNppConfig(nf=8, input_channels=6 if cond == "both" else 4), seed=32))
+    m._error_loading_ema = True
+    m = m.eval().to(dev)
+    it = iter(T(g[f"storm_{cond}_noise"]))
+    x = m.enhance(T(g["wav_in"]), N=3, corrector="none", snr=0.5, noise_fn=lambda: next(it))
+    assert rel_l2(x, g[f"storm_{cond}_out"]) < 1e-3
+
+
+def test_enhance_batch_equals_single(dev):
+    """new surface: B utterances per call == B reference-style single calls (same injected noise)"""
+    m = score_model(dev)
+    g = torch.Generator().manual_seed(3)
+    wav = torch.randn(2, 4000, generator=g) * 0.1
+    shape = (1, 1, 256, 64)
+    zs = [torch.randn(2, *shape[1:], dtype=torch.complex64, generator=g) for _ in range(1 + 2 * 2)]
+    it = iter(zs)
+    xb = m.enhance_batch(wav, N=2, corrector="ald", snr=0.5, noise_fn=lambda: next(it)).cpu()
+    for b in range(2):
+        itb = iter([z[b:b + 1] for z in zs])
+        xs = m.enhance(wav[b:b + 1], N=2, corrector="ald", snr=0.5, noise_fn=lambda: next(itb))
+        assert rel_l2(xb[b], xs) < 1e-5
+
+
+def test_checkpoint_reader_and_ema(dev, tmp_path):
+    """Lightning-style .ckpt: state_dict + hyper_parameters + torch_ema state; eval() runs on EMA weights."""
+    from storm_amd.model import ScoreModel
+    cfg = NR.NCSNppConfig(nf=8, input_channels=4)
+    live, ema = NR.seeded_state_dict(cfg, seed=1), NR.seeded_state_dict(cfg, seed=2)
+    ref = ScoreModel(backbone="ncsnpp", **dict(COMMON))
+    ref.dnn.load_state_dict(ema)
+    shadow = [p.detach().clone() for p in ref.parameters()]
+    ckpt = {"state_dict": {"dnn." + k: v for k, v in live.items()},
+            "hyper_parameters": dict(backbone="ncsnpp", **COMMON),
+            "ema": {"decay": 0.999, "num_updates": 10, "shadow_params": shadow, "collected_params": None}}
+    path = os.path.join(tmp_path, "m.ckpt")
+    torch.save(ckpt, path)
+    m = ScoreModel.load_from_checkpoint(path, base_dir="", batch_size=1, num_workers=0, kwargs=dict(gpu=False))
+    assert all(torch.equal(m.dnn.state_dict()[k], live[k]) for k in live)
+    m.eval(no_ema=False)
+    assert all(torch.equal(m.dnn.state_dict()[k], ema[k]) for k in ema)      # EMA weights live (model.py:97-108)
+    m.train(True)
+    assert all(torch.equal(m.dnn.state_dict()[k], live[k]) for k in live)
+    m.eval(no_ema=False)
+    m = m.to(dev)
+    x = torch.randn(1, 1, 32, 64, dtype=torch.complex64, generator=torch.Generator().manual_seed(0)).to(dev)
+    t = torch.tensor([0.5], device=dev)
+    with torch.no_grad():
+        want = -NR.ncsnpp_forward(ema, cfg, torch.cat([x.cpu(), x.cpu()], 1), t.cpu())
+    assert rel_l2(m(x, t, x).cpu(), want) < 1e-4
+
+
+def test_no_cpu_fallback():
+    """the product path refuses CPU tensors when the real library is bound"""
+    from storm_amd import _lib
+    if not os.path.exists(_lib.LIB_PATH):
+        pytest.skip("libstorm_hip.so not built")
+    _lib._lib, _lib._sim = None, False
+    _lib.lib()
+    from storm_amd import ops
+    with pytest.raises(_lib.StormError):
+        ops.peak_abs(torch.zeros(1, 100))
