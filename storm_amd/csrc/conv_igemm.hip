@@ -20,6 +20,7 @@
 //     skip / bias reads) are 16-32 B per lane, full 128-B lines per 4-8 lanes.
 //   * bf16 operands: v_mfma_f32_32x32x16_bf16 (fp32 accumulate).  fp32 operands:
 //     v_mfma_f32_32x32x2_f32 (exact fp32, used by the parity path).
+#include <cstdlib>
 #include <cstring>
 #include "common.h"
 #include "conv_index.h"
@@ -43,21 +44,24 @@ template <> struct Mma<float> {
     }
 };
 
-template <int TAPS, int WM, int WAVES_M>
+template <int TAPS, int WM, int WAVES_M, int WAVES_N>
 struct ConvCfg {
-    static constexpr int WAVES_N = 4 / WAVES_M;
+    static constexpr int NWAVES = WAVES_M * WAVES_N;
+    static constexpr int THREADS = 64 * NWAVES;
     static constexpr int WN = TILE_H / WAVES_N;          // pixel tile rows (of 32 px) per wave
     static constexpr int BN = WAVES_M * WM * 32;          // output channels per workgroup
     static constexpr int NPIX = Geo<TAPS>::NPIX;
     static constexpr int PATCH_BYTES = NPIX * PIX_BYTES;
     static constexpr int WBUF_BYTES = BN * PIX_BYTES;
-    static constexpr int STAGE_BYTES = 4 * 64 * WM * 128;
+    static constexpr int PR = (WN >= 2 && NWAVES * 64 * WM * 128 <= 96 * 1024) ? 2 : 1;   // pixel rows staged per epilogue pass
+    static constexpr int STAGE_BYTES = NWAVES * 32 * PR * WM * 128;
     static constexpr int MAIN_BYTES = PATCH_BYTES + 2 * WBUF_BYTES;
     static constexpr int LDS_BYTES = MAIN_BYTES > STAGE_BYTES ? MAIN_BYTES : STAGE_BYTES;
     static constexpr int PU = (NPIX * 8 + THREADS - 1) / THREADS;   // patch 16-B units per thread
     static constexpr int WU = BN * 8 / THREADS;                      // weight units per thread
-    static_assert(WN % 2 == 0, "epilogue stages two pixel rows per pass");
+    static_assert(WN % PR == 0, "epilogue passes");
     static_assert(BN * 8 % THREADS == 0, "");
+    static_assert(WAVES_N * WN == TILE_H, "");
 };
 
 // Kernel-side view of storm_conv_args: the K dimension as up to four single-source "runs"
@@ -79,12 +83,13 @@ struct ConvParams {
     const void* skip; long long skip_bstride; float scale; int pad_;
 };
 
-template <typename T, int TAPS, int WM, int WAVES_M>
-__global__ __launch_bounds__(256, 2)
+template <typename T, int TAPS, int WM, int WAVES_M, int WAVES_N>
+__global__ __launch_bounds__(64 * WAVES_M * WAVES_N, 2 * WAVES_M * WAVES_N / 4)
 void conv_igemm_kernel(const ConvParams a, const int n_ct, const int tiles_per_xcd,
                        const int ntiles, const int tiles_x, const int tiles_per_img) {
-    typedef ConvCfg<TAPS, WM, WAVES_M> Cfg;
+    typedef ConvCfg<TAPS, WM, WAVES_M, WAVES_N> Cfg;
     typedef typename Mma<T>::Frag Frag;
+    constexpr int THREADS = Cfg::THREADS;
     constexpr int PER16 = Elem<T>::PER16;
     constexpr int KC = 8 * PER16;              // channels per K-chunk (128 B)
     constexpr int KG = 2 * PER16;              // channels per k-group (one fragment slot pair)
@@ -182,22 +187,33 @@ void conv_igemm_kernel(const ConvParams a, const int n_ct, const int tiles_per_x
         int prow[WN];
 #pragma unroll
         for (int ni = 0; ni < WN; ++ni) prow[ni] = patch_pixel<TAPS>(lane, wn * WN + ni, dy, dx);
-        auto kgroup = [&](int j) {
+        auto load_frags = [&](int j, Frag (&fa)[WM], Frag (&fb)[WN]) {
             const int slot = frag_slot(lane, j);
-            Frag fa[WM], fb[WN];
 #pragma unroll
             for (int mi = 0; mi < WM; ++mi) fa[mi] = *reinterpret_cast<const Frag*>(wb + lds_off(arow[mi], slot));
 #pragma unroll
             for (int ni = 0; ni < WN; ++ni) fb[ni] = *reinterpret_cast<const Frag*>(patch + lds_off(prow[ni], slot));
+        };
+        auto mma = [&](const Frag (&fa)[WM], const Frag (&fb)[WN]) {
 #pragma unroll
             for (int mi = 0; mi < WM; ++mi)
 #pragma unroll
                 for (int ni = 0; ni < WN; ++ni) Mma<T>::run(fa[mi], fb[ni], acc[mi][ni]);
         };
-        // one rolled loop (a second, unrolled copy makes the register allocator keep two homes for the
-        // 128 accumulator registers and shuffle / spill them at the join)
+        // ONE rolled loop over pairs of k-groups with two fragment sets: the LDS reads of the next group
+        // fly under the current group's 8 MFMAs.  (A second, unrolled copy of the MFMA code makes the
+        // register allocator keep two homes for the 128 accumulator registers.)  An odd nk runs one
+        // extra group on zero-filled slots.
+        Frag fa0[WM], fb0[WN], fa1[WM], fb1[WN];
+        load_frags(0, fa0, fb0);
+        const int npair = (nk + 1) >> 1;
 #pragma unroll 1
-        for (int j = 0; j < nk; ++j) kgroup(j);
+        for (int jj = 0; jj < npair; ++jj) {
+            load_frags(2 * jj + 1, fa1, fb1);
+            mma(fa0, fb0);
+            load_frags(min(2 * jj + 2, 3), fa0, fb0);     // (re-reads a valid group on the last pass; unused)
+            mma(fa1, fb1);
+        }
     };
 
     // ---- main loop: runs x K-chunks x taps ------------------------------------------------------
@@ -245,31 +261,33 @@ void conv_igemm_kernel(const ConvParams a, const int n_ct, const int tiles_per_x
 
     // ---- epilogue: LDS transpose -> (bias, temb bias, skip, scale) -> wide stores ---------
     __syncthreads();
-    char* const stage = smem + wave * (64 * WM * 128);
+    constexpr int PR = Cfg::PR;                 // pixel rows (of 32 px) staged per pass and wave
+    constexpr int SROWS = 32 * PR;
+    char* const stage = smem + wave * (SROWS * WM * 128);
     constexpr int LPR = WM * 4;                 // lanes per staged row (8 couts each)
     constexpr int RPI = 64 / LPR;               // rows per read iteration
     const int skipC = a.outC;
 #pragma unroll
-    for (int pass = 0; pass < WN / 2; ++pass) {
+    for (int pass = 0; pass < WN / PR; ++pass) {
 #pragma unroll
-        for (int nn = 0; nn < 2; ++nn)
+        for (int nn = 0; nn < PR; ++nn)
 #pragma unroll
             for (int mi = 0; mi < WM; ++mi)
 #pragma unroll
                 for (int g = 0; g < 4; ++g) {
                     const int row = nn * 32 + (lane & 31);
-                    const f32x16& c = acc[mi][pass * 2 + nn];
+                    const f32x16& c = acc[mi][pass * PR + nn];
                     *reinterpret_cast<float4*>(stage + stage_off<WM>(row, stage_wslot(lane, mi, g))) =
                         make_float4(c[4 * g], c[4 * g + 1], c[4 * g + 2], c[4 * g + 3]);
                 }
         __syncthreads();
 #pragma unroll 2
-        for (int it = 0; it < LPR; ++it) {
+        for (int it = 0; it < SROWS / RPI; ++it) {
             const int row = it * RPI + lane / LPR, c8 = lane % LPR;
             const float4 v0 = *reinterpret_cast<const float4*>(stage + stage_off<WM>(row, 2 * c8));
             const float4 v1 = *reinterpret_cast<const float4*>(stage + stage_off<WM>(row, 2 * c8 + 1));
             float v[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
-            const int trow = wn * WN + pass * 2 + (row >> 5), n = row & 31;
+            const int trow = wn * WN + pass * PR + (row >> 5), n = row & 31;
             long long pix;
             bool ok;
             if (TAPS == 9) {
@@ -313,7 +331,7 @@ void conv_igemm_kernel(const ConvParams a, const int n_ct, const int tiles_per_x
                 else store8(reinterpret_cast<T*>(a.out) + o, v);
             }
         }
-        if (pass + 1 < WN / 2) __syncthreads();
+        if (pass + 1 < WN / PR) __syncthreads();
     }
 }
 
@@ -342,10 +360,10 @@ static ConvParams make_params(const storm_conv_args& a) {
     return p;
 }
 
-template <typename T, int TAPS, int WM, int WAVES_M>
+template <typename T, int TAPS, int WM, int WAVES_M, int WAVES_N>
 static int launch_conv(const storm_conv_args& a, hipStream_t st) {
-    typedef ConvCfg<TAPS, WM, WAVES_M> Cfg;
-    auto kern = conv_igemm_kernel<T, TAPS, WM, WAVES_M>;
+    typedef ConvCfg<TAPS, WM, WAVES_M, WAVES_N> Cfg;
+    auto kern = conv_igemm_kernel<T, TAPS, WM, WAVES_M, WAVES_N>;
     static bool attr_set = false;          // per instantiation; benign race (idempotent)
     if (!attr_set) {
         STORM_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
@@ -365,7 +383,7 @@ static int launch_conv(const storm_conv_args& a, hipStream_t st) {
     const long long grid = 8LL * tiles_per_xcd * n_ct;
     STORM_CHECK(grid > 0 && grid < (1LL << 31), "storm_conv: grid %lld out of range", grid);
     const ConvParams prm = make_params(a);
-    hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(THREADS), Cfg::LDS_BYTES, st, prm, n_ct,
+    hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(Cfg::THREADS), Cfg::LDS_BYTES, st, prm, n_ct,
                        tiles_per_xcd, (int)ntiles, tiles_x, tiles_per_img);
     STORM_LAUNCH_CHECK();
     return STORM_OK;
@@ -376,8 +394,15 @@ static int dispatch_conv(const storm_conv_args& a, hipStream_t st) {
     bool any9 = false;
     for (int s = 0; s < a.nseg; ++s) any9 = any9 || a.seg[s].ntaps == 9;
     const bool small = a.outC <= 32;
-    if (any9) return small ? launch_conv<T, 9, 1, 1>(a, st) : launch_conv<T, 9, 2, 2>(a, st);
-    return small ? launch_conv<T, 1, 1, 1>(a, st) : launch_conv<T, 1, 2, 2>(a, st);
+    // big tile: 128 cout x 256 px.  Variant 0: 4 waves (64 cout x 128 px each, 128 accumulator VGPRs);
+    // variant 1: 8 waves (64 x 64 each) -> 16 waves / CU hide LDS + barrier latency by occupancy.
+    static const int variant = getenv("STORM_CONV_VARIANT") ? atoi(getenv("STORM_CONV_VARIANT")) : 1;
+    if (any9) {
+        if (small) return launch_conv<T, 9, 1, 1, 4>(a, st);
+        return variant == 0 ? launch_conv<T, 9, 2, 2, 2>(a, st) : launch_conv<T, 9, 2, 2, 4>(a, st);
+    }
+    if (small) return launch_conv<T, 1, 1, 1, 4>(a, st);
+    return variant == 0 ? launch_conv<T, 1, 2, 2, 2>(a, st) : launch_conv<T, 1, 2, 2, 4>(a, st);
 }
 
 }  // namespace storm

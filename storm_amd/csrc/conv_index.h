@@ -14,7 +14,6 @@ namespace storm { namespace cidx {
 constexpr int TILE_H = 8;          // output tile: 8 rows x 32 pixels = 256 pixels
 constexpr int TILE_W = 32;
 constexpr int PIX_BYTES = 128;     // one K-chunk of one pixel / weight row in LDS: 8 slots x 16 B
-constexpr int THREADS = 256;
 
 template <int TAPS> struct Geo;
 template <> struct Geo<9> { static constexpr int PH = TILE_H + 2, PW = TILE_W + 2, NPIX = PH * PW; };

@@ -1,0 +1,45 @@
+#!/usr/bin/env python
+"""Micro-probe: run a few representative launches of the hot kernels (for rocprofv3 --pmc passes)."""
+import argparse
+import sys
+import time
+
+import torch
+
+sys.path.insert(0, ".")
+from storm_amd import ops  # noqa: E402
+
+p = argparse.ArgumentParser()
+p.add_argument("--reps", type=int, default=3)
+p.add_argument("--B", type=int, default=16)
+args = p.parse_args()
+dev = torch.device("cuda:0")
+dt = torch.bfloat16
+g = torch.Generator().manual_seed(0)
+
+
+def rnd(*s):
+    return torch.randn(*s, generator=g)
+
+
+cases = [("c256_128x256", 256, 256, 128, 256), ("c128_256x512", 128, 128, 256, 512), ("c512_64x128", 512, 256, 64, 128)]
+for name, cin, cout, H, W in cases:
+    x = rnd(args.B, H, W, cin).to(dt).to(dev)
+    w = ops.pack_conv_weight((rnd(cout, cin, 3, 3) * 0.05).to(dev), dt)
+    b = rnd(cout).to(dev)
+    for _ in range(args.reps):
+        y = ops.conv([ops.Seg(x, w, 9)], cout, bias=b)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.reps):
+        y = ops.conv([ops.Seg(x, w, 9)], cout, bias=b)
+    torch.cuda.synchronize()
+    ms = (time.perf_counter() - t0) / args.reps * 1e3
+    fl = 2 * args.B * H * W * cout * cin * 9
+    print(f"{name}: {ms:.3f} ms  {fl / ms / 1e9:.0f} TF")
+    # GN on the conv output
+    gam, bet = torch.ones(cout, device=dev), torch.zeros(cout, device=dev)
+    for _ in range(args.reps):
+        st = ops.gn_stats(y)
+        a = ops.gn_apply(y, st, gam, bet)
+    torch.cuda.synchronize()
