@@ -44,6 +44,12 @@ template <> struct Mma<float> {
     }
 };
 
+// 16-byte global load at (wave-uniform base pointer) + (32-bit per-lane byte offset): lowers to the
+// saddr + voffset addressing form, so no 64-bit per-lane address is ever kept (or spilled).
+__device__ __forceinline__ uint4 ld16(const void* base, uint32_t byte_off) {
+    return *reinterpret_cast<const uint4*>(static_cast<const char*>(base) + byte_off);
+}
+
 template <int TAPS, int WM, int WAVES_M, int WAVES_N>
 struct ConvCfg {
     static constexpr int NWAVES = WAVES_M * WAVES_N;
@@ -130,8 +136,7 @@ void conv_igemm_kernel(const ConvParams a, const int n_ct, const int tiles_per_x
             const int row = u >> 3, slot = u & 7;
             const int co = cout0 + row, c = kbeg + slot * PER16;
             uint4 v = make_uint4(0u, 0u, 0u, 0u);
-            if (co < w_rows && c < klim)
-                v = *reinterpret_cast<const uint4*>(wbase + (long long)co * CinP + c);
+            if (co < w_rows && c < klim) v = ld16(wbase, (uint32_t)(co * CinP + c) * (uint32_t)sizeof(T));
             wreg[i] = v;
         }
     };
@@ -154,19 +159,19 @@ void conv_igemm_kernel(const ConvParams a, const int n_ct, const int tiles_per_x
             for (int k = 0; k < HALF; ++k) {
                 const int u = tid + (h0 + k) * THREADS;
                 const int p = u >> 3, slot = u & 7;
-                long long pix;
+                int pix;
                 bool ok = (h0 + k < Cfg::PU) && (u < Cfg::NPIX * 8) && (slot * PER16 < cvalid);
                 if (TAPS == 9) {
                     const int py = p / PW, px = p - py * PW;
                     const int gy = ty0 + py - 1, gx = tx0 + px - 1;
                     ok = ok && gy >= 0 && gy < a.H && gx >= 0 && gx < a.W;
-                    pix = (long long)gy * a.W + gx;
+                    pix = gy * a.W + gx;
                 } else {
-                    pix = lin0 + p;
-                    ok = ok && pix < npix;
+                    pix = (int)lin0 + p;
+                    ok = ok && pix < (int)npix;
                 }
                 uint4 v = make_uint4(0u, 0u, 0u, 0u);
-                if (ok) v = *reinterpret_cast<const uint4*>(src + pix * C + cbeg + slot * PER16);
+                if (ok) v = ld16(src, (uint32_t)(pix * C + cbeg + slot * PER16) * (uint32_t)sizeof(T));
                 preg[k] = v;
             }
 #pragma unroll
@@ -288,15 +293,15 @@ void conv_igemm_kernel(const ConvParams a, const int n_ct, const int tiles_per_x
             const float4 v1 = *reinterpret_cast<const float4*>(stage + stage_off<WM>(row, 2 * c8 + 1));
             float v[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
             const int trow = wn * WN + pass * PR + (row >> 5), n = row & 31;
-            long long pix;
+            int pix;                               // pixel index inside this batch image (fits 32 bits)
             bool ok;
             if (TAPS == 9) {
                 const int gy = ty0 + trow, gx = tx0 + n;
                 ok = gy < a.H && gx < a.W;
-                pix = (long long)gy * a.W + gx;
+                pix = gy * a.W + gx;
             } else {
-                pix = lin0 + trow * TILE_W + n;
-                ok = pix < npix;
+                pix = (int)lin0 + trow * TILE_W + n;
+                ok = pix < (int)npix;
             }
             const int co = cout0 + wm * WM * 32 + c8 * 8;
             if (ok && co < a.outC) {
@@ -320,15 +325,15 @@ void conv_igemm_kernel(const ConvParams a, const int n_ct, const int tiles_per_x
                 }
                 if (a.skip) {
                     float sk[8];
-                    load8(reinterpret_cast<const T*>(a.skip) + (long long)b * a.skip_bstride + pix * skipC + co, sk);
+                    load8(reinterpret_cast<const T*>(a.skip) + (long long)b * a.skip_bstride + (uint32_t)(pix * skipC + co), sk);
 #pragma unroll
                     for (int e = 0; e < 8; ++e) v[e] += sk[e];
                 }
 #pragma unroll
                 for (int e = 0; e < 8; ++e) v[e] *= a.scale;
-                const long long o = (long long)b * a.out_bstride + pix * a.outC + co;
-                if (a.out_f32) store8(reinterpret_cast<float*>(a.out) + o, v);
-                else store8(reinterpret_cast<T*>(a.out) + o, v);
+                const uint32_t o = (uint32_t)(pix * a.outC + co);
+                if (a.out_f32) store8(reinterpret_cast<float*>(a.out) + (long long)b * a.out_bstride + o, v);
+                else store8(reinterpret_cast<T*>(a.out) + (long long)b * a.out_bstride + o, v);
             }
         }
         if (pass + 1 < WN / PR) __syncthreads();
