@@ -202,7 +202,7 @@ def main():
         peak = BF16_MFMA_PEAK_TFLOPS if args.precision == "bf16" else F32_MFMA_PEAK_TFLOPS
         ach = flops / (ms * 1e-3) / 1e12
         names = {0: "memset", 1: "pack_input", 2: "temb", 3: "dense", 4: "conv", 5: "gn_stats", 6: "gn_apply",
-                 7: "fir_up", 8: "fir_down", 9: "softmax", 10: "output_head"}
+                 7: "fir_up", 8: "fir_down", 9: "softmax", 10: "output_head", 11: "gn_finalize"}
         by_kind = {}
         for r in rows:
             by_kind[names[r["code"]]] = by_kind.get(names[r["code"]], 0.0) + r["ms"]

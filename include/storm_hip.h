@@ -95,9 +95,13 @@ typedef struct storm_conv_args {
     float scale;
     int out_f32;                /* !=0: write fp32 whatever the operand dtype (scores)    */
     int dtype;                  /* STORM_F32 / STORM_BF16 operands + activations          */
+    float* gn_part;             /* optional fused GroupNorm statistics: per-tile (sum, sumsq) of
+                                   the output, fp32 [B][storm_conv_tiles()][outC][2]; NULL = off */
 } storm_conv_args;
 
 int storm_conv(const storm_conv_args* a, storm_stream_t s);
+/* number of pixel tiles per batch item the kernel will use for this call (size of gn_part) */
+int storm_conv_tiles(const storm_conv_args* a);
 
 /* ------------------------------------------------------------------------------------------
  * GroupNorm(min(C/4,32) groups, eps) [+ SiLU] [+ FIR x2 up / down of BOTH the activated and
@@ -109,6 +113,10 @@ int storm_conv(const storm_conv_args* a, storm_stream_t s);
  * ------------------------------------------------------------------------------------------ */
 int storm_gn_stats(const void* xa, int Ca, const void* xb, int Cb, int B, int HW,
                    int groups, double* stats, int dtype, storm_stream_t s);
+/* stats from the per-tile partials a producing storm_conv left in gn_part (no pass over the
+ * tensor): channel c < Ca comes from part_a [B][tiles_a][Ca][2], else part_b [B][tiles_b][Cb][2]. */
+int storm_gn_finalize(const float* part_a, int Ca, int tiles_a, const float* part_b, int Cb, int tiles_b,
+                      int B, int groups, double* stats, storm_stream_t s);
 /* resample: 0 none, 1 FIR up x2, 2 FIR down x2.  out_act gets act(GN(x)) (resampled),
  * out_raw (may be NULL; required non-NULL only if wanted) gets the resampled raw concat. */
 int storm_gn_apply(const void* xa, int Ca, const void* xb, int Cb, int B, int H, int W,
@@ -222,7 +230,7 @@ int storm_istft(const float* spec, const float* peak, float* wav, float* frames,
 enum {
     STORM_OP_MEMSET = 0, STORM_OP_PACK_INPUT = 1, STORM_OP_TEMB = 2, STORM_OP_DENSE = 3,
     STORM_OP_CONV = 4, STORM_OP_GN_STATS = 5, STORM_OP_GN_APPLY = 6, STORM_OP_FIR_UP = 7,
-    STORM_OP_FIR_DOWN = 8, STORM_OP_SOFTMAX = 9, STORM_OP_OUTPUT_HEAD = 10
+    STORM_OP_FIR_DOWN = 8, STORM_OP_SOFTMAX = 9, STORM_OP_OUTPUT_HEAD = 10, STORM_OP_GN_FINALIZE = 11
 };
 #define STORM_OP_NPTR 12
 #define STORM_OP_NINT 24

@@ -36,7 +36,7 @@ class ConvArgs(C.Structure):
                 ("out", C.c_void_p), ("outC", C.c_int), ("Cout", C.c_int), ("out_bstride", C.c_longlong),
                 ("bias", C.c_void_p), ("tbias", C.c_void_p), ("tbias_stride", C.c_int),
                 ("skip", C.c_void_p), ("skip_bstride", C.c_longlong), ("scale", C.c_float),
-                ("out_f32", C.c_int), ("dtype", C.c_int)]
+                ("out_f32", C.c_int), ("dtype", C.c_int), ("gn_part", C.c_void_p)]
 
 
 class Ouve(C.Structure):
@@ -59,6 +59,8 @@ _SIGNATURES = {
     "storm_pack_conv_weight": ([_vp, _vp, _i, _i, _i, _i, _i, _i, _vp], C.c_int),
     "storm_pack_matrix": ([_vp, _vp, _i, _i, _i, _i, _i, _i, _vp], C.c_int),
     "storm_conv": ([C.POINTER(ConvArgs), _vp], C.c_int),
+    "storm_conv_tiles": ([C.POINTER(ConvArgs)], C.c_int),
+    "storm_gn_finalize": ([_vp, _i, _i, _vp, _i, _i, _i, _i, _vp, _vp], C.c_int),
     "storm_gn_stats": ([_vp, _i, _vp, _i, _i, _i, _i, _vp, _i, _vp], C.c_int),
     "storm_gn_apply": ([_vp, _i, _vp, _i, _i, _i, _i, _i, _vp, _vp, _vp, _f, _i, _i, _vp, _vp, _i, _vp], C.c_int),
     "storm_fir_up2": ([_vp, _vp, _vp, _i, _i, _i, _i, _i, _vp], C.c_int),

@@ -17,7 +17,7 @@ from .. import _lib as L
 
 # op codes (include/storm_hip.h)
 OP_MEMSET, OP_PACK_INPUT, OP_TEMB, OP_DENSE, OP_CONV, OP_GN_STATS, OP_GN_APPLY, OP_FIR_UP, OP_FIR_DOWN, \
-    OP_SOFTMAX, OP_OUTPUT_HEAD = range(11)
+    OP_SOFTMAX, OP_OUTPUT_HEAD, OP_GN_FINALIZE = range(12)
 
 # buffer slots of storm_program_run
 BUF_WS, BUF_PARAMS, BUF_IN0, BUF_IN1, BUF_IN2, BUF_T, BUF_OUT = range(7)
@@ -268,11 +268,14 @@ class Act:
     W: int
     C: int
     external: Optional[int] = None     # buffer slot if not in the workspace
+    part: Optional[int] = None         # fused GroupNorm partials [B][tiles][C][2] fp32 left by the producing conv
+    tiles: int = 0
 
 
 class Program:
-    def __init__(self, cfg: NCSNppConfig, layout: ParamLayout, B: int, F: int, T: int):
+    def __init__(self, cfg: NCSNppConfig, layout: ParamLayout, B: int, F: int, T: int, fuse_stats: bool = True):
         self.cfg, self.layout, self.B, self.F, self.T = cfg, layout, B, F, T
+        self.fuse_stats = fuse_stats       # GroupNorm statistics from the producing conv's epilogue (no stats pass)
         self.dtype = layout.dtype
         self.esize = layout.esize
         self.ops: List[L.Op] = []
@@ -312,6 +315,8 @@ class Program:
 
     def free(self, a: Act):
         self.arena.release(a.off)
+        if a.part is not None:
+            self.arena.release(a.part)
 
     def new_stats(self, G):
         off = self.stats_cursor
@@ -324,12 +329,21 @@ class Program:
         Cc = xa.C + (xb.C if xb else 0)
         G = min(Cc // 4, 32)
         st = self.new_stats(G)
-        op = self._op(OP_GN_STATS)
-        self._ws(op, 0, xa)
-        if xb:
-            self._ws(op, 1, xb)
-        self._ws(op, 2, st)
-        op.i[0], op.i[1], op.i[2], op.i[3], op.i[4] = xa.C, (xb.C if xb else 0), self.B, xa.H * xa.W, G
+        if xa.part is not None and (xb is None or xb.part is not None):
+            op = self._op(OP_GN_FINALIZE)          # statistics were accumulated by the producing conv epilogues
+            self._ws(op, 0, xa.part)
+            if xb:
+                self._ws(op, 1, xb.part)
+            self._ws(op, 2, st)
+            op.i[0], op.i[1], op.i[2], op.i[3] = xa.C, xa.tiles, (xb.C if xb else 0), (xb.tiles if xb else 0)
+            op.i[4], op.i[5] = self.B, G
+        else:
+            op = self._op(OP_GN_STATS)
+            self._ws(op, 0, xa)
+            if xb:
+                self._ws(op, 1, xb)
+            self._ws(op, 2, st)
+            op.i[0], op.i[1], op.i[2], op.i[3], op.i[4] = xa.C, (xb.C if xb else 0), self.B, xa.H * xa.W, G
         OH, OW = (2 * xa.H, 2 * xa.W) if resample == 1 else ((xa.H // 2, xa.W // 2) if resample == 2 else (xa.H, xa.W))
         out = self.new_act(OH, OW, Cc)
         raw = self.new_act(OH, OW, Cc) if resample else None
@@ -349,7 +363,7 @@ class Program:
         return out, raw
 
     def conv(self, segs, Cout, H, W, outC=None, bias_key=None, tbias=None, skip: Optional[Act] = None, scale=1.0,
-             out_f32=False, out_bstride=-1, src0_bstride=-1):
+             out_f32=False, out_bstride=-1, src0_bstride=-1, want_part=False):
         """segs: list of dict(a=Act|(buf,off,C), b=Act|None, w=('par',key)|('ws',off), CinP, rows, taps,
         w_bstride, w_tapstride)."""
         outC = outC or _up(Cout, 8)
@@ -389,6 +403,11 @@ class Program:
             assert skip.C == outC and skip.H == H and skip.W == W
             self._ws(op, 9, skip)
         op.f[0] = scale
+        if want_part:
+            any9 = any(sg["taps"] == 9 for sg in segs)
+            out.tiles = (-(-W // 32)) * (-(-H // 8)) if any9 else -(-(H * W) // 256)
+            out.part = self.arena.alloc(self.B * out.tiles * outC * 2 * 4)
+            self._ws(op, 10, out.part)
         return out
 
     def wseg(self, a, key, taps, b=None):
@@ -404,7 +423,8 @@ class Program:
         tb = None
         if self.cfg.conditional:
             tb = (self.dense_out + 4 * self.layout.dense_off[idx], self.layout.dense_rows)
-        u = self.conv([self.wseg(a, k + "Conv_0.weight", 9)], o, a.H, a.W, bias_key=k + "Conv_0.bias", tbias=tb)
+        u = self.conv([self.wseg(a, k + "Conv_0.weight", 9)], o, a.H, a.W, bias_key=k + "Conv_0.bias", tbias=tb,
+                      want_part=self.fuse_stats)
         self.free(a)
         a2, _ = self.gn(u, None, k + "GroupNorm_1.weight", k + "GroupNorm_1.bias", True, 0)
         self.free(u)
@@ -414,11 +434,12 @@ class Program:
                 s2 = self.wseg(xr, k + "Conv_2.weight", 1)
             else:
                 s2 = self.wseg(xa, k + "Conv_2.weight", 1, b=xb)
-            out = self.conv([self.wseg(a2, k + "Conv_1.weight", 9), s2], o, a2.H, a2.W, bias_key=k + "bias12", scale=inv)
+            out = self.conv([self.wseg(a2, k + "Conv_1.weight", 9), s2], o, a2.H, a2.W, bias_key=k + "bias12", scale=inv,
+                            want_part=self.fuse_stats)
         else:
             assert xb is None and xr is None and xa.C == o
             out = self.conv([self.wseg(a2, k + "Conv_1.weight", 9)], o, a2.H, a2.W, bias_key=k + "Conv_1.bias",
-                            skip=xa, scale=inv)
+                            skip=xa, scale=inv, want_part=self.fuse_stats)
         self.free(a2)
         if xr is not None:
             self.free(xr)
@@ -452,9 +473,9 @@ class Program:
         self.free(P); self.free(vT)
         xl = Act(x.off, 1, Lp, Cc)
         out = self.conv([self.wseg(o, k + "NIN_3.W", 1)], Cc, 1, Lp, bias_key=k + "NIN_3.b", skip=xl,
-                        scale=1.0 / math.sqrt(2.0))
+                        scale=1.0 / math.sqrt(2.0), want_part=self.fuse_stats)
         self.free(o)
-        return Act(out.off, x.H, x.W, Cc)
+        return Act(out.off, x.H, x.W, Cc, part=out.part, tiles=out.tiles)
 
     # ---- whole network ---------------------------------------------------------------------
     def _build(self):
@@ -496,7 +517,7 @@ class Program:
 
         ip = x0
         k = f"all_modules.{midx}."
-        hs = [self.conv([self.wseg(x0, k + "weight", 9)], cfg.nf, F, T, bias_key=k + "bias")]
+        hs = [self.conv([self.wseg(x0, k + "weight", 9)], cfg.nf, F, T, bias_key=k + "bias", want_part=self.fuse_stats)]
         midx += 1
         for lvl in range(nres):
             for _ in range(cfg.num_res_blocks):
@@ -513,7 +534,8 @@ class Program:
                 op.i[0], op.i[1], op.i[2], op.i[3] = B, ip.H, ip.W, 8
                 self.free(ip); ip = ipd
                 kk = f"all_modules.{midx}."                          # Combine (layerspp.py:52-57), method 'sum'
-                hc = self.conv([self.wseg(ip, kk + "Conv_0.weight", 1)], h.C, h.H, h.W, bias_key=kk + "Conv_0.bias", skip=h)
+                hc = self.conv([self.wseg(ip, kk + "Conv_0.weight", 1)], h.C, h.H, h.W, bias_key=kk + "Conv_0.bias", skip=h,
+                               want_part=self.fuse_stats)
                 midx += 1
                 self.free(h)
                 hs.append(hc)

@@ -87,6 +87,7 @@ struct ConvParams {
     void* out; int outC, Cout; long long out_bstride;
     const float* bias; const float* tbias; int tbias_stride, out_f32;
     const void* skip; long long skip_bstride; float scale; int pad_;
+    float* gn_part;   // optional [B][tiles_per_img][outC][2] per-tile (sum, sumsq) of the stored output
 };
 
 template <typename T, int TAPS, int WM, int WAVES_M, int WAVES_N>
@@ -272,6 +273,9 @@ void conv_igemm_kernel(const ConvParams a, const int n_ct, const int tiles_per_x
     constexpr int LPR = WM * 4;                 // lanes per staged row (8 couts each)
     constexpr int RPI = 64 / LPR;               // rows per read iteration
     const int skipC = a.outC;
+    float gsum[8], gsq[8];                      // GroupNorm partials of this lane's 8 channels (fused statistics)
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { gsum[e] = 0.f; gsq[e] = 0.f; }
 #pragma unroll
     for (int pass = 0; pass < WN / PR; ++pass) {
 #pragma unroll
@@ -330,13 +334,39 @@ void conv_igemm_kernel(const ConvParams a, const int n_ct, const int tiles_per_x
                     for (int e = 0; e < 8; ++e) v[e] += sk[e];
                 }
 #pragma unroll
-                for (int e = 0; e < 8; ++e) v[e] *= a.scale;
+                for (int e = 0; e < 8; ++e) { v[e] *= a.scale; gsum[e] += v[e]; gsq[e] = fmaf(v[e], v[e], gsq[e]); }
                 const uint32_t o = (uint32_t)(pix * a.outC + co);
                 if (a.out_f32) store8(reinterpret_cast<float*>(a.out) + (long long)b * a.out_bstride + o, v);
                 else store8(reinterpret_cast<T*>(a.out) + (long long)b * a.out_bstride + o, v);
             }
         }
         if (pass + 1 < WN / PR) __syncthreads();
+    }
+    if (a.gn_part != nullptr) {
+        // lanes with equal (lane % LPR) hold the same 8 channels: butterfly over the row lanes, then
+        // across the WAVES_N waves of a cout range through LDS; one coalesced [BN][2] store per block.
+#pragma unroll
+        for (int off = LPR; off < 64; off <<= 1)
+#pragma unroll
+            for (int e = 0; e < 8; ++e) { gsum[e] += __shfl_xor(gsum[e], off, 64); gsq[e] += __shfl_xor(gsq[e], off, 64); }
+        __syncthreads();                         // staging reads of the last pass are done
+        float* red = reinterpret_cast<float*>(smem);      // [WAVES_N][BN][2]
+        if (lane < LPR) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const int chl = wm * WM * 32 + lane * 8 + e;
+                red[(wn * BN + chl) * 2] = gsum[e];
+                red[(wn * BN + chl) * 2 + 1] = gsq[e];
+            }
+        }
+        __syncthreads();
+        if (tid < BN && cout0 + tid < a.outC) {
+            float s0 = 0.f, s1 = 0.f;
+#pragma unroll
+            for (int w = 0; w < WAVES_N; ++w) { s0 += red[(w * BN + tid) * 2]; s1 += red[(w * BN + tid) * 2 + 1]; }
+            float* dst = a.gn_part + ((long long)bm.tile * a.outC + cout0 + tid) * 2;
+            dst[0] = s0; dst[1] = s1;
+        }
     }
 }
 
@@ -362,6 +392,7 @@ static ConvParams make_params(const storm_conv_args& a) {
     p.out = a.out; p.outC = a.outC; p.Cout = a.Cout; p.out_bstride = a.out_bstride;
     p.bias = a.bias; p.tbias = a.tbias; p.tbias_stride = a.tbias_stride; p.out_f32 = a.out_f32;
     p.skip = a.skip; p.skip_bstride = a.skip_bstride; p.scale = a.scale;
+    p.gn_part = a.gn_part;
     return p;
 }
 
@@ -411,6 +442,15 @@ static int dispatch_conv(const storm_conv_args& a, hipStream_t st) {
 }
 
 }  // namespace storm
+
+extern "C" int storm_conv_tiles(const storm_conv_args* ap) {
+    if (ap == nullptr) return 0;
+    bool any9 = false;
+    for (int s = 0; s < ap->nseg; ++s) any9 = any9 || ap->seg[s].ntaps == 9;
+    using namespace storm::cidx;
+    if (any9) return storm::cdiv(ap->W, TILE_W) * storm::cdiv(ap->H, TILE_H);
+    return storm::cdiv((long long)ap->H * ap->W, TILE_H * TILE_W);
+}
 
 extern "C" int storm_conv(const storm_conv_args* ap, storm_stream_t s) {
     using namespace storm;

@@ -73,6 +73,23 @@ __global__ void gn_stats_kernel(const T* __restrict__ xa, int Ca, const T* __res
     }
 }
 
+// Finalise fused statistics: sum the per-tile fp32 partials of a conv epilogue into [B][G][2] fp64.
+__global__ void gn_finalize_kernel(const float* __restrict__ pa, int Ca, int tiles_a, const float* __restrict__ pb,
+                                   int Cb, int tiles_b, int G, double* __restrict__ stats) {
+    const int g = blockIdx.x, b = blockIdx.y, lane = threadIdx.x;
+    const int C = Ca + Cb, gs = C / G;
+    double s0 = 0.0, s1 = 0.0;
+    for (int k = 0; k < gs; ++k) {
+        const int c = g * gs + k;
+        const float* p; int Cs, cc, nt;
+        if (c < Ca) { p = pa; Cs = Ca; cc = c; nt = tiles_a; } else { p = pb; Cs = Cb; cc = c - Ca; nt = tiles_b; }
+        const float2* q = reinterpret_cast<const float2*>(p) + (long long)b * nt * Cs + cc;
+        for (int t = lane; t < nt; t += 64) { const float2 v = q[(long long)t * Cs]; s0 += (double)v.x; s1 += (double)v.y; }
+    }
+    s0 = wave_sum_d(s0); s1 = wave_sum_d(s1);
+    if (lane == 0) { stats[((long long)b * G + g) * 2] = s0; stats[((long long)b * G + g) * 2 + 1] = s1; }
+}
+
 // FIR taps: down: k = [1,3,3,1]/8 per axis over input 2o-1..2o+2; up: out[2i+a] = 3/4 x[i] + 1/4 x[i -/+ 1].
 struct GnParams { float mean[8], a[8], beta[8]; };
 
@@ -362,6 +379,17 @@ extern "C" int storm_gn_stats(const void* xa, int Ca, const void* xb, int Cb, in
     if (dtype == STORM_BF16) return gn_stats_t<bf16_t>(xa, Ca, xb, Cb, B, HW, groups, stats, st);
     if (dtype == STORM_F32) return gn_stats_t<float>(xa, Ca, xb, Cb, B, HW, groups, stats, st);
     STORM_CHECK(false, "storm_gn_stats: dtype %d", dtype);
+}
+
+extern "C" int storm_gn_finalize(const float* part_a, int Ca, int tiles_a, const float* part_b, int Cb, int tiles_b,
+                                 int B, int groups, double* stats, storm_stream_t s) {
+    if (int e = check_c("storm_gn_finalize", Ca, Cb, groups)) return e;
+    STORM_CHECK(part_a && stats && B > 0 && tiles_a > 0, "storm_gn_finalize: bad arguments");
+    STORM_CHECK((Cb == 0) == (part_b == nullptr), "storm_gn_finalize: part_b / Cb mismatch");
+    hipLaunchKernelGGL(gn_finalize_kernel, dim3(groups, B), dim3(64), 0, (hipStream_t)s, part_a, Ca, tiles_a, part_b, Cb,
+                       tiles_b, groups, stats);
+    STORM_LAUNCH_CHECK();
+    return STORM_OK;
 }
 
 extern "C" int storm_gn_apply(const void* xa, int Ca, const void* xb, int Cb, int B, int H, int W, int groups,

@@ -62,11 +62,16 @@ static int run_ops(const storm_op* ops, int n_ops, void* const* bufs, int n_bufs
                 a.skip_bstride = hw * a.outC;
                 a.scale = op.f[0];
                 a.dtype = dtype;
+                a.gn_part = (float*)p[10];
                 rc = storm_conv(&a, s);
                 break;
             }
             case STORM_OP_GN_STATS:
                 rc = storm_gn_stats(p[0], (int)i[0], p[1], (int)i[1], (int)i[2], (int)i[3], (int)i[4], (double*)p[2], dtype, s);
+                break;
+            case STORM_OP_GN_FINALIZE:
+                rc = storm_gn_finalize((const float*)p[0], (int)i[0], (int)i[1], (const float*)p[1], (int)i[2], (int)i[3],
+                                       (int)i[4], (int)i[5], (double*)p[2], s);
                 break;
             case STORM_OP_GN_APPLY:
                 rc = storm_gn_apply(p[0], (int)i[0], p[1], (int)i[1], (int)i[2], (int)i[3], (int)i[4], (int)i[5],

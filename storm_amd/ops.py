@@ -57,7 +57,7 @@ class Seg:
 
 
 def conv(segs, Cout, out=None, outC=None, bias=None, tbias=None, skip=None, scale=1.0, out_f32=False,
-         B=None, H=None, W=None):
+         B=None, H=None, W=None, gn_partials=False):
     """out[b,h,w,co] = (sum_seg conv(seg) + bias + tbias[b] + skip) * scale   (storm_conv)."""
     x = segs[0].src_a
     if B is None:
@@ -87,8 +87,24 @@ def conv(segs, Cout, out=None, outC=None, bias=None, tbias=None, skip=None, scal
     if skip is not None:
         a.skip, a.skip_bstride = L.ptr(skip), H * W * outC
     a.scale, a.out_f32, a.dtype = scale, int(out_f32), L.dt(dtype)
+    part = None
+    if gn_partials:
+        tiles = L.lib().storm_conv_tiles(C.byref(a))
+        part = torch.zeros((B, tiles, outC, 2), dtype=torch.float32, device=x.device)
+        a.gn_part = L.ptr(part)
     L.check(L.lib().storm_conv(C.byref(a), L.stream()), "storm_conv")
-    return out
+    return (out, part) if gn_partials else out
+
+
+def gn_finalize(part_a, part_b=None):
+    """[B][tiles][C][2] conv-epilogue partials (optionally of two concatenated tensors) -> stats [B][G][2] fp64."""
+    B, ta, Ca, _ = part_a.shape
+    tb, Cb = (part_b.shape[1], part_b.shape[2]) if part_b is not None else (0, 0)
+    G = gn_groups(Ca + Cb)
+    stats = torch.empty((B, G, 2), dtype=torch.float64, device=part_a.device)
+    L.check(L.lib().storm_gn_finalize(L.ptr(part_a), Ca, ta, L.ptr(part_b), Cb, tb, B, G, L.ptr(stats), L.stream()),
+            "storm_gn_finalize")
+    return stats
 
 
 # ---------------------------------------------------------------- norm / resample ---------

@@ -278,3 +278,25 @@ def test_stft_batched_ragged_vs_oracle(dev):
     for b in range(3):
         Yb, nf, T0 = FR.wav_to_spec(y[b:b + 1])
         assert rel_l2(w[b], FR.spec_to_wav(Yb, nf, T0)) < 5e-6
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("k", [3, 1])
+def test_conv_fused_gn_statistics(dev, dtype, k):
+    """per-tile (sum, sumsq) partials from the conv epilogue + finalize == a statistics pass over the output,
+    also for the channel concat of two producers (up-path skip connections)."""
+    from storm_amd import ops
+    g = torch.Generator().manual_seed(12)
+    B, Cin, Cout, H, W = 2, 16, 40, 9, 37
+    x = torch.randn(B, Cin, H, W, generator=g)
+    w1, w2 = torch.randn(Cout, Cin, k, k, generator=g) * 0.3, torch.randn(24, Cin, k, k, generator=g) * 0.3
+    xd = nhwc(x).to(dtype).to(dev)
+    y1, p1 = ops.conv([ops.Seg(xd, ops.pack_conv_weight(w1.to(dev), dtype), k * k)], Cout, gn_partials=True)
+    y2, p2 = ops.conv([ops.Seg(xd, ops.pack_conv_weight(w2.to(dev), dtype), k * k)], 24, gn_partials=True, scale=0.5)
+    rtol = 1e-5 if dtype == torch.float32 else 2e-3
+    st = ops.gn_finalize(p1).cpu()
+    ref = ops.gn_stats(y1).cpu()
+    assert torch.allclose(st, ref, rtol=rtol, atol=rtol * float(ref.abs().max()))
+    st = ops.gn_finalize(p1, p2).cpu()
+    ref = ops.gn_stats(y1, y2).cpu()
+    assert torch.allclose(st, ref, rtol=rtol, atol=rtol * float(ref.abs().max()))
