@@ -77,6 +77,10 @@ typedef struct storm_conv_seg {
     int ntaps;                  /* 9 (3x3, pad 1) or 1                                    */
     long long w_bstride;        /* elements between per-batch weight matrices, 0 = shared */
     long long w_tapstride;      /* elements between taps of w                             */
+    const float* gn_ss;         /* optional: fused GroupNorm apply on load, fp32 [B][Ca+Cb][2] =
+                                   (scale, shift) per batch item and channel from storm_gn_finalize:
+                                   the conv consumes act(x*scale+shift) (zero padded) instead of x   */
+    int gn_silu;                /* apply SiLU after the affine                            */
 } storm_conv_seg;
 
 typedef struct storm_conv_args {
@@ -117,6 +121,11 @@ int storm_gn_stats(const void* xa, int Ca, const void* xb, int Cb, int B, int HW
  * tensor): channel c < Ca comes from part_a [B][tiles_a][Ca][2], else part_b [B][tiles_b][Cb][2]. */
 int storm_gn_finalize(const float* part_a, int Ca, int tiles_a, const float* part_b, int Cb, int tiles_b,
                       int B, int groups, double* stats, storm_stream_t s);
+/* Same, and also the per-channel affine of the normalisation for consumers that fuse the apply:
+ * ss[b][c] = (rstd*gamma[c], beta[c] - mean*rstd*gamma[c]); count = elements per channel (H*W). */
+int storm_gn_finalize_ss(const float* part_a, int Ca, int tiles_a, const float* part_b, int Cb, int tiles_b,
+                         int B, int groups, long long count, const float* gamma, const float* beta, float eps,
+                         double* stats, float* ss, storm_stream_t s);
 /* resample: 0 none, 1 FIR up x2, 2 FIR down x2.  out_act gets act(GN(x)) (resampled),
  * out_raw (may be NULL; required non-NULL only if wanted) gets the resampled raw concat. */
 int storm_gn_apply(const void* xa, int Ca, const void* xb, int Cb, int B, int H, int W,

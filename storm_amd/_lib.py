@@ -28,7 +28,8 @@ class ConvSeg(C.Structure):
     _fields_ = [("src_a", C.c_void_p), ("src_b", C.c_void_p), ("Ca", C.c_int), ("Cb", C.c_int),
                 ("bstride_a", C.c_longlong), ("bstride_b", C.c_longlong), ("w", C.c_void_p),
                 ("CinP", C.c_int), ("w_rows", C.c_int), ("ntaps", C.c_int),
-                ("w_bstride", C.c_longlong), ("w_tapstride", C.c_longlong)]
+                ("w_bstride", C.c_longlong), ("w_tapstride", C.c_longlong), ("gn_ss", C.c_void_p),
+                ("gn_silu", C.c_int)]
 
 
 class ConvArgs(C.Structure):
@@ -61,6 +62,7 @@ _SIGNATURES = {
     "storm_conv": ([C.POINTER(ConvArgs), _vp], C.c_int),
     "storm_conv_tiles": ([C.POINTER(ConvArgs)], C.c_int),
     "storm_gn_finalize": ([_vp, _i, _i, _vp, _i, _i, _i, _i, _vp, _vp], C.c_int),
+    "storm_gn_finalize_ss": ([_vp, _i, _i, _vp, _i, _i, _i, _i, _ll, _vp, _vp, _f, _vp, _vp, _vp], C.c_int),
     "storm_gn_stats": ([_vp, _i, _vp, _i, _i, _i, _i, _vp, _i, _vp], C.c_int),
     "storm_gn_apply": ([_vp, _i, _vp, _i, _i, _i, _i, _i, _vp, _vp, _vp, _f, _i, _i, _vp, _vp, _i, _vp], C.c_int),
     "storm_fir_up2": ([_vp, _vp, _vp, _i, _i, _i, _i, _i, _vp], C.c_int),

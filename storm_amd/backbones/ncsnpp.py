@@ -8,6 +8,7 @@ whole network once per (B, F, T, dtype) (plan.py) and runs it with one ``storm_p
 call.  There is no PyTorch/CPU execution path.
 """
 import math
+import os
 
 import numpy as np
 import torch
@@ -225,7 +226,8 @@ class NCSNpp(nn.Module):
         ent = self._programs.get(key)
         if ent is None:
             layout, _ = self._get_arena(dtype_code, device)
-            prog = Program(self.cfg, layout, B, F, T)
+            prog = Program(self.cfg, layout, B, F, T, fuse_stats=os.environ.get("STORM_FUSE_GN_STATS", "1") != "0",
+                           fuse_apply=os.environ.get("STORM_FUSE_GN_APPLY", "1") != "0")
             prog.ops[-1].i[4] = int(self.negate_output)
             prog.op_array = (L.Op * len(prog.ops))(*prog.ops)
             ws = torch.empty(prog.ws_bytes, dtype=torch.uint8, device=device)

@@ -273,9 +273,11 @@ class Act:
 
 
 class Program:
-    def __init__(self, cfg: NCSNppConfig, layout: ParamLayout, B: int, F: int, T: int, fuse_stats: bool = True):
+    def __init__(self, cfg: NCSNppConfig, layout: ParamLayout, B: int, F: int, T: int, fuse_stats: bool = True,
+                 fuse_apply: bool = True):
         self.cfg, self.layout, self.B, self.F, self.T = cfg, layout, B, F, T
         self.fuse_stats = fuse_stats       # GroupNorm statistics from the producing conv's epilogue (no stats pass)
+        self.fuse_apply = fuse_apply and fuse_stats   # GroupNorm apply + SiLU inside the consuming conv's operand load
         self.dtype = layout.dtype
         self.esize = layout.esize
         self.ops: List[L.Op] = []
@@ -362,6 +364,27 @@ class Program:
         op.f[0] = 1e-6
         return out, raw
 
+    def gn_affine(self, xa: Act, xb: Optional[Act], wkey, bkey):
+        """GroupNorm as a per-(batch, channel) affine (scale, shift) table for a conv that fuses the apply
+        (+SiLU) into its operand load: one tiny finalize launch, no pass over the activation."""
+        assert xa.part is not None and (xb is None or xb.part is not None)
+        Cc = xa.C + (xb.C if xb else 0)
+        G = min(Cc // 4, 32)
+        st = self.new_stats(G)
+        ss = self.arena.alloc(self.B * Cc * 2 * 4)
+        op = self._op(OP_GN_FINALIZE)
+        self._ws(op, 0, xa.part)
+        if xb:
+            self._ws(op, 1, xb.part)
+        self._ws(op, 2, st)
+        self._par(op, 3, wkey)
+        self._par(op, 4, bkey)
+        self._ws(op, 5, ss)
+        op.i[0], op.i[1], op.i[2], op.i[3] = xa.C, xa.tiles, (xb.C if xb else 0), (xb.tiles if xb else 0)
+        op.i[4], op.i[5], op.i[6] = self.B, G, xa.H * xa.W
+        op.f[0] = 1e-6
+        return ss
+
     def conv(self, segs, Cout, H, W, outC=None, bias_key=None, tbias=None, skip: Optional[Act] = None, scale=1.0,
              out_f32=False, out_bstride=-1, src0_bstride=-1, want_part=False):
         """segs: list of dict(a=Act|(buf,off,C), b=Act|None, w=('par',key)|('ws',off), CinP, rows, taps,
@@ -393,6 +416,9 @@ class Program:
             op.i[q + 5], op.i[q + 6] = s.get("w_bstride", 0), s.get("w_tapstride", s["CinP"] * s["rows"])
             self.flops += 2 * self.B * H * W * Cout * (Ca + Cb) * s["taps"]
         op.i[22], op.i[23] = src0_bstride, out_bstride
+        if segs[0].get("gn") is not None:
+            self._ws(op, 11, segs[0]["gn"])
+            op.f[1] = 1.0 if segs[0].get("gn_silu", True) else 0.0
         self._ws(op, 6, out)
         if bias_key:
             self._par(op, 7, bias_key)
@@ -410,37 +436,55 @@ class Program:
             self._ws(op, 10, out.part)
         return out
 
-    def wseg(self, a, key, taps, b=None):
+    def wseg(self, a, key, taps, b=None, gn=None):
         e = self.layout.entries[key]
-        return dict(a=a, b=b, w=("par", key), CinP=e.shape[2], rows=e.shape[1], taps=taps)
+        return dict(a=a, b=b, w=("par", key), CinP=e.shape[2], rows=e.shape[1], taps=taps, gn=gn)
 
     # ---- blocks ----------------------------------------------------------------------------
     def resblock(self, idx, p, xa: Act, xb: Optional[Act] = None, resample=0):
         """ResnetBlockBigGANpp.forward (layerspp.py:242-274) as 6-7 fused ops."""
         k = f"all_modules.{idx}."
         o = p["o"]
-        a, xr = self.gn(xa, xb, k + "GroupNorm_0.weight", k + "GroupNorm_0.bias", True, resample)
         tb = None
         if self.cfg.conditional:
             tb = (self.dense_out + 4 * self.layout.dense_off[idx], self.layout.dense_rows)
-        u = self.conv([self.wseg(a, k + "Conv_0.weight", 9)], o, a.H, a.W, bias_key=k + "Conv_0.bias", tbias=tb,
-                      want_part=self.fuse_stats)
-        self.free(a)
-        a2, _ = self.gn(u, None, k + "GroupNorm_1.weight", k + "GroupNorm_1.bias", True, 0)
-        self.free(u)
         inv = 1.0 / math.sqrt(2.0)
+        fuse = self.fuse_apply and xa.part is not None and (xb is None or xb.part is not None)
+        xr = None
+        if fuse and not resample:
+            # GroupNorm_0 + SiLU ride in Conv_0's operand load (no normalised copy of x in HBM)
+            ss0 = self.gn_affine(xa, xb, k + "GroupNorm_0.weight", k + "GroupNorm_0.bias")
+            u = self.conv([self.wseg(xa, k + "Conv_0.weight", 9, b=xb, gn=ss0)], o, xa.H, xa.W, bias_key=k + "Conv_0.bias",
+                          tbias=tb, want_part=True)
+            self.arena.release(ss0)
+        else:
+            a, xr = self.gn(xa, xb, k + "GroupNorm_0.weight", k + "GroupNorm_0.bias", True, resample)
+            u = self.conv([self.wseg(a, k + "Conv_0.weight", 9)], o, a.H, a.W, bias_key=k + "Conv_0.bias", tbias=tb,
+                          want_part=self.fuse_stats)
+            self.free(a)
+        if fuse:
+            ss1 = self.gn_affine(u, None, k + "GroupNorm_1.weight", k + "GroupNorm_1.bias")
+            s1 = self.wseg(u, k + "Conv_1.weight", 9, gn=ss1)
+            a2 = None
+        else:
+            a2, _ = self.gn(u, None, k + "GroupNorm_1.weight", k + "GroupNorm_1.bias", True, 0)
+            self.free(u)
+            s1 = self.wseg(a2, k + "Conv_1.weight", 9)
+        H2, W2 = u.H, u.W
         if (k + "Conv_2.weight") in self.layout.entries:
             if xr is not None:
                 s2 = self.wseg(xr, k + "Conv_2.weight", 1)
             else:
                 s2 = self.wseg(xa, k + "Conv_2.weight", 1, b=xb)
-            out = self.conv([self.wseg(a2, k + "Conv_1.weight", 9), s2], o, a2.H, a2.W, bias_key=k + "bias12", scale=inv,
-                            want_part=self.fuse_stats)
+            out = self.conv([s1, s2], o, H2, W2, bias_key=k + "bias12", scale=inv, want_part=self.fuse_stats)
         else:
             assert xb is None and xr is None and xa.C == o
-            out = self.conv([self.wseg(a2, k + "Conv_1.weight", 9)], o, a2.H, a2.W, bias_key=k + "Conv_1.bias",
-                            skip=xa, scale=inv, want_part=self.fuse_stats)
-        self.free(a2)
+            out = self.conv([s1], o, H2, W2, bias_key=k + "Conv_1.bias", skip=xa, scale=inv, want_part=self.fuse_stats)
+        if fuse:
+            self.arena.release(ss1)
+            self.free(u)
+        else:
+            self.free(a2)
         if xr is not None:
             self.free(xr)
         return out
@@ -557,10 +601,15 @@ class Program:
                 hn = self.attnblock(midx, mods[midx][1], h); midx += 1
                 self.free(h); h = hn
             kg, kc = f"all_modules.{midx}.", f"all_modules.{midx + 1}."
-            a, _ = self.gn(h, None, kg + "weight", kg + "bias", True, 0)
-            ph = self.conv([self.wseg(a, kc + "weight", 9)], total, h.H, h.W, outC=8, bias_key=kc + "bias")
+            if self.fuse_apply and h.part is not None:
+                ssp = self.gn_affine(h, None, kg + "weight", kg + "bias")
+                ph = self.conv([self.wseg(h, kc + "weight", 9, gn=ssp)], total, h.H, h.W, outC=8, bias_key=kc + "bias")
+                self.arena.release(ssp)
+            else:
+                a, _ = self.gn(h, None, kg + "weight", kg + "bias", True, 0)
+                ph = self.conv([self.wseg(a, kc + "weight", 9)], total, h.H, h.W, outC=8, bias_key=kc + "bias")
+                self.free(a)
             midx += 2
-            self.free(a)
             if pyramid is None:
                 pyramid = ph
             else:

@@ -50,6 +50,31 @@ __device__ __forceinline__ uint4 ld16(const void* base, uint32_t byte_off) {
     return *reinterpret_cast<const uint4*>(static_cast<const char*>(base) + byte_off);
 }
 
+// y = act(x * scale + shift) on the 16-byte slot held in `v` (GroupNorm-apply + SiLU fused into the
+// operand load: the normalised tensor is never written to HBM).
+__device__ __forceinline__ float fast_silu(float y) { return y * __frcp_rn(1.0f + __expf(-y)); }
+__device__ __forceinline__ uint4 gn_act_slot(uint4 v, const float (&ss)[16], int silu, bf16_t*) {
+    uint32_t w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        float lo = __uint_as_float(w[i] << 16), hi = __uint_as_float(w[i] & 0xffff0000u);
+        lo = fmaf(lo, ss[4 * i], ss[4 * i + 1]);
+        hi = fmaf(hi, ss[4 * i + 2], ss[4 * i + 3]);
+        if (silu) { lo = fast_silu(lo); hi = fast_silu(hi); }
+        w[i] = (uint32_t)f32_to_bf16_bits(lo) | ((uint32_t)f32_to_bf16_bits(hi) << 16);
+    }
+    return make_uint4(w[0], w[1], w[2], w[3]);
+}
+__device__ __forceinline__ uint4 gn_act_slot(uint4 v, const float (&ss)[16], int silu, float*) {
+    float x[4] = {__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w)};
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        x[i] = fmaf(x[i], ss[2 * i], ss[2 * i + 1]);
+        if (silu) x[i] = silu_f(x[i]);
+    }
+    return make_uint4(__float_as_uint(x[0]), __float_as_uint(x[1]), __float_as_uint(x[2]), __float_as_uint(x[3]));
+}
+
 template <int TAPS, int WM, int WAVES_M, int WAVES_N>
 struct ConvCfg {
     static constexpr int NWAVES = WAVES_M * WAVES_N;
@@ -79,7 +104,10 @@ struct ConvRun {
     int C;          // channel stride of src
     int c0, cn;     // channels [c0, c0+cn) of src ...
     int wc0;        // ... multiply weight columns [wc0, wc0+cn)
-    int CinP, w_rows, ntaps, pad_;
+    int CinP, w_rows, ntaps;
+    int gn_silu;    // SiLU after the fused GroupNorm affine
+    const float* gn_ss;   // optional fused GroupNorm apply on load: [B][gn_C][2] (scale, shift); channel
+    int gn_C, pad_;       //   index of element (c) of this run = wc0 + c
 };
 struct ConvParams {
     ConvRun run[4];
@@ -149,8 +177,19 @@ void conv_igemm_kernel(const ConvParams a, const int n_ct, const int tiles_per_x
             *reinterpret_cast<uint4*>(dst + lds_off(u >> 3, u & 7)) = wreg[i];
         }
     };
-    auto load_patch = [&](const T* src, int C, int cbeg, int cvalid) {
-        // channels [cbeg, cbeg + cvalid) of the haloed tile -> LDS; everything else zero
+    auto load_patch = [&](const T* src, int C, int cbeg, int cvalid, const float* gn_ss, int gn_silu) {
+        // channels [cbeg, cbeg + cvalid) of the haloed tile -> LDS; everything else zero.
+        // gn_ss != nullptr: (scale, shift) pairs of this thread's PER16 channels -> fused GN apply (+SiLU)
+        float ss[16];
+        if (gn_ss != nullptr) {
+            const float* q = gn_ss + 2 * ((tid & 7) * PER16);
+#pragma unroll
+            for (int i = 0; i < 2 * PER16; i += 4) {
+                float4 t4 = make_float4(1.f, 0.f, 1.f, 0.f);
+                if ((tid & 7) * PER16 < cvalid) t4 = *reinterpret_cast<const float4*>(q + i);
+                ss[i] = t4.x; ss[i + 1] = t4.y; ss[i + 2] = t4.z; ss[i + 3] = t4.w;
+            }
+        }
         // two half-batches keep the staging registers at ~6 x 16 B per thread
         constexpr int HALF = (Cfg::PU + 1) / 2;
 #pragma unroll
@@ -172,7 +211,10 @@ void conv_igemm_kernel(const ConvParams a, const int n_ct, const int tiles_per_x
                     ok = ok && pix < (int)npix;
                 }
                 uint4 v = make_uint4(0u, 0u, 0u, 0u);
-                if (ok) v = ld16(src, (uint32_t)(pix * C + cbeg + slot * PER16) * (uint32_t)sizeof(T));
+                if (ok) {
+                    v = ld16(src, (uint32_t)(pix * C + cbeg + slot * PER16) * (uint32_t)sizeof(T));
+                    if (gn_ss != nullptr) v = gn_act_slot(v, ss, gn_silu, (T*)nullptr);   // zero padding stays zero
+                }
                 preg[k] = v;
             }
 #pragma unroll
@@ -238,12 +280,15 @@ void conv_igemm_kernel(const ConvParams a, const int n_ct, const int tiles_per_x
         const long long w_tapstride = R.w_tapstride;
         const int klim = CinP - R.wc0;
         const int nch = (cn + KC - 1) / KC;
+        const float* const gn_ss = R.gn_ss ? R.gn_ss + 2 * ((long long)b * R.gn_C + R.wc0) : nullptr;
+        const int gn_silu = R.gn_silu;
         const bool has_nr = r + 1 < nruns;
         const ConvRun& NR = a.run[has_nr ? r + 1 : r];
         for (int ch = 0; ch < nch; ++ch) {
             const int cvalid = min(KC, cn - ch * KC);
             __syncthreads();                       // every wave finished reading the previous patch
-            load_patch(src, C, c0 + ch * KC, cvalid);
+            load_patch(src, C, c0 + ch * KC, cvalid,
+                       gn_ss ? gn_ss + 2 * (ch * KC) : nullptr, gn_silu);
             const int nk = (cvalid + KG - 1) / KG;
             for (int tp = 0; tp < ntaps; ++tp) {
                 // prefetch the next step's weight tile into registers (flies during the MFMAs below)
@@ -386,6 +431,7 @@ static ConvParams make_params(const storm_conv_args& a) {
             r.wc0 = part == 0 ? 0 : g.Ca;
             r.w = g.w; r.w_bstride = g.w_bstride; r.w_tapstride = g.w_tapstride;
             r.CinP = g.CinP; r.w_rows = g.w_rows; r.ntaps = g.ntaps;
+            r.gn_ss = g.gn_ss; r.gn_C = g.Ca + g.Cb; r.gn_silu = g.gn_silu;
         }
     }
     p.nruns = n; p.B = a.B; p.H = a.H; p.W = a.W;

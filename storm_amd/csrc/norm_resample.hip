@@ -75,7 +75,9 @@ __global__ void gn_stats_kernel(const T* __restrict__ xa, int Ca, const T* __res
 
 // Finalise fused statistics: sum the per-tile fp32 partials of a conv epilogue into [B][G][2] fp64.
 __global__ void gn_finalize_kernel(const float* __restrict__ pa, int Ca, int tiles_a, const float* __restrict__ pb,
-                                   int Cb, int tiles_b, int G, double* __restrict__ stats) {
+                                   int Cb, int tiles_b, int G, double* __restrict__ stats, long long count,
+                                   const float* __restrict__ gamma, const float* __restrict__ beta, float eps,
+                                   float* __restrict__ ss) {
     const int g = blockIdx.x, b = blockIdx.y, lane = threadIdx.x;
     const int C = Ca + Cb, gs = C / G;
     double s0 = 0.0, s1 = 0.0;
@@ -88,6 +90,19 @@ __global__ void gn_finalize_kernel(const float* __restrict__ pa, int Ca, int til
     }
     s0 = wave_sum_d(s0); s1 = wave_sum_d(s1);
     if (lane == 0) { stats[((long long)b * G + g) * 2] = s0; stats[((long long)b * G + g) * 2 + 1] = s1; }
+    if (ss != nullptr) {
+        const double n = (double)gs * (double)count;
+        const double m = s0 / n;
+        double var = s1 / n - m * m;
+        if (var < 0.0) var = 0.0;
+        const float rstd = (float)(1.0 / sqrt(var + (double)eps));
+        for (int k = lane; k < gs; k += 64) {
+            const int c = g * gs + k;
+            const float sc = rstd * gamma[c];
+            ss[((long long)b * C + c) * 2] = sc;
+            ss[((long long)b * C + c) * 2 + 1] = beta[c] - (float)m * sc;
+        }
+    }
 }
 
 // FIR taps: down: k = [1,3,3,1]/8 per axis over input 2o-1..2o+2; up: out[2i+a] = 3/4 x[i] + 1/4 x[i -/+ 1].
@@ -387,7 +402,19 @@ extern "C" int storm_gn_finalize(const float* part_a, int Ca, int tiles_a, const
     STORM_CHECK(part_a && stats && B > 0 && tiles_a > 0, "storm_gn_finalize: bad arguments");
     STORM_CHECK((Cb == 0) == (part_b == nullptr), "storm_gn_finalize: part_b / Cb mismatch");
     hipLaunchKernelGGL(gn_finalize_kernel, dim3(groups, B), dim3(64), 0, (hipStream_t)s, part_a, Ca, tiles_a, part_b, Cb,
-                       tiles_b, groups, stats);
+                       tiles_b, groups, stats, 0LL, (const float*)nullptr, (const float*)nullptr, 0.f, (float*)nullptr);
+    STORM_LAUNCH_CHECK();
+    return STORM_OK;
+}
+
+extern "C" int storm_gn_finalize_ss(const float* part_a, int Ca, int tiles_a, const float* part_b, int Cb, int tiles_b,
+                                    int B, int groups, long long count, const float* gamma, const float* beta, float eps,
+                                    double* stats, float* ss, storm_stream_t s) {
+    if (int e = check_c("storm_gn_finalize_ss", Ca, Cb, groups)) return e;
+    STORM_CHECK(part_a && stats && ss && gamma && beta && B > 0 && tiles_a > 0 && count > 0, "storm_gn_finalize_ss: bad arguments");
+    STORM_CHECK((Cb == 0) == (part_b == nullptr), "storm_gn_finalize_ss: part_b / Cb mismatch");
+    hipLaunchKernelGGL(gn_finalize_kernel, dim3(groups, B), dim3(64), 0, (hipStream_t)s, part_a, Ca, tiles_a, part_b, Cb,
+                       tiles_b, groups, stats, count, gamma, beta, eps, ss);
     STORM_LAUNCH_CHECK();
     return STORM_OK;
 }

@@ -63,6 +63,8 @@ static int run_ops(const storm_op* ops, int n_ops, void* const* bufs, int n_bufs
                 a.scale = op.f[0];
                 a.dtype = dtype;
                 a.gn_part = (float*)p[10];
+                a.seg[0].gn_ss = (const float*)p[11];
+                a.seg[0].gn_silu = op.f[1] != 0.f;
                 rc = storm_conv(&a, s);
                 break;
             }
@@ -70,8 +72,13 @@ static int run_ops(const storm_op* ops, int n_ops, void* const* bufs, int n_bufs
                 rc = storm_gn_stats(p[0], (int)i[0], p[1], (int)i[1], (int)i[2], (int)i[3], (int)i[4], (double*)p[2], dtype, s);
                 break;
             case STORM_OP_GN_FINALIZE:
-                rc = storm_gn_finalize((const float*)p[0], (int)i[0], (int)i[1], (const float*)p[1], (int)i[2], (int)i[3],
-                                       (int)i[4], (int)i[5], (double*)p[2], s);
+                if (p[5] != nullptr)
+                    rc = storm_gn_finalize_ss((const float*)p[0], (int)i[0], (int)i[1], (const float*)p[1], (int)i[2], (int)i[3],
+                                              (int)i[4], (int)i[5], (long long)i[6], (const float*)p[3], (const float*)p[4],
+                                              op.f[0], (double*)p[2], (float*)p[5], s);
+                else
+                    rc = storm_gn_finalize((const float*)p[0], (int)i[0], (int)i[1], (const float*)p[1], (int)i[2], (int)i[3],
+                                           (int)i[4], (int)i[5], (double*)p[2], s);
                 break;
             case STORM_OP_GN_APPLY:
                 rc = storm_gn_apply(p[0], (int)i[0], p[1], (int)i[1], (int)i[2], (int)i[3], (int)i[4], (int)i[5],

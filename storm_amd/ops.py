@@ -51,9 +51,10 @@ class Seg:
     """One K-segment of storm_conv: activations (optionally the channel concat of two tensors)
     and packed weights [ntaps][rows][CinP] (or a per-batch activation used as the weight matrix)."""
 
-    def __init__(self, src_a, w, ntaps, src_b=None, w_batched=False, src_bstride=None):
+    def __init__(self, src_a, w, ntaps, src_b=None, w_batched=False, src_bstride=None, gn_ss=None, gn_silu=True):
         self.src_a, self.src_b, self.w, self.ntaps = src_a, src_b, w, ntaps
         self.w_batched, self.src_bstride = w_batched, src_bstride
+        self.gn_ss, self.gn_silu = gn_ss, gn_silu      # fused GroupNorm apply (+SiLU) on load
 
 
 def conv(segs, Cout, out=None, outC=None, bias=None, tbias=None, skip=None, scale=1.0, out_f32=False,
@@ -79,6 +80,8 @@ def conv(segs, Cout, out=None, outC=None, bias=None, tbias=None, skip=None, scal
         g.CinP, g.w_rows = s.w.shape[-1], s.w.shape[-2]
         g.w_tapstride = s.w.shape[-1] * s.w.shape[-2]
         g.w_bstride = s.w.shape[-1] * s.w.shape[-2] if s.w_batched else 0
+        if s.gn_ss is not None:
+            g.gn_ss, g.gn_silu = L.ptr(s.gn_ss), int(s.gn_silu)
     a.B, a.H, a.W = B, H, W
     a.out, a.outC, a.Cout, a.out_bstride = L.ptr(out), outC, Cout, H * W * outC
     a.bias = L.ptr(bias)
@@ -96,15 +99,21 @@ def conv(segs, Cout, out=None, outC=None, bias=None, tbias=None, skip=None, scal
     return (out, part) if gn_partials else out
 
 
-def gn_finalize(part_a, part_b=None):
-    """[B][tiles][C][2] conv-epilogue partials (optionally of two concatenated tensors) -> stats [B][G][2] fp64."""
+def gn_finalize(part_a, part_b=None, gamma=None, beta=None, count=None, eps=1e-6):
+    """[B][tiles][C][2] conv-epilogue partials (optionally of two concatenated tensors) -> stats [B][G][2] fp64;
+    with gamma/beta/count also the per-channel affine ss [B][C][2] for convs that fuse the apply."""
     B, ta, Ca, _ = part_a.shape
     tb, Cb = (part_b.shape[1], part_b.shape[2]) if part_b is not None else (0, 0)
     G = gn_groups(Ca + Cb)
     stats = torch.empty((B, G, 2), dtype=torch.float64, device=part_a.device)
-    L.check(L.lib().storm_gn_finalize(L.ptr(part_a), Ca, ta, L.ptr(part_b), Cb, tb, B, G, L.ptr(stats), L.stream()),
-            "storm_gn_finalize")
-    return stats
+    if gamma is None:
+        L.check(L.lib().storm_gn_finalize(L.ptr(part_a), Ca, ta, L.ptr(part_b), Cb, tb, B, G, L.ptr(stats), L.stream()),
+                "storm_gn_finalize")
+        return stats
+    ss = torch.empty((B, Ca + Cb, 2), dtype=torch.float32, device=part_a.device)
+    L.check(L.lib().storm_gn_finalize_ss(L.ptr(part_a), Ca, ta, L.ptr(part_b), Cb, tb, B, G, int(count), L.ptr(gamma),
+                                         L.ptr(beta), eps, L.ptr(stats), L.ptr(ss), L.stream()), "storm_gn_finalize_ss")
+    return stats, ss
 
 
 # ---------------------------------------------------------------- norm / resample ---------

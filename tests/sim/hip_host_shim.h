@@ -52,6 +52,7 @@ void launch(dim3 grid, dim3 block, size_t lds_bytes, const std::function<void()>
 inline float __uint_as_float(uint32_t u) { float f; memcpy(&f, &u, 4); return f; }
 inline uint32_t __float_as_uint(float f) { uint32_t u; memcpy(&u, &f, 4); return u; }
 inline float __expf(float x) { return expf(x); }
+inline float __frcp_rn(float x) { return 1.0f / x; }
 inline int min(int a, int b) { return a < b ? a : b; }
 inline int max(int a, int b) { return a > b ? a : b; }
 inline long long min(long long a, long long b) { return a < b ? a : b; }

@@ -300,3 +300,25 @@ def test_conv_fused_gn_statistics(dev, dtype, k):
     st = ops.gn_finalize(p1, p2).cpu()
     ref = ops.gn_stats(y1, y2).cpu()
     assert torch.allclose(st, ref, rtol=rtol, atol=rtol * float(ref.abs().max()))
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_conv_fused_groupnorm_apply(dev, dtype):
+    """conv3x3(SiLU(GN(cat[xa, xb]))) with the normalisation applied inside the conv's operand load
+    (statistics from the producers' epilogues) == GroupNorm -> SiLU -> conv of the oracle."""
+    from storm_amd import ops
+    g = torch.Generator().manual_seed(13)
+    B, C0, Ca, Cb, Co, H, W = 2, 8, 24, 16, 40, 10, 36
+    x0 = torch.randn(B, C0, H, W, generator=g)
+    wa, wb = torch.randn(Ca, C0, 3, 3, generator=g) * 0.4, torch.randn(Cb, C0, 1, 1, generator=g) * 0.7
+    w = torch.randn(Co, Ca + Cb, 3, 3, generator=g) * 0.1
+    gam, bet = 1 + 0.1 * torch.randn(Ca + Cb, generator=g), 0.1 * torch.randn(Ca + Cb, generator=g)
+    x0d = nhwc(x0).to(dtype).to(dev)
+    xa, pa = ops.conv([ops.Seg(x0d, ops.pack_conv_weight(wa.to(dev), dtype), 9)], Ca, gn_partials=True)
+    xb, pb = ops.conv([ops.Seg(x0d, ops.pack_conv_weight(wb.to(dev), dtype), 1)], Cb, gn_partials=True)
+    st, ss = ops.gn_finalize(pa, pb, gamma=gam.to(dev), beta=bet.to(dev), count=H * W)
+    y = ops.conv([ops.Seg(xa, ops.pack_conv_weight(w.to(dev), dtype), 9, src_b=xb, gn_ss=ss, gn_silu=True)], Co)
+    xcat = torch.cat([nchw(xa.float().cpu()), nchw(xb.float().cpu())], 1)
+    a = NR.silu(NR.group_norm(xcat, gam, bet))
+    ref = F.conv2d(q(a, dtype), q(w, dtype), padding=1)
+    assert rel_l2(nchw(y.float().cpu()), ref) < tol(dtype, 5e-6, 1e-2)
