@@ -36,6 +36,33 @@ __host__ __device__ inline float bf16_bits_to_f32(uint16_t h) {
     return c.f;
 }
 
+// two fp32 -> packed bf16x2 (lo in bits 0-15), round-to-nearest-even: one v_cvt_pk_bf16_f32 on gfx950
+__device__ inline uint32_t pack_bf16x2(float lo, float hi) {
+#ifdef STORM_HOST_SIM
+    return (uint32_t)f32_to_bf16_bits(lo) | ((uint32_t)f32_to_bf16_bits(hi) << 16);
+#else
+    uint32_t r;
+    asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(r) : "v"(lo), "v"(hi));
+    return r;
+#endif
+}
+// raw hardware transcendentals (v_exp_f32 / v_rcp_f32, ~1 ulp): used where the result is rounded to bf16 anyway
+__device__ inline float hw_exp2(float x) {
+#ifdef STORM_HOST_SIM
+    return exp2f(x);
+#else
+    return __builtin_amdgcn_exp2f(x);
+#endif
+}
+__device__ inline float hw_rcp(float x) {
+#ifdef STORM_HOST_SIM
+    return 1.0f / x;
+#else
+    return __builtin_amdgcn_rcpf(x);
+#endif
+}
+__device__ inline float fast_silu(float y) { return y * hw_rcp(1.0f + hw_exp2(-1.44269504088896341f * y)); }
+
 template <typename T> struct Elem;
 template <> struct Elem<float> {
     static constexpr int PER16 = 4;                 // elements per 16-byte slot
@@ -68,8 +95,7 @@ __device__ inline void store8(float* p, const float (&v)[8]) {
 __device__ inline void store8(bf16_t* p, const float (&v)[8]) {
     uint32_t w[4];
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
-        w[i] = (uint32_t)f32_to_bf16_bits(v[2 * i]) | ((uint32_t)f32_to_bf16_bits(v[2 * i + 1]) << 16);
+    for (int i = 0; i < 4; ++i) w[i] = pack_bf16x2(v[2 * i], v[2 * i + 1]);
     *reinterpret_cast<uint4*>(p) = make_uint4(w[0], w[1], w[2], w[3]);
 }
 __device__ inline float to_f32(float x) { return x; }

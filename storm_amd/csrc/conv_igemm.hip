@@ -52,7 +52,6 @@ __device__ __forceinline__ uint4 ld16(const void* base, uint32_t byte_off) {
 
 // y = act(x * scale + shift) on the 16-byte slot held in `v` (GroupNorm-apply + SiLU fused into the
 // operand load: the normalised tensor is never written to HBM).
-__device__ __forceinline__ float fast_silu(float y) { return y * __frcp_rn(1.0f + __expf(-y)); }
 __device__ __forceinline__ uint4 gn_act_slot(uint4 v, const float (&ss)[16], int silu, bf16_t*) {
     uint32_t w[4] = {v.x, v.y, v.z, v.w};
 #pragma unroll
@@ -61,7 +60,7 @@ __device__ __forceinline__ uint4 gn_act_slot(uint4 v, const float (&ss)[16], int
         lo = fmaf(lo, ss[4 * i], ss[4 * i + 1]);
         hi = fmaf(hi, ss[4 * i + 2], ss[4 * i + 3]);
         if (silu) { lo = fast_silu(lo); hi = fast_silu(hi); }
-        w[i] = (uint32_t)f32_to_bf16_bits(lo) | ((uint32_t)f32_to_bf16_bits(hi) << 16);
+        w[i] = pack_bf16x2(lo, hi);
     }
     return make_uint4(w[0], w[1], w[2], w[3]);
 }
