@@ -74,8 +74,9 @@ __device__ __forceinline__ uint4 gn_act_slot(uint4 v, const float (&ss)[16], int
     return make_uint4(__float_as_uint(x[0]), __float_as_uint(x[1]), __float_as_uint(x[2]), __float_as_uint(x[3]));
 }
 
-template <int TAPS, int WM, int WAVES_M, int WAVES_N>
+template <int TAPS, int WM, int WAVES_M, int WAVES_N, bool PF>
 struct ConvCfg {
+    static constexpr bool PREFETCH = PF;       // double-buffered patch, next chunk fetched under the MFMAs
     static constexpr int NWAVES = WAVES_M * WAVES_N;
     static constexpr int THREADS = 64 * NWAVES;
     static constexpr int WN = TILE_H / WAVES_N;          // pixel tile rows (of 32 px) per wave
@@ -83,10 +84,13 @@ struct ConvCfg {
     static constexpr int NPIX = Geo<TAPS>::NPIX;
     static constexpr int PATCH_BYTES = NPIX * PIX_BYTES;
     static constexpr int WBUF_BYTES = BN * PIX_BYTES;
-    static constexpr int PR = (WN >= 2 && NWAVES * 64 * WM * 128 <= 96 * 1024) ? 2 : 1;   // pixel rows staged per epilogue pass
+    static constexpr int NPBUF = PF ? 2 : 1;
+    static constexpr int MAIN_BYTES = NPBUF * PATCH_BYTES + 2 * WBUF_BYTES;
+    static constexpr int PR = (WN >= 2 && NWAVES * 64 * WM * 128 <= MAIN_BYTES) ? 2 : 1;   // pixel rows staged per epilogue pass
     static constexpr int STAGE_BYTES = NWAVES * 32 * PR * WM * 128;
-    static constexpr int MAIN_BYTES = PATCH_BYTES + 2 * WBUF_BYTES;
     static constexpr int LDS_BYTES = MAIN_BYTES > STAGE_BYTES ? MAIN_BYTES : STAGE_BYTES;
+    static constexpr int BLOCKS_PER_CU = (160 * 1024) / LDS_BYTES >= 2 ? 2 : 1;
+    static constexpr int MIN_WAVES_PER_SIMD = BLOCKS_PER_CU * NWAVES / 4;
     static constexpr int PU = (NPIX * 8 + THREADS - 1) / THREADS;   // patch 16-B units per thread
     static constexpr int WU = BN * 8 / THREADS;                      // weight units per thread
     static_assert(WN % PR == 0, "epilogue passes");
@@ -117,11 +121,11 @@ struct ConvParams {
     float* gn_part;   // optional [B][tiles_per_img][outC][2] per-tile (sum, sumsq) of the stored output
 };
 
-template <typename T, int TAPS, int WM, int WAVES_M, int WAVES_N>
-__global__ __launch_bounds__(64 * WAVES_M * WAVES_N, 2 * WAVES_M * WAVES_N / 4)
+template <typename T, int TAPS, int WM, int WAVES_M, int WAVES_N, bool PF>
+__global__ __launch_bounds__(64 * WAVES_M * WAVES_N, (ConvCfg<TAPS, WM, WAVES_M, WAVES_N, PF>::MIN_WAVES_PER_SIMD))
 void conv_igemm_kernel(const ConvParams a, const int n_ct, const int tiles_per_xcd,
                        const int ntiles, const int tiles_x, const int tiles_per_img) {
-    typedef ConvCfg<TAPS, WM, WAVES_M, WAVES_N> Cfg;
+    typedef ConvCfg<TAPS, WM, WAVES_M, WAVES_N, PF> Cfg;
     typedef typename Mma<T>::Frag Frag;
     constexpr int THREADS = Cfg::THREADS;
     constexpr int PER16 = Elem<T>::PER16;
@@ -130,8 +134,8 @@ void conv_igemm_kernel(const ConvParams a, const int n_ct, const int tiles_per_x
     constexpr int WN = Cfg::WN, BN = Cfg::BN, PW = Geo<TAPS>::PW;
 
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    char* const patch = smem;
-    char* const wbuf = smem + Cfg::PATCH_BYTES;
+    char* const pbuf = smem;                                    // NPBUF patch buffers, then the 2-deep weight ring
+    char* const wbuf = smem + Cfg::NPBUF * Cfg::PATCH_BYTES;
 
     const BlockMap bm = block_map(blockIdx.x, n_ct, tiles_per_xcd);
     if (bm.tile >= ntiles) return;
@@ -154,17 +158,37 @@ void conv_igemm_kernel(const ConvParams a, const int n_ct, const int tiles_per_x
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[mi][ni][r] = 0.0f;
 
-    // ---- loaders (all arguments wave-uniform scalars) -----------------------------------------
+    // ---- per-chunk scalars (one K-chunk = 128 B of channels of one run) ----------------------------
+    struct Chunk {
+        const T* src; const T* w; const float* gn_ss;
+        int C, cbeg, cvalid, CinP, w_rows, ntaps, kbeg, klim, gn_silu;
+        long long w_tapstride;
+    };
+    auto get_chunk = [&](int r, int ch) {
+        const ConvRun& R = a.run[r];               // r is wave-uniform: scalar loads from the kernarg segment
+        Chunk c;
+        c.src = reinterpret_cast<const T*>(R.src) + (long long)b * R.src_bstride;
+        c.w = reinterpret_cast<const T*>(R.w) + (long long)b * R.w_bstride + R.wc0;
+        c.C = R.C; c.cbeg = R.c0 + ch * KC; c.cvalid = min(KC, R.cn - ch * KC);
+        c.CinP = R.CinP; c.w_rows = R.w_rows; c.ntaps = R.ntaps; c.w_tapstride = R.w_tapstride;
+        c.kbeg = ch * KC; c.klim = R.CinP - R.wc0;
+        c.gn_ss = R.gn_ss ? R.gn_ss + 2 * ((long long)b * R.gn_C + R.wc0 + ch * KC) : nullptr;
+        c.gn_silu = R.gn_silu;
+        return c;
+    };
+    auto chunks_of = [&](int r) { return (a.run[r].cn + KC - 1) / KC; };
+
+    // ---- loaders --------------------------------------------------------------------------------
     uint4 wreg[Cfg::WU];
-    auto load_w = [&](const T* wbase, int CinP, int w_rows, int kbeg, int klim) {
-        // weight tile rows cout0.., columns [kbeg, kbeg + KC) of a row of the current run (klim = row end)
+    auto load_w = [&](const Chunk& c, int tp) {
+        const T* wbase = c.w + (long long)tp * c.w_tapstride;
 #pragma unroll
         for (int i = 0; i < Cfg::WU; ++i) {
             const int u = tid + i * THREADS;
             const int row = u >> 3, slot = u & 7;
-            const int co = cout0 + row, c = kbeg + slot * PER16;
+            const int co = cout0 + row, k = c.kbeg + slot * PER16;
             uint4 v = make_uint4(0u, 0u, 0u, 0u);
-            if (co < w_rows && c < klim) v = ld16(wbase, (uint32_t)(co * CinP + c) * (uint32_t)sizeof(T));
+            if (co < c.w_rows && k < c.klim) v = ld16(wbase, (uint32_t)(co * c.CinP + k) * (uint32_t)sizeof(T));
             wreg[i] = v;
         }
     };
@@ -176,51 +200,52 @@ void conv_igemm_kernel(const ConvParams a, const int n_ct, const int tiles_per_x
             *reinterpret_cast<uint4*>(dst + lds_off(u >> 3, u & 7)) = wreg[i];
         }
     };
-    auto load_patch = [&](const T* src, int C, int cbeg, int cvalid, const float* gn_ss, int gn_silu) {
-        // channels [cbeg, cbeg + cvalid) of the haloed tile -> LDS; everything else zero.
-        // gn_ss != nullptr: (scale, shift) pairs of this thread's PER16 channels -> fused GN apply (+SiLU)
+    // patch staging is split: issue (global loads -> registers) ... commit (GroupNorm affine + SiLU when fused,
+    // then LDS); with PREFETCH the commit of chunk c+1 happens after the MFMAs of chunk c's first tap.
+    uint4 preg[Cfg::PU];
+    uint32_t pmask = 0;                          // bit i: unit i was inside the image (zero padding stays zero)
+    auto patch_issue = [&](const Chunk& c, int i0, int i1) {
+#pragma unroll
+        for (int i = 0; i < Cfg::PU; ++i) {
+            if (i < i0 || i >= i1) continue;
+            const int u = tid + i * THREADS;
+            const int p = u >> 3, slot = u & 7;
+            int pix;
+            bool ok = (u < Cfg::NPIX * 8) && (slot * PER16 < c.cvalid);
+            if (TAPS == 9) {
+                const int py = p / PW, px = p - py * PW;
+                const int gy = ty0 + py - 1, gx = tx0 + px - 1;
+                ok = ok && gy >= 0 && gy < a.H && gx >= 0 && gx < a.W;
+                pix = gy * a.W + gx;
+            } else {
+                pix = (int)lin0 + p;
+                ok = ok && pix < (int)npix;
+            }
+            uint4 v = make_uint4(0u, 0u, 0u, 0u);
+            if (ok) v = ld16(c.src, (uint32_t)(pix * c.C + c.cbeg + slot * PER16) * (uint32_t)sizeof(T));
+            preg[i] = v;
+            pmask = ok ? (pmask | (1u << i)) : (pmask & ~(1u << i));
+        }
+    };
+    auto patch_commit = [&](const Chunk& c, char* dst, int i0, int i1) {
         float ss[16];
-        if (gn_ss != nullptr) {
-            const float* q = gn_ss + 2 * ((tid & 7) * PER16);
+        if (c.gn_ss != nullptr) {
+            const float* q = c.gn_ss + 2 * ((tid & 7) * PER16);
 #pragma unroll
             for (int i = 0; i < 2 * PER16; i += 4) {
                 float4 t4 = make_float4(1.f, 0.f, 1.f, 0.f);
-                if ((tid & 7) * PER16 < cvalid) t4 = *reinterpret_cast<const float4*>(q + i);
+                if ((tid & 7) * PER16 < c.cvalid) t4 = *reinterpret_cast<const float4*>(q + i);
                 ss[i] = t4.x; ss[i + 1] = t4.y; ss[i + 2] = t4.z; ss[i + 3] = t4.w;
             }
         }
-        // two half-batches keep the staging registers at ~6 x 16 B per thread
-        constexpr int HALF = (Cfg::PU + 1) / 2;
 #pragma unroll
-        for (int h0 = 0; h0 < Cfg::PU; h0 += HALF) {
-            uint4 preg[HALF];
-#pragma unroll
-            for (int k = 0; k < HALF; ++k) {
-                const int u = tid + (h0 + k) * THREADS;
-                const int p = u >> 3, slot = u & 7;
-                int pix;
-                bool ok = (h0 + k < Cfg::PU) && (u < Cfg::NPIX * 8) && (slot * PER16 < cvalid);
-                if (TAPS == 9) {
-                    const int py = p / PW, px = p - py * PW;
-                    const int gy = ty0 + py - 1, gx = tx0 + px - 1;
-                    ok = ok && gy >= 0 && gy < a.H && gx >= 0 && gx < a.W;
-                    pix = gy * a.W + gx;
-                } else {
-                    pix = (int)lin0 + p;
-                    ok = ok && pix < (int)npix;
-                }
-                uint4 v = make_uint4(0u, 0u, 0u, 0u);
-                if (ok) {
-                    v = ld16(src, (uint32_t)(pix * C + cbeg + slot * PER16) * (uint32_t)sizeof(T));
-                    if (gn_ss != nullptr) v = gn_act_slot(v, ss, gn_silu, (T*)nullptr);   // zero padding stays zero
-                }
-                preg[k] = v;
-            }
-#pragma unroll
-            for (int k = 0; k < HALF; ++k) {
-                const int u = tid + (h0 + k) * THREADS;
-                if (h0 + k < Cfg::PU && u < Cfg::NPIX * 8)
-                    *reinterpret_cast<uint4*>(patch + lds_off(u >> 3, u & 7)) = preg[k];
+        for (int i = 0; i < Cfg::PU; ++i) {
+            if (i < i0 || i >= i1) continue;
+            const int u = tid + i * THREADS;
+            if (u < Cfg::NPIX * 8) {
+                uint4 v = preg[i];
+                if (c.gn_ss != nullptr && (pmask >> i) & 1u) v = gn_act_slot(v, ss, c.gn_silu, (T*)nullptr);
+                *reinterpret_cast<uint4*>(dst + lds_off(u >> 3, u & 7)) = v;
             }
         }
     };
@@ -230,83 +255,73 @@ void conv_igemm_kernel(const ConvParams a, const int n_ct, const int tiles_per_x
 #pragma unroll
     for (int mi = 0; mi < WM; ++mi) arow[mi] = (wm * WM + mi) * 32 + (lane & 31);
 
-    auto compute = [&](const char* wb, int dy, int dx, int nk) {
+    auto compute = [&](const char* patch, const char* wb, int dy, int dx, int nk) {
         int prow[WN];
 #pragma unroll
         for (int ni = 0; ni < WN; ++ni) prow[ni] = patch_pixel<TAPS>(lane, wn * WN + ni, dy, dx);
-        auto load_frags = [&](int j, Frag (&fa)[WM], Frag (&fb)[WN]) {
+        // ONE rolled loop over k-groups (a second, unrolled copy of the MFMA code makes the register
+        // allocator keep two homes for the accumulators and shuffle / spill them at the join).
+#pragma unroll 1
+        for (int j = 0; j < nk; ++j) {
             const int slot = frag_slot(lane, j);
+            Frag fa[WM], fb[WN];
 #pragma unroll
             for (int mi = 0; mi < WM; ++mi) fa[mi] = *reinterpret_cast<const Frag*>(wb + lds_off(arow[mi], slot));
 #pragma unroll
             for (int ni = 0; ni < WN; ++ni) fb[ni] = *reinterpret_cast<const Frag*>(patch + lds_off(prow[ni], slot));
-        };
-        auto mma = [&](const Frag (&fa)[WM], const Frag (&fb)[WN]) {
 #pragma unroll
             for (int mi = 0; mi < WM; ++mi)
 #pragma unroll
                 for (int ni = 0; ni < WN; ++ni) Mma<T>::run(fa[mi], fb[ni], acc[mi][ni]);
-        };
-        // ONE rolled loop over pairs of k-groups with two fragment sets: the LDS reads of the next group
-        // fly under the current group's 8 MFMAs.  (A second, unrolled copy of the MFMA code makes the
-        // register allocator keep two homes for the 128 accumulator registers.)  An odd nk runs one
-        // extra group on zero-filled slots.
-        Frag fa0[WM], fb0[WN], fa1[WM], fb1[WN];
-        load_frags(0, fa0, fb0);
-        const int npair = (nk + 1) >> 1;
-#pragma unroll 1
-        for (int jj = 0; jj < npair; ++jj) {
-            load_frags(2 * jj + 1, fa1, fb1);
-            mma(fa0, fb0);
-            load_frags(min(2 * jj + 2, 3), fa0, fb0);     // (re-reads a valid group on the last pass; unused)
-            mma(fa1, fb1);
         }
     };
 
-    // ---- main loop: runs x K-chunks x taps ------------------------------------------------------
-    int step = 0;
-    {
-        const ConvRun& R0 = a.run[0];
-        load_w(reinterpret_cast<const T*>(R0.w) + (long long)b * R0.w_bstride + R0.wc0, R0.CinP, R0.w_rows, 0, R0.CinP - R0.wc0);
-        store_w(0);
-    }
+    // ---- main loop: K-chunks (runs flattened) x taps ------------------------------------------------
     const int nruns = a.nruns;
-    for (int r = 0; r < nruns; ++r) {
-        const ConvRun& R = a.run[r];
-        const T* const src = reinterpret_cast<const T*>(R.src) + (long long)b * R.src_bstride;
-        const T* const w = reinterpret_cast<const T*>(R.w) + (long long)b * R.w_bstride + R.wc0;
-        const int C = R.C, c0 = R.c0, cn = R.cn, CinP = R.CinP, w_rows = R.w_rows, ntaps = R.ntaps;
-        const long long w_tapstride = R.w_tapstride;
-        const int klim = CinP - R.wc0;
-        const int nch = (cn + KC - 1) / KC;
-        const float* const gn_ss = R.gn_ss ? R.gn_ss + 2 * ((long long)b * R.gn_C + R.wc0) : nullptr;
-        const int gn_silu = R.gn_silu;
-        const bool has_nr = r + 1 < nruns;
-        const ConvRun& NR = a.run[has_nr ? r + 1 : r];
-        for (int ch = 0; ch < nch; ++ch) {
-            const int cvalid = min(KC, cn - ch * KC);
+    int r = 0, ch = 0, nch_r = chunks_of(0), step = 0, ci = 0;
+    Chunk cur = get_chunk(0, 0);
+    constexpr int HALF = (Cfg::PU + 1) / 2;      // non-prefetch mode stages the patch in two register halves
+    if (PF) {
+        patch_issue(cur, 0, Cfg::PU);
+        patch_commit(cur, pbuf, 0, Cfg::PU);
+    }
+    load_w(cur, 0);
+    store_w(0);
+    while (true) {
+        int nr = r, nc = ch + 1;
+        if (nc == nch_r) { nc = 0; ++nr; }
+        const bool has_nc = nr < nruns;
+        const Chunk nxt = get_chunk(has_nc ? nr : r, has_nc ? nc : ch);
+        if (!PF) {
             __syncthreads();                       // every wave finished reading the previous patch
-            load_patch(src, C, c0 + ch * KC, cvalid,
-                       gn_ss ? gn_ss + 2 * (ch * KC) : nullptr, gn_silu);
-            const int nk = (cvalid + KG - 1) / KG;
-            for (int tp = 0; tp < ntaps; ++tp) {
-                // prefetch the next step's weight tile into registers (flies during the MFMAs below)
-                bool has_next = true;
-                if (tp + 1 < ntaps) load_w(w + (long long)(tp + 1) * w_tapstride, CinP, w_rows, ch * KC, klim);
-                else if (ch + 1 < nch) load_w(w, CinP, w_rows, (ch + 1) * KC, klim);
-                else if (has_nr) load_w(reinterpret_cast<const T*>(NR.w) + (long long)b * NR.w_bstride + NR.wc0, NR.CinP,
-                                        NR.w_rows, 0, NR.CinP - NR.wc0);
-                else has_next = false;
-                __syncthreads();                   // patch + wbuf[step&1] visible
-                int dy = 0, dx = 0;
-                if (TAPS == 9) {
-                    if (ntaps == 9) { dy = tp / 3; dx = tp - dy * 3; } else { dy = 1; dx = 1; }
-                }
-                compute(wbuf + (step & 1) * Cfg::WBUF_BYTES, dy, dx, nk);
-                if (has_next) store_w((step + 1) & 1);   // that buffer was last read in step-1 (barrier passed)
-                ++step;
-            }
+            patch_issue(cur, 0, HALF); patch_commit(cur, pbuf, 0, HALF);
+            patch_issue(cur, HALF, Cfg::PU); patch_commit(cur, pbuf, HALF, Cfg::PU);
         }
+        const char* const patch = pbuf + (PF ? (ci & 1) * Cfg::PATCH_BYTES : 0);
+        const int nk = (cur.cvalid + KG - 1) / KG;
+        const int ntaps = cur.ntaps;
+        for (int tp = 0; tp < ntaps; ++tp) {
+            // next step's weight tile -> registers; (PF, first tap) next chunk's patch -> registers.
+            // Both fly during the MFMAs below and are written to LDS after them.
+            const bool more_taps = tp + 1 < ntaps;
+            const bool has_next = more_taps || has_nc;
+            if (more_taps) load_w(cur, tp + 1);
+            else if (has_nc) load_w(nxt, 0);
+            const bool pf_now = PF && tp == 0 && has_nc;
+            if (pf_now) patch_issue(nxt, 0, Cfg::PU);
+            __syncthreads();                       // patch + wbuf[step&1] visible; ring slots of step-1 free
+            int dy = 0, dx = 0;
+            if (TAPS == 9) {
+                if (ntaps == 9) { dy = tp / 3; dx = tp - dy * 3; } else { dy = 1; dx = 1; }
+            }
+            compute(patch, wbuf + (step & 1) * Cfg::WBUF_BYTES, dy, dx, nk);
+            if (has_next) store_w((step + 1) & 1);
+            if (pf_now) patch_commit(nxt, pbuf + ((ci + 1) & 1) * Cfg::PATCH_BYTES, 0, Cfg::PU);
+            ++step;
+        }
+        if (!has_nc) break;
+        if (nr != r) nch_r = chunks_of(nr);
+        cur = nxt; r = nr; ch = nc; ++ci;
     }
 
     // ---- epilogue: LDS transpose -> (bias, temb bias, skip, scale) -> wide stores ---------
@@ -441,10 +456,10 @@ static ConvParams make_params(const storm_conv_args& a) {
     return p;
 }
 
-template <typename T, int TAPS, int WM, int WAVES_M, int WAVES_N>
+template <typename T, int TAPS, int WM, int WAVES_M, int WAVES_N, bool PF>
 static int launch_conv(const storm_conv_args& a, hipStream_t st) {
-    typedef ConvCfg<TAPS, WM, WAVES_M, WAVES_N> Cfg;
-    auto kern = conv_igemm_kernel<T, TAPS, WM, WAVES_M, WAVES_N>;
+    typedef ConvCfg<TAPS, WM, WAVES_M, WAVES_N, PF> Cfg;
+    auto kern = conv_igemm_kernel<T, TAPS, WM, WAVES_M, WAVES_N, PF>;
     static bool attr_set = false;          // per instantiation; benign race (idempotent)
     if (!attr_set) {
         STORM_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
@@ -475,15 +490,21 @@ static int dispatch_conv(const storm_conv_args& a, hipStream_t st) {
     bool any9 = false;
     for (int s = 0; s < a.nseg; ++s) any9 = any9 || a.seg[s].ntaps == 9;
     const bool small = a.outC <= 32;
-    // big tile: 128 cout x 256 px.  Variant 0: 4 waves (64 cout x 128 px each, 128 accumulator VGPRs);
-    // variant 1: 8 waves (64 x 64 each) -> 16 waves / CU hide LDS + barrier latency by occupancy.
-    static const int variant = getenv("STORM_CONV_VARIANT") ? atoi(getenv("STORM_CONV_VARIANT")) : 1;
+    // Tile variants (STORM_CONV_VARIANT overrides the choice, for A/B runs):
+    //   0: 128 cout x 256 px, 4 waves (64x128 each), 2 workgroups / CU overlap each other's staging
+    //   1: 128 cout x 256 px, 8 waves (64x64 each), 2 workgroups / CU
+    //   2: 256 cout x 256 px, 8 waves (64x128 each), 1 workgroup / CU, patch double-buffered and the
+    //      next K-chunk prefetched under the MFMAs (one patch load + GN transform per 256 couts)
+    static const int forced = getenv("STORM_CONV_VARIANT") ? atoi(getenv("STORM_CONV_VARIANT")) : -1;
+    const int variant = forced >= 0 ? forced : (a.outC > 128 ? 2 : 0);
     if (any9) {
-        if (small) return launch_conv<T, 9, 1, 1, 4>(a, st);
-        return variant == 0 ? launch_conv<T, 9, 2, 2, 2>(a, st) : launch_conv<T, 9, 2, 2, 4>(a, st);
+        if (small) return launch_conv<T, 9, 1, 1, 4, false>(a, st);
+        if (variant == 2) return launch_conv<T, 9, 2, 4, 2, true>(a, st);
+        return variant == 1 ? launch_conv<T, 9, 2, 2, 4, false>(a, st) : launch_conv<T, 9, 2, 2, 2, false>(a, st);
     }
-    if (small) return launch_conv<T, 1, 1, 1, 4>(a, st);
-    return variant == 0 ? launch_conv<T, 1, 2, 2, 2>(a, st) : launch_conv<T, 1, 2, 2, 4>(a, st);
+    if (small) return launch_conv<T, 1, 1, 1, 4, false>(a, st);
+    if (variant == 2) return launch_conv<T, 1, 2, 4, 2, true>(a, st);
+    return variant == 1 ? launch_conv<T, 1, 2, 2, 4, false>(a, st) : launch_conv<T, 1, 2, 2, 2, false>(a, st);
 }
 
 }  // namespace storm
