@@ -1,0 +1,85 @@
+#!/usr/bin/env python
+"""Inference CLI — drop-in for the reference enhancement.py (same flags, enhancement.py:28-36):
+
+    python enhancement.py --test_dir noisy/ --enhanced_dir out/ --ckpt model.ckpt --mode storm \
+        [--corrector ald --corrector-steps 1 --snr 0.5 --N 50]
+
+Additions: --precision {fp32,bf16}, --batch (equal-length utterances per sampler call) and multi-GPU
+sharding when launched with torchrun (one process per GPU, files dealt by length; no collectives in the
+sampler).  WAV I/O uses scipy.io.wavfile (torchaudio is not required)."""
+import glob
+import os
+from argparse import ArgumentParser
+
+import numpy as np
+import torch
+
+
+def read_wav(path):
+    from scipy.io import wavfile
+    sr, x = wavfile.read(path)
+    if x.dtype.kind == "i":
+        x = x.astype(np.float32) / float(np.iinfo(x.dtype).max + 1)
+    elif x.dtype.kind == "u":
+        x = (x.astype(np.float32) - 128.0) / 128.0
+    x = x.astype(np.float32)
+    if x.ndim == 2:
+        x = x.T
+    else:
+        x = x[None]
+    return torch.from_numpy(np.ascontiguousarray(x)), sr
+
+
+def write_wav(path, x, sr):
+    from scipy.io import wavfile
+    wavfile.write(path, sr, x.detach().cpu().numpy().astype(np.float32))
+
+
+def main():
+    p = ArgumentParser()
+    p.add_argument("--test_dir", type=str, required=True, help="Directory containing your corrupted files to enhance.")
+    p.add_argument("--enhanced_dir", type=str, required=True, help="Where to write your cleaned files.")
+    p.add_argument("--ckpt", type=str, required=True)
+    p.add_argument("--mode", required=True, choices=["score-only", "denoiser-only", "storm"])
+    p.add_argument("--corrector", type=str, choices=("ald", "langevin", "none"), default="ald")
+    p.add_argument("--corrector-steps", type=int, default=1)
+    p.add_argument("--snr", type=float, default=0.5)
+    p.add_argument("--N", type=int, default=50)
+    p.add_argument("--precision", choices=("fp32", "bf16"), default="fp32")
+    p.add_argument("--batch", type=int, default=16)
+    args = p.parse_args()
+
+    from storm_amd import distributed as D
+    from storm_amd.model import DiscriminativeModel, ScoreModel, StochasticRegenerationModel
+    rank, world, local = D.init()
+    torch.cuda.set_device(local)
+    os.makedirs(args.enhanced_dir, exist_ok=True)
+    model_cls = {"storm": StochasticRegenerationModel, "score-only": ScoreModel, "denoiser-only": DiscriminativeModel}[args.mode]
+    model = model_cls.load_from_checkpoint(args.ckpt, base_dir="", batch_size=1, num_workers=0, kwargs=dict(gpu=False))
+    model.eval(no_ema=False)
+    model.cuda()
+    model.set_precision(args.precision)
+
+    files = sorted(glob.glob(os.path.join(args.test_dir, "*.wav")))
+    wavs, lengths = [], []
+    for f in files:
+        y, sr = read_wav(f)
+        assert sr == 16000, "You need to make sure sample_sr matches model_sr --> resample to 16kHz"
+        wavs.append(y[:1])
+        lengths.append(y.shape[1])
+    mine = D.shard_indices(len(files), rank, world, lengths)
+    for batch in D.group_by_length([lengths[i] for i in mine], args.batch):
+        ids = [mine[k] for k in batch]
+        y = torch.cat([wavs[i] for i in ids], 0)
+        if args.mode == "denoiser-only":
+            outs = [model.enhance(wavs[i]) for i in ids]
+        else:
+            x_hat = model.enhance_batch(y, corrector=args.corrector, N=args.N, corrector_steps=args.corrector_steps, snr=args.snr)
+            outs = list(x_hat)
+        for i, x in zip(ids, outs):
+            write_wav(os.path.join(args.enhanced_dir, os.path.basename(files[i])), x.float().reshape(-1), 16000)
+    D.barrier()
+
+
+if __name__ == "__main__":
+    main()

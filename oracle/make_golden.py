@@ -68,8 +68,33 @@ def check(name, got, want, tol):
     return e
 
 
+def gen_f7(ref):
+    """F7: probability-flow ODE sampler (scipy RK45 on the host, sampling/__init__.py:71-141) with an
+    analytic score on a toy state: end point + nfev."""
+    print("F7 ODE sampler")
+    g = torch.Generator().manual_seed(77)
+    y = torch.randn(2, 1, 8, 16, dtype=torch.complex64, generator=g) * 0.3
+    z = SR.complex_randn(y.shape, g)
+    sde = ref["sdes"].OUVESDE(theta=1.5, sigma_min=0.05, sigma_max=0.5, N=30)
+
+    def score(x, t, yy):
+        return -(x - yy) / (sde._std(t)[:, None, None, None] ** 2 + 0.1)
+    orig = torch.randn_like
+    torch.randn_like = lambda x, *a, **k: z.to(x.dtype)
+    try:
+        sampler = ref["sampling"].get_ode_sampler(sde, score, y=y, eps=0.03, device="cpu")
+        x, nfe = sampler()
+    finally:
+        torch.randn_like = orig
+    print(f"  ode: nfev {nfe}")
+    np.savez_compressed(os.path.join(OUT, "f7_ode.npz"), y=c2np(y), z=c2np(z), out=c2np(x), nfe=np.array(nfe))
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
+    if "--only-f7" in sys.argv:
+        gen_f7(import_reference())
+        return
     torch.set_num_threads(8)
     torch.manual_seed(0)
     ref = import_reference()
@@ -309,6 +334,7 @@ def main():
         f6.update({f"storm_{cond}_noise": np.stack([c2np(n) for n in noises]), f"storm_{cond}_out": xh_ref.numpy()})
     np.savez_compressed(os.path.join(OUT, "f6_enhance.npz"), **f6)
 
+    gen_f7(ref)
     for fn in sorted(os.listdir(OUT)):
         print(f"  {fn}: {os.path.getsize(os.path.join(OUT, fn))/1024:.0f} KiB")
     print("golden fixtures written to", OUT)

@@ -496,7 +496,8 @@ static int dispatch_conv(const storm_conv_args& a, hipStream_t st) {
     //   2: 256 cout x 256 px, 8 waves (64x128 each), 1 workgroup / CU, patch double-buffered and the
     //      next K-chunk prefetched under the MFMAs (one patch load + GN transform per 256 couts)
     static const int forced = getenv("STORM_CONV_VARIANT") ? atoi(getenv("STORM_CONV_VARIANT")) : -1;
-    const int variant = forced >= 0 ? forced : (a.outC > 128 ? 2 : 0);
+    const long long px_tiles = (long long)a.B * cdiv((long long)a.H * a.W, TILE_H * TILE_W);
+    const int variant = forced >= 0 ? forced : ((a.outC > 128 && px_tiles >= 512) ? 2 : 0);
     if (any9) {
         if (small) return launch_conv<T, 9, 1, 1, 4, false>(a, st);
         if (variant == 2) return launch_conv<T, 9, 2, 4, 2, true>(a, st);

@@ -1,0 +1,65 @@
+"""Utterance sharding over the GPUs of one node: one process per GPU (torchrun), utterances are
+independent units (every op on the path is per sample), so ranks never exchange data inside the
+sampler — torch.distributed (RCCL on ROCm, gloo in CPU tests) is used for the start/stop barriers
+and the optional gather of results only."""
+import os
+
+import torch
+
+
+def init(backend=None):
+    """Initialise torch.distributed from the torchrun environment; returns (rank, world, local_rank)."""
+    import torch.distributed as dist
+    rank, world = int(os.environ.get("RANK", 0)), int(os.environ.get("WORLD_SIZE", 1))
+    local = int(os.environ.get("LOCAL_RANK", 0))
+    if world > 1 and not dist.is_initialized():
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        backend = backend or ("nccl" if torch.cuda.is_available() else "gloo")
+        dist.init_process_group(backend, rank=rank, world_size=world)
+    return rank, world, local
+
+
+def shard_indices(n_items, rank, world, lengths=None):
+    """Indices of the utterances rank `rank` processes.  With `lengths`, items are dealt longest-first in
+    a serpentine order so every rank gets a similar amount of audio (tail effect of ragged batches)."""
+    idx = list(range(n_items))
+    if lengths is not None:
+        order = sorted(idx, key=lambda i: -lengths[i])
+        mine = []
+        for k, i in enumerate(order):
+            rnd, pos = divmod(k, world)
+            owner = pos if rnd % 2 == 0 else world - 1 - pos
+            if owner == rank:
+                mine.append(i)
+        return sorted(mine)
+    return idx[rank::world]
+
+
+def group_by_length(lengths, max_batch):
+    """Batches of equal-length utterances (each utterance keeps its own padded frame count, so a batched
+    call equals per-utterance calls): list of index lists, at most max_batch long."""
+    by_len = {}
+    for i, n in enumerate(lengths):
+        by_len.setdefault(int(n), []).append(i)
+    batches = []
+    for n in sorted(by_len):
+        ids = by_len[n]
+        for k in range(0, len(ids), max_batch):
+            batches.append(ids[k:k + max_batch])
+    return batches
+
+
+def gather_objects(obj, rank, world):
+    """All ranks' python objects on rank 0 (None elsewhere)."""
+    if world == 1:
+        return [obj]
+    import torch.distributed as dist
+    out = [None] * world if rank == 0 else None
+    dist.gather_object(obj, out, dst=0)
+    return out
+
+
+def barrier():
+    import torch.distributed as dist
+    if dist.is_available() and dist.is_initialized():
+        dist.barrier()

@@ -70,3 +70,19 @@ def test_philox_sampler_is_seeded(dev):
     run = lambda seed: get_pc_sampler("reverse_diffusion", "ald", sde=sde, score_fn=score, y=y, snr=0.5, seed=seed)()[0].cpu()
     a, b, c = run(1), run(1), run(2)
     assert torch.equal(a, b) and not torch.equal(a, c) and torch.isfinite(a).all()
+
+
+def test_ode_sampler_vs_reference(dev, golden):
+    """device Dormand-Prince with scipy's step controller vs the reference's scipy.solve_ivp run"""
+    from storm_amd.sampling import get_ode_sampler
+    from storm_amd.sdes import OUVESDE
+    g = golden["f7_ode"]
+    sde = OUVESDE(1.5, 0.05, 0.5, N=30)
+
+    def score(x, t, y):
+        return -(x - y) / (sde._std(t)[:, None, None, None] ** 2 + 0.1)
+    z = T(g["z"]).to(dev)
+    sampler = get_ode_sampler(sde, score, y=T(g["y"]).to(dev), eps=0.03, noise_fn=lambda: z)
+    x, nfe = sampler()
+    assert abs(nfe - int(g["nfe"])) <= 12, (nfe, int(g["nfe"]))
+    assert rel_l2(x.cpu(), g["out"]) < 1e-3
