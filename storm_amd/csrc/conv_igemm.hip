@@ -74,9 +74,10 @@ __device__ __forceinline__ uint4 gn_act_slot(uint4 v, const float (&ss)[16], int
     return make_uint4(__float_as_uint(x[0]), __float_as_uint(x[1]), __float_as_uint(x[2]), __float_as_uint(x[3]));
 }
 
-template <int TAPS, int WM, int WAVES_M, int WAVES_N, bool PF>
+template <int TAPS, int WM, int WAVES_M, int WAVES_N, bool PF, bool FP = false>
 struct ConvCfg {
     static constexpr bool PREFETCH = PF;       // double-buffered patch, next chunk fetched under the MFMAs
+    static constexpr bool FRAG_PIPE = FP;      // two fragment sets, hand software-pipelined k-loop
     static constexpr int NWAVES = WAVES_M * WAVES_N;
     static constexpr int THREADS = 64 * NWAVES;
     static constexpr int WN = TILE_H / WAVES_N;          // pixel tile rows (of 32 px) per wave
@@ -121,11 +122,11 @@ struct ConvParams {
     float* gn_part;   // optional [B][tiles_per_img][outC][2] per-tile (sum, sumsq) of the stored output
 };
 
-template <typename T, int TAPS, int WM, int WAVES_M, int WAVES_N, bool PF>
-__global__ __launch_bounds__(64 * WAVES_M * WAVES_N, (ConvCfg<TAPS, WM, WAVES_M, WAVES_N, PF>::MIN_WAVES_PER_SIMD))
+template <typename T, int TAPS, int WM, int WAVES_M, int WAVES_N, bool PF, bool FP>
+__global__ __launch_bounds__(64 * WAVES_M * WAVES_N, (ConvCfg<TAPS, WM, WAVES_M, WAVES_N, PF, FP>::MIN_WAVES_PER_SIMD))
 void conv_igemm_kernel(const ConvParams a, const int n_ct, const int tiles_per_xcd,
                        const int ntiles, const int tiles_x, const int tiles_per_img) {
-    typedef ConvCfg<TAPS, WM, WAVES_M, WAVES_N, PF> Cfg;
+    typedef ConvCfg<TAPS, WM, WAVES_M, WAVES_N, PF, FP> Cfg;
     typedef typename Mma<T>::Frag Frag;
     constexpr int THREADS = Cfg::THREADS;
     constexpr int PER16 = Elem<T>::PER16;
@@ -259,20 +260,45 @@ void conv_igemm_kernel(const ConvParams a, const int n_ct, const int tiles_per_x
         int prow[WN];
 #pragma unroll
         for (int ni = 0; ni < WN; ++ni) prow[ni] = patch_pixel<TAPS>(lane, wn * WN + ni, dy, dx);
-        // ONE rolled loop over k-groups (a second, unrolled copy of the MFMA code makes the register
-        // allocator keep two homes for the accumulators and shuffle / spill them at the join).
-#pragma unroll 1
-        for (int j = 0; j < nk; ++j) {
+        auto load_frags = [&](int j, Frag (&fa)[WM], Frag (&fb)[WN]) {
             const int slot = frag_slot(lane, j);
-            Frag fa[WM], fb[WN];
 #pragma unroll
             for (int mi = 0; mi < WM; ++mi) fa[mi] = *reinterpret_cast<const Frag*>(wb + lds_off(arow[mi], slot));
 #pragma unroll
             for (int ni = 0; ni < WN; ++ni) fb[ni] = *reinterpret_cast<const Frag*>(patch + lds_off(prow[ni], slot));
+        };
+        auto mma = [&](const Frag (&fa)[WM], const Frag (&fb)[WN]) {
 #pragma unroll
             for (int mi = 0; mi < WM; ++mi)
 #pragma unroll
                 for (int ni = 0; ni < WN; ++ni) Mma<T>::run(fa[mi], fb[ni], acc[mi][ni]);
+        };
+        // ONE rolled loop (a second, unrolled copy of the MFMA code makes the register allocator keep two
+        // homes for the accumulators).  Two fragment sets, software pipelined by hand: the LDS reads of
+        // k-group j+1 are issued BEFORE the 8 MFMAs of group j (sched_barrier pins that order), so a wave's
+        // MFMA stream does not stop for its own LDS latency.  An odd nk runs one group on zero slots.
+        if (Cfg::FRAG_PIPE) {
+            Frag fa0[WM], fb0[WN], fa1[WM], fb1[WN];
+            load_frags(0, fa0, fb0);
+            const int npair = (nk + 1) >> 1;
+#pragma unroll 1
+            for (int jj = 0; jj < npair; ++jj) {
+                load_frags(2 * jj + 1, fa1, fb1);
+                __builtin_amdgcn_sched_barrier(0);
+                mma(fa0, fb0);
+                __builtin_amdgcn_sched_barrier(0);
+                load_frags(min(2 * jj + 2, 3), fa0, fb0);     // (re-reads a valid group on the last pass; unused)
+                __builtin_amdgcn_sched_barrier(0);
+                mma(fa1, fb1);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        } else {
+#pragma unroll 1
+            for (int j = 0; j < nk; ++j) {
+                Frag fa[WM], fb[WN];
+                load_frags(j, fa, fb);
+                mma(fa, fb);
+            }
         }
     };
 
@@ -456,10 +482,10 @@ static ConvParams make_params(const storm_conv_args& a) {
     return p;
 }
 
-template <typename T, int TAPS, int WM, int WAVES_M, int WAVES_N, bool PF>
+template <typename T, int TAPS, int WM, int WAVES_M, int WAVES_N, bool PF, bool FP = false>
 static int launch_conv(const storm_conv_args& a, hipStream_t st) {
-    typedef ConvCfg<TAPS, WM, WAVES_M, WAVES_N, PF> Cfg;
-    auto kern = conv_igemm_kernel<T, TAPS, WM, WAVES_M, WAVES_N, PF>;
+    typedef ConvCfg<TAPS, WM, WAVES_M, WAVES_N, PF, FP> Cfg;
+    auto kern = conv_igemm_kernel<T, TAPS, WM, WAVES_M, WAVES_N, PF, FP>;
     static bool attr_set = false;          // per instantiation; benign race (idempotent)
     if (!attr_set) {
         STORM_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
@@ -496,12 +522,14 @@ static int dispatch_conv(const storm_conv_args& a, hipStream_t st) {
     //   2: 256 cout x 256 px, 8 waves (64x128 each), 1 workgroup / CU, patch double-buffered and the
     //      next K-chunk prefetched under the MFMAs (one patch load + GN transform per 256 couts)
     static const int forced = getenv("STORM_CONV_VARIANT") ? atoi(getenv("STORM_CONV_VARIANT")) : -1;
+    static const bool frag_pipe = getenv("STORM_FRAG_PIPE") ? atoi(getenv("STORM_FRAG_PIPE")) != 0 : true;
     const long long px_tiles = (long long)a.B * cdiv((long long)a.H * a.W, TILE_H * TILE_W);
     const int variant = forced >= 0 ? forced : ((a.outC > 128 && px_tiles >= 512) ? 2 : 0);
     if (any9) {
         if (small) return launch_conv<T, 9, 1, 1, 4, false>(a, st);
         if (variant == 2) return launch_conv<T, 9, 2, 4, 2, true>(a, st);
-        return variant == 1 ? launch_conv<T, 9, 2, 2, 4, false>(a, st) : launch_conv<T, 9, 2, 2, 2, false>(a, st);
+        if (variant == 1) return launch_conv<T, 9, 2, 2, 4, false>(a, st);
+        return frag_pipe ? launch_conv<T, 9, 2, 2, 2, false, true>(a, st) : launch_conv<T, 9, 2, 2, 2, false, false>(a, st);
     }
     if (small) return launch_conv<T, 1, 1, 1, 4, false>(a, st);
     if (variant == 2) return launch_conv<T, 1, 2, 4, 2, true>(a, st);

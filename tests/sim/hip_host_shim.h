@@ -122,6 +122,7 @@ inline sim_f32x16 mfma_f32(float a, float b, sim_f32x16 c, int, int, int) {
     return r;
 }
 }  // namespace simrt
+#define __builtin_amdgcn_sched_barrier(x) ((void)0)
 #define __builtin_amdgcn_mfma_f32_32x32x16_bf16 simrt::mfma_bf16
 #define __builtin_amdgcn_mfma_f32_32x32x2f32 simrt::mfma_f32
 
