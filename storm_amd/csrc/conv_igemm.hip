@@ -74,8 +74,9 @@ __device__ __forceinline__ uint4 gn_act_slot(uint4 v, const float (&ss)[16], int
     return make_uint4(__float_as_uint(x[0]), __float_as_uint(x[1]), __float_as_uint(x[2]), __float_as_uint(x[3]));
 }
 
-template <int TAPS, int WM, int WAVES_M, int WAVES_N, bool PF, bool FP = false>
+template <int TAPS, int WM, int WAVES_M, int WAVES_N, bool PF, bool FP = false, int ABL_ = 0>
 struct ConvCfg {
+    static constexpr int ABL = ABL_;           // profiling-only ablation mask (separate instantiations)
     static constexpr bool PREFETCH = PF;       // double-buffered patch, next chunk fetched under the MFMAs
     static constexpr bool FRAG_PIPE = FP;      // two fragment sets, hand software-pipelined k-loop
     static constexpr int NWAVES = WAVES_M * WAVES_N;
@@ -122,11 +123,11 @@ struct ConvParams {
     float* gn_part;   // optional [B][tiles_per_img][outC][2] per-tile (sum, sumsq) of the stored output
 };
 
-template <typename T, int TAPS, int WM, int WAVES_M, int WAVES_N, bool PF, bool FP>
-__global__ __launch_bounds__(64 * WAVES_M * WAVES_N, (ConvCfg<TAPS, WM, WAVES_M, WAVES_N, PF, FP>::MIN_WAVES_PER_SIMD))
+template <typename T, int TAPS, int WM, int WAVES_M, int WAVES_N, bool PF, bool FP, int ABL>
+__global__ __launch_bounds__(64 * WAVES_M * WAVES_N, (ConvCfg<TAPS, WM, WAVES_M, WAVES_N, PF, FP, ABL>::MIN_WAVES_PER_SIMD))
 void conv_igemm_kernel(const ConvParams a, const int n_ct, const int tiles_per_xcd,
                        const int ntiles, const int tiles_x, const int tiles_per_img) {
-    typedef ConvCfg<TAPS, WM, WAVES_M, WAVES_N, PF, FP> Cfg;
+    typedef ConvCfg<TAPS, WM, WAVES_M, WAVES_N, PF, FP, ABL> Cfg;
     typedef typename Mma<T>::Frag Frag;
     constexpr int THREADS = Cfg::THREADS;
     constexpr int PER16 = Elem<T>::PER16;
@@ -292,6 +293,22 @@ void conv_igemm_kernel(const ConvParams a, const int n_ct, const int tiles_per_x
                 mma(fa1, fb1);
                 __builtin_amdgcn_sched_barrier(0);
             }
+        } else if (ABL & 3) {                          // profiling ablations (own instantiations, never dispatched in production)
+            Frag fa[WM], fb[WN];
+            load_frags(0, fa, fb);
+#pragma unroll 1
+            for (int j = 0; j < nk; ++j) {
+                if (!(ABL & 2)) load_frags(j, fa, fb);
+                if (!(ABL & 1)) mma(fa, fb);
+#ifndef STORM_HOST_SIM
+                else {
+#pragma unroll
+                    for (int mi = 0; mi < WM; ++mi) asm volatile("" ::"v"(fa[mi]));
+#pragma unroll
+                    for (int ni = 0; ni < WN; ++ni) asm volatile("" ::"v"(fb[ni]));
+                }
+#endif
+            }
         } else {
 #pragma unroll 1
             for (int j = 0; j < nk; ++j) {
@@ -318,7 +335,7 @@ void conv_igemm_kernel(const ConvParams a, const int n_ct, const int tiles_per_x
         if (nc == nch_r) { nc = 0; ++nr; }
         const bool has_nc = nr < nruns;
         const Chunk nxt = get_chunk(has_nc ? nr : r, has_nc ? nc : ch);
-        if (!PF) {
+        if (!PF && !((ABL & 4) && ci > 0)) {
             __syncthreads();                       // every wave finished reading the previous patch
             patch_issue(cur, 0, HALF); patch_commit(cur, pbuf, 0, HALF);
             patch_issue(cur, HALF, Cfg::PU); patch_commit(cur, pbuf, HALF, Cfg::PU);
@@ -331,9 +348,11 @@ void conv_igemm_kernel(const ConvParams a, const int n_ct, const int tiles_per_x
             // Both fly during the MFMAs below and are written to LDS after them.
             const bool more_taps = tp + 1 < ntaps;
             const bool has_next = more_taps || has_nc;
-            if (more_taps) load_w(cur, tp + 1);
-            else if (has_nc) load_w(nxt, 0);
-            const bool pf_now = PF && tp == 0 && has_nc;
+            if (!(ABL & 4)) {
+                if (more_taps) load_w(cur, tp + 1);
+                else if (has_nc) load_w(nxt, 0);
+            }
+            const bool pf_now = PF && tp == 0 && has_nc && !(ABL & 4);
             if (pf_now) patch_issue(nxt, 0, Cfg::PU);
             __syncthreads();                       // patch + wbuf[step&1] visible; ring slots of step-1 free
             int dy = 0, dx = 0;
@@ -352,6 +371,15 @@ void conv_igemm_kernel(const ConvParams a, const int n_ct, const int tiles_per_x
 
     // ---- epilogue: LDS transpose -> (bias, temb bias, skip, scale) -> wide stores ---------
     __syncthreads();
+#ifndef STORM_HOST_SIM
+    if (ABL & 8) {                                      // profiling ablation: keep the accumulators alive, store nothing
+#pragma unroll
+        for (int mi = 0; mi < WM; ++mi)
+#pragma unroll
+            for (int ni = 0; ni < WN; ++ni) asm volatile("" ::"v"(acc[mi][ni]));
+        return;
+    }
+#endif
     constexpr int PR = Cfg::PR;                 // pixel rows (of 32 px) staged per pass and wave
     constexpr int SROWS = 32 * PR;
     char* const stage = smem + wave * (SROWS * WM * 128);
@@ -482,10 +510,10 @@ static ConvParams make_params(const storm_conv_args& a) {
     return p;
 }
 
-template <typename T, int TAPS, int WM, int WAVES_M, int WAVES_N, bool PF, bool FP = false>
+template <typename T, int TAPS, int WM, int WAVES_M, int WAVES_N, bool PF, bool FP = false, int ABL = 0>
 static int launch_conv(const storm_conv_args& a, hipStream_t st) {
-    typedef ConvCfg<TAPS, WM, WAVES_M, WAVES_N, PF, FP> Cfg;
-    auto kern = conv_igemm_kernel<T, TAPS, WM, WAVES_M, WAVES_N, PF, FP>;
+    typedef ConvCfg<TAPS, WM, WAVES_M, WAVES_N, PF, FP, ABL> Cfg;
+    auto kern = conv_igemm_kernel<T, TAPS, WM, WAVES_M, WAVES_N, PF, FP, ABL>;
     static bool attr_set = false;          // per instantiation; benign race (idempotent)
     if (!attr_set) {
         STORM_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
@@ -522,9 +550,22 @@ static int dispatch_conv(const storm_conv_args& a, hipStream_t st) {
     //   2: 256 cout x 256 px, 8 waves (64x128 each), 1 workgroup / CU, patch double-buffered and the
     //      next K-chunk prefetched under the MFMAs (one patch load + GN transform per 256 couts)
     static const int forced = getenv("STORM_CONV_VARIANT") ? atoi(getenv("STORM_CONV_VARIANT")) : -1;
-    static const bool frag_pipe = getenv("STORM_FRAG_PIPE") ? atoi(getenv("STORM_FRAG_PIPE")) != 0 : true;
+    static const bool frag_pipe = getenv("STORM_FRAG_PIPE") ? atoi(getenv("STORM_FRAG_PIPE")) != 0 : false;
     const long long px_tiles = (long long)a.B * cdiv((long long)a.H * a.W, TILE_H * TILE_W);
     const int variant = forced >= 0 ? forced : ((a.outC > 128 && px_tiles >= 512) ? 2 : 0);
+    static const int abl = getenv("STORM_CONV_ABLATE") ? atoi(getenv("STORM_CONV_ABLATE")) : 0;
+    if (any9 && !small && abl) {                        // profiling only
+        const bool v2 = variant == 2;
+        switch (abl) {
+            case 1: return v2 ? launch_conv<T, 9, 2, 4, 2, true, false, 1>(a, st) : launch_conv<T, 9, 2, 2, 2, false, false, 1>(a, st);
+            case 2: return v2 ? launch_conv<T, 9, 2, 4, 2, true, false, 2>(a, st) : launch_conv<T, 9, 2, 2, 2, false, false, 2>(a, st);
+            case 4: return v2 ? launch_conv<T, 9, 2, 4, 2, true, false, 4>(a, st) : launch_conv<T, 9, 2, 2, 2, false, false, 4>(a, st);
+            case 8: return v2 ? launch_conv<T, 9, 2, 4, 2, true, false, 8>(a, st) : launch_conv<T, 9, 2, 2, 2, false, false, 8>(a, st);
+            case 6: return v2 ? launch_conv<T, 9, 2, 4, 2, true, false, 6>(a, st) : launch_conv<T, 9, 2, 2, 2, false, false, 6>(a, st);
+            case 5: return v2 ? launch_conv<T, 9, 2, 4, 2, true, false, 5>(a, st) : launch_conv<T, 9, 2, 2, 2, false, false, 5>(a, st);
+            default: break;
+        }
+    }
     if (any9) {
         if (small) return launch_conv<T, 9, 1, 1, 4, false>(a, st);
         if (variant == 2) return launch_conv<T, 9, 2, 4, 2, true>(a, st);
