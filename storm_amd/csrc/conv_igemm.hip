@@ -300,7 +300,7 @@ void conv_igemm_kernel(const ConvParams a, const int n_ct, const int tiles_per_x
             for (int j = 0; j < nk; ++j) {
                 if (!(ABL & 2)) load_frags(j, fa, fb);
                 if (!(ABL & 1)) mma(fa, fb);
-#ifndef STORM_HOST_SIM
+#if defined(__HIP_DEVICE_COMPILE__)
                 else {
 #pragma unroll
                     for (int mi = 0; mi < WM; ++mi) asm volatile("" ::"v"(fa[mi]));
@@ -371,7 +371,7 @@ void conv_igemm_kernel(const ConvParams a, const int n_ct, const int tiles_per_x
 
     // ---- epilogue: LDS transpose -> (bias, temb bias, skip, scale) -> wide stores ---------
     __syncthreads();
-#ifndef STORM_HOST_SIM
+#if defined(__HIP_DEVICE_COMPILE__)
     if (ABL & 8) {                                      // profiling ablation: keep the accumulators alive, store nothing
 #pragma unroll
         for (int mi = 0; mi < WM; ++mi)
