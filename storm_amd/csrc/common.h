@@ -122,6 +122,18 @@ __device__ inline double wave_sum_d(double v) {
     return v;
 }
 
+// Wave-level ordering point: the LDS executes one wave's requests in issue order, so data a wave wrote is
+// visible to its own later reads without a workgroup barrier; this only stops compiler reordering.
+__device__ inline void wave_sync() {
+#ifdef STORM_HOST_SIM
+    simrt::wave_rendezvous();
+#else
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#endif
+}
+
 inline int cdiv(long long a, long long b) { return (int)((a + b - 1) / b); }
 
 }  // namespace storm

@@ -382,15 +382,38 @@ void conv_igemm_kernel(const ConvParams a, const int n_ct, const int tiles_per_x
 #endif
     constexpr int PR = Cfg::PR;                 // pixel rows (of 32 px) staged per pass and wave
     constexpr int SROWS = 32 * PR;
-    char* const stage = smem + wave * (SROWS * WM * 128);
+    char* const stage = smem + wave * (SROWS * WM * 128);      // private to this wave: only wave-level ordering needed
     constexpr int LPR = WM * 4;                 // lanes per staged row (8 couts each)
     constexpr int RPI = 64 / LPR;               // rows per read iteration
     const int skipC = a.outC;
+    const int c8 = lane % LPR;
+    const int co = cout0 + wm * WM * 32 + c8 * 8;              // this lane's 8 output channels (same in every iteration)
+    float badd[8];                              // bias + per-batch time-embedding bias, loaded once
+#pragma unroll
+    for (int e = 0; e < 8; ++e) badd[e] = 0.f;
+    if (co + 8 <= a.Cout) {
+        if (a.bias) { float bb[8]; load8(a.bias + co, bb);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) badd[e] += bb[e]; }
+        if (a.tbias) { float bb[8]; load8(a.tbias + (long long)b * a.tbias_stride + co, bb);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) badd[e] += bb[e]; }
+    } else {
+#pragma unroll
+        for (int e = 0; e < 8; ++e)
+            if (co + e < a.Cout) {
+                if (a.bias) badd[e] += a.bias[co + e];
+                if (a.tbias) badd[e] += a.tbias[(long long)b * a.tbias_stride + co + e];
+            }
+    }
+    const bool co_ok = co < a.outC;
+    const T* const skip_b = reinterpret_cast<const T*>(a.skip) + (long long)b * a.skip_bstride;
     float gsum[8], gsq[8];                      // GroupNorm partials of this lane's 8 channels (fused statistics)
 #pragma unroll
     for (int e = 0; e < 8; ++e) { gsum[e] = 0.f; gsq[e] = 0.f; }
 #pragma unroll
     for (int pass = 0; pass < WN / PR; ++pass) {
+        if (pass > 0) wave_sync();              // this wave's reads of the previous pass are done
 #pragma unroll
         for (int nn = 0; nn < PR; ++nn)
 #pragma unroll
@@ -402,10 +425,10 @@ void conv_igemm_kernel(const ConvParams a, const int n_ct, const int tiles_per_x
                     *reinterpret_cast<float4*>(stage + stage_off<WM>(row, stage_wslot(lane, mi, g))) =
                         make_float4(c[4 * g], c[4 * g + 1], c[4 * g + 2], c[4 * g + 3]);
                 }
-        __syncthreads();
-#pragma unroll 2
+        wave_sync();                            // LDS executes a wave's requests in order: no workgroup barrier
+#pragma unroll 4
         for (int it = 0; it < SROWS / RPI; ++it) {
-            const int row = it * RPI + lane / LPR, c8 = lane % LPR;
+            const int row = it * RPI + lane / LPR;
             const float4 v0 = *reinterpret_cast<const float4*>(stage + stage_off<WM>(row, 2 * c8));
             const float4 v1 = *reinterpret_cast<const float4*>(stage + stage_off<WM>(row, 2 * c8 + 1));
             float v[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
@@ -420,29 +443,12 @@ void conv_igemm_kernel(const ConvParams a, const int n_ct, const int tiles_per_x
                 pix = (int)lin0 + trow * TILE_W + n;
                 ok = pix < (int)npix;
             }
-            const int co = cout0 + wm * WM * 32 + c8 * 8;
-            if (ok && co < a.outC) {
-                if (co + 8 <= a.Cout) {               // fast path: 8 aligned floats per source
-                    if (a.bias) { float bb[8]; load8(a.bias + co, bb);
+            if (ok && co_ok) {
 #pragma unroll
-                        for (int e = 0; e < 8; ++e) v[e] += bb[e]; }
-                    if (a.tbias) { float bb[8]; load8(a.tbias + (long long)b * a.tbias_stride + co, bb);
-#pragma unroll
-                        for (int e = 0; e < 8; ++e) v[e] += bb[e]; }
-                } else {
-#pragma unroll
-                    for (int e = 0; e < 8; ++e) {
-                        float add = 0.0f;
-                        if (co + e < a.Cout) {
-                            if (a.bias) add += a.bias[co + e];
-                            if (a.tbias) add += a.tbias[(long long)b * a.tbias_stride + co + e];
-                        }
-                        v[e] += add;
-                    }
-                }
+                for (int e = 0; e < 8; ++e) v[e] += badd[e];
                 if (a.skip) {
                     float sk[8];
-                    load8(reinterpret_cast<const T*>(a.skip) + (long long)b * a.skip_bstride + (uint32_t)(pix * skipC + co), sk);
+                    load8(skip_b + (uint32_t)(pix * skipC + co), sk);
 #pragma unroll
                     for (int e = 0; e < 8; ++e) v[e] += sk[e];
                 }
@@ -453,7 +459,6 @@ void conv_igemm_kernel(const ConvParams a, const int n_ct, const int tiles_per_x
                 else store8(reinterpret_cast<T*>(a.out) + (long long)b * a.out_bstride + o, v);
             }
         }
-        if (pass + 1 < WN / PR) __syncthreads();
     }
     if (a.gn_part != nullptr) {
         // lanes with equal (lane % LPR) hold the same 8 channels: butterfly over the row lanes, then

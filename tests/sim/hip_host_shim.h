@@ -40,6 +40,8 @@ void block_barrier();
 typedef void (*CollFn)(const void* const* in, char (*out)[64], int nlanes, long long ctx);
 void wave_collective(const void* my_in, void* my_out, size_t out_bytes, CollFn fn, long long ctx);
 void launch(dim3 grid, dim3 block, size_t lds_bytes, const std::function<void()>& body);
+inline void noop_fn(const void* const*, char (*)[64], int, long long) {}
+inline void wave_rendezvous() { int d = 0, r; wave_collective(&d, &r, 0, &noop_fn, 0); }
 }  // namespace simrt
 
 #define threadIdx (simrt::thread_idx())
