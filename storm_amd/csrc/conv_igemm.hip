@@ -79,6 +79,8 @@ struct ConvCfg {
     static constexpr int ABL = ABL_;           // profiling-only ablation mask (separate instantiations)
     static constexpr bool PREFETCH = PF;       // double-buffered patch, next chunk fetched under the MFMAs
     static constexpr bool FRAG_PIPE = FP;      // two fragment sets, hand software-pipelined k-loop
+    static constexpr bool SPLIT_PATCH = !PF;
+    static constexpr int PF_COMMIT_TAP = 3;
     static constexpr int NWAVES = WAVES_M * WAVES_N;
     static constexpr int THREADS = 64 * NWAVES;
     static constexpr int WN = TILE_H / WAVES_N;          // pixel tile rows (of 32 px) per wave
@@ -119,7 +121,7 @@ struct ConvParams {
     int nruns, B, H, W;
     void* out; int outC, Cout; long long out_bstride;
     const float* bias; const float* tbias; int tbias_stride, out_f32;
-    const void* skip; long long skip_bstride; float scale; int pad_;
+    const void* skip; long long skip_bstride; float scale; int stagger;   // experiment: start-up delay of every other workgroup
     float* gn_part;   // optional [B][tiles_per_img][outC][2] per-tile (sum, sumsq) of the stored output
 };
 
@@ -141,6 +143,10 @@ void conv_igemm_kernel(const ConvParams a, const int n_ct, const int tiles_per_x
 
     const BlockMap bm = block_map(blockIdx.x, n_ct, tiles_per_xcd);
     if (bm.tile >= ntiles) return;
+#if defined(__HIP_DEVICE_COMPILE__)
+    if (a.stagger > 0 && blockIdx.x < 4096 && ((blockIdx.x >> (a.stagger >> 16)) & 1))
+        for (int i = 0; i < (a.stagger & 0xffff); ++i) __builtin_amdgcn_s_sleep(127);
+#endif
     const int b = bm.tile / tiles_per_img;
     const int trem = bm.tile - b * tiles_per_img;
     const int ty0 = (TAPS == 9) ? (trem / tiles_x) * TILE_H : 0;
@@ -181,25 +187,37 @@ void conv_igemm_kernel(const ConvParams a, const int n_ct, const int tiles_per_x
     auto chunks_of = [&](int r) { return (a.run[r].cn + KC - 1) / KC; };
 
     // ---- loaders --------------------------------------------------------------------------------
-    uint4 wreg[Cfg::WU];
-    auto load_w = [&](const Chunk& c, int tp) {
-        const T* wbase = c.w + (long long)tp * c.w_tapstride;
+    // Weight tiles are fetched TWO steps ahead through two register sets (a tile issued at step s is written
+    // to the LDS ring after the MFMAs of step s+1): an L2 / HBM round trip under load (2-3k cycles) is longer
+    // than one tap's MFMA phase (~1k cycles), with one step of slack every step stalled on it.
+    struct WPos { int r, ch, tp; };
+    auto wpos_next = [&](WPos p) {
+        const ConvRun& R = a.run[p.r];
+        WPos q = p;
+        if (++q.tp == R.ntaps) { q.tp = 0; if (++q.ch == (R.cn + KC - 1) / KC) { q.ch = 0; ++q.r; } }
+        return q;
+    };
+    uint4 wregA[Cfg::WU], wregB[Cfg::WU];
+    auto load_w = [&](uint4 (&dst)[Cfg::WU], WPos p) {
+        const ConvRun& R = a.run[p.r];             // wave-uniform index: scalar loads
+        const T* wbase = reinterpret_cast<const T*>(R.w) + (long long)b * R.w_bstride + R.wc0 + (long long)p.tp * R.w_tapstride;
+        const int CinP = R.CinP, w_rows = R.w_rows, kbeg = p.ch * KC, klim = R.CinP - R.wc0;
 #pragma unroll
         for (int i = 0; i < Cfg::WU; ++i) {
             const int u = tid + i * THREADS;
             const int row = u >> 3, slot = u & 7;
-            const int co = cout0 + row, k = c.kbeg + slot * PER16;
+            const int co = cout0 + row, k = kbeg + slot * PER16;
             uint4 v = make_uint4(0u, 0u, 0u, 0u);
-            if (co < c.w_rows && k < c.klim) v = ld16(wbase, (uint32_t)(co * c.CinP + k) * (uint32_t)sizeof(T));
-            wreg[i] = v;
+            if (co < w_rows && k < klim) v = ld16(wbase, (uint32_t)(co * CinP + k) * (uint32_t)sizeof(T));
+            dst[i] = v;
         }
     };
-    auto store_w = [&](int buf) {
+    auto store_w = [&](const uint4 (&src)[Cfg::WU], int buf) {
         char* dst = wbuf + buf * Cfg::WBUF_BYTES;
 #pragma unroll
         for (int i = 0; i < Cfg::WU; ++i) {
             const int u = tid + i * THREADS;
-            *reinterpret_cast<uint4*>(dst + lds_off(u >> 3, u & 7)) = wreg[i];
+            *reinterpret_cast<uint4*>(dst + lds_off(u >> 3, u & 7)) = src[i];
         }
     };
     // patch staging is split: issue (global loads -> registers) ... commit (GroupNorm affine + SiLU when fused,
@@ -328,8 +346,13 @@ void conv_igemm_kernel(const ConvParams a, const int n_ct, const int tiles_per_x
         patch_issue(cur, 0, Cfg::PU);
         patch_commit(cur, pbuf, 0, Cfg::PU);
     }
-    load_w(cur, 0);
-    store_w(0);
+    int nsteps = 0;
+    for (int q = 0; q < nruns; ++q) nsteps += chunks_of(q) * a.run[q].ntaps;
+    WPos wp{0, 0, 0};                             // position of the weight tile to fetch next
+    load_w(wregA, wp); store_w(wregA, 0);         // step 0 (synchronous)
+    wp = wpos_next(wp);
+    if (nsteps > 1) load_w(wregA, wp);            // step 1 -> set A (pending)
+    wp = wpos_next(wp);
     while (true) {
         int nr = r, nc = ch + 1;
         if (nc == nch_r) { nc = 0; ++nr; }
@@ -337,20 +360,23 @@ void conv_igemm_kernel(const ConvParams a, const int n_ct, const int tiles_per_x
         const Chunk nxt = get_chunk(has_nc ? nr : r, has_nc ? nc : ch);
         if (!PF && !((ABL & 4) && ci > 0)) {
             __syncthreads();                       // every wave finished reading the previous patch
-            patch_issue(cur, 0, HALF); patch_commit(cur, pbuf, 0, HALF);
-            patch_issue(cur, HALF, Cfg::PU); patch_commit(cur, pbuf, HALF, Cfg::PU);
+            if (Cfg::SPLIT_PATCH) {                // two register halves (less VGPR pressure, two memory round trips)
+                patch_issue(cur, 0, HALF); patch_commit(cur, pbuf, 0, HALF);
+                patch_issue(cur, HALF, Cfg::PU); patch_commit(cur, pbuf, HALF, Cfg::PU);
+            } else {
+                patch_issue(cur, 0, Cfg::PU); patch_commit(cur, pbuf, 0, Cfg::PU);
+            }
         }
         const char* const patch = pbuf + (PF ? (ci & 1) * Cfg::PATCH_BYTES : 0);
         const int nk = (cur.cvalid + KG - 1) / KG;
         const int ntaps = cur.ntaps;
         for (int tp = 0; tp < ntaps; ++tp) {
-            // next step's weight tile -> registers; (PF, first tap) next chunk's patch -> registers.
-            // Both fly during the MFMAs below and are written to LDS after them.
-            const bool more_taps = tp + 1 < ntaps;
-            const bool has_next = more_taps || has_nc;
-            if (!(ABL & 4)) {
-                if (more_taps) load_w(cur, tp + 1);
-                else if (has_nc) load_w(nxt, 0);
+            // weight tile of step+2 -> the free register set; (PF, first tap) next chunk's patch -> registers.
+            // Both fly during the MFMAs below; the set fetched a step earlier goes to the LDS ring after them.
+            const bool even = (step & 1) == 0;
+            if (step + 2 < nsteps && !(ABL & 4)) {
+                if (even) load_w(wregB, wp); else load_w(wregA, wp);
+                wp = wpos_next(wp);
             }
             const bool pf_now = PF && tp == 0 && has_nc && !(ABL & 4);
             if (pf_now) patch_issue(nxt, 0, Cfg::PU);
@@ -360,8 +386,12 @@ void conv_igemm_kernel(const ConvParams a, const int n_ct, const int tiles_per_x
                 if (ntaps == 9) { dy = tp / 3; dx = tp - dy * 3; } else { dy = 1; dx = 1; }
             }
             compute(patch, wbuf + (step & 1) * Cfg::WBUF_BYTES, dy, dx, nk);
-            if (has_next) store_w((step + 1) & 1);
-            if (pf_now) patch_commit(nxt, pbuf + ((ci + 1) & 1) * Cfg::PATCH_BYTES, 0, Cfg::PU);
+            if (step + 1 < nsteps) {
+                if (even) store_w(wregA, (step + 1) & 1); else store_w(wregB, (step + 1) & 1);
+            }
+            // the prefetched patch is committed a few taps later: its global loads get several MFMA phases of slack
+            if (PF && has_nc && !(ABL & 4) && tp == min(Cfg::PF_COMMIT_TAP, ntaps - 1))
+                patch_commit(nxt, pbuf + ((ci + 1) & 1) * Cfg::PATCH_BYTES, 0, Cfg::PU);
             ++step;
         }
         if (!has_nc) break;
@@ -512,6 +542,8 @@ static ConvParams make_params(const storm_conv_args& a) {
     p.bias = a.bias; p.tbias = a.tbias; p.tbias_stride = a.tbias_stride; p.out_f32 = a.out_f32;
     p.skip = a.skip; p.skip_bstride = a.skip_bstride; p.scale = a.scale;
     p.gn_part = a.gn_part;
+    static const int stagger = getenv("STORM_CONV_STAGGER") ? atoi(getenv("STORM_CONV_STAGGER")) : 0;
+    p.stagger = stagger;
     return p;
 }
 
