@@ -198,7 +198,10 @@ void conv_igemm_kernel(const ConvParams a, const int n_ct, const int tiles_per_x
         return q;
     };
     uint4 wregA[Cfg::WU], wregB[Cfg::WU];
-    auto load_w = [&](uint4 (&dst)[Cfg::WU], WPos p) {
+    uint32_t wmaskA = 0, wmaskB = 0;             // bit i: unit i lies inside the weight matrix (else stored as zero)
+    // Loads are UNCONDITIONAL (out-of-range lanes read element 0 and are zeroed when the set is written to
+    // LDS): no exec-masked branches around VMEM, so the compiler's s_waitcnt stays counted, never vmcnt(0).
+    auto load_w = [&](uint4 (&dst)[Cfg::WU], uint32_t& mask, WPos p) {
         const ConvRun& R = a.run[p.r];             // wave-uniform index: scalar loads
         const T* wbase = reinterpret_cast<const T*>(R.w) + (long long)b * R.w_bstride + R.wc0 + (long long)p.tp * R.w_tapstride;
         const int CinP = R.CinP, w_rows = R.w_rows, kbeg = p.ch * KC, klim = R.CinP - R.wc0;
@@ -207,17 +210,17 @@ void conv_igemm_kernel(const ConvParams a, const int n_ct, const int tiles_per_x
             const int u = tid + i * THREADS;
             const int row = u >> 3, slot = u & 7;
             const int co = cout0 + row, k = kbeg + slot * PER16;
-            uint4 v = make_uint4(0u, 0u, 0u, 0u);
-            if (co < w_rows && k < klim) v = ld16(wbase, (uint32_t)(co * CinP + k) * (uint32_t)sizeof(T));
-            dst[i] = v;
+            const bool ok = co < w_rows && k < klim;
+            dst[i] = ld16(wbase, ok ? (uint32_t)(co * CinP + k) * (uint32_t)sizeof(T) : 0u);
+            mask = ok ? (mask | (1u << i)) : (mask & ~(1u << i));
         }
     };
-    auto store_w = [&](const uint4 (&src)[Cfg::WU], int buf) {
+    auto store_w = [&](const uint4 (&src)[Cfg::WU], uint32_t mask, int buf) {
         char* dst = wbuf + buf * Cfg::WBUF_BYTES;
 #pragma unroll
         for (int i = 0; i < Cfg::WU; ++i) {
             const int u = tid + i * THREADS;
-            *reinterpret_cast<uint4*>(dst + lds_off(u >> 3, u & 7)) = src[i];
+            *reinterpret_cast<uint4*>(dst + lds_off(u >> 3, u & 7)) = ((mask >> i) & 1u) ? src[i] : make_uint4(0u, 0u, 0u, 0u);
         }
     };
     // patch staging is split: issue (global loads -> registers) ... commit (GroupNorm affine + SiLU when fused,
@@ -241,9 +244,7 @@ void conv_igemm_kernel(const ConvParams a, const int n_ct, const int tiles_per_x
                 pix = (int)lin0 + p;
                 ok = ok && pix < (int)npix;
             }
-            uint4 v = make_uint4(0u, 0u, 0u, 0u);
-            if (ok) v = ld16(c.src, (uint32_t)(pix * c.C + c.cbeg + slot * PER16) * (uint32_t)sizeof(T));
-            preg[i] = v;
+            preg[i] = ld16(c.src, ok ? (uint32_t)(pix * c.C + c.cbeg + slot * PER16) * (uint32_t)sizeof(T) : 0u);
             pmask = ok ? (pmask | (1u << i)) : (pmask & ~(1u << i));
         }
     };
@@ -264,7 +265,8 @@ void conv_igemm_kernel(const ConvParams a, const int n_ct, const int tiles_per_x
             const int u = tid + i * THREADS;
             if (u < Cfg::NPIX * 8) {
                 uint4 v = preg[i];
-                if (c.gn_ss != nullptr && (pmask >> i) & 1u) v = gn_act_slot(v, ss, c.gn_silu, (T*)nullptr);
+                if (c.gn_ss != nullptr) v = gn_act_slot(v, ss, c.gn_silu, (T*)nullptr);
+                if (!((pmask >> i) & 1u)) v = make_uint4(0u, 0u, 0u, 0u);      // zero padding (after the activation)
                 *reinterpret_cast<uint4*>(dst + lds_off(u >> 3, u & 7)) = v;
             }
         }
@@ -349,54 +351,64 @@ void conv_igemm_kernel(const ConvParams a, const int n_ct, const int tiles_per_x
     int nsteps = 0;
     for (int q = 0; q < nruns; ++q) nsteps += chunks_of(q) * a.run[q].ntaps;
     WPos wp{0, 0, 0};                             // position of the weight tile to fetch next
-    load_w(wregA, wp); store_w(wregA, 0);         // step 0 (synchronous)
+    load_w(wregA, wmaskA, wp); store_w(wregA, wmaskA, 0);         // step 0 (synchronous)
     wp = wpos_next(wp);
-    if (nsteps > 1) load_w(wregA, wp);            // step 1 -> set A (pending)
+    if (nsteps > 1) load_w(wregA, wmaskA, wp);    // step 1 -> set A (pending)
     wp = wpos_next(wp);
-    while (true) {
-        int nr = r, nc = ch + 1;
-        if (nc == nch_r) { nc = 0; ++nr; }
-        const bool has_nc = nr < nruns;
-        const Chunk nxt = get_chunk(has_nc ? nr : r, has_nc ? nc : ch);
-        if (!PF && !((ABL & 4) && ci > 0)) {
-            __syncthreads();                       // every wave finished reading the previous patch
-            if (Cfg::SPLIT_PATCH) {                // two register halves (less VGPR pressure, two memory round trips)
-                patch_issue(cur, 0, HALF); patch_commit(cur, pbuf, 0, HALF);
-                patch_issue(cur, HALF, Cfg::PU); patch_commit(cur, pbuf, HALF, Cfg::PU);
-            } else {
-                patch_issue(cur, 0, Cfg::PU); patch_commit(cur, pbuf, 0, Cfg::PU);
+    int tp = 0;
+    Chunk nxt = cur;
+    bool has_nc = false;
+    int nr = 0, nc = 0;
+    // One step = one tap of one K-chunk.  The two register sets alternate STATICALLY (the step body is
+    // instantiated twice, back to back): a runtime-selected set would be rotated with register copies, and
+    // copying the destination of an in-flight load forces s_waitcnt vmcnt(0) right after issuing it.
+    auto do_step = [&](uint4 (&pend)[Cfg::WU], uint32_t& pmk, uint4 (&fre)[Cfg::WU], uint32_t& fmk) -> bool {
+        if (tp == 0) {                             // ---- chunk start
+            nr = r; nc = ch + 1;
+            if (nc == nch_r) { nc = 0; ++nr; }
+            has_nc = nr < nruns;
+            nxt = get_chunk(has_nc ? nr : r, has_nc ? nc : ch);
+            if (!PF && !((ABL & 4) && ci > 0)) {
+                __syncthreads();                   // every wave finished reading the previous patch
+                if (Cfg::SPLIT_PATCH) {            // two register halves (less VGPR pressure, two memory round trips)
+                    patch_issue(cur, 0, HALF); patch_commit(cur, pbuf, 0, HALF);
+                    patch_issue(cur, HALF, Cfg::PU); patch_commit(cur, pbuf, HALF, Cfg::PU);
+                } else {
+                    patch_issue(cur, 0, Cfg::PU); patch_commit(cur, pbuf, 0, Cfg::PU);
+                }
             }
         }
         const char* const patch = pbuf + (PF ? (ci & 1) * Cfg::PATCH_BYTES : 0);
         const int nk = (cur.cvalid + KG - 1) / KG;
         const int ntaps = cur.ntaps;
-        for (int tp = 0; tp < ntaps; ++tp) {
-            // weight tile of step+2 -> the free register set; (PF, first tap) next chunk's patch -> registers.
-            // Both fly during the MFMAs below; the set fetched a step earlier goes to the LDS ring after them.
-            const bool even = (step & 1) == 0;
-            if (step + 2 < nsteps && !(ABL & 4)) {
-                if (even) load_w(wregB, wp); else load_w(wregA, wp);
-                wp = wpos_next(wp);
-            }
-            const bool pf_now = PF && tp == 0 && has_nc && !(ABL & 4);
-            if (pf_now) patch_issue(nxt, 0, Cfg::PU);
-            __syncthreads();                       // patch + wbuf[step&1] visible; ring slots of step-1 free
-            int dy = 0, dx = 0;
-            if (TAPS == 9) {
-                if (ntaps == 9) { dy = tp / 3; dx = tp - dy * 3; } else { dy = 1; dx = 1; }
-            }
-            compute(patch, wbuf + (step & 1) * Cfg::WBUF_BYTES, dy, dx, nk);
-            if (step + 1 < nsteps) {
-                if (even) store_w(wregA, (step + 1) & 1); else store_w(wregB, (step + 1) & 1);
-            }
-            // the prefetched patch is committed a few taps later: its global loads get several MFMA phases of slack
-            if (PF && has_nc && !(ABL & 4) && tp == min(Cfg::PF_COMMIT_TAP, ntaps - 1))
-                patch_commit(nxt, pbuf + ((ci + 1) & 1) * Cfg::PATCH_BYTES, 0, Cfg::PU);
-            ++step;
+        // weight tile of step+2 -> the free register set; (PF, first tap) next chunk's patch -> registers.
+        // Both fly during the MFMAs below; the set fetched a step earlier goes to the LDS ring after them.
+        if (step + 2 < nsteps && !(ABL & 4)) {
+            load_w(fre, fmk, wp);
+            wp = wpos_next(wp);
         }
-        if (!has_nc) break;
-        if (nr != r) nch_r = chunks_of(nr);
-        cur = nxt; r = nr; ch = nc; ++ci;
+        if (PF && tp == 0 && has_nc && !(ABL & 4)) patch_issue(nxt, 0, Cfg::PU);
+        __syncthreads();                           // patch + wbuf[step&1] visible; ring slot of step-1 free
+        int dy = 0, dx = 0;
+        if (TAPS == 9) {
+            if (ntaps == 9) { dy = tp / 3; dx = tp - dy * 3; } else { dy = 1; dx = 1; }
+        }
+        compute(patch, wbuf + (step & 1) * Cfg::WBUF_BYTES, dy, dx, nk);
+        if (step + 1 < nsteps) store_w(pend, pmk, (step + 1) & 1);
+        // the prefetched patch is committed a few taps later: its global loads get several MFMA phases of slack
+        if (PF && has_nc && !(ABL & 4) && tp == min(Cfg::PF_COMMIT_TAP, ntaps - 1))
+            patch_commit(nxt, pbuf + ((ci + 1) & 1) * Cfg::PATCH_BYTES, 0, Cfg::PU);
+        ++step;
+        if (++tp == ntaps) {                       // ---- chunk end
+            if (!has_nc) return false;
+            if (nr != r) nch_r = chunks_of(nr);
+            cur = nxt; r = nr; ch = nc; ++ci; tp = 0;
+        }
+        return true;
+    };
+    while (true) {
+        if (!do_step(wregA, wmaskA, wregB, wmaskB)) break;         // even steps: A holds step+1, B receives step+2
+        if (!do_step(wregB, wmaskB, wregA, wmaskA)) break;         // odd steps: roles swapped
     }
 
     // ---- epilogue: LDS transpose -> (bias, temb bias, skip, scale) -> wide stores ---------
