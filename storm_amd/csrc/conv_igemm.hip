@@ -79,8 +79,6 @@ struct ConvCfg {
     static constexpr int ABL = ABL_;           // profiling-only ablation mask (separate instantiations)
     static constexpr bool PREFETCH = PF;       // double-buffered patch, next chunk fetched under the MFMAs
     static constexpr bool FRAG_PIPE = FP;      // two fragment sets, hand software-pipelined k-loop
-    static constexpr bool SPLIT_PATCH = !PF;
-    static constexpr int PF_COMMIT_TAP = 3;
     static constexpr int NWAVES = WAVES_M * WAVES_N;
     static constexpr int THREADS = 64 * NWAVES;
     static constexpr int WN = TILE_H / WAVES_N;          // pixel tile rows (of 32 px) per wave
@@ -121,7 +119,7 @@ struct ConvParams {
     int nruns, B, H, W;
     void* out; int outC, Cout; long long out_bstride;
     const float* bias; const float* tbias; int tbias_stride, out_f32;
-    const void* skip; long long skip_bstride; float scale; int stagger;   // experiment: start-up delay of every other workgroup
+    const void* skip; long long skip_bstride; float scale; int pad_;
     float* gn_part;   // optional [B][tiles_per_img][outC][2] per-tile (sum, sumsq) of the stored output
 };
 
@@ -143,10 +141,6 @@ void conv_igemm_kernel(const ConvParams a, const int n_ct, const int tiles_per_x
 
     const BlockMap bm = block_map(blockIdx.x, n_ct, tiles_per_xcd);
     if (bm.tile >= ntiles) return;
-#if defined(__HIP_DEVICE_COMPILE__)
-    if (a.stagger > 0 && blockIdx.x < 4096 && ((blockIdx.x >> (a.stagger >> 16)) & 1))
-        for (int i = 0; i < (a.stagger & 0xffff); ++i) __builtin_amdgcn_s_sleep(127);
-#endif
     const int b = bm.tile / tiles_per_img;
     const int trem = bm.tile - b * tiles_per_img;
     const int ty0 = (TAPS == 9) ? (trem / tiles_x) * TILE_H : 0;
@@ -187,40 +181,25 @@ void conv_igemm_kernel(const ConvParams a, const int n_ct, const int tiles_per_x
     auto chunks_of = [&](int r) { return (a.run[r].cn + KC - 1) / KC; };
 
     // ---- loaders --------------------------------------------------------------------------------
-    // Weight tiles are fetched TWO steps ahead through two register sets (a tile issued at step s is written
-    // to the LDS ring after the MFMAs of step s+1): an L2 / HBM round trip under load (2-3k cycles) is longer
-    // than one tap's MFMA phase (~1k cycles), with one step of slack every step stalled on it.
-    struct WPos { int r, ch, tp; };
-    auto wpos_next = [&](WPos p) {
-        const ConvRun& R = a.run[p.r];
-        WPos q = p;
-        if (++q.tp == R.ntaps) { q.tp = 0; if (++q.ch == (R.cn + KC - 1) / KC) { q.ch = 0; ++q.r; } }
-        return q;
-    };
-    uint4 wregA[Cfg::WU], wregB[Cfg::WU];
-    uint32_t wmaskA = 0, wmaskB = 0;             // bit i: unit i lies inside the weight matrix (else stored as zero)
-    // Loads are UNCONDITIONAL (out-of-range lanes read element 0 and are zeroed when the set is written to
-    // LDS): no exec-masked branches around VMEM, so the compiler's s_waitcnt stays counted, never vmcnt(0).
-    auto load_w = [&](uint4 (&dst)[Cfg::WU], uint32_t& mask, WPos p) {
-        const ConvRun& R = a.run[p.r];             // wave-uniform index: scalar loads
-        const T* wbase = reinterpret_cast<const T*>(R.w) + (long long)b * R.w_bstride + R.wc0 + (long long)p.tp * R.w_tapstride;
-        const int CinP = R.CinP, w_rows = R.w_rows, kbeg = p.ch * KC, klim = R.CinP - R.wc0;
+    uint4 wreg[Cfg::WU];
+    auto load_w = [&](const Chunk& c, int tp) {
+        const T* wbase = c.w + (long long)tp * c.w_tapstride;
 #pragma unroll
         for (int i = 0; i < Cfg::WU; ++i) {
             const int u = tid + i * THREADS;
             const int row = u >> 3, slot = u & 7;
-            const int co = cout0 + row, k = kbeg + slot * PER16;
-            const bool ok = co < w_rows && k < klim;
-            dst[i] = ld16(wbase, ok ? (uint32_t)(co * CinP + k) * (uint32_t)sizeof(T) : 0u);
-            mask = ok ? (mask | (1u << i)) : (mask & ~(1u << i));
+            const int co = cout0 + row, k = c.kbeg + slot * PER16;
+            uint4 v = make_uint4(0u, 0u, 0u, 0u);
+            if (co < c.w_rows && k < c.klim) v = ld16(wbase, (uint32_t)(co * c.CinP + k) * (uint32_t)sizeof(T));
+            wreg[i] = v;
         }
     };
-    auto store_w = [&](const uint4 (&src)[Cfg::WU], uint32_t mask, int buf) {
+    auto store_w = [&](int buf) {
         char* dst = wbuf + buf * Cfg::WBUF_BYTES;
 #pragma unroll
         for (int i = 0; i < Cfg::WU; ++i) {
             const int u = tid + i * THREADS;
-            *reinterpret_cast<uint4*>(dst + lds_off(u >> 3, u & 7)) = ((mask >> i) & 1u) ? src[i] : make_uint4(0u, 0u, 0u, 0u);
+            *reinterpret_cast<uint4*>(dst + lds_off(u >> 3, u & 7)) = wreg[i];
         }
     };
     // patch staging is split: issue (global loads -> registers) ... commit (GroupNorm affine + SiLU when fused,
@@ -244,7 +223,9 @@ void conv_igemm_kernel(const ConvParams a, const int n_ct, const int tiles_per_x
                 pix = (int)lin0 + p;
                 ok = ok && pix < (int)npix;
             }
-            preg[i] = ld16(c.src, ok ? (uint32_t)(pix * c.C + c.cbeg + slot * PER16) * (uint32_t)sizeof(T) : 0u);
+            uint4 v = make_uint4(0u, 0u, 0u, 0u);
+            if (ok) v = ld16(c.src, (uint32_t)(pix * c.C + c.cbeg + slot * PER16) * (uint32_t)sizeof(T));
+            preg[i] = v;
             pmask = ok ? (pmask | (1u << i)) : (pmask & ~(1u << i));
         }
     };
@@ -265,8 +246,7 @@ void conv_igemm_kernel(const ConvParams a, const int n_ct, const int tiles_per_x
             const int u = tid + i * THREADS;
             if (u < Cfg::NPIX * 8) {
                 uint4 v = preg[i];
-                if (c.gn_ss != nullptr) v = gn_act_slot(v, ss, c.gn_silu, (T*)nullptr);
-                if (!((pmask >> i) & 1u)) v = make_uint4(0u, 0u, 0u, 0u);      // zero padding (after the activation)
+                if (c.gn_ss != nullptr && (pmask >> i) & 1u) v = gn_act_slot(v, ss, c.gn_silu, (T*)nullptr);
                 *reinterpret_cast<uint4*>(dst + lds_off(u >> 3, u & 7)) = v;
             }
         }
@@ -348,67 +328,45 @@ void conv_igemm_kernel(const ConvParams a, const int n_ct, const int tiles_per_x
         patch_issue(cur, 0, Cfg::PU);
         patch_commit(cur, pbuf, 0, Cfg::PU);
     }
-    int nsteps = 0;
-    for (int q = 0; q < nruns; ++q) nsteps += chunks_of(q) * a.run[q].ntaps;
-    WPos wp{0, 0, 0};                             // position of the weight tile to fetch next
-    load_w(wregA, wmaskA, wp); store_w(wregA, wmaskA, 0);         // step 0 (synchronous)
-    wp = wpos_next(wp);
-    if (nsteps > 1) load_w(wregA, wmaskA, wp);    // step 1 -> set A (pending)
-    wp = wpos_next(wp);
-    int tp = 0;
-    Chunk nxt = cur;
-    bool has_nc = false;
-    int nr = 0, nc = 0;
-    // One step = one tap of one K-chunk.  The two register sets alternate STATICALLY (the step body is
-    // instantiated twice, back to back): a runtime-selected set would be rotated with register copies, and
-    // copying the destination of an in-flight load forces s_waitcnt vmcnt(0) right after issuing it.
-    auto do_step = [&](uint4 (&pend)[Cfg::WU], uint32_t& pmk, uint4 (&fre)[Cfg::WU], uint32_t& fmk) -> bool {
-        if (tp == 0) {                             // ---- chunk start
-            nr = r; nc = ch + 1;
-            if (nc == nch_r) { nc = 0; ++nr; }
-            has_nc = nr < nruns;
-            nxt = get_chunk(has_nc ? nr : r, has_nc ? nc : ch);
-            if (!PF && !((ABL & 4) && ci > 0)) {
-                __syncthreads();                   // every wave finished reading the previous patch
-                if (Cfg::SPLIT_PATCH) {            // two register halves (less VGPR pressure, two memory round trips)
-                    patch_issue(cur, 0, HALF); patch_commit(cur, pbuf, 0, HALF);
-                    patch_issue(cur, HALF, Cfg::PU); patch_commit(cur, pbuf, HALF, Cfg::PU);
-                } else {
-                    patch_issue(cur, 0, Cfg::PU); patch_commit(cur, pbuf, 0, Cfg::PU);
-                }
-            }
+    load_w(cur, 0);
+    store_w(0);
+    while (true) {
+        int nr = r, nc = ch + 1;
+        if (nc == nch_r) { nc = 0; ++nr; }
+        const bool has_nc = nr < nruns;
+        const Chunk nxt = get_chunk(has_nc ? nr : r, has_nc ? nc : ch);
+        if (!PF && !((ABL & 4) && ci > 0)) {
+            __syncthreads();                       // every wave finished reading the previous patch
+            patch_issue(cur, 0, HALF); patch_commit(cur, pbuf, 0, HALF);
+            patch_issue(cur, HALF, Cfg::PU); patch_commit(cur, pbuf, HALF, Cfg::PU);
         }
         const char* const patch = pbuf + (PF ? (ci & 1) * Cfg::PATCH_BYTES : 0);
         const int nk = (cur.cvalid + KG - 1) / KG;
         const int ntaps = cur.ntaps;
-        // weight tile of step+2 -> the free register set; (PF, first tap) next chunk's patch -> registers.
-        // Both fly during the MFMAs below; the set fetched a step earlier goes to the LDS ring after them.
-        if (step + 2 < nsteps && !(ABL & 4)) {
-            load_w(fre, fmk, wp);
-            wp = wpos_next(wp);
+        for (int tp = 0; tp < ntaps; ++tp) {
+            // next step's weight tile -> registers; (PF, first tap) next chunk's patch -> registers.
+            // Both fly during the MFMAs below and are written to LDS after them.
+            const bool more_taps = tp + 1 < ntaps;
+            const bool has_next = more_taps || has_nc;
+            if (!(ABL & 4)) {
+                if (more_taps) load_w(cur, tp + 1);
+                else if (has_nc) load_w(nxt, 0);
+            }
+            const bool pf_now = PF && tp == 0 && has_nc && !(ABL & 4);
+            if (pf_now) patch_issue(nxt, 0, Cfg::PU);
+            __syncthreads();                       // patch + wbuf[step&1] visible; ring slots of step-1 free
+            int dy = 0, dx = 0;
+            if (TAPS == 9) {
+                if (ntaps == 9) { dy = tp / 3; dx = tp - dy * 3; } else { dy = 1; dx = 1; }
+            }
+            compute(patch, wbuf + (step & 1) * Cfg::WBUF_BYTES, dy, dx, nk);
+            if (has_next) store_w((step + 1) & 1);
+            if (pf_now) patch_commit(nxt, pbuf + ((ci + 1) & 1) * Cfg::PATCH_BYTES, 0, Cfg::PU);
+            ++step;
         }
-        if (PF && tp == 0 && has_nc && !(ABL & 4)) patch_issue(nxt, 0, Cfg::PU);
-        __syncthreads();                           // patch + wbuf[step&1] visible; ring slot of step-1 free
-        int dy = 0, dx = 0;
-        if (TAPS == 9) {
-            if (ntaps == 9) { dy = tp / 3; dx = tp - dy * 3; } else { dy = 1; dx = 1; }
-        }
-        compute(patch, wbuf + (step & 1) * Cfg::WBUF_BYTES, dy, dx, nk);
-        if (step + 1 < nsteps) store_w(pend, pmk, (step + 1) & 1);
-        // the prefetched patch is committed a few taps later: its global loads get several MFMA phases of slack
-        if (PF && has_nc && !(ABL & 4) && tp == min(Cfg::PF_COMMIT_TAP, ntaps - 1))
-            patch_commit(nxt, pbuf + ((ci + 1) & 1) * Cfg::PATCH_BYTES, 0, Cfg::PU);
-        ++step;
-        if (++tp == ntaps) {                       // ---- chunk end
-            if (!has_nc) return false;
-            if (nr != r) nch_r = chunks_of(nr);
-            cur = nxt; r = nr; ch = nc; ++ci; tp = 0;
-        }
-        return true;
-    };
-    while (true) {
-        if (!do_step(wregA, wmaskA, wregB, wmaskB)) break;         // even steps: A holds step+1, B receives step+2
-        if (!do_step(wregB, wmaskB, wregA, wmaskA)) break;         // odd steps: roles swapped
+        if (!has_nc) break;
+        if (nr != r) nch_r = chunks_of(nr);
+        cur = nxt; r = nr; ch = nc; ++ci;
     }
 
     // ---- epilogue: LDS transpose -> (bias, temb bias, skip, scale) -> wide stores ---------
@@ -554,8 +512,6 @@ static ConvParams make_params(const storm_conv_args& a) {
     p.bias = a.bias; p.tbias = a.tbias; p.tbias_stride = a.tbias_stride; p.out_f32 = a.out_f32;
     p.skip = a.skip; p.skip_bstride = a.skip_bstride; p.scale = a.scale;
     p.gn_part = a.gn_part;
-    static const int stagger = getenv("STORM_CONV_STAGGER") ? atoi(getenv("STORM_CONV_STAGGER")) : 0;
-    p.stagger = stagger;
     return p;
 }
 
