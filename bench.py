@@ -195,10 +195,21 @@ def main():
     if rank == 0 and not args.no_roofline:
         Y, _, _ = model._prepare(wav)
         rows, prog = profile_ops(model.dnn, Y, args.profile_nfe)
-        big = [r for r in rows if r["code"] == 4 and r["big"] and 9 in r["taps"]]
+        # the 3x3 implicit-GEMM kernel has two tile instantiations (dispatch rule of conv_igemm.hip):
+        #   256 cout x 256 px (8 waves, prefetched patch) when outC > 128 and >= 512 pixel tiles, else 128 cout x 256 px
+        tname = "storm::bf16_t" if args.precision == "bf16" else "float"
+        groups = {}
+        for r in rows:
+            if r["code"] == 4 and r["big"] and 9 in r["taps"]:
+                v2 = r["Cout"] > 128 and args.batch * ((r["H"] * r["W"] + 255) // 256) >= 512
+                key = (f"storm::conv_igemm_kernel<{tname}, 9, 2, 4, 2, true, false, 0>" if v2
+                       else f"storm::conv_igemm_kernel<{tname}, 9, 2, 2, 2, false, false, 0>")
+                groups.setdefault(key, []).append(r)
+        kname, big = max(groups.items(), key=lambda kv: sum(r["ms"] for r in kv[1]))
         flops, ms = sum(r["flops"] for r in big), sum(r["ms"] for r in big)
         total_ms = sum(r["ms"] for r in rows)
         all_conv = [r for r in rows if r["code"] == 4]
+        all3 = [r for g in groups.values() for r in g]
         peak = BF16_MFMA_PEAK_TFLOPS if args.precision == "bf16" else F32_MFMA_PEAK_TFLOPS
         ach = flops / (ms * 1e-3) / 1e12
         names = {0: "memset", 1: "pack_input", 2: "temb", 3: "dense", 4: "conv", 5: "gn_stats", 6: "gn_apply",
@@ -206,13 +217,19 @@ def main():
         by_kind = {}
         for r in rows:
             by_kind[names[r["code"]]] = by_kind.get(names[r["code"]], 0.0) + r["ms"]
+        traffic = None
+        tpath = os.path.join(ROOT, "profiles", "conv_traffic.json")     # PMC pass (scripts/pmc_round.sh), per launch
+        if os.path.exists(tpath):
+            traffic = json.load(open(tpath)).get(kname.split("<")[1].split(">")[0].replace(" ", ""), {}).get("hbm_bytes_per_launch")
         result["roofline"] = {
-            "bound": "mfma", "kernel": "conv_igemm_kernel<%s, 9 taps, 128 cout x 256 px tile>" % args.precision,
-            "achieved": ach, "peak": peak, "unit": "TFLOP/s", "frac": ach / peak, "traffic": None,
+            "bound": "mfma", "kernel": kname,
+            "achieved": ach, "peak": peak, "unit": "TFLOP/s", "frac": ach / peak, "traffic": traffic,
             "launches_per_nfe": len(big), "avg_launch_ms": ms / len(big), "avg_launch_gflop": flops / len(big) / 1e9,
             "nfe_ms_profiled": total_ms, "ms_by_op_kind": {k: round(v, 3) for k, v in by_kind.items()},
+            "all_3x3_tflops": sum(r["flops"] for r in all3) / (sum(r["ms"] for r in all3) * 1e-3) / 1e12,
             "all_conv_tflops": sum(r["flops"] for r in all_conv) / (sum(r["ms"] for r in all_conv) * 1e-3) / 1e12,
-            "method": f"HIP events per op on the launch stream over {args.profile_nfe} score evaluations at batch {args.batch}",
+            "method": f"HIP events per op on the launch stream (storm_program_run_timed) over {args.profile_nfe} score "
+                      f"evaluations at batch {args.batch}; algorithmic FLOPs = 2*B*H*W*Cout*Cin*taps per launch",
         }
         if args.ops_json:
             with open(args.ops_json, "w") as f:

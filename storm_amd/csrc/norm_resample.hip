@@ -233,28 +233,43 @@ void gn_apply_resample_kernel(const T* __restrict__ xa, int Ca, const T* __restr
     }
     const long long ibase = (long long)b * H * W;
     // ---- stage: raw + activated input tile -> LDS (zeros outside the image) ----
-    for (int u = tid; u < RS_NPIX * 8; u += 256) {
+    // all global loads of the thread are issued before the first dependent use (one memory round trip)
+    constexpr int NU = (RS_NPIX * 8 + 255) / 256;
+    uint4 rawv[NU];
+    bool okv[NU];
+#pragma unroll
+    for (int k = 0; k < NU; ++k) {
+        const int u = tid + k * 256;
         const int p = u >> 3;                        // (u & 7) == slot because 256 % 8 == 0
         const int py = p / RS_IW, px = p - py * RS_IW;
         const int iy = iy0 + py, ix = ix0 + px;
-        alignas(16) T raw[PER16];
-        alignas(16) T act[PER16];
-        const bool ok = cvalid && iy >= 0 && iy < H && ix >= 0 && ix < W;
-        if (ok) {
+        okv[k] = (u < RS_NPIX * 8) && cvalid && iy >= 0 && iy < H && ix >= 0 && ix < W;
+        rawv[k] = make_uint4(0u, 0u, 0u, 0u);
+        if (okv[k]) {
             const long long pix = ibase + (long long)iy * W + ix;
             const T* src = (c < Ca) ? (xa + pix * Ca + c) : (xb + pix * Cb + (c - Ca));
-            *reinterpret_cast<uint4*>(raw) = *reinterpret_cast<const uint4*>(src);
+            rawv[k] = *reinterpret_cast<const uint4*>(src);
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < NU; ++k) {
+        const int u = tid + k * 256;
+        if (u >= RS_NPIX * 8) continue;
+        const int p = u >> 3;
+        alignas(16) T raw[PER16];
+        alignas(16) T act[PER16];
+        *reinterpret_cast<uint4*>(raw) = rawv[k];
+        if (okv[k]) {
 #pragma unroll
             for (int e = 0; e < PER16; ++e) {
                 float y = (to_f32(raw[e]) - pm[e]) * pa[e] + pb[e];
-                if (silu) y = silu_f(y);
+                if (silu) y = (sizeof(T) == 2) ? fast_silu(y) : silu_f(y);
                 from_f32(act[e], y);
             }
         } else {
-            *reinterpret_cast<uint4*>(raw) = make_uint4(0u, 0u, 0u, 0u);
             *reinterpret_cast<uint4*>(act) = make_uint4(0u, 0u, 0u, 0u);
         }
-        *reinterpret_cast<uint4*>(t_raw + p * 128 + slot * 16) = *reinterpret_cast<const uint4*>(raw);
+        *reinterpret_cast<uint4*>(t_raw + p * 128 + slot * 16) = rawv[k];
         *reinterpret_cast<uint4*>(t_act + p * 128 + slot * 16) = *reinterpret_cast<const uint4*>(act);
     }
     __syncthreads();
