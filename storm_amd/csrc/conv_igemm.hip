@@ -24,55 +24,10 @@
 #include <cstring>
 #include "common.h"
 #include "conv_index.h"
+#include "conv_params.h"
 
 namespace storm {
 using namespace cidx;
-
-template <typename T> struct Mma;
-template <> struct Mma<bf16_t> {
-    typedef bf16x8 Frag;
-    static __device__ __forceinline__ void run(const Frag& a, const Frag& b, f32x16& c) {
-        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
-    }
-};
-template <> struct Mma<float> {
-    typedef f32x4 Frag;
-    static __device__ __forceinline__ void run(const Frag& a, const Frag& b, f32x16& c) {
-        // the 4 floats of a slot are 4 k-positions; pairing (a[r], b[r]) keeps A and B consistent
-#pragma unroll
-        for (int r = 0; r < 4; ++r) c = __builtin_amdgcn_mfma_f32_32x32x2f32(a[r], b[r], c, 0, 0, 0);
-    }
-};
-
-// 16-byte global load at (wave-uniform base pointer) + (32-bit per-lane byte offset): lowers to the
-// saddr + voffset addressing form, so no 64-bit per-lane address is ever kept (or spilled).
-__device__ __forceinline__ uint4 ld16(const void* base, uint32_t byte_off) {
-    return *reinterpret_cast<const uint4*>(static_cast<const char*>(base) + byte_off);
-}
-
-// y = act(x * scale + shift) on the 16-byte slot held in `v` (GroupNorm-apply + SiLU fused into the
-// operand load: the normalised tensor is never written to HBM).
-__device__ __forceinline__ uint4 gn_act_slot(uint4 v, const float (&ss)[16], int silu, bf16_t*) {
-    uint32_t w[4] = {v.x, v.y, v.z, v.w};
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        float lo = __uint_as_float(w[i] << 16), hi = __uint_as_float(w[i] & 0xffff0000u);
-        lo = fmaf(lo, ss[4 * i], ss[4 * i + 1]);
-        hi = fmaf(hi, ss[4 * i + 2], ss[4 * i + 3]);
-        if (silu) { lo = fast_silu(lo); hi = fast_silu(hi); }
-        w[i] = pack_bf16x2(lo, hi);
-    }
-    return make_uint4(w[0], w[1], w[2], w[3]);
-}
-__device__ __forceinline__ uint4 gn_act_slot(uint4 v, const float (&ss)[16], int silu, float*) {
-    float x[4] = {__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w)};
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        x[i] = fmaf(x[i], ss[2 * i], ss[2 * i + 1]);
-        if (silu) x[i] = silu_f(x[i]);
-    }
-    return make_uint4(__float_as_uint(x[0]), __float_as_uint(x[1]), __float_as_uint(x[2]), __float_as_uint(x[3]));
-}
 
 template <int TAPS, int WM, int WAVES_M, int WAVES_N, bool PF, bool FP = false, int ABL_ = 0>
 struct ConvCfg {
@@ -100,33 +55,10 @@ struct ConvCfg {
     static_assert(WAVES_N * WN == TILE_H, "");
 };
 
-// Kernel-side view of storm_conv_args: the K dimension as up to four single-source "runs"
-// (a segment reading cat[xa, xb] becomes two runs), so the inner loops never select a source per
-// element and every run field is a scalar loaded once per run.
-struct ConvRun {
-    const void* src; const void* w;
-    long long src_bstride, w_bstride, w_tapstride;
-    int C;          // channel stride of src
-    int c0, cn;     // channels [c0, c0+cn) of src ...
-    int wc0;        // ... multiply weight columns [wc0, wc0+cn)
-    int CinP, w_rows, ntaps;
-    int gn_silu;    // SiLU after the fused GroupNorm affine
-    const float* gn_ss;   // optional fused GroupNorm apply on load: [B][gn_C][2] (scale, shift); channel
-    int gn_C, pad_;       //   index of element (c) of this run = wc0 + c
-};
-struct ConvParams {
-    ConvRun run[4];
-    int nruns, B, H, W;
-    void* out; int outC, Cout; long long out_bstride;
-    const float* bias; const float* tbias; int tbias_stride, out_f32;
-    const void* skip; long long skip_bstride; float scale; int pad_;
-    float* gn_part;   // optional [B][tiles_per_img][outC][2] per-tile (sum, sumsq) of the stored output
-};
 
 template <typename T, int TAPS, int WM, int WAVES_M, int WAVES_N, bool PF, bool FP, int ABL>
-__global__ __launch_bounds__(64 * WAVES_M * WAVES_N, (ConvCfg<TAPS, WM, WAVES_M, WAVES_N, PF, FP, ABL>::MIN_WAVES_PER_SIMD))
-void conv_igemm_kernel(const ConvParams a, const int n_ct, const int tiles_per_xcd,
-                       const int ntiles, const int tiles_x, const int tiles_per_img) {
+__device__ __forceinline__ void conv_tile(const ConvParams& a, const int vblock, const int n_ct, const int tiles_per_xcd,
+                                          const int ntiles, const int tiles_x, const int tiles_per_img) {
     typedef ConvCfg<TAPS, WM, WAVES_M, WAVES_N, PF, FP, ABL> Cfg;
     typedef typename Mma<T>::Frag Frag;
     constexpr int THREADS = Cfg::THREADS;
@@ -139,7 +71,7 @@ void conv_igemm_kernel(const ConvParams a, const int n_ct, const int tiles_per_x
     char* const pbuf = smem;                                    // NPBUF patch buffers, then the 2-deep weight ring
     char* const wbuf = smem + Cfg::NPBUF * Cfg::PATCH_BYTES;
 
-    const BlockMap bm = block_map(blockIdx.x, n_ct, tiles_per_xcd);
+    const BlockMap bm = block_map(vblock, n_ct, tiles_per_xcd);
     if (bm.tile >= ntiles) return;
     const int b = bm.tile / tiles_per_img;
     const int trem = bm.tile - b * tiles_per_img;
@@ -149,8 +81,30 @@ void conv_igemm_kernel(const ConvParams a, const int n_ct, const int tiles_per_x
     const long long lin0 = (long long)trem * (TILE_H * TILE_W);     // TAPS==1: linear pixel base
     const int cout0 = bm.ct * BN;
 
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    int tid_ = threadIdx.x;
+#if defined(__HIP_DEVICE_COMPILE__)
+    asm volatile("" : "+v"(tid_));       // per-tile opaque: keeps lane-derived address math out of the persistent loop's preheader
+#endif
+#if defined(__HIP_DEVICE_COMPILE__)
+    const int tid = tid_, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+#else
+    const int tid = tid_, lane = tid & 63, wave = tid >> 6;
+#endif
     const int wm = wave % WAVES_M, wn = wave / WAVES_M;
+#if defined(__HIP_DEVICE_COMPILE__)
+    unsigned long long* const trace_rec = (ABL & 64) && a.trace ? a.trace + ((long long)vblock * (WAVES_M * WAVES_N) + wave) * TRACE_SLOTS : nullptr;
+    auto stamp = [&](int idx) {
+        if ((ABL & 64) && trace_rec && idx < TRACE_SLOTS) {
+            const unsigned long long t = __builtin_amdgcn_s_memtime();
+            if (lane == 0) trace_rec[idx] = t;
+        }
+    };
+    if ((ABL & 64) && trace_rec && lane == 0)
+        trace_rec[0] = (unsigned long long)__builtin_amdgcn_s_getreg((31 << 11) | 4) | ((unsigned long long)__builtin_amdgcn_s_getreg((31 << 11) | 20) << 32);
+#else
+    auto stamp = [&](int) {};
+#endif
+    stamp(1);
 
     f32x16 acc[WM][WN];
 #pragma unroll
@@ -330,15 +284,20 @@ void conv_igemm_kernel(const ConvParams a, const int n_ct, const int tiles_per_x
     }
     load_w(cur, 0);
     store_w(0);
+    stamp(2);
     while (true) {
         int nr = r, nc = ch + 1;
         if (nc == nch_r) { nc = 0; ++nr; }
         const bool has_nc = nr < nruns;
         const Chunk nxt = get_chunk(has_nc ? nr : r, has_nc ? nc : ch);
-        if (!PF && !((ABL & 4) && ci > 0)) {
+        if (!PF && !((ABL & (4 | 32)) && ci > 0)) {
+            stamp(400 + 4 * ci);
             __syncthreads();                       // every wave finished reading the previous patch
+            stamp(401 + 4 * ci);
             patch_issue(cur, 0, HALF); patch_commit(cur, pbuf, 0, HALF);
+            stamp(402 + 4 * ci);
             patch_issue(cur, HALF, Cfg::PU); patch_commit(cur, pbuf, HALF, Cfg::PU);
+            stamp(403 + 4 * ci);
         }
         const char* const patch = pbuf + (PF ? (ci & 1) * Cfg::PATCH_BYTES : 0);
         const int nk = (cur.cvalid + KG - 1) / KG;
@@ -348,20 +307,24 @@ void conv_igemm_kernel(const ConvParams a, const int n_ct, const int tiles_per_x
             // Both fly during the MFMAs below and are written to LDS after them.
             const bool more_taps = tp + 1 < ntaps;
             const bool has_next = more_taps || has_nc;
-            if (!(ABL & 4)) {
+            if (!(ABL & (4 | 16))) {
                 if (more_taps) load_w(cur, tp + 1);
                 else if (has_nc) load_w(nxt, 0);
             }
-            const bool pf_now = PF && tp == 0 && has_nc && !(ABL & 4);
+            const bool pf_now = PF && tp == 0 && has_nc && !(ABL & (4 | 32));
             if (pf_now) patch_issue(nxt, 0, Cfg::PU);
+            stamp(4 + 4 * step);
             __syncthreads();                       // patch + wbuf[step&1] visible; ring slots of step-1 free
+            stamp(5 + 4 * step);
             int dy = 0, dx = 0;
             if (TAPS == 9) {
                 if (ntaps == 9) { dy = tp / 3; dx = tp - dy * 3; } else { dy = 1; dx = 1; }
             }
             compute(patch, wbuf + (step & 1) * Cfg::WBUF_BYTES, dy, dx, nk);
+            stamp(6 + 4 * step);
             if (has_next) store_w((step + 1) & 1);
             if (pf_now) patch_commit(nxt, pbuf + ((ci + 1) & 1) * Cfg::PATCH_BYTES, 0, Cfg::PU);
+            stamp(7 + 4 * step);
             ++step;
         }
         if (!has_nc) break;
@@ -370,7 +333,9 @@ void conv_igemm_kernel(const ConvParams a, const int n_ct, const int tiles_per_x
     }
 
     // ---- epilogue: LDS transpose -> (bias, temb bias, skip, scale) -> wide stores ---------
+    stamp(500);
     __syncthreads();
+    stamp(501);
 #if defined(__HIP_DEVICE_COMPILE__)
     if (ABL & 8) {                                      // profiling ablation: keep the accumulators alive, store nothing
 #pragma unroll
@@ -460,6 +425,10 @@ void conv_igemm_kernel(const ConvParams a, const int n_ct, const int tiles_per_x
             }
         }
     }
+    stamp(502);
+#if defined(__HIP_DEVICE_COMPILE__)
+    if (ABL & 64) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); stamp(503); }
+#endif
     if (a.gn_part != nullptr) {
         // lanes with equal (lane % LPR) hold the same 8 channels: butterfly over the row lanes, then
         // across the WAVES_N waves of a cout range through LDS; one coalesced [BN][2] store per block.
@@ -488,32 +457,33 @@ void conv_igemm_kernel(const ConvParams a, const int n_ct, const int tiles_per_x
     }
 }
 
-static ConvParams make_params(const storm_conv_args& a) {
-    ConvParams p;
-    memset(&p, 0, sizeof(p));
-    int n = 0;
-    for (int s = 0; s < a.nseg; ++s) {
-        const storm_conv_seg& g = a.seg[s];
-        for (int part = 0; part < 2; ++part) {
-            if (part == 1 && g.Cb == 0) break;
-            ConvRun& r = p.run[n++];
-            r.src = part == 0 ? g.src_a : g.src_b;
-            r.src_bstride = part == 0 ? g.bstride_a : g.bstride_b;
-            r.C = part == 0 ? g.Ca : g.Cb;
-            r.c0 = 0; r.cn = r.C;
-            r.wc0 = part == 0 ? 0 : g.Ca;
-            r.w = g.w; r.w_bstride = g.w_bstride; r.w_tapstride = g.w_tapstride;
-            r.CinP = g.CinP; r.w_rows = g.w_rows; r.ntaps = g.ntaps;
-            r.gn_ss = g.gn_ss; r.gn_C = g.Ca + g.Cb; r.gn_silu = g.gn_silu;
-        }
+// Persistent launch: at most (CUs x workgroups per CU) workgroups, each walking virtual block ids
+// blockIdx.x, blockIdx.x + gridDim.x, ... (gridDim.x is a multiple of 8, so a workgroup stays on its XCD's
+// tile range).  A workgroup's output stores drain while it already stages the next tile, there is no
+// per-tile dispatch gap, and the chip-wide load / store bursts of equal-length tiles de-phase.
+template <typename T, int TAPS, int WM, int WAVES_M, int WAVES_N, bool PF, bool FP, int ABL>
+__global__ __launch_bounds__(64 * WAVES_M * WAVES_N, (ConvCfg<TAPS, WM, WAVES_M, WAVES_N, PF, FP, ABL>::MIN_WAVES_PER_SIMD))
+void conv_igemm_kernel(const ConvParams a, const int n_ct, const int tiles_per_xcd,
+                       const int ntiles, const int tiles_x, const int tiles_per_img, const int total_vblocks) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    // The parameter block is read through the kernarg segment pointer (ConvParams is the first argument, offset
+    // 0), re-laundered every tile: otherwise LICM hoists every s_load of the block out of the tile loop and the
+    // ~150 live SGPRs spill into VGPRs and on into scratch.
+    typedef const ConvParams __attribute__((address_space(4)))* KArgPtr;
+    KArgPtr kp = (KArgPtr)__builtin_amdgcn_kernarg_segment_ptr();
+    (void)a;
+#endif
+    for (int vb = blockIdx.x; vb < total_vblocks; vb += gridDim.x) {
+        if (vb != (int)blockIdx.x) __syncthreads();      // LDS of the previous tile (staging / statistics) is free
+#if defined(__HIP_DEVICE_COMPILE__)
+        asm volatile("" : "+s"(kp));
+        conv_tile<T, TAPS, WM, WAVES_M, WAVES_N, PF, FP, ABL>(*(const ConvParams*)kp, vb, n_ct, tiles_per_xcd, ntiles, tiles_x, tiles_per_img);
+#else
+        conv_tile<T, TAPS, WM, WAVES_M, WAVES_N, PF, FP, ABL>(a, vb, n_ct, tiles_per_xcd, ntiles, tiles_x, tiles_per_img);
+#endif
     }
-    p.nruns = n; p.B = a.B; p.H = a.H; p.W = a.W;
-    p.out = a.out; p.outC = a.outC; p.Cout = a.Cout; p.out_bstride = a.out_bstride;
-    p.bias = a.bias; p.tbias = a.tbias; p.tbias_stride = a.tbias_stride; p.out_f32 = a.out_f32;
-    p.skip = a.skip; p.skip_bstride = a.skip_bstride; p.scale = a.scale;
-    p.gn_part = a.gn_part;
-    return p;
 }
+
 
 template <typename T, int TAPS, int WM, int WAVES_M, int WAVES_N, bool PF, bool FP = false, int ABL = 0>
 static int launch_conv(const storm_conv_args& a, hipStream_t st) {
@@ -535,11 +505,29 @@ static int launch_conv(const storm_conv_args& a, hipStream_t st) {
     const long long ntiles = (long long)a.B * tiles_per_img;
     const int n_ct = cdiv(a.outC, Cfg::BN);
     const int tiles_per_xcd = cdiv(ntiles, 8);
-    const long long grid = 8LL * tiles_per_xcd * n_ct;
-    STORM_CHECK(grid > 0 && grid < (1LL << 31), "storm_conv: grid %lld out of range", grid);
-    const ConvParams prm = make_params(a);
+    const long long vblocks = 8LL * tiles_per_xcd * n_ct;
+    STORM_CHECK(vblocks > 0 && vblocks < (1LL << 31), "storm_conv: grid %lld out of range", vblocks);
+    static const int persist = getenv("STORM_CONV_PERSIST") ? atoi(getenv("STORM_CONV_PERSIST")) : 0;
+    static int n_cu = 0;
+    if (n_cu == 0) {
+        int dev = 0; hipDeviceProp_t prop;
+        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) n_cu = prop.multiProcessorCount;
+        if (n_cu <= 0) n_cu = 256;
+    }
+    long long grid = vblocks;
+    if (persist) {
+        const char* cus_env = getenv("STORM_CONV_CUS");            // test hook: pretend the device has this many CUs
+        const int cus = cus_env ? ((atoi(cus_env) + 7) / 8) * 8 : ((n_cu + 7) / 8) * 8;
+        const long long resident = (long long)cus * Cfg::BLOCKS_PER_CU * persist;      // multiple of 8
+        if (grid > resident) grid = resident;
+    }
+    ConvParams prm = make_params(a);
+    if (ABL & 64) {                                              // profiling: device buffer address handed over by the probe tool
+        const char* tp = getenv("STORM_CONV_TRACE_PTR");
+        prm.trace = tp ? reinterpret_cast<unsigned long long*>(strtoull(tp, nullptr, 0)) : nullptr;
+    }
     hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(Cfg::THREADS), Cfg::LDS_BYTES, st, prm, n_ct,
-                       tiles_per_xcd, (int)ntiles, tiles_x, tiles_per_img);
+                       tiles_per_xcd, (int)ntiles, tiles_x, tiles_per_img, (int)vblocks);
     STORM_LAUNCH_CHECK();
     return STORM_OK;
 }
@@ -554,12 +542,13 @@ static int dispatch_conv(const storm_conv_args& a, hipStream_t st) {
     //   1: 128 cout x 256 px, 8 waves (64x64 each), 2 workgroups / CU
     //   2: 256 cout x 256 px, 8 waves (64x128 each), 1 workgroup / CU, patch double-buffered and the
     //      next K-chunk prefetched under the MFMAs (one patch load + GN transform per 256 couts)
-    static const int forced = getenv("STORM_CONV_VARIANT") ? atoi(getenv("STORM_CONV_VARIANT")) : -1;
+    const char* forced_env = getenv("STORM_CONV_VARIANT");          // read per launch: tests and probes switch it at run time
+    const int forced = forced_env ? atoi(forced_env) : -1;
     static const bool frag_pipe = getenv("STORM_FRAG_PIPE") ? atoi(getenv("STORM_FRAG_PIPE")) != 0 : false;
     const long long px_tiles = (long long)a.B * cdiv((long long)a.H * a.W, TILE_H * TILE_W);
     const int variant = forced >= 0 ? forced : ((a.outC > 128 && px_tiles >= 512) ? 2 : 0);
     static const int abl = getenv("STORM_CONV_ABLATE") ? atoi(getenv("STORM_CONV_ABLATE")) : 0;
-    if (any9 && !small && abl) {                        // profiling only
+    if (any9 && !small && abl && variant != 3) {        // profiling only
         const bool v2 = variant == 2;
         switch (abl) {
             case 1: return v2 ? launch_conv<T, 9, 2, 4, 2, true, false, 1>(a, st) : launch_conv<T, 9, 2, 2, 2, false, false, 1>(a, st);
@@ -568,11 +557,16 @@ static int dispatch_conv(const storm_conv_args& a, hipStream_t st) {
             case 8: return v2 ? launch_conv<T, 9, 2, 4, 2, true, false, 8>(a, st) : launch_conv<T, 9, 2, 2, 2, false, false, 8>(a, st);
             case 6: return v2 ? launch_conv<T, 9, 2, 4, 2, true, false, 6>(a, st) : launch_conv<T, 9, 2, 2, 2, false, false, 6>(a, st);
             case 5: return v2 ? launch_conv<T, 9, 2, 4, 2, true, false, 5>(a, st) : launch_conv<T, 9, 2, 2, 2, false, false, 5>(a, st);
+            case 16: return v2 ? launch_conv<T, 9, 2, 4, 2, true, false, 16>(a, st) : launch_conv<T, 9, 2, 2, 2, false, false, 16>(a, st);
+            case 32: return v2 ? launch_conv<T, 9, 2, 4, 2, true, false, 32>(a, st) : launch_conv<T, 9, 2, 2, 2, false, false, 32>(a, st);
+            case 64: return v2 ? launch_conv<T, 9, 2, 4, 2, true, false, 64>(a, st) : launch_conv<T, 9, 2, 2, 2, false, false, 64>(a, st);
+            case 40: return v2 ? launch_conv<T, 9, 2, 4, 2, true, false, 40>(a, st) : launch_conv<T, 9, 2, 2, 2, false, false, 40>(a, st);
             default: break;
         }
     }
     if (any9) {
         if (small) return launch_conv<T, 9, 1, 1, 4, false>(a, st);
+        if (variant == 3 && conv_pipe_supports(a)) return launch_conv_pipe(a, st);
         if (variant == 2) return launch_conv<T, 9, 2, 4, 2, true>(a, st);
         if (variant == 1) return launch_conv<T, 9, 2, 2, 4, false>(a, st);
         return frag_pipe ? launch_conv<T, 9, 2, 2, 2, false, true>(a, st) : launch_conv<T, 9, 2, 2, 2, false, false>(a, st);

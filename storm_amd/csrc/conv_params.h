@@ -1,0 +1,114 @@
+// Shared between the convolution kernels (conv_igemm.hip, conv_pipe.hip): the kernel-side parameter block,
+// MFMA wrappers and the fused GroupNorm-apply slot transform.
+#pragma once
+#include <cstring>
+#include "common.h"
+#include "conv_index.h"
+
+namespace storm {
+
+template <typename T> struct Mma;
+template <> struct Mma<bf16_t> {
+    typedef bf16x8 Frag;
+    static __device__ __forceinline__ void run(const Frag& a, const Frag& b, f32x16& c) {
+        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
+    }
+};
+template <> struct Mma<float> {
+    typedef f32x4 Frag;
+    static __device__ __forceinline__ void run(const Frag& a, const Frag& b, f32x16& c) {
+        // the 4 floats of a slot are 4 k-positions; pairing (a[r], b[r]) keeps A and B consistent
+#pragma unroll
+        for (int r = 0; r < 4; ++r) c = __builtin_amdgcn_mfma_f32_32x32x2f32(a[r], b[r], c, 0, 0, 0);
+    }
+};
+
+// 16-byte global load at (wave-uniform base pointer) + (32-bit per-lane byte offset): lowers to the
+// saddr + voffset addressing form, so no 64-bit per-lane address is ever kept (or spilled).
+__device__ __forceinline__ uint4 ld16(const void* base, uint32_t byte_off) {
+    return *reinterpret_cast<const uint4*>(static_cast<const char*>(base) + byte_off);
+}
+
+// y = act(x * scale + shift) on the 16-byte slot held in `v` (GroupNorm-apply + SiLU fused into the
+// operand load: the normalised tensor is never written to HBM).
+__device__ __forceinline__ uint4 gn_act_slot(uint4 v, const float (&ss)[16], int silu, bf16_t*) {
+    uint32_t w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        float lo = __uint_as_float(w[i] << 16), hi = __uint_as_float(w[i] & 0xffff0000u);
+        lo = fmaf(lo, ss[4 * i], ss[4 * i + 1]);
+        hi = fmaf(hi, ss[4 * i + 2], ss[4 * i + 3]);
+        if (silu) { lo = fast_silu(lo); hi = fast_silu(hi); }
+        w[i] = pack_bf16x2(lo, hi);
+    }
+    return make_uint4(w[0], w[1], w[2], w[3]);
+}
+__device__ __forceinline__ uint4 gn_act_slot(uint4 v, const float (&ss)[16], int silu, float*) {
+    float x[4] = {__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w)};
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        x[i] = fmaf(x[i], ss[2 * i], ss[2 * i + 1]);
+        if (silu) x[i] = silu_f(x[i]);
+    }
+    return make_uint4(__float_as_uint(x[0]), __float_as_uint(x[1]), __float_as_uint(x[2]), __float_as_uint(x[3]));
+}
+
+
+// Kernel-side view of storm_conv_args: the K dimension as up to four single-source "runs"
+// (a segment reading cat[xa, xb] becomes two runs), so the inner loops never select a source per
+// element and every run field is a scalar loaded once per run.
+struct ConvRun {
+    const void* src; const void* w;
+    long long src_bstride, w_bstride, w_tapstride;
+    int C;          // channel stride of src
+    int c0, cn;     // channels [c0, c0+cn) of src ...
+    int wc0;        // ... multiply weight columns [wc0, wc0+cn)
+    int CinP, w_rows, ntaps;
+    int gn_silu;    // SiLU after the fused GroupNorm affine
+    const float* gn_ss;   // optional fused GroupNorm apply on load: [B][gn_C][2] (scale, shift); channel
+    int gn_C, pad_;       //   index of element (c) of this run = wc0 + c
+};
+struct ConvParams {
+    ConvRun run[4];
+    int nruns, B, H, W;
+    void* out; int outC, Cout; long long out_bstride;
+    const float* bias; const float* tbias; int tbias_stride, out_f32;
+    const void* skip; long long skip_bstride; float scale; int pad_;
+    float* gn_part;   // optional [B][tiles_per_img][outC][2] per-tile (sum, sumsq) of the stored output
+    unsigned long long* trace;   // profiling instantiation (ABL & 64) only: [vblock][wave][TRACE_SLOTS] s_memtime stamps
+};
+constexpr int TRACE_SLOTS = 512;
+
+static inline ConvParams make_params(const storm_conv_args& a) {
+    ConvParams p;
+    memset(&p, 0, sizeof(p));
+    int n = 0;
+    for (int s = 0; s < a.nseg; ++s) {
+        const storm_conv_seg& g = a.seg[s];
+        for (int part = 0; part < 2; ++part) {
+            if (part == 1 && g.Cb == 0) break;
+            ConvRun& r = p.run[n++];
+            r.src = part == 0 ? g.src_a : g.src_b;
+            r.src_bstride = part == 0 ? g.bstride_a : g.bstride_b;
+            r.C = part == 0 ? g.Ca : g.Cb;
+            r.c0 = 0; r.cn = r.C;
+            r.wc0 = part == 0 ? 0 : g.Ca;
+            r.w = g.w; r.w_bstride = g.w_bstride; r.w_tapstride = g.w_tapstride;
+            r.CinP = g.CinP; r.w_rows = g.w_rows; r.ntaps = g.ntaps;
+            r.gn_ss = g.gn_ss; r.gn_C = g.Ca + g.Cb; r.gn_silu = g.gn_silu;
+        }
+    }
+    p.nruns = n; p.B = a.B; p.H = a.H; p.W = a.W;
+    p.out = a.out; p.outC = a.outC; p.Cout = a.Cout; p.out_bstride = a.out_bstride;
+    p.bias = a.bias; p.tbias = a.tbias; p.tbias_stride = a.tbias_stride; p.out_f32 = a.out_f32;
+    p.skip = a.skip; p.skip_bstride = a.skip_bstride; p.scale = a.scale;
+    p.gn_part = a.gn_part;
+    p.trace = nullptr;
+    return p;
+}
+
+// defined in conv_pipe.hip: software-pipelined 256-cout x 256-pixel 3x3 kernel (bf16)
+bool conv_pipe_supports(const storm_conv_args& a);
+int launch_conv_pipe(const storm_conv_args& a, hipStream_t st);
+
+}  // namespace storm

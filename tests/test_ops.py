@@ -43,6 +43,26 @@ def test_conv(dev, dtype, shape):
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("k", [3, 1])
+def test_conv_persistent_tile_loop(dev, dtype, k, monkeypatch):
+    """More tiles than resident workgroups: every workgroup walks several tiles (output + statistics partials)."""
+    from storm_amd import ops
+    monkeypatch.setenv("STORM_CONV_CUS", "8")
+    g = torch.Generator().manual_seed(21)
+    B, Cin, Cout, H, W = 3, 16, 40, 35, 70
+    x = torch.randn(B, Cin, H, W, generator=g)
+    w = torch.randn(Cout, Cin, k, k, generator=g) * 0.2
+    b = torch.randn(Cout, generator=g)
+    xq = nhwc(x).to(dtype).to(dev)
+    y, part = ops.conv([ops.Seg(xq, ops.pack_conv_weight(w.to(dev), dtype), k * k)], Cout, bias=b.to(dev), gn_partials=True)
+    ref = F.conv2d(q(x, dtype), q(w, dtype), b, padding=k // 2)
+    assert rel_l2(nchw(y.float().cpu())[:, :Cout], ref) < tol(dtype, 2e-6, 6e-3)
+    rtol = 1e-5 if dtype == torch.float32 else 2e-3
+    st, sref = ops.gn_finalize(part).cpu(), ops.gn_stats(y).cpu()
+    assert torch.allclose(st, sref, rtol=rtol, atol=rtol * float(sref.abs().max()))
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
 def test_conv_fused_block_tail(dev, dtype):
     """Conv_1 3x3 over h + Conv_2 1x1 over cat[xa, xb] + bias + temb bias, rescaled (layerspp.py:266-274)."""
     from storm_amd import ops
