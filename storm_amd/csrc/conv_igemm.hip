@@ -547,7 +547,8 @@ static int dispatch_conv(const storm_conv_args& a, hipStream_t st) {
     static const bool frag_pipe = getenv("STORM_FRAG_PIPE") ? atoi(getenv("STORM_FRAG_PIPE")) != 0 : false;
     const long long px_tiles = (long long)a.B * cdiv((long long)a.H * a.W, TILE_H * TILE_W);
     const int variant = forced >= 0 ? forced : ((a.outC > 128 && px_tiles >= 512) ? 2 : 0);
-    static const int abl = getenv("STORM_CONV_ABLATE") ? atoi(getenv("STORM_CONV_ABLATE")) : 0;
+    const char* abl_env = getenv("STORM_CONV_ABLATE");
+    const int abl = abl_env ? atoi(abl_env) : 0;
     if (any9 && !small && abl && variant != 3) {        // profiling only
         const bool v2 = variant == 2;
         switch (abl) {

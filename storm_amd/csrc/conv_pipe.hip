@@ -35,15 +35,17 @@ typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 
 constexpr int WM = 2, WN = 4, WAVES_M = 4, WAVES_N = 2, NWAVES = 8, THREADS = 512, BN = 256;
 constexpr int PW = Geo<9>::PW, NPIX = Geo<9>::NPIX;
-constexpr int PATCH_BYTES = NPIX * PIX_BYTES;                 // 43520
-constexpr int PU = (NPIX * 8 + THREADS - 1) / THREADS;        // 16-byte patch units per thread (6)
+constexpr int PATCH_ROWS = (NPIX + 7) / 8 * 8;                // 344: whole 8-row (1 KiB) LDS-DMA pieces
+constexpr int PATCH_BYTES = PATCH_ROWS * PIX_BYTES;           // 44032
+constexpr int PPIECES = PATCH_ROWS / 8;                       // 43 wave-instructions cover a patch
+constexpr int PU = (PPIECES + NWAVES - 1) / NWAVES;           // pieces per wave (6; the surplus re-issues a piece)
 constexpr int WROW = 64;                                      // bytes per weight row and phase
 constexpr int WPHASE_BYTES = BN * WROW;                       // 16 KiB
 constexpr int RING = 4;
 constexpr int OFF_RING = 2 * PATCH_BYTES;
 constexpr int OFF_SS = OFF_RING + RING * WPHASE_BYTES;
 constexpr int SS_BYTES = 1024;                                // one wave-instruction: 64 channels x (scale, shift) + pad
-constexpr int MAIN_BYTES = OFF_SS + 2 * SS_BYTES;             // 154624
+constexpr int MAIN_BYTES = OFF_SS + 2 * SS_BYTES;             // 155648
 constexpr int PR = 2;                                         // pixel rows (of 32 px) staged per epilogue pass and wave
 constexpr int STAGE_BYTES = NWAVES * 32 * PR * WM * 128;      // 128 KiB
 constexpr int LDS_BYTES = MAIN_BYTES > STAGE_BYTES ? MAIN_BYTES : STAGE_BYTES;
@@ -67,33 +69,11 @@ __device__ __forceinline__ void glds16(const void* base, uint32_t voff, char* ld
     memcpy(lds_wave + 16 * lane, static_cast<const char*>(base) + voff, 16);
 #endif
 }
-// 16-B global load whose result must not be touched before vm_wait_regs() on it.
-__device__ __forceinline__ u32x4 gload16_async(const void* base, uint32_t voff) {
-    u32x4 v;
-#if defined(__HIP_DEVICE_COMPILE__)
-    asm volatile("global_load_dwordx4 %0, %1, %2" : "=&v"(v) : "v"(voff), "s"(base) : "memory");
-#else
-    memcpy(&v, static_cast<const char*>(base) + voff, 16);
-#endif
-    return v;
-}
 template <int N> __device__ __forceinline__ void vm_wait() {
 #if defined(__HIP_DEVICE_COMPILE__)
     asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
 #elif defined(STORM_HOST_SIM)
     simrt::wave_rendezvous();          // simulator lanes are not in lockstep: every lane's copy is done past this point
-#endif
-}
-// the wait that makes the patch registers readable: ties them so no consumer is scheduled above it
-template <int N> __device__ __forceinline__ void vm_wait_regs(u32x4 (&r)[PU]) {
-#if defined(__HIP_DEVICE_COMPILE__)
-    static_assert(PU == 6, "operand list");
-    asm volatile("s_waitcnt vmcnt(%6)" : "+v"(r[0]), "+v"(r[1]), "+v"(r[2]), "+v"(r[3]), "+v"(r[4]), "+v"(r[5]) : "n"(N) : "memory");
-#elif defined(STORM_HOST_SIM)
-    (void)r;
-    simrt::wave_rendezvous();
-#else
-    (void)r;
 #endif
 }
 // workgroup barrier WITHOUT a vmcnt drain: LDS traffic of this wave retired (lgkmcnt), loads keep flying
@@ -143,15 +123,21 @@ void conv_pipe_kernel(const ConvParams a, const int n_ct, const int tiles_per_xc
 #if defined(__HIP_DEVICE_COMPILE__)
     unsigned long long* const trace_rec = (ABL & 64) && a.trace ? a.trace + ((long long)blockIdx.x * NWAVES + wave) * TRACE_SLOTS : nullptr;
     auto stamp = [&](int idx) {                  // profiling instantiation only (tools/conv_trace.py)
-        if ((ABL & 64) && trace_rec && idx < TRACE_SLOTS) {
+        if ((ABL & 64) && trace_rec && idx < 496) {
             const unsigned long long t = __builtin_amdgcn_s_memtime();
             if (lane == 0) trace_rec[idx] = t;
         }
+    };
+    auto stamp_tail = [&](int idx) {
+#if defined(__HIP_DEVICE_COMPILE__)
+        if ((ABL & 64) && trace_rec) { const unsigned long long t = __builtin_amdgcn_s_memtime(); if (lane == 0) trace_rec[idx] = t; }
+#endif
     };
     if ((ABL & 64) && trace_rec && lane == 0)
         trace_rec[0] = (unsigned long long)__builtin_amdgcn_s_getreg((31 << 11) | 4) | ((unsigned long long)__builtin_amdgcn_s_getreg((31 << 11) | 20) << 32);
 #else
     auto stamp = [&](int) {};
+    auto stamp_tail = [&](int) {};
 #endif
     stamp(1);
 
@@ -224,19 +210,24 @@ void conv_pipe_kernel(const ConvParams a, const int n_ct, const int tiles_per_xc
         }
     };
 
-    // ---- patch staging: issue (async loads -> registers) ... commit (GN affine + SiLU, LDS) -------
-    u32x4 preg[PU];
-    uint32_t pmask = 0;
+    // ---- patch staging: issue (LDS-DMA, raw activations straight into the next patch buffer, swizzle on the
+    //      source address) ... commit (in place, every lane fixes up the 16-B units it fetched itself: zeros for
+    //      the padding halo / channels past the run, GroupNorm affine + SiLU when fused).  No staging registers:
+    //      nothing asynchronous ever targets a VGPR, so the compiler cannot touch data that has not landed.
+    uint32_t pmask = 0;                        // bit i: unit i of this lane is real input (inside the image, channel valid)
     auto patch_issue = [&](const Chunk& c, int parity) {
+        char* dst = smem + parity * PATCH_BYTES;
 #pragma unroll
         for (int i = 0; i < PU; ++i) {
-            const int u = tid + i * THREADS;
-            const int p = u >> 3, slot = u & 7;
-            const int py = p / PW, px = p - py * PW;
+            int k = wave + i * NWAVES;                           // piece: patch rows 8k .. 8k+7
+            if (k >= PPIECES) k -= NWAVES;                       // surplus slot: same piece again (keeps the VMEM count uniform)
+            const int row = k * 8 + (lane >> 3);
+            const int slot = (lane & 7) ^ ((row >> 1) & 7);      // logical 16-B slot that lands in physical slot lane & 7
+            const int py = row / PW, px = row - py * PW;
             const int gy = ty0 + py - 1, gx = tx0 + px - 1;
-            const bool ok = (u < NPIX * 8) && (slot * 8 < c.cvalid) && gy >= 0 && gy < a.H && gx >= 0 && gx < a.W;
+            const bool ok = row < NPIX && slot * 8 < c.cvalid && gy >= 0 && gy < a.H && gx >= 0 && gx < a.W;
             const uint32_t voff = ok ? (uint32_t)((gy * a.W + gx) * c.C + c.cbeg + slot * 8) * 2u : 0u;
-            preg[i] = gload16_async(c.src, voff);
+            glds16(c.src, voff, dst + k * 1024, lane);
             pmask = ok ? (pmask | (1u << i)) : (pmask & ~(1u << i));
         }
         // (scale, shift) of the chunk's channels -> LDS table; lanes past the chunk re-read channel 0
@@ -247,24 +238,27 @@ void conv_pipe_kernel(const ConvParams a, const int n_ct, const int tiles_per_xc
     };
     auto patch_commit = [&](const Chunk& c, int parity) {
         char* dst = smem + parity * PATCH_BYTES;
-        float ss[16];
         const bool gn = c.gn_ss != nullptr;
-        if (gn) {
-            const float* q = reinterpret_cast<const float*>(smem + OFF_SS + parity * SS_BYTES) + 16 * (tid & 7);
-#pragma unroll
-            for (int i = 0; i < 16; i += 4) {
-                const float4 t4 = *reinterpret_cast<const float4*>(q + i);
-                ss[i] = t4.x; ss[i + 1] = t4.y; ss[i + 2] = t4.z; ss[i + 3] = t4.w;
-            }
-        }
 #pragma unroll
         for (int i = 0; i < PU; ++i) {
-            const int u = tid + i * THREADS;
-            if (u < NPIX * 8) {
+            const int k = wave + i * NWAVES;
+            if (k < PPIECES) {
+                const int row = k * 8 + (lane >> 3);
+                const int slot = (lane & 7) ^ ((row >> 1) & 7);
+                uint4* const q = reinterpret_cast<uint4*>(dst + k * 1024 + lane * 16);
                 const bool ok = (pmask >> i) & 1u;
-                uint4 v = ok ? make_uint4(preg[i][0], preg[i][1], preg[i][2], preg[i][3]) : make_uint4(0u, 0u, 0u, 0u);
-                if (gn && ok) v = gn_act_slot(v, ss, c.gn_silu, (T*)nullptr);
-                *reinterpret_cast<uint4*>(dst + lds_off(u >> 3, u & 7)) = v;
+                if (!ok) {
+                    *q = make_uint4(0u, 0u, 0u, 0u);
+                } else if (gn) {
+                    float ss[16];
+                    const float* t = reinterpret_cast<const float*>(smem + OFF_SS + parity * SS_BYTES) + 16 * slot;
+#pragma unroll
+                    for (int j = 0; j < 16; j += 4) {
+                        const float4 t4 = *reinterpret_cast<const float4*>(t + j);
+                        ss[j] = t4.x; ss[j + 1] = t4.y; ss[j + 2] = t4.z; ss[j + 3] = t4.w;
+                    }
+                    *q = gn_act_slot(*q, ss, c.gn_silu, (T*)nullptr);
+                }
             }
         }
     };
@@ -297,85 +291,102 @@ void conv_pipe_kernel(const ConvParams a, const int n_ct, const int tiles_per_xc
         if (ntaps == 9) { dy = tp / 3; dx = tp - dy * 3; } else { dy = 1; dx = 1; }
     };
 
-    // ---- prologue: first patch, first three weight phases ----------------------------------------
-    int r = 0, ch = 0, nch_r = chunks_of(0), ci = 0, q = 0;
+    // ---- prologue: first patch, first two weight phases -------------------------------------------
+    int r = 0, ch = 0, nch_r = chunks_of(0), ci = 0;
     Chunk cur = get_chunk(0, 0);
+    w_issue(0); w_issue(1);
     patch_issue(cur, 0);
-    w_issue(0); w_issue(1); w_issue(2);
-    vm_wait_regs<0>(preg);
+    vm_wait<0>();
     patch_commit(cur, 0);
     raw_barrier();
-    Frag fa0[WM], fb0[WN], fa1[WM], fb1[WN];
-    {
-        int dy, dx;
-        tap_offsets(cur.ntaps, 0, dy, dx);
-        set_tap(0, dy, dx);
-        read_frags(fa0, fb0, 0, 0);
-    }
+    // Ping-pong: waves 4-7 (the second wave of every SIMD) run one barrier interval behind waves 0-3, so one
+    // group's MFMA interval coincides with the other's staging interval (waits, LDS-DMA issue, fragment reads,
+    // patch commit) and the matrix pipe of a SIMD always has one wave feeding it.
+    const int grp = (ABL & 2) ? 0 : wave >> 2;        // (ABL & 2: profiling variant without the stagger)
+    if (grp == 1) raw_barrier();
     stamp(2);
-    int step = 0;
+    Frag fa0[WM], fb0[WN], fa1[WM], fb1[WN];
 
-    // ---- main loop: K-chunks (runs flattened) x taps; one step = two phases = four k-groups ----------
-    while (true) {
+    // ---- main loop: one iteration = one phase P = (chunk, tap, half): staging interval S(P), MFMA interval C(P) ----
+    //   S(P): [commit the patch fetched two phases ago]  issue weights of phase P+2 -> slot (P+2)&3
+    //         [second phase of a chunk: issue the next chunk's patch LDS-DMA]  read k-group 0 of P
+    //         vmcnt: own share of phase P+1 landed | barrier
+    //   C(P): read k-group 1 | 16 MFMAs | barrier
+    // LDS lifetimes (intervals counted in barriers; group 1 lags by one): phase P's slot is read in intervals
+    // 2P..2P+2, slot (P+2)&3 = (P-2)&3 was last read in interval 2P-2 -> free in S(P).  The patch buffer of the
+    // next chunk was last read in the interval of S(P0) itself (by the lagging group) -> DMA into it from S(P0+1) on.
+    int P = 0, tp = 0, h = 0, since_issue = 99, step = 0;       // since_issue: phases since the last patch issue
+    bool has_nc, commit_pending = false; Chunk nxt = cur;
+    {
         int nr = r, nc = ch + 1;
         if (nc == nch_r) { nc = 0; ++nr; }
-        const bool has_nc = nr < nruns;
-        const Chunk nxt = get_chunk(has_nc ? nr : r, has_nc ? nc : ch);
-        const int ntaps = cur.ntaps;
-        const int par = ci & 1;
-        for (int tp = 0; tp < ntaps; ++tp) {
-            const bool pf = tp == 0 && has_nc;                 // this step fetches the next chunk's patch
-            const bool early = pf && ntaps == 1;               // ... and must publish it before its own phase B
-            // -------- phase A (q): k-groups 0, 1 --------
-            stamp(4 + 6 * step);
-            vm_wait<2>();
-            raw_barrier();
-            stamp(5 + 6 * step);
-            if (pf) patch_issue(nxt, par ^ 1);
-            w_issue(q + 3);
-            read_frags(fa1, fb1, q, 1);
-            __builtin_amdgcn_sched_barrier(0);
-            mma(fa0, fb0);
-            __builtin_amdgcn_sched_barrier(0);
-            read_frags(fa0, fb0, q + 1, 2);
-            __builtin_amdgcn_sched_barrier(0);
-            mma(fa1, fb1);
-            __builtin_amdgcn_sched_barrier(0);
-            if (early) { vm_wait_regs<2>(preg); patch_commit(nxt, par ^ 1); }
-            // -------- phase B (q + 1): k-groups 2, 3 --------
-            stamp(6 + 6 * step);
-            if (pf && !early) vm_wait<2 + NP>(); else vm_wait<2>();
-            raw_barrier();
-            stamp(7 + 6 * step);
-            w_issue(q + 4);
-            read_frags(fa1, fb1, q + 1, 3);
-            __builtin_amdgcn_sched_barrier(0);
-            mma(fa0, fb0);
-            __builtin_amdgcn_sched_barrier(0);
-            {   // k-group 0 of the next step: next tap of this chunk, or tap 0 of the next chunk's patch
-                int dy, dx;
-                if (tp + 1 < ntaps) { tap_offsets(ntaps, tp + 1, dy, dx); set_tap(par, dy, dx); }
-                else if (has_nc) { tap_offsets(nxt.ntaps, 0, dy, dx); set_tap(par ^ 1, dy, dx); }
-                read_frags(fa0, fb0, q + 2, 0);
-            }
-            __builtin_amdgcn_sched_barrier(0);
-            mma(fa1, fb1);
-            __builtin_amdgcn_sched_barrier(0);
-            stamp(8 + 6 * step);
-            if (pf && !early) { vm_wait_regs<4>(preg); patch_commit(nxt, par ^ 1); }
-            stamp(9 + 6 * step);
-            q += 2; ++step;
-        }
-        if (!has_nc) break;
-        if (nr != r) nch_r = chunks_of(nr);
-        cur = nxt; r = nr; ch = nc; ++ci;
+        has_nc = nr < nruns;
+        nxt = get_chunk(has_nc ? nr : r, has_nc ? nc : ch);
     }
+    while (true) {
+        const int ntaps = cur.ntaps, par = ci & 1;
+        // ---------------- S(P) ----------------
+        stamp(4 + 8 * step);
+        if (commit_pending && since_issue == 2) {               // 9-tap chunk: patch issued two phases ago
+            vm_wait<2>();
+            patch_commit(nxt, par ^ 1);
+            commit_pending = false;
+        }
+        w_issue(P + 2);
+        // The other patch buffer was read until the lagging group's C(P0 - 1), which shares its interval with the
+        // leading group's S(P0): the LDS-DMA into it may start in the chunk's SECOND phase.
+        const bool issue_now = tp == 0 && h == 1 && has_nc;
+        if (issue_now) { patch_issue(nxt, par ^ 1); since_issue = 0; commit_pending = ntaps != 1; }
+        stamp(5 + 8 * step);
+        if (h == 0) { int dy, dx; tap_offsets(ntaps, tp, dy, dx); set_tap(par, dy, dx); }
+        read_frags(fa0, fb0, P, 2 * h);
+        if (issue_now && ntaps == 1) {                          // two-phase chunk: the next phase already reads it
+            vm_wait<0>();
+            patch_commit(nxt, par ^ 1);
+        }
+        stamp(6 + 8 * step);
+        if (since_issue <= 1) vm_wait<2 + NP>(); else vm_wait<2>();
+        stamp(7 + 8 * step);
+        raw_barrier();
+        // ---------------- C(P) ----------------
+        stamp(8 + 8 * step);
+        read_frags(fa1, fb1, P, 2 * h + 1);
+        __builtin_amdgcn_sched_barrier(0);
+        if (!(ABL & 1)) prio(1);
+        mma(fa0, fb0);
+        if (ABL & 64) { __builtin_amdgcn_sched_barrier(0); stamp(9 + 8 * step); __builtin_amdgcn_sched_barrier(0); }
+        mma(fa1, fb1);
+        if (!(ABL & 1)) prio(0);
+        __builtin_amdgcn_sched_barrier(0);
+        stamp(10 + 8 * step);
+        raw_barrier();
+        stamp(11 + 8 * step);
+        // ---------------- advance ----------------
+        ++P; ++since_issue; ++step;
+        h ^= 1;
+        if (h == 0) {
+            ++tp;
+            if (tp == ntaps) {
+                if (!has_nc) break;
+                tp = 0;
+                int nr = r, nc = ch + 1;
+                if (nc == nch_r) { nc = 0; ++nr; }
+                if (nr != r) nch_r = chunks_of(nr);
+                cur = nxt; r = nr; ch = nc; ++ci;
+                nr = r; nc = ch + 1;
+                if (nc == nch_r) { nc = 0; ++nr; }
+                has_nc = nr < nruns;
+                nxt = get_chunk(has_nc ? nr : r, has_nc ? nc : ch);
+            }
+        }
+    }
+    if (grp == 0) raw_barrier();                        // balance the stagger: every wave has executed the same barriers
 
     // ---- epilogue: LDS transpose -> (bias, temb bias, skip, scale) -> wide stores (as conv_igemm.hip) ------
-    stamp(500);
+    stamp_tail(500);
     vm_wait<0>();                                       // trailing ring re-loads landed: LDS is free to reuse
     raw_barrier();
-    stamp(501);
+    stamp_tail(501);
     constexpr int SROWS = 32 * PR;
     char* const stage = smem + wave * (SROWS * WM * 128);
     constexpr int LPR = WM * 4;                 // lanes per staged row (8 couts each)
@@ -448,8 +459,8 @@ void conv_pipe_kernel(const ConvParams a, const int n_ct, const int tiles_per_xc
             }
         }
     }
-    stamp(502);
-    if (ABL & 64) { vm_wait<0>(); stamp(503); }
+    stamp_tail(502);
+    if (ABL & 64) { vm_wait<0>(); stamp_tail(503); }
     if (a.gn_part != nullptr) {
 #pragma unroll
         for (int off = LPR; off < 64; off <<= 1)
@@ -486,12 +497,22 @@ bool conv_pipe_supports(const storm_conv_args& a) {
 int launch_conv_pipe(const storm_conv_args& a, hipStream_t st) {
     using namespace pipe;
     const char* abl_env = getenv("STORM_CONV_ABLATE");
-    const bool traced = abl_env && atoi(abl_env) == 64;          // profiling instantiation (tools/conv_trace.py)
-    auto kern = traced ? conv_pipe_kernel<64> : conv_pipe_kernel<0>;
-    static bool attr_set[2] = {false, false};
-    if (!attr_set[traced]) {
+    const int abl = abl_env ? atoi(abl_env) : 0;                 // profiling instantiations (tools/conv_trace.py, A/B probes)
+    const bool traced = (abl & 64) != 0;
+    auto kern = conv_pipe_kernel<0>;
+    int ki = 0;
+    switch (abl) {
+        case 1: kern = conv_pipe_kernel<1>; ki = 1; break;       // no s_setprio
+        case 2: kern = conv_pipe_kernel<2>; ki = 2; break;       // no stagger
+        case 64: kern = conv_pipe_kernel<64>; ki = 3; break;     // wave timeline stamps
+        case 65: kern = conv_pipe_kernel<65>; ki = 4; break;
+        case 66: kern = conv_pipe_kernel<66>; ki = 5; break;
+        default: break;
+    }
+    static bool attr_set[6] = {false, false, false, false, false, false};
+    if (!attr_set[ki]) {
         STORM_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES));
-        attr_set[traced] = true;
+        attr_set[ki] = true;
     }
     const int tiles_x = cdiv(a.W, TILE_W);
     const int tiles_per_img = tiles_x * cdiv(a.H, TILE_H);

@@ -12,7 +12,7 @@ import sys
 import numpy as np
 import torch
 
-os.environ["STORM_CONV_ABLATE"] = "64"
+os.environ["STORM_CONV_ABLATE"] = str(64 + int(os.environ.get("STORM_TRACE_EXTRA", "0")))
 sys.path.insert(0, ".")
 from storm_amd import ops  # noqa: E402
 
@@ -70,43 +70,29 @@ print(f"effective shader clock ~ {1.0 / tick_ns:.2f} GHz")
 print(f"variant {variant}: {ms:.3f} ms, {nb} workgroups x {nwaves} waves, span {span} ticks, {tick_ns:.3f} ns/tick")
 
 if variant == 3:
-    steps = int(((t[0, 0, 4:400].reshape(-1, 6)[:, 0]) > 0).sum())
+    raw = t[:, :, 4:4 + 8 * 61].reshape(nb, nwaves, 61, 8)
+    steps = int((raw[0, 0, :, 0] > 0).sum())
+    st = raw[:, :, :steps]
     us3 = lambda d: d * tick_ns / 1e3  # noqa: E731
-
-    def stat3(name, d):
-        d = us3(np.asarray(d, dtype=np.float64))
-        print(f"  {name:40s} mean {d.mean():8.3f} us   p10 {np.percentile(d, 10):8.3f}   p90 {np.percentile(d, 90):8.3f}")
-    print(f"per wave and tile ({steps} steps):")
-    stat3("tile total (start -> stores drained)", t[:, :, 503] - t[:, :, 1])
-    stat3("prologue", t[:, :, 2] - t[:, :, 1])
-    st = t[:, :, 4:4 + 6 * steps].reshape(nb, nwaves, steps, 6)
-    stat3("sum: phase A wait + barrier", (st[..., 1] - st[..., 0]).sum(-1))
-    stat3("sum: phase A issue + MFMA (+early commit)", (st[..., 2] - st[..., 1]).sum(-1))
-    stat3("sum: phase B wait + barrier", (st[..., 3] - st[..., 2]).sum(-1))
-    stat3("sum: phase B issue + MFMA", (st[..., 4] - st[..., 3]).sum(-1))
-    stat3("sum: late patch commit", (st[..., 5] - st[..., 4]).sum(-1))
-    nxt3 = np.concatenate([st[:, :, 1:, 0], t[:, :, 500][..., None]], -1)
-    stat3("sum: loop overhead between steps", (nxt3 - st[..., 5]).sum(-1))
-    stat3("epilogue drain + barrier", t[:, :, 501] - t[:, :, 500])
-    stat3("epilogue (transpose + stores issue)", t[:, :, 502] - t[:, :, 501])
-    stat3("store drain (vmcnt 0)", t[:, :, 503] - t[:, :, 502])
-    ideal = 2.0 * 64 * 128 * args.cin * 9 / 1024 * tick_ns / 1e3
-    print(f"  MFMA pipe time of one wave's tile at this clock: {ideal:.2f} us (x2 waves per SIMD)")
+    names = ["S: commit? + weight DMA issue (+patch issue)", "S: tap offsets + k-group 0 reads issue", "S: vmcnt wait",
+             "S: lgkmcnt + barrier", "C: k-group 1 reads + 8 MFMA", "C: 8 MFMA", "C: lgkmcnt + barrier"]
+    print(f"per wave, first {steps} phases (units: us; tick->us calibrated on the launch, tick is NOT exactly a cycle):")
+    for gname, sel in (("g0 (waves 0-3)", slice(0, 4)), ("g1 (waves 4-7)", slice(4, 8))):
+        print(f" {gname}: tile total {us3((t[:, sel, 503] - t[:, sel, 1]).mean()):.2f}, prologue {us3((t[:, sel, 2] - t[:, sel, 1]).mean()):.2f}")
+        for i, nm in enumerate(names):
+            d = us3((st[:, sel, :, i + 1] - st[:, sel, :, i]).astype(np.float64))
+            print(f"   {nm:46s} mean/phase {d.mean():7.3f}   p10 {np.percentile(d, 10):7.3f}   p90 {np.percentile(d, 90):7.3f}")
+        adv = us3((st[:, sel, 1:, 0] - st[:, sel, :-1, 7]).astype(np.float64))
+        print(f"   {'loop advance (to next S)':46s} mean/phase {adv.mean():7.3f}   p10 {np.percentile(adv, 10):7.3f}   p90 {np.percentile(adv, 90):7.3f}")
+    print(f" epilogue: drain+barrier {us3((t[:, :, 501] - t[:, :, 500]).mean()):.2f}, transpose+stores {us3((t[:, :, 502] - t[:, :, 501]).mean()):.2f}, store drain {us3((t[:, :, 503] - t[:, :, 502]).mean()):.2f}")
     order = np.argsort(t[:, 0, 503] - t[:, 0, 1])
     mid = order[len(order) // 2]
-    print(f"median workgroup (index {mid}), wave 0, first 12 steps: [A wait, A work, B wait, B work, commit] us")
-    for s_ in range(min(steps, 12)):
-        a_ = st[mid, 0, s_]
-        print("    step %2d: " % s_ + " ".join("%7.3f" % us3(a_[i + 1] - a_[i]) for i in range(5)))
-    hw = t[:, 0, 0]
-    cu = ((hw >> 8) & 0xF) | (((hw >> 13) & 0x7) << 4) | (((hw >> 32) & 0xF) << 8)
-    ids = np.unique(cu)
-    one = np.where(cu == ids[0])[0]
-    one = one[np.argsort(t[one, 0, 1])]
-    t0 = t[one[0], 0, 1]
-    print("timeline on one CU (us): start, main loop, epilogue start, end")
-    for i in one[:10]:
-        print(f"    wg {i:5d}: {us3(t[i, 0, 1] - t0):8.2f} {us3(t[i, 0, 2] - t0):8.2f} {us3(t[i, 0, 500] - t0):8.2f} {us3(t[i, 0, 503] - t0):8.2f}")
+    print(f"median workgroup (index {mid}), wave 0 | wave 4, phases 4..23: the 7 segments above + advance")
+    for s_ in range(4, min(steps - 1, 24)):
+        a_, b_ = st[mid, 0], st[mid, 4]
+        fa = " ".join("%6.3f" % us3(a_[s_, i + 1] - a_[s_, i]) for i in range(7)) + " %6.3f" % us3(a_[s_ + 1, 0] - a_[s_, 7])
+        fb = " ".join("%6.3f" % us3(b_[s_, i + 1] - b_[s_, i]) for i in range(7)) + " %6.3f" % us3(b_[s_ + 1, 0] - b_[s_, 7])
+        print(f"    phase {s_:2d}: {fa}   |   {fb}")
     sys.exit(0)
 steps = int(((t[0, 0, 4:400].reshape(-1, 4)[:, 0]) > 0).sum())
 nchunks = int((t[0, 0, 400:500].reshape(-1, 4)[:, 0] > 0).sum())
