@@ -4,25 +4,32 @@
 // staging pipeline, built for ONE 8-wave workgroup per CU (2 waves / SIMD, 256 registers each):
 //   * tile: 256 output channels x (8 x 32) pixels; wave grid 4 (cout) x 2 (pixel rows), 64 x 128 per wave
 //     = 8 accumulator tiles of v_mfma_f32_32x32x16_bf16.
-//   * weights never touch registers: every "phase" (half a tap of one 128-byte K-chunk: 256 rows x 64 B = 16 KiB)
-//     is copied global -> LDS by two global_load_lds_dwordx4 per wave into a 4-slot ring, issued THREE phases
-//     before use.  The LDS image is lane-linear per instruction, so the bank swizzle is applied to the per-lane
-//     SOURCE address (and again on the fragment read).
-//   * the haloed 10 x 34 pixel patch of a K-chunk is double buffered; the next chunk's patch is fetched to
-//     registers by inline-asm global loads issued under the MFMAs of the current chunk's first tap, gets the
-//     fused GroupNorm-apply + SiLU (scale / shift table fetched to LDS the same way) and is written to the other
-//     buffer one or two phases later.
-//   * all VMEM of the main loop is inline asm, so the counted `s_waitcnt vmcnt(N)` below are the only waits:
-//     loads stay in flight across the one raw s_barrier per phase (a compiler-visible load would drain the queue
-//     with vmcnt(0) at every barrier).  Counting rule: N = number of VMEM instructions this wave issued AFTER
-//     the one that must have landed (loads return in order).
-//   * fragments are read one k-group ahead of the MFMAs that use them (two register sets), across the barrier
-//     too, so a wave's MFMA stream does not stop for LDS latency.
+//   * nothing asynchronous ever targets a VGPR.  Weights: every "phase" (half a tap of one 128-byte K-chunk:
+//     256 rows x 64 B = 16 KiB) is copied global -> LDS by two `buffer_load_dwordx4 ... lds` per wave into a
+//     4-slot ring, issued two phases before use.  The LDS image of such an instruction is lane-linear, so the
+//     bank swizzle is applied to the per-lane SOURCE offset (constant for a whole run of the K dimension; the
+//     moving part - tap, chunk, half - is the scalar offset) and again on the fragment read.
+//   * the haloed 10 x 34 pixel patch of a K-chunk is double buffered and fetched the same way, raw, straight into
+//     the other buffer; padding pixels / channels past the run are out-of-range buffer reads = hardware zeros.
+//     With a fused GroupNorm-apply + SiLU every lane then rewrites the 16-byte units it fetched itself in place
+//     (scale / shift table fetched to LDS alongside).
+//   * all VMEM of the main loop is inline asm, so the counted `s_waitcnt vmcnt(N)` below are the only waits and
+//     loads stay in flight across the raw s_barriers (a compiler-visible load would drain the queue with
+//     vmcnt(0) at every barrier).  Counting rule: N = number of VMEM instructions this wave issued AFTER the one
+//     that must have landed (they return in order).
+//   * ping-pong: waves 4-7 (the second wave of every SIMD) run one barrier interval behind waves 0-3, so one
+//     group's MFMA interval C coincides with the other's staging interval S and the matrix pipe of a SIMD always
+//     has a wave feeding it.  The hot loop is hand-thinned to ~70 non-MFMA instructions per phase: a SIMD hides
+//     about five of them per MFMA.
 //
-// Per phase q (two k-groups, 16 MFMAs per wave):
-//     vmcnt(N): own pieces of phase q+1's weights landed | s_barrier: everyone's landed, reads of q-1 done
-//     [first tap of a chunk: issue next chunk's patch loads]  issue weights of phase q+3 -> ring slot (q+3)&3
-//     read frag set 1 <- k-group 1 of q | MFMA set 0 | read set 0 <- k-group 0 of q+1 | MFMA set 1
+// Phase P = (chunk, tap, half), two k-groups, 16 MFMAs per wave:
+//   S(P): [patch commit]  DMA weights of phase P+2 -> ring slot (P+2)&3  [DMA next chunk's patch]
+//         read k-group 0 of P | vmcnt: own share of phase P+1 landed | barrier
+//   C(P): read k-group 1 | 16 MFMAs | barrier
+// LDS lifetimes (intervals counted in barriers; group 1 lags by one): phase P's ring slot is read in intervals
+// 2P..2P+2; slot (P+2)&3 = (P-2)&3 was last read in interval 2P-2 -> free in S(P).  The other patch buffer was
+// last read in the interval of S(P0) itself (by the lagging group), P0 = first phase of a chunk -> the DMA into it
+// starts in S(P0+1).
 #include <cstdlib>
 #include <cstring>
 #include "conv_params.h"
@@ -50,23 +57,41 @@ constexpr int PR = 2;                                         // pixel rows (of 
 constexpr int STAGE_BYTES = NWAVES * 32 * PR * WM * 128;      // 128 KiB
 constexpr int LDS_BYTES = MAIN_BYTES > STAGE_BYTES ? MAIN_BYTES : STAGE_BYTES;
 constexpr int NP = PU + 1;                                    // VMEM instructions of one patch issue (+ the table)
+constexpr uint32_t OOB = 0x80000000u;                         // per-lane offset that is out of range of every buffer here
 static_assert(LDS_BYTES <= 160 * 1024, "LDS budget");
 
-// LDS byte offset of 16-B slot s (0..3) of row `row` of a weight phase tile.  16 lanes of a ds_read_b128 group
-// (distinct rows mod 16... see MI355X LDS notes) hit 16 distinct 16-B bank groups.
+// LDS byte offset of 16-B slot s (0..3) of row `row` of a weight phase tile: the 16 lanes of a ds_read_b128
+// group hit 16 distinct 16-B bank groups.
 STORM_HD int w_off(int row, int s) { return row * WROW + ((s ^ ((row >> 2) & 3)) << 4); }
 
-// ---- asynchronous memory primitives (inline asm on the device; synchronous on the host simulator) ----------
-// 16 B per lane, global (uniform base + 32-bit lane offset) -> LDS at (uniform lds_wave + 16 * lane).
-__device__ __forceinline__ void glds16(const void* base, uint32_t voff, char* lds_wave, int lane) {
+// Raw buffer resource (stride 0): reads past num_records return zeros (and write zeros to LDS).
+__device__ __forceinline__ u32x4 make_srd(const void* base, uint32_t bytes) {
+    const uint64_t p = reinterpret_cast<uint64_t>(base);
+    u32x4 r;
+#if defined(__HIP_DEVICE_COMPILE__)
+    r[0] = __builtin_amdgcn_readfirstlane((uint32_t)p);
+    r[1] = __builtin_amdgcn_readfirstlane((uint32_t)(p >> 32) & 0xffffu);
+    r[2] = __builtin_amdgcn_readfirstlane(bytes);
+    r[3] = 0x00020000u;
+#else
+    r[0] = (uint32_t)p; r[1] = (uint32_t)(p >> 32); r[2] = bytes; r[3] = 0;
+#endif
+    return r;
+}
+// ---- asynchronous copy (inline asm on the device; synchronous on the host simulator) --------------------
+// 16 B per lane: buffer (srd) at voff + soff  ->  LDS at (uniform lds_wave + 16 * lane).
+__device__ __forceinline__ void dma16(u32x4 srd, uint32_t voff, uint32_t soff, char* lds_wave, int lane) {
 #if defined(__HIP_DEVICE_COMPILE__)
     (void)lane;
     const uint32_t la = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)lds_wave);
     uint32_t keep;
-    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
-                 : "=&s"(keep) : "v"(voff), "s"(base), "s"(la) : "memory");
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %4\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(voff), "s"(srd), "s"(soff), "s"(la) : "memory");
 #else
-    memcpy(lds_wave + 16 * lane, static_cast<const char*>(base) + voff, 16);
+    const uint64_t off = (uint64_t)voff + soff;
+    const char* base = reinterpret_cast<const char*>(((uint64_t)srd[1] << 32) | srd[0]);
+    if (off + 16 <= srd[2]) memcpy(lds_wave + 16 * lane, base + off, 16);
+    else memset(lds_wave + 16 * lane, 0, 16);
 #endif
 }
 template <int N> __device__ __forceinline__ void vm_wait() {
@@ -91,7 +116,14 @@ __device__ __forceinline__ void prio(int p) {
     (void)p;
 #endif
 }
-
+// keep a wave-uniform value in an SGPR: stops the compiler re-loading it from the kernarg segment (an s_load +
+// lgkmcnt(0) in the hot loop drains the LDS queue as well)
+__device__ __forceinline__ int pin(int x) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    asm volatile("" : "+s"(x));
+#endif
+    return x;
+}
 }  // namespace pipe
 using namespace pipe;
 
@@ -129,9 +161,7 @@ void conv_pipe_kernel(const ConvParams a, const int n_ct, const int tiles_per_xc
         }
     };
     auto stamp_tail = [&](int idx) {
-#if defined(__HIP_DEVICE_COMPILE__)
         if ((ABL & 64) && trace_rec) { const unsigned long long t = __builtin_amdgcn_s_memtime(); if (lane == 0) trace_rec[idx] = t; }
-#endif
     };
     if ((ABL & 64) && trace_rec && lane == 0)
         trace_rec[0] = (unsigned long long)__builtin_amdgcn_s_getreg((31 << 11) | 4) | ((unsigned long long)__builtin_amdgcn_s_getreg((31 << 11) | 20) << 32);
@@ -149,74 +179,69 @@ void conv_pipe_kernel(const ConvParams a, const int n_ct, const int tiles_per_xc
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[mi][ni][r] = 0.0f;
 
-    // ---- K-chunk descriptors (wave-uniform) -----------------------------------------------------
+    // ---- K-chunk descriptors (wave-uniform; built at chunk boundaries only) --------------------------
     struct Chunk {
-        const T* src; const float* gn_ss;
-        int C, cbeg, cvalid, ntaps, gn_silu;
+        u32x4 srd;                   // the batch image of the run's source tensor
+        u32x4 ss_srd;                // this chunk's (scale, shift) pairs, or an empty buffer
+        int C, cbeg, cvalid, ntaps, gn_silu, gn;
     };
     auto get_chunk = [&](int r, int ch) {
         const ConvRun& R = a.run[r];
         Chunk c;
-        c.src = reinterpret_cast<const T*>(R.src) + (long long)b * R.src_bstride;
         c.C = R.C; c.cbeg = R.c0 + ch * KC; c.cvalid = min(KC, R.cn - ch * KC);
-        c.ntaps = R.ntaps;
-        c.gn_ss = R.gn_ss ? R.gn_ss + 2 * ((long long)b * R.gn_C + R.wc0 + ch * KC) : nullptr;
-        c.gn_silu = R.gn_silu;
+        c.ntaps = R.ntaps; c.gn_silu = R.gn_silu; c.gn = R.gn_ss != nullptr;
+        c.srd = make_srd(reinterpret_cast<const T*>(R.src) + (long long)b * R.src_bstride, (uint32_t)a.H * a.W * R.C * 2u);
+        const float* ssp = R.gn_ss ? R.gn_ss + 2 * ((long long)b * R.gn_C + R.wc0 + ch * KC) : reinterpret_cast<const float*>(R.src);
+        c.ss_srd = make_srd(ssp, R.gn_ss ? (uint32_t)c.cvalid * 8u : 0u);
         return c;
     };
     auto chunks_of = [&](int r) { return (a.run[r].cn + KC - 1) / KC; };
     const int nruns = a.nruns;
+    int total_steps = 0;                                   // tap-steps (two phases each) of the whole K loop
+    for (int r = 0; r < nruns; ++r) total_steps += chunks_of(r) * a.run[r].ntaps;
 
-    // ---- weight stream: cursor over (run, chunk, tap, half), three phases ahead of the MFMAs -----
-    int w_r = 0, w_ch = 0, w_tp = 0, w_h = 0;
-    const T* w_run; int w_tapstride, w_CinP, w_klim, w_rows, w_ntaps, w_nch;
+    // ---- weight stream: cursor over tap-steps, one step ahead of the MFMAs --------------------------
+    // per run: buffer resource + this lane's two row offsets (swizzled slot included); per step: scalar offset
+    u32x4 w_srd; uint32_t w_voff[2];
+    int w_r = 0, w_ch = 0, w_tp = 0, w_soff = 0, w_tapbytes, w_ntaps, w_nch, w_left = total_steps;
     auto w_enter_run = [&](int r) {
         const ConvRun& R = a.run[r];
-        w_run = reinterpret_cast<const T*>(R.w) + (long long)b * R.w_bstride + R.wc0;
-        w_tapstride = (int)R.w_tapstride; w_CinP = R.CinP; w_klim = R.CinP - R.wc0; w_rows = R.w_rows;
-        w_ntaps = R.ntaps; w_nch = (R.cn + KC - 1) / KC;
-    };
-    w_enter_run(0);
-    int grow[2], gk8[2];                       // this lane's row / logical k offset (elements) inside a phase tile
-#pragma unroll
-    for (int j = 0; j < 2; ++j) {
-        const int row = (wave * 2 + j) * 16 + (lane >> 2);
-        grow[j] = cout0 + row;
-        gk8[j] = ((lane & 3) ^ ((row >> 2) & 3)) * 8;
-    }
-    auto w_issue = [&](int q) {                // weights of the cursor's phase -> ring slot q & 3; then advance
-        const T* tapbase = w_run + (long long)w_tp * w_tapstride;
-        const int k0 = w_ch * KC + w_h * 32;
-        char* dst = smem + OFF_RING + (q & (RING - 1)) * WPHASE_BYTES + wave * 2048;
+        const T* base = reinterpret_cast<const T*>(R.w) + (long long)b * R.w_bstride + R.wc0;
+        w_tapbytes = (int)R.w_tapstride * 2; w_ntaps = R.ntaps; w_nch = (R.cn + KC - 1) / KC;
+        w_srd = make_srd(base, (uint32_t)(R.ntaps * (int)R.w_tapstride - R.wc0) * 2u);
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
-            const int co = min(grow[j], w_rows - 1);             // rows past the matrix: any valid row (never stored)
-            const int k = k0 + gk8[j];
-            const uint32_t voff = (uint32_t)(co * w_CinP + (k < w_klim ? k : 0)) * 2u;   // k past the row: finite data x zero patch
-            glds16(tapbase, voff, dst + j * 1024, lane);
+            const int row = (wave * 2 + j) * 16 + (lane >> 2);
+            const int co = cout0 + row;                          // rows past the matrix: zeros (never stored)
+            w_voff[j] = co < R.w_rows ? (uint32_t)(co * R.CinP + ((lane & 3) ^ ((row >> 2) & 3)) * 8) * 2u : OOB;
         }
-        // advance; past the end the cursor stays on the last phase (harmless re-load into a free slot)
-        int h = w_h ^ 1, tp = w_tp, ch = w_ch, r = w_r;
-        if (h == 0) {
-            ++tp;
-            if (tp == w_ntaps) {
-                tp = 0; ++ch;
-                if (ch == w_nch) { ch = 0; ++r; }
+        w_soff = 0; w_ch = 0; w_tp = 0;
+    };
+    w_enter_run(0);
+    auto w_issue = [&](int q, int h) {                     // half h of the cursor's step -> ring slot q & 3
+        if ((ABL & 8) && q > 1) return;                     // (profiling: no weight DMA after the prologue)
+        char* dst = smem + OFF_RING + (q & (RING - 1)) * WPHASE_BYTES + wave * 2048;
+        const uint32_t so = (uint32_t)(w_soff + h * WROW);
+        dma16(w_srd, w_voff[0], so, dst, lane);
+        dma16(w_srd, w_voff[1], so, dst + 1024, lane);
+    };
+    auto w_advance = [&]() {                               // past the end the cursor stays (harmless re-load)
+        if (--w_left > 0) {
+            ++w_tp;
+            if (w_tp < w_ntaps) w_soff += w_tapbytes;
+            else {
+                w_tp = 0; ++w_ch;
+                if (w_ch < w_nch) w_soff = w_ch * (2 * WROW);
+                else { ++w_r; w_enter_run(w_r); }
             }
-        }
-        if (r < nruns) {
-            if (r != w_r) w_enter_run(r);
-            w_h = h; w_tp = tp; w_ch = ch; w_r = r;
         }
     };
 
-    // ---- patch staging: issue (LDS-DMA, raw activations straight into the next patch buffer, swizzle on the
-    //      source address) ... commit (in place, every lane fixes up the 16-B units it fetched itself: zeros for
-    //      the padding halo / channels past the run, GroupNorm affine + SiLU when fused).  No staging registers:
-    //      nothing asynchronous ever targets a VGPR, so the compiler cannot touch data that has not landed.
-    uint32_t pmask = 0;                        // bit i: unit i of this lane is real input (inside the image, channel valid)
+    // ---- patch staging ---------------------------------------------------------------------------------
+    uint32_t pmask = 0;                        // bit i: unit i of this lane is real input (needs the GN transform)
     auto patch_issue = [&](const Chunk& c, int parity) {
         char* dst = smem + parity * PATCH_BYTES;
+        const uint32_t so = (uint32_t)c.cbeg * 2u;
 #pragma unroll
         for (int i = 0; i < PU; ++i) {
             int k = wave + i * NWAVES;                           // piece: patch rows 8k .. 8k+7
@@ -226,158 +251,198 @@ void conv_pipe_kernel(const ConvParams a, const int n_ct, const int tiles_per_xc
             const int py = row / PW, px = row - py * PW;
             const int gy = ty0 + py - 1, gx = tx0 + px - 1;
             const bool ok = row < NPIX && slot * 8 < c.cvalid && gy >= 0 && gy < a.H && gx >= 0 && gx < a.W;
-            const uint32_t voff = ok ? (uint32_t)((gy * a.W + gx) * c.C + c.cbeg + slot * 8) * 2u : 0u;
-            glds16(c.src, voff, dst + k * 1024, lane);
+            dma16(c.srd, ok ? (uint32_t)((gy * a.W + gx) * c.C + slot * 8) * 2u : OOB, so, dst + k * 1024, lane);
             pmask = ok ? (pmask | (1u << i)) : (pmask & ~(1u << i));
         }
-        // (scale, shift) of the chunk's channels -> LDS table; lanes past the chunk re-read channel 0
-        const bool has = c.gn_ss != nullptr;
-        const void* tb = has ? static_cast<const void*>(c.gn_ss) : static_cast<const void*>(c.src);
-        const uint32_t toff = (has && 2 * lane < c.cvalid) ? (uint32_t)lane * 16u : 0u;
-        glds16(tb, toff, smem + OFF_SS + parity * SS_BYTES, lane);
+        dma16(c.ss_srd, (uint32_t)lane * 16u, 0u, smem + OFF_SS + parity * SS_BYTES, lane);
     };
-    auto patch_commit = [&](const Chunk& c, int parity) {
+    auto patch_commit = [&](const Chunk& c, int parity) {   // only with a fused GroupNorm: in place, own units
         char* dst = smem + parity * PATCH_BYTES;
-        const bool gn = c.gn_ss != nullptr;
 #pragma unroll
         for (int i = 0; i < PU; ++i) {
             const int k = wave + i * NWAVES;
-            if (k < PPIECES) {
+            if (k < PPIECES && ((pmask >> i) & 1u)) {
                 const int row = k * 8 + (lane >> 3);
                 const int slot = (lane & 7) ^ ((row >> 1) & 7);
                 uint4* const q = reinterpret_cast<uint4*>(dst + k * 1024 + lane * 16);
-                const bool ok = (pmask >> i) & 1u;
-                if (!ok) {
-                    *q = make_uint4(0u, 0u, 0u, 0u);
-                } else if (gn) {
-                    float ss[16];
-                    const float* t = reinterpret_cast<const float*>(smem + OFF_SS + parity * SS_BYTES) + 16 * slot;
+                float ss[16];
+                const float* t = reinterpret_cast<const float*>(smem + OFF_SS + parity * SS_BYTES) + 16 * slot;
 #pragma unroll
-                    for (int j = 0; j < 16; j += 4) {
-                        const float4 t4 = *reinterpret_cast<const float4*>(t + j);
-                        ss[j] = t4.x; ss[j + 1] = t4.y; ss[j + 2] = t4.z; ss[j + 3] = t4.w;
-                    }
-                    *q = gn_act_slot(*q, ss, c.gn_silu, (T*)nullptr);
+                for (int j = 0; j < 16; j += 4) {
+                    const float4 t4 = *reinterpret_cast<const float4*>(t + j);
+                    ss[j] = t4.x; ss[j + 1] = t4.y; ss[j + 2] = t4.z; ss[j + 3] = t4.w;
                 }
+                *q = gn_act_slot(*q, ss, c.gn_silu, (T*)nullptr);
             }
         }
     };
 
-    // ---- fragment reads ----------------------------------------------------------------------------
-    int aoff[WM];                              // weight-tile offsets of this lane's rows, k-group 0 of a phase
-#pragma unroll
-    for (int mi = 0; mi < WM; ++mi) aoff[mi] = w_off((wm * WM + mi) * 32 + (lane & 31), lane >> 5);
-    int pbase[WN];                             // patch offsets for the tap being read, k-group 0 of the chunk
-    auto set_tap = [&](int parity, int dy, int dx) {
+    // ---- fragment reads ----------------------------------------------------------------------------------
+    const int aoff = w_off(wm * WM * 32 + (lane & 31), lane >> 5);   // row of mi = 1 is +32 rows = +2048 B, same swizzle
+    const int prow0 = (wn * WN) * PW + (lane & 31);                 // patch pixel of ni = 0 under tap (0, 0)
+    int pbase[WN];                             // patch offsets of the tap being read, k-group 0 of the chunk
+    auto set_tap = [&](int parity, int tapoff) {   // tapoff = dy * PW + dx
 #pragma unroll
         for (int ni = 0; ni < WN; ++ni)
-            pbase[ni] = parity * PATCH_BYTES + lds_off(patch_pixel<9>(lane, wn * WN + ni, dy, dx), lane >> 5);
+            pbase[ni] = parity * PATCH_BYTES + lds_off(prow0 + ni * PW + tapoff, lane >> 5);
     };
     // k-group kg (0..3) of the chunk = k-group (kg & 1) of ring phase q
     auto read_frags = [&](Frag (&fa)[WM], Frag (&fb)[WN], int q, int kg) {
-        const char* wb = smem + OFF_RING + (q & (RING - 1)) * WPHASE_BYTES;
+        if ((ABL & 16) && q > 0) {                          // (profiling: no fragment reads after the first phase)
+#if defined(__HIP_DEVICE_COMPILE__)
 #pragma unroll
-        for (int mi = 0; mi < WM; ++mi) fa[mi] = *reinterpret_cast<const Frag*>(wb + (aoff[mi] ^ ((kg & 1) << 5)));
+            for (int mi = 0; mi < WM; ++mi) asm volatile("" : "+v"(fa[mi]));
+#pragma unroll
+            for (int ni = 0; ni < WN; ++ni) asm volatile("" : "+v"(fb[ni]));
+#endif
+            return;
+        }
+        const char* wb = smem + OFF_RING + (q & (RING - 1)) * WPHASE_BYTES + (aoff ^ ((kg & 1) << 5));
+        fa[0] = *reinterpret_cast<const Frag*>(wb);
+        fa[1] = *reinterpret_cast<const Frag*>(wb + 32 * WROW);
 #pragma unroll
         for (int ni = 0; ni < WN; ++ni) fb[ni] = *reinterpret_cast<const Frag*>(smem + (pbase[ni] ^ (kg << 5)));
     };
     auto mma = [&](const Frag (&fa)[WM], const Frag (&fb)[WN]) {
+        if (ABL & 32) {                                     // (profiling: no MFMAs; operands stay live)
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma unroll
+            for (int mi = 0; mi < WM; ++mi) asm volatile("" ::"v"(fa[mi]));
+#pragma unroll
+            for (int ni = 0; ni < WN; ++ni) asm volatile("" ::"v"(fb[ni]));
+#endif
+            return;
+        }
 #pragma unroll
         for (int mi = 0; mi < WM; ++mi)
 #pragma unroll
             for (int ni = 0; ni < WN; ++ni) Mma<T>::run(fa[mi], fb[ni], acc[mi][ni]);
     };
-    auto tap_offsets = [&](int ntaps, int tp, int& dy, int& dx) {
-        if (ntaps == 9) { dy = tp / 3; dx = tp - dy * 3; } else { dy = 1; dx = 1; }
-    };
 
-    // ---- prologue: first patch, first two weight phases -------------------------------------------
+    // ---- prologue: first patch, first step's weights --------------------------------------------------
     int r = 0, ch = 0, nch_r = chunks_of(0), ci = 0;
     Chunk cur = get_chunk(0, 0);
-    w_issue(0); w_issue(1);
+    w_issue(0, 0); w_issue(1, 1); w_advance();
     patch_issue(cur, 0);
     vm_wait<0>();
-    patch_commit(cur, 0);
+    if (cur.gn) patch_commit(cur, 0);
     raw_barrier();
-    // Ping-pong: waves 4-7 (the second wave of every SIMD) run one barrier interval behind waves 0-3, so one
-    // group's MFMA interval coincides with the other's staging interval (waits, LDS-DMA issue, fragment reads,
-    // patch commit) and the matrix pipe of a SIMD always has one wave feeding it.
     const int grp = (ABL & 2) ? 0 : wave >> 2;        // (ABL & 2: profiling variant without the stagger)
     if (grp == 1) raw_barrier();
     stamp(2);
     Frag fa0[WM], fb0[WN], fa1[WM], fb1[WN];
 
-    // ---- main loop: one iteration = one phase P = (chunk, tap, half): staging interval S(P), MFMA interval C(P) ----
-    //   S(P): [commit the patch fetched two phases ago]  issue weights of phase P+2 -> slot (P+2)&3
-    //         [second phase of a chunk: issue the next chunk's patch LDS-DMA]  read k-group 0 of P
-    //         vmcnt: own share of phase P+1 landed | barrier
-    //   C(P): read k-group 1 | 16 MFMAs | barrier
-    // LDS lifetimes (intervals counted in barriers; group 1 lags by one): phase P's slot is read in intervals
-    // 2P..2P+2, slot (P+2)&3 = (P-2)&3 was last read in interval 2P-2 -> free in S(P).  The patch buffer of the
-    // next chunk was last read in the interval of S(P0) itself (by the lagging group) -> DMA into it from S(P0+1) on.
-    int P = 0, tp = 0, h = 0, since_issue = 99, step = 0;       // since_issue: phases since the last patch issue
-    bool has_nc, commit_pending = false; Chunk nxt = cur;
+    // ---- main loop: one iteration = one tap-step = phases P (half 0) and P+1 (half 1) ------------------
+    int P = 0, tp = 0, step = 0, steps_left = pin(total_steps);
+    bool has_nc, commit_pending = false, issued_prev = false;
+    Chunk nxt = cur;
     {
         int nr = r, nc = ch + 1;
         if (nc == nch_r) { nc = 0; ++nr; }
         has_nc = nr < nruns;
         nxt = get_chunk(has_nc ? nr : r, has_nc ? nc : ch);
     }
+    int ntaps = pin(cur.ntaps), par = 0;
+    int tapoff = ntaps == 9 ? 0 : PW + 1, tapdx = 0;          // LDS pixel offset of the current tap, its column
+    set_tap(0, tapoff);
+    // Interleave hint for an MFMA interval: the fragment reads first, then one MFMA : a few VALU / SALU of the
+    // bookkeeping placed in the same region (it rides in the MFMA issue gaps instead of lengthening a staging interval).
+    auto interleave = [&]() {
+#if defined(__HIP_DEVICE_COMPILE__)
+        __builtin_amdgcn_sched_group_barrier(0x100, 6, 0);        // 6 DS reads
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);    // 1 MFMA
+            __builtin_amdgcn_sched_group_barrier(0x002, 3, 0);    // <= 3 VALU
+            __builtin_amdgcn_sched_group_barrier(0x004, 2, 0);    // <= 2 SALU
+        }
+#endif
+    };
     while (true) {
-        const int ntaps = cur.ntaps, par = ci & 1;
-        // ---------------- S(P) ----------------
-        stamp(4 + 8 * step);
-        if (commit_pending && since_issue == 2) {               // 9-tap chunk: patch issued two phases ago
-            vm_wait<2>();
-            patch_commit(nxt, par ^ 1);
-            commit_pending = false;
-        }
-        w_issue(P + 2);
-        // The other patch buffer was read until the lagging group's C(P0 - 1), which shares its interval with the
-        // leading group's S(P0): the LDS-DMA into it may start in the chunk's SECOND phase.
-        const bool issue_now = tp == 0 && h == 1 && has_nc;
-        if (issue_now) { patch_issue(nxt, par ^ 1); since_issue = 0; commit_pending = ntaps != 1; }
-        stamp(5 + 8 * step);
-        if (h == 0) { int dy, dx; tap_offsets(ntaps, tp, dy, dx); set_tap(par, dy, dx); }
-        read_frags(fa0, fb0, P, 2 * h);
-        if (issue_now && ntaps == 1) {                          // two-phase chunk: the next phase already reads it
-            vm_wait<0>();
-            patch_commit(nxt, par ^ 1);
-        }
-        stamp(6 + 8 * step);
-        if (since_issue <= 1) vm_wait<2 + NP>(); else vm_wait<2>();
-        stamp(7 + 8 * step);
+        // ================= phase P (half 0) =================
+        stamp(4 + 16 * step);
+        w_issue(P + 2, 0);
+        read_frags(fa0, fb0, P, 0);
+        stamp(6 + 16 * step);
+        if (issued_prev) vm_wait<2 + NP>(); else vm_wait<2>();
         raw_barrier();
-        // ---------------- C(P) ----------------
-        stamp(8 + 8 * step);
-        read_frags(fa1, fb1, P, 2 * h + 1);
+        stamp(8 + 16 * step);
         __builtin_amdgcn_sched_barrier(0);
         if (!(ABL & 1)) prio(1);
+        read_frags(fa1, fb1, P, 1);
         mma(fa0, fb0);
-        if (ABL & 64) { __builtin_amdgcn_sched_barrier(0); stamp(9 + 8 * step); __builtin_amdgcn_sched_barrier(0); }
         mma(fa1, fb1);
-        if (!(ABL & 1)) prio(0);
+        if (!(ABL & 4)) interleave();
         __builtin_amdgcn_sched_barrier(0);
-        stamp(10 + 8 * step);
+        if (!(ABL & 1)) prio(0);
+        stamp(10 + 16 * step);
         raw_barrier();
-        stamp(11 + 8 * step);
-        // ---------------- advance ----------------
-        ++P; ++since_issue; ++step;
-        h ^= 1;
-        if (h == 0) {
-            ++tp;
-            if (tp == ntaps) {
-                if (!has_nc) break;
-                tp = 0;
-                int nr = r, nc = ch + 1;
-                if (nc == nch_r) { nc = 0; ++nr; }
-                if (nr != r) nch_r = chunks_of(nr);
-                cur = nxt; r = nr; ch = nc; ++ci;
-                nr = r; nc = ch + 1;
-                if (nc == nch_r) { nc = 0; ++nr; }
-                has_nc = nr < nruns;
-                nxt = get_chunk(has_nc ? nr : r, has_nc ? nc : ch);
-            }
+        stamp(11 + 16 * step);
+        // ================= phase P+1 (half 1) =================
+        if (commit_pending && tp == 1) {                        // 9-tap chunk: the patch was issued two phases ago
+            if (nxt.gn) { vm_wait<2>(); patch_commit(nxt, par ^ 1); }
+            commit_pending = false;
+        }
+        w_issue(P + 3, 1);
+        // The other patch buffer was read until the lagging group's C(P0 - 1), which shares its interval with the
+        // leading group's S(P0): the DMA into it starts in the chunk's SECOND phase.
+        const bool issue_now = tp == 0 && has_nc;
+        if (issue_now) { patch_issue(nxt, par ^ 1); commit_pending = ntaps != 1; }
+        read_frags(fa0, fb0, P + 1, 2);
+        stamp(12 + 16 * step);
+        if (issue_now && ntaps == 1) {                          // two-phase chunk: the next phase already reads the patch
+            vm_wait<0>();
+            if (nxt.gn) patch_commit(nxt, par ^ 1);
+        } else if (issue_now) vm_wait<2 + NP>(); else vm_wait<2>();
+        issued_prev = issue_now;
+        raw_barrier();
+        stamp(13 + 16 * step);
+        __builtin_amdgcn_sched_barrier(0);
+        if (!(ABL & 1)) prio(1);
+        read_frags(fa1, fb1, P + 1, 3);
+        // Bookkeeping for the next step rides in this MFMA interval, branch-free so that it stays in the MFMAs'
+        // basic block (common case: next tap of the same chunk / same run); chunk and run changes are fixed
+        // up after the interval's barrier.
+        const int adv = --w_left > 0 ? 1 : 0;                   // weight cursor: past the end it stays (harmless re-load)
+        const int wtn = w_tp + adv;
+        const bool w_slow = wtn >= w_ntaps;
+        w_soff += (adv && !w_slow) ? w_tapbytes : 0;
+        w_tp = w_slow ? w_tp : wtn;
+        P += 2; ++step;
+        const bool last = --steps_left == 0;
+        const int tpn = tp + 1;
+        const bool wrap = tpn == ntaps;
+        tp = wrap ? 0 : tpn;
+        const bool row_end = tapdx == 2;                        // 3x3 taps in raster order: offset dy * PW + dx
+        tapoff = ntaps == 9 ? (wrap ? 0 : tapoff + (row_end ? PW - 2 : 1)) : PW + 1;
+        tapdx = (row_end || wrap) ? 0 : tapdx + 1;
+        set_tap(par, tapoff);                                   // (re-done below when the chunk changes)
+        mma(fa0, fb0);
+        mma(fa1, fb1);
+        if (!(ABL & 4)) interleave();
+        __builtin_amdgcn_sched_barrier(0);
+        if (!(ABL & 1)) prio(0);
+        stamp(14 + 16 * step - 16);
+        raw_barrier();
+        stamp(15 + 16 * step - 16);
+        if (last) break;
+        if (w_slow) {                                           // next chunk of the run, or the next run
+            w_tp = 0; ++w_ch;
+            if (w_ch < w_nch) w_soff = w_ch * (2 * WROW);
+            else { ++w_r; w_enter_run(w_r); }
+        }
+        if (wrap) {
+            int nr = r, nc = ch + 1;
+            if (nc == nch_r) { nc = 0; ++nr; }
+            if (nr != r) nch_r = chunks_of(nr);
+            cur = nxt; r = nr; ch = nc; ++ci;
+            nr = r; nc = ch + 1;
+            if (nc == nch_r) { nc = 0; ++nr; }
+            has_nc = nr < nruns;
+            nxt = get_chunk(has_nc ? nr : r, has_nc ? nc : ch);
+            ntaps = pin(cur.ntaps); par = ci & 1;
+            tapoff = ntaps == 9 ? 0 : PW + 1; tapdx = 0;
+            set_tap(par, tapoff);
         }
     }
     if (grp == 0) raw_barrier();                        // balance the stagger: every wave has executed the same barriers
@@ -504,12 +569,19 @@ int launch_conv_pipe(const storm_conv_args& a, hipStream_t st) {
     switch (abl) {
         case 1: kern = conv_pipe_kernel<1>; ki = 1; break;       // no s_setprio
         case 2: kern = conv_pipe_kernel<2>; ki = 2; break;       // no stagger
+        case 4: kern = conv_pipe_kernel<4>; ki = 6; break;       // no sched_group_barrier interleave hint
+        case 8: kern = conv_pipe_kernel<8>; ki = 7; break;       // no weight DMA
+        case 16: kern = conv_pipe_kernel<16>; ki = 8; break;     // no fragment reads
+        case 32: kern = conv_pipe_kernel<32>; ki = 9; break;     // no MFMA
+        case 24: kern = conv_pipe_kernel<24>; ki = 10; break;    // no DMA, no fragment reads
+        case 48: kern = conv_pipe_kernel<48>; ki = 11; break;    // no fragment reads, no MFMA
+        case 56: kern = conv_pipe_kernel<56>; ki = 12; break;    // barriers + bookkeeping only
         case 64: kern = conv_pipe_kernel<64>; ki = 3; break;     // wave timeline stamps
         case 65: kern = conv_pipe_kernel<65>; ki = 4; break;
         case 66: kern = conv_pipe_kernel<66>; ki = 5; break;
         default: break;
     }
-    static bool attr_set[6] = {false, false, false, false, false, false};
+    static bool attr_set[13] = {};
     if (!attr_set[ki]) {
         STORM_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES));
         attr_set[ki] = true;
