@@ -195,14 +195,15 @@ def main():
     if rank == 0 and not args.no_roofline:
         Y, _, _ = model._prepare(wav)
         rows, prog = profile_ops(model.dnn, Y, args.profile_nfe)
-        # the 3x3 implicit-GEMM kernel has two tile instantiations (dispatch rule of conv_igemm.hip):
-        #   256 cout x 256 px (8 waves, prefetched patch) when outC > 128 and >= 512 pixel tiles, else 128 cout x 256 px
+        # the 3x3 implicit-GEMM convolution has two kernels (dispatch rule of conv_igemm.hip): the pipelined
+        #   256 cout x 256 px kernel of conv_pipe.hip when outC > 128 and >= 512 pixel tiles, else 128 cout x 256 px
         tname = "storm::bf16_t" if args.precision == "bf16" else "float"
         groups = {}
         for r in rows:
             if r["code"] == 4 and r["big"] and 9 in r["taps"]:
                 v2 = r["Cout"] > 128 and args.batch * ((r["H"] * r["W"] + 255) // 256) >= 512
-                key = (f"storm::conv_igemm_kernel<{tname}, 9, 2, 4, 2, true, false, 0>" if v2
+                key = ("storm::conv_pipe_kernel<4, 2, 0>" if v2 and args.precision == "bf16"
+                       else f"storm::conv_igemm_kernel<{tname}, 9, 2, 4, 2, true, false, 0>" if v2
                        else f"storm::conv_igemm_kernel<{tname}, 9, 2, 2, 2, false, false, 0>")
                 groups.setdefault(key, []).append(r)
         kname, big = max(groups.items(), key=lambda kv: sum(r["ms"] for r in kv[1]))
@@ -220,7 +221,7 @@ def main():
         traffic = None
         tpath = os.path.join(ROOT, "profiles", "conv_traffic.json")     # PMC pass (scripts/pmc_round.sh), per launch
         if os.path.exists(tpath):
-            traffic = json.load(open(tpath)).get(kname.split("<")[1].split(">")[0].replace(" ", ""), {}).get("hbm_bytes_per_launch")
+            traffic = json.load(open(tpath)).get(kname.replace("storm::", "").replace(" ", ""), {}).get("hbm_bytes_per_launch")
         result["roofline"] = {
             "bound": "mfma", "kernel": kname,
             "achieved": ach, "peak": peak, "unit": "TFLOP/s", "frac": ach / peak, "traffic": traffic,
@@ -247,6 +248,7 @@ def main():
     if rank == 0:
         print(json.dumps(result))
     if dist is not None:
+        dist.barrier()                     # rank 0 profiles after the timed region: leave together
         dist.destroy_process_group()
 
 

@@ -542,14 +542,16 @@ static int dispatch_conv(const storm_conv_args& a, hipStream_t st) {
     //   1: 128 cout x 256 px, 8 waves (64x64 each), 2 workgroups / CU
     //   2: 256 cout x 256 px, 8 waves (64x128 each), 1 workgroup / CU, patch double-buffered and the
     //      next K-chunk prefetched under the MFMAs (one patch load + GN transform per 256 couts)
+    //   3: conv_pipe.hip, 256 cout x 256 px, 8 waves in two ping-pong groups, operands by LDS-DMA (bf16 3x3 only)
+    //   4: conv_pipe.hip, same tile, 4 waves of 128x128 (one per SIMD)
     const char* forced_env = getenv("STORM_CONV_VARIANT");          // read per launch: tests and probes switch it at run time
     const int forced = forced_env ? atoi(forced_env) : -1;
     static const bool frag_pipe = getenv("STORM_FRAG_PIPE") ? atoi(getenv("STORM_FRAG_PIPE")) != 0 : false;
     const long long px_tiles = (long long)a.B * cdiv((long long)a.H * a.W, TILE_H * TILE_W);
-    const int variant = forced >= 0 ? forced : ((a.outC > 128 && px_tiles >= 512) ? 2 : 0);
+    const int variant = forced >= 0 ? forced : ((a.outC > 128 && px_tiles >= 512) ? (any9 && conv_pipe_supports(a) ? 3 : 2) : 0);
     const char* abl_env = getenv("STORM_CONV_ABLATE");
     const int abl = abl_env ? atoi(abl_env) : 0;
-    if (any9 && !small && abl && variant != 3) {        // profiling only
+    if (any9 && !small && abl && variant != 3 && variant != 4) {        // profiling only
         const bool v2 = variant == 2;
         switch (abl) {
             case 1: return v2 ? launch_conv<T, 9, 2, 4, 2, true, false, 1>(a, st) : launch_conv<T, 9, 2, 2, 2, false, false, 1>(a, st);
@@ -567,7 +569,7 @@ static int dispatch_conv(const storm_conv_args& a, hipStream_t st) {
     }
     if (any9) {
         if (small) return launch_conv<T, 9, 1, 1, 4, false>(a, st);
-        if (variant == 3 && conv_pipe_supports(a)) return launch_conv_pipe(a, st);
+        if ((variant == 3 || variant == 4) && conv_pipe_supports(a)) return launch_conv_pipe(a, st, variant == 4 ? 1 : 2);
         if (variant == 2) return launch_conv<T, 9, 2, 4, 2, true>(a, st);
         if (variant == 1) return launch_conv<T, 9, 2, 2, 4, false>(a, st);
         return frag_pipe ? launch_conv<T, 9, 2, 2, 2, false, true>(a, st) : launch_conv<T, 9, 2, 2, 2, false, false>(a, st);

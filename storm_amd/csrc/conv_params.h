@@ -109,6 +109,6 @@ static inline ConvParams make_params(const storm_conv_args& a) {
 
 // defined in conv_pipe.hip: software-pipelined 256-cout x 256-pixel 3x3 kernel (bf16)
 bool conv_pipe_supports(const storm_conv_args& a);
-int launch_conv_pipe(const storm_conv_args& a, hipStream_t st);
+int launch_conv_pipe(const storm_conv_args& a, hipStream_t st, int layout);
 
 }  // namespace storm

@@ -40,12 +40,11 @@ using namespace cidx;
 namespace pipe {
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 
-constexpr int WM = 2, WN = 4, WAVES_M = 4, WAVES_N = 2, NWAVES = 8, THREADS = 512, BN = 256;
+constexpr int BN = 256;
 constexpr int PW = Geo<9>::PW, NPIX = Geo<9>::NPIX;
 constexpr int PATCH_ROWS = (NPIX + 7) / 8 * 8;                // 344: whole 8-row (1 KiB) LDS-DMA pieces
 constexpr int PATCH_BYTES = PATCH_ROWS * PIX_BYTES;           // 44032
 constexpr int PPIECES = PATCH_ROWS / 8;                       // 43 wave-instructions cover a patch
-constexpr int PU = (PPIECES + NWAVES - 1) / NWAVES;           // pieces per wave (6; the surplus re-issues a piece)
 constexpr int WROW = 64;                                      // bytes per weight row and phase
 constexpr int WPHASE_BYTES = BN * WROW;                       // 16 KiB
 constexpr int RING = 4;
@@ -54,11 +53,24 @@ constexpr int OFF_SS = OFF_RING + RING * WPHASE_BYTES;
 constexpr int SS_BYTES = 1024;                                // one wave-instruction: 64 channels x (scale, shift) + pad
 constexpr int MAIN_BYTES = OFF_SS + 2 * SS_BYTES;             // 155648
 constexpr int PR = 2;                                         // pixel rows (of 32 px) staged per epilogue pass and wave
-constexpr int STAGE_BYTES = NWAVES * 32 * PR * WM * 128;      // 128 KiB
-constexpr int LDS_BYTES = MAIN_BYTES > STAGE_BYTES ? MAIN_BYTES : STAGE_BYTES;
-constexpr int NP = PU + 1;                                    // VMEM instructions of one patch issue (+ the table)
 constexpr uint32_t OOB = 0x80000000u;                         // per-lane offset that is out of range of every buffer here
-static_assert(LDS_BYTES <= 160 * 1024, "LDS budget");
+
+// Two wave layouts of the 256-cout x 256-pixel tile:
+//   <4, 2>: 8 waves (2 / SIMD, 256 registers each), 64 x 128 per wave, the two waves of a SIMD ping-pong
+//   <2, 2>: 4 waves (1 / SIMD, 512 registers), 128 x 128 per wave: half the barriers and LDS fragment reads per
+//           MFMA; everything else rides in the wave's own MFMA issue gaps
+template <int WAVES_M_, int WAVES_N_> struct PCfg {
+    static constexpr int WAVES_M = WAVES_M_, WAVES_N = WAVES_N_, NWAVES = WAVES_M * WAVES_N, THREADS = 64 * NWAVES;
+    static constexpr int WM = BN / 32 / WAVES_M;              // 32-cout tiles per wave
+    static constexpr int WN = TILE_H / WAVES_N;               // pixel rows (32 px) per wave
+    static constexpr int PU = (PPIECES + NWAVES - 1) / NWAVES;   // patch pieces per wave (the surplus re-issues a piece)
+    static constexpr int NP = PU + 1;                         // VMEM instructions of one patch issue (+ the table)
+    static constexpr int NWD = BN / 16 / NWAVES;              // weight DMA instructions per wave and phase (16 rows each)
+    static constexpr int STAGE_BYTES = NWAVES * 32 * PR * WM * 128;
+    static constexpr int LDS_BYTES = MAIN_BYTES > STAGE_BYTES ? MAIN_BYTES : STAGE_BYTES;
+    static_assert(LDS_BYTES <= 160 * 1024, "LDS budget");
+    static_assert(PU * NWAVES - PPIECES < NWAVES && PU <= 31, "patch pieces");
+};
 
 // LDS byte offset of 16-B slot s (0..3) of row `row` of a weight phase tile: the 16 lanes of a ds_read_b128
 // group hit 16 distinct 16-B bank groups.
@@ -127,10 +139,12 @@ __device__ __forceinline__ int pin(int x) {
 }  // namespace pipe
 using namespace pipe;
 
-template <int ABL>
-__global__ __launch_bounds__(pipe::THREADS, 2)
+template <int WAVES_M, int WAVES_N, int ABL>
+__global__ __launch_bounds__((pipe::PCfg<WAVES_M, WAVES_N>::THREADS), (pipe::PCfg<WAVES_M, WAVES_N>::NWAVES / 4))
 void conv_pipe_kernel(const ConvParams a, const int n_ct, const int tiles_per_xcd,
                       const int ntiles, const int tiles_x, const int tiles_per_img) {
+    typedef PCfg<WAVES_M, WAVES_N> Cfg;
+    constexpr int NWAVES = Cfg::NWAVES, WM = Cfg::WM, WN = Cfg::WN, PU = Cfg::PU, NP = Cfg::NP, NWD = Cfg::NWD;
     typedef bf16_t T;
     typedef bf16x8 Frag;
     constexpr int KC = 64;                                      // channels per K-chunk (128 B)
@@ -202,7 +216,7 @@ void conv_pipe_kernel(const ConvParams a, const int n_ct, const int tiles_per_xc
 
     // ---- weight stream: cursor over tap-steps, one step ahead of the MFMAs --------------------------
     // per run: buffer resource + this lane's two row offsets (swizzled slot included); per step: scalar offset
-    u32x4 w_srd; uint32_t w_voff[2];
+    u32x4 w_srd; uint32_t w_voff[NWD];
     int w_r = 0, w_ch = 0, w_tp = 0, w_soff = 0, w_tapbytes, w_ntaps, w_nch, w_left = total_steps;
     auto w_enter_run = [&](int r) {
         const ConvRun& R = a.run[r];
@@ -210,8 +224,8 @@ void conv_pipe_kernel(const ConvParams a, const int n_ct, const int tiles_per_xc
         w_tapbytes = (int)R.w_tapstride * 2; w_ntaps = R.ntaps; w_nch = (R.cn + KC - 1) / KC;
         w_srd = make_srd(base, (uint32_t)(R.ntaps * (int)R.w_tapstride - R.wc0) * 2u);
 #pragma unroll
-        for (int j = 0; j < 2; ++j) {
-            const int row = (wave * 2 + j) * 16 + (lane >> 2);
+        for (int j = 0; j < NWD; ++j) {
+            const int row = (wave * NWD + j) * 16 + (lane >> 2);
             const int co = cout0 + row;                          // rows past the matrix: zeros (never stored)
             w_voff[j] = co < R.w_rows ? (uint32_t)(co * R.CinP + ((lane & 3) ^ ((row >> 2) & 3)) * 8) * 2u : OOB;
         }
@@ -220,10 +234,10 @@ void conv_pipe_kernel(const ConvParams a, const int n_ct, const int tiles_per_xc
     w_enter_run(0);
     auto w_issue = [&](int q, int h) {                     // half h of the cursor's step -> ring slot q & 3
         if ((ABL & 8) && q > 1) return;                     // (profiling: no weight DMA after the prologue)
-        char* dst = smem + OFF_RING + (q & (RING - 1)) * WPHASE_BYTES + wave * 2048;
+        char* dst = smem + OFF_RING + (q & (RING - 1)) * WPHASE_BYTES + wave * (NWD * 1024);
         const uint32_t so = (uint32_t)(w_soff + h * WROW);
-        dma16(w_srd, w_voff[0], so, dst, lane);
-        dma16(w_srd, w_voff[1], so, dst + 1024, lane);
+#pragma unroll
+        for (int j = 0; j < NWD; ++j) dma16(w_srd, w_voff[j], so, dst + j * 1024, lane);
     };
     auto w_advance = [&]() {                               // past the end the cursor stays (harmless re-load)
         if (--w_left > 0) {
@@ -298,8 +312,8 @@ void conv_pipe_kernel(const ConvParams a, const int n_ct, const int tiles_per_xc
             return;
         }
         const char* wb = smem + OFF_RING + (q & (RING - 1)) * WPHASE_BYTES + (aoff ^ ((kg & 1) << 5));
-        fa[0] = *reinterpret_cast<const Frag*>(wb);
-        fa[1] = *reinterpret_cast<const Frag*>(wb + 32 * WROW);
+#pragma unroll
+        for (int mi = 0; mi < WM; ++mi) fa[mi] = *reinterpret_cast<const Frag*>(wb + mi * 32 * WROW);
 #pragma unroll
         for (int ni = 0; ni < WN; ++ni) fb[ni] = *reinterpret_cast<const Frag*>(smem + (pbase[ni] ^ (kg << 5)));
     };
@@ -319,133 +333,246 @@ void conv_pipe_kernel(const ConvParams a, const int n_ct, const int tiles_per_xc
             for (int ni = 0; ni < WN; ++ni) Mma<T>::run(fa[mi], fb[ni], acc[mi][ni]);
     };
 
-    // ---- prologue: first patch, first step's weights --------------------------------------------------
     int r = 0, ch = 0, nch_r = chunks_of(0), ci = 0;
     Chunk cur = get_chunk(0, 0);
-    w_issue(0, 0); w_issue(1, 1); w_advance();
-    patch_issue(cur, 0);
-    vm_wait<0>();
-    if (cur.gn) patch_commit(cur, 0);
-    raw_barrier();
-    const int grp = (ABL & 2) ? 0 : wave >> 2;        // (ABL & 2: profiling variant without the stagger)
-    if (grp == 1) raw_barrier();
-    stamp(2);
     Frag fa0[WM], fb0[WN], fa1[WM], fb1[WN];
+    if constexpr (NWAVES == 8) {
+        // ---- prologue: first patch, first step's weights --------------------------------------------------
+        w_issue(0, 0); w_issue(1, 1); w_advance();
+        patch_issue(cur, 0);
+        vm_wait<0>();
+        if (cur.gn) patch_commit(cur, 0);
+        raw_barrier();
+        const int grp = (ABL & 2) ? 0 : wave >> 2;        // (ABL & 2: profiling variant without the stagger)
+        if (grp == 1) raw_barrier();
+        stamp(2);
 
-    // ---- main loop: one iteration = one tap-step = phases P (half 0) and P+1 (half 1) ------------------
-    int P = 0, tp = 0, step = 0, steps_left = pin(total_steps);
-    bool has_nc, commit_pending = false, issued_prev = false;
-    Chunk nxt = cur;
-    {
-        int nr = r, nc = ch + 1;
-        if (nc == nch_r) { nc = 0; ++nr; }
-        has_nc = nr < nruns;
-        nxt = get_chunk(has_nc ? nr : r, has_nc ? nc : ch);
-    }
-    int ntaps = pin(cur.ntaps), par = 0;
-    int tapoff = ntaps == 9 ? 0 : PW + 1, tapdx = 0;          // LDS pixel offset of the current tap, its column
-    set_tap(0, tapoff);
-    // Interleave hint for an MFMA interval: the fragment reads first, then one MFMA : a few VALU / SALU of the
-    // bookkeeping placed in the same region (it rides in the MFMA issue gaps instead of lengthening a staging interval).
-    auto interleave = [&]() {
-#if defined(__HIP_DEVICE_COMPILE__)
-        __builtin_amdgcn_sched_group_barrier(0x100, 6, 0);        // 6 DS reads
-#pragma unroll
-        for (int i = 0; i < 16; ++i) {
-            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);    // 1 MFMA
-            __builtin_amdgcn_sched_group_barrier(0x002, 3, 0);    // <= 3 VALU
-            __builtin_amdgcn_sched_group_barrier(0x004, 2, 0);    // <= 2 SALU
-        }
-#endif
-    };
-    while (true) {
-        // ================= phase P (half 0) =================
-        stamp(4 + 16 * step);
-        w_issue(P + 2, 0);
-        read_frags(fa0, fb0, P, 0);
-        stamp(6 + 16 * step);
-        if (issued_prev) vm_wait<2 + NP>(); else vm_wait<2>();
-        raw_barrier();
-        stamp(8 + 16 * step);
-        __builtin_amdgcn_sched_barrier(0);
-        if (!(ABL & 1)) prio(1);
-        read_frags(fa1, fb1, P, 1);
-        mma(fa0, fb0);
-        mma(fa1, fb1);
-        if (!(ABL & 4)) interleave();
-        __builtin_amdgcn_sched_barrier(0);
-        if (!(ABL & 1)) prio(0);
-        stamp(10 + 16 * step);
-        raw_barrier();
-        stamp(11 + 16 * step);
-        // ================= phase P+1 (half 1) =================
-        if (commit_pending && tp == 1) {                        // 9-tap chunk: the patch was issued two phases ago
-            if (nxt.gn) { vm_wait<2>(); patch_commit(nxt, par ^ 1); }
-            commit_pending = false;
-        }
-        w_issue(P + 3, 1);
-        // The other patch buffer was read until the lagging group's C(P0 - 1), which shares its interval with the
-        // leading group's S(P0): the DMA into it starts in the chunk's SECOND phase.
-        const bool issue_now = tp == 0 && has_nc;
-        if (issue_now) { patch_issue(nxt, par ^ 1); commit_pending = ntaps != 1; }
-        read_frags(fa0, fb0, P + 1, 2);
-        stamp(12 + 16 * step);
-        if (issue_now && ntaps == 1) {                          // two-phase chunk: the next phase already reads the patch
-            vm_wait<0>();
-            if (nxt.gn) patch_commit(nxt, par ^ 1);
-        } else if (issue_now) vm_wait<2 + NP>(); else vm_wait<2>();
-        issued_prev = issue_now;
-        raw_barrier();
-        stamp(13 + 16 * step);
-        __builtin_amdgcn_sched_barrier(0);
-        if (!(ABL & 1)) prio(1);
-        read_frags(fa1, fb1, P + 1, 3);
-        // Bookkeeping for the next step rides in this MFMA interval, branch-free so that it stays in the MFMAs'
-        // basic block (common case: next tap of the same chunk / same run); chunk and run changes are fixed
-        // up after the interval's barrier.
-        const int adv = --w_left > 0 ? 1 : 0;                   // weight cursor: past the end it stays (harmless re-load)
-        const int wtn = w_tp + adv;
-        const bool w_slow = wtn >= w_ntaps;
-        w_soff += (adv && !w_slow) ? w_tapbytes : 0;
-        w_tp = w_slow ? w_tp : wtn;
-        P += 2; ++step;
-        const bool last = --steps_left == 0;
-        const int tpn = tp + 1;
-        const bool wrap = tpn == ntaps;
-        tp = wrap ? 0 : tpn;
-        const bool row_end = tapdx == 2;                        // 3x3 taps in raster order: offset dy * PW + dx
-        tapoff = ntaps == 9 ? (wrap ? 0 : tapoff + (row_end ? PW - 2 : 1)) : PW + 1;
-        tapdx = (row_end || wrap) ? 0 : tapdx + 1;
-        set_tap(par, tapoff);                                   // (re-done below when the chunk changes)
-        mma(fa0, fb0);
-        mma(fa1, fb1);
-        if (!(ABL & 4)) interleave();
-        __builtin_amdgcn_sched_barrier(0);
-        if (!(ABL & 1)) prio(0);
-        stamp(14 + 16 * step - 16);
-        raw_barrier();
-        stamp(15 + 16 * step - 16);
-        if (last) break;
-        if (w_slow) {                                           // next chunk of the run, or the next run
-            w_tp = 0; ++w_ch;
-            if (w_ch < w_nch) w_soff = w_ch * (2 * WROW);
-            else { ++w_r; w_enter_run(w_r); }
-        }
-        if (wrap) {
+        // ---- main loop: one iteration = one tap-step = phases P (half 0) and P+1 (half 1) ------------------
+        int P = 0, tp = 0, step = 0, steps_left = pin(total_steps);
+        bool has_nc, commit_pending = false, issued_prev = false;
+        Chunk nxt = cur;
+        {
             int nr = r, nc = ch + 1;
-            if (nc == nch_r) { nc = 0; ++nr; }
-            if (nr != r) nch_r = chunks_of(nr);
-            cur = nxt; r = nr; ch = nc; ++ci;
-            nr = r; nc = ch + 1;
             if (nc == nch_r) { nc = 0; ++nr; }
             has_nc = nr < nruns;
             nxt = get_chunk(has_nc ? nr : r, has_nc ? nc : ch);
-            ntaps = pin(cur.ntaps); par = ci & 1;
-            tapoff = ntaps == 9 ? 0 : PW + 1; tapdx = 0;
-            set_tap(par, tapoff);
+        }
+        int ntaps = pin(cur.ntaps), par = 0;
+        int tapoff = ntaps == 9 ? 0 : PW + 1, tapdx = 0;          // LDS pixel offset of the current tap, its column
+        set_tap(0, tapoff);
+        // Interleave hint for an MFMA interval: the fragment reads first, then one MFMA : a few VALU / SALU of the
+        // bookkeeping placed in the same region (it rides in the MFMA issue gaps instead of lengthening a staging interval).
+        auto interleave = [&]() {
+    #if defined(__HIP_DEVICE_COMPILE__)
+            __builtin_amdgcn_sched_group_barrier(0x100, 6, 0);        // 6 DS reads
+    #pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);    // 1 MFMA
+                __builtin_amdgcn_sched_group_barrier(0x002, 3, 0);    // <= 3 VALU
+                __builtin_amdgcn_sched_group_barrier(0x004, 2, 0);    // <= 2 SALU
+            }
+    #endif
+        };
+        while (true) {
+            // ================= phase P (half 0) =================
+            stamp(4 + 16 * step);
+            w_issue(P + 2, 0);
+            read_frags(fa0, fb0, P, 0);
+            stamp(6 + 16 * step);
+            if (issued_prev) vm_wait<2 + NP>(); else vm_wait<2>();
+            raw_barrier();
+            stamp(8 + 16 * step);
+            __builtin_amdgcn_sched_barrier(0);
+            if (!(ABL & 1)) prio(1);
+            read_frags(fa1, fb1, P, 1);
+            mma(fa0, fb0);
+            mma(fa1, fb1);
+            if (!(ABL & 4)) interleave();
+            __builtin_amdgcn_sched_barrier(0);
+            if (!(ABL & 1)) prio(0);
+            stamp(10 + 16 * step);
+            raw_barrier();
+            stamp(11 + 16 * step);
+            // ================= phase P+1 (half 1) =================
+            if (commit_pending && tp == 1) {                        // 9-tap chunk: the patch was issued two phases ago
+                if (nxt.gn) { vm_wait<2>(); patch_commit(nxt, par ^ 1); }
+                commit_pending = false;
+            }
+            w_issue(P + 3, 1);
+            // The other patch buffer was read until the lagging group's C(P0 - 1), which shares its interval with the
+            // leading group's S(P0): the DMA into it starts in the chunk's SECOND phase.
+            const bool issue_now = tp == 0 && has_nc;
+            if (issue_now) { patch_issue(nxt, par ^ 1); commit_pending = ntaps != 1; }
+            read_frags(fa0, fb0, P + 1, 2);
+            stamp(12 + 16 * step);
+            if (issue_now && ntaps == 1) {                          // two-phase chunk: the next phase already reads the patch
+                vm_wait<0>();
+                if (nxt.gn) patch_commit(nxt, par ^ 1);
+            } else if (issue_now) vm_wait<2 + NP>(); else vm_wait<2>();
+            issued_prev = issue_now;
+            raw_barrier();
+            stamp(13 + 16 * step);
+            __builtin_amdgcn_sched_barrier(0);
+            if (!(ABL & 1)) prio(1);
+            read_frags(fa1, fb1, P + 1, 3);
+            // Bookkeeping for the next step rides in this MFMA interval, branch-free so that it stays in the MFMAs'
+            // basic block (common case: next tap of the same chunk / same run); chunk and run changes are fixed
+            // up after the interval's barrier.
+            const int adv = --w_left > 0 ? 1 : 0;                   // weight cursor: past the end it stays (harmless re-load)
+            const int wtn = w_tp + adv;
+            const bool w_slow = wtn >= w_ntaps;
+            w_soff += (adv && !w_slow) ? w_tapbytes : 0;
+            w_tp = w_slow ? w_tp : wtn;
+            P += 2; ++step;
+            const bool last = --steps_left == 0;
+            const int tpn = tp + 1;
+            const bool wrap = tpn == ntaps;
+            tp = wrap ? 0 : tpn;
+            const bool row_end = tapdx == 2;                        // 3x3 taps in raster order: offset dy * PW + dx
+            tapoff = ntaps == 9 ? (wrap ? 0 : tapoff + (row_end ? PW - 2 : 1)) : PW + 1;
+            tapdx = (row_end || wrap) ? 0 : tapdx + 1;
+            set_tap(par, tapoff);                                   // (re-done below when the chunk changes)
+            mma(fa0, fb0);
+            mma(fa1, fb1);
+            if (!(ABL & 4)) interleave();
+            __builtin_amdgcn_sched_barrier(0);
+            if (!(ABL & 1)) prio(0);
+            stamp(14 + 16 * step - 16);
+            raw_barrier();
+            stamp(15 + 16 * step - 16);
+            if (last) break;
+            if (w_slow) {                                           // next chunk of the run, or the next run
+                w_tp = 0; ++w_ch;
+                if (w_ch < w_nch) w_soff = w_ch * (2 * WROW);
+                else { ++w_r; w_enter_run(w_r); }
+            }
+            if (wrap) {
+                int nr = r, nc = ch + 1;
+                if (nc == nch_r) { nc = 0; ++nr; }
+                if (nr != r) nch_r = chunks_of(nr);
+                cur = nxt; r = nr; ch = nc; ++ci;
+                nr = r; nc = ch + 1;
+                if (nc == nch_r) { nc = 0; ++nr; }
+                has_nc = nr < nruns;
+                nxt = get_chunk(has_nc ? nr : r, has_nc ? nc : ch);
+                ntaps = pin(cur.ntaps); par = ci & 1;
+                tapoff = ntaps == 9 ? 0 : PW + 1; tapdx = 0;
+                set_tap(par, tapoff);
+            }
+        }
+        if (grp == 0) raw_barrier();                        // balance the stagger: every wave has executed the same barriers
+
+    } else {
+        // =========================== one wave per SIMD (4 waves, 128 x 128 each) ===========================
+        // No partner wave: every phase is ONE straight-line block in which the staging instructions ride in the
+        // MFMA issue gaps (sched_group_barrier), one barrier per phase, fragments read one k-group ahead.
+        //   phase P:  vmcnt: own share of phase P+1's weights landed | barrier (reads of P-1 retired everywhere)
+        //             DMA weights of phase P+3 -> slot (P+3)&3   [first phase of a chunk: DMA the next chunk's patch]
+        //             read k-group 1 | 16 MFMA (k-group 0) | read k-group 0 of phase P+1 | 16 MFMA (k-group 1)
+        w_issue(0, 0); w_issue(1, 1); w_advance(); w_issue(2, 0);
+        patch_issue(cur, 0);
+        vm_wait<0>();
+        if (cur.gn) patch_commit(cur, 0);
+        raw_barrier();
+        stamp(2);
+        int P = 0, tp = 0, step = 0, steps_left = pin(total_steps);
+        bool has_nc, issued_prev = false;
+        Chunk nxt = cur;
+        {
+            int nr = r, nc = ch + 1;
+            if (nc == nch_r) { nc = 0; ++nr; }
+            has_nc = nr < nruns;
+            nxt = get_chunk(has_nc ? nr : r, has_nc ? nc : ch);
+        }
+        int ntaps = pin(cur.ntaps), par = 0;
+        int tapoff = ntaps == 9 ? 0 : PW + 1, tapdx = 0;
+        set_tap(0, tapoff);
+        read_frags(fa0, fb0, 0, 0);
+        auto interleave1 = [&]() {                              // scheduling hint for one k-group region
+#if defined(__HIP_DEVICE_COMPILE__)
+            __builtin_amdgcn_sched_group_barrier(0x100, WM + WN, 0);      // the fragment reads first
+#pragma unroll
+            for (int i = 0; i < WM * WN; ++i) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);        // 1 MFMA
+                __builtin_amdgcn_sched_group_barrier(0x002, 2, 0);        // <= 2 VALU
+                __builtin_amdgcn_sched_group_barrier(0x004, 2, 0);        // <= 2 SALU
+            }
+#endif
+        };
+        while (true) {
+            // ================= phase P (half 0) =================
+            const bool issue_now = tp == 0 && has_nc;           // P is the chunk's first phase
+            if (issued_prev) vm_wait<NWD + NP>(); else vm_wait<NWD>();
+            raw_barrier();
+            __builtin_amdgcn_sched_barrier(0);
+            w_issue(P + 3, 1);
+            const int adv = --w_left > 0 ? 1 : 0;               // weight cursor -> next tap-step (branch-free common case)
+            const int wtn = w_tp + adv;
+            const bool w_slow = wtn >= w_ntaps;
+            w_soff += (adv && !w_slow) ? w_tapbytes : 0;
+            w_tp = w_slow ? w_tp : wtn;
+            if (issue_now) patch_issue(nxt, par ^ 1);
+            if (tp == 1 && ntaps != 1 && nxt.gn && has_nc) {    // long chunk: patch issued two phases ago
+                vm_wait<2 * NWD>();
+                patch_commit(nxt, par ^ 1);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            read_frags(fa1, fb1, P, 1);
+            mma(fa0, fb0);
+            if (!(ABL & 4)) interleave1();
+            __builtin_amdgcn_sched_barrier(0);
+            read_frags(fa0, fb0, P + 1, 2);
+            mma(fa1, fb1);
+            if (!(ABL & 4)) interleave1();
+            __builtin_amdgcn_sched_barrier(0);
+            if (w_slow) {                                       // next chunk of the run, or the next run
+                w_tp = 0; ++w_ch;
+                if (w_ch < w_nch) w_soff = w_ch * (2 * WROW);
+                else { ++w_r; w_enter_run(w_r); }
+            }
+            // ================= phase P+1 (half 1) =================
+            if (issue_now && ntaps == 1) {                      // two-phase chunk: this phase already reads the new patch
+                vm_wait<0>();
+                if (nxt.gn) patch_commit(nxt, par ^ 1);
+            } else if (issue_now) vm_wait<NWD + NP>(); else vm_wait<NWD>();
+            issued_prev = issue_now;
+            raw_barrier();
+            __builtin_amdgcn_sched_barrier(0);
+            w_issue(P + 4, 0);
+            read_frags(fa1, fb1, P + 1, 3);
+            // next tap (branch-free; a chunk change is completed after the MFMAs)
+            P += 2; ++step;
+            const bool last = --steps_left == 0;
+            const int tpn = tp + 1;
+            const bool wrap = tpn == ntaps;
+            tp = wrap ? 0 : tpn;
+            const bool row_end = tapdx == 2;
+            const int nxt_first = nxt.ntaps == 9 ? 0 : PW + 1;
+            tapoff = wrap ? nxt_first : (ntaps == 9 ? tapoff + (row_end ? PW - 2 : 1) : PW + 1);
+            tapdx = (row_end || wrap) ? 0 : tapdx + 1;
+            const int par_n = wrap ? par ^ 1 : par;
+            set_tap(par_n, tapoff);
+            mma(fa0, fb0);
+            if (!(ABL & 4)) interleave1();
+            __builtin_amdgcn_sched_barrier(0);
+            read_frags(fa0, fb0, P, 0);
+            mma(fa1, fb1);
+            if (!(ABL & 4)) interleave1();
+            __builtin_amdgcn_sched_barrier(0);
+            if (last) break;
+            if (wrap) {
+                int nr = r, nc = ch + 1;
+                if (nc == nch_r) { nc = 0; ++nr; }
+                if (nr != r) nch_r = chunks_of(nr);
+                cur = nxt; r = nr; ch = nc; ++ci;
+                nr = r; nc = ch + 1;
+                if (nc == nch_r) { nc = 0; ++nr; }
+                has_nc = nr < nruns;
+                nxt = get_chunk(has_nc ? nr : r, has_nc ? nc : ch);
+                ntaps = pin(cur.ntaps); par = ci & 1;
+            }
         }
     }
-    if (grp == 0) raw_barrier();                        // balance the stagger: every wave has executed the same barriers
 
     // ---- epilogue: LDS transpose -> (bias, temb bias, skip, scale) -> wide stores (as conv_igemm.hip) ------
     stamp_tail(500);
@@ -559,32 +686,15 @@ bool conv_pipe_supports(const storm_conv_args& a) {
     return true;
 }
 
-int launch_conv_pipe(const storm_conv_args& a, hipStream_t st) {
+template <int WAVES_M, int WAVES_N, int ABL>
+static int launch_pipe(const storm_conv_args& a, hipStream_t st) {
     using namespace pipe;
-    const char* abl_env = getenv("STORM_CONV_ABLATE");
-    const int abl = abl_env ? atoi(abl_env) : 0;                 // profiling instantiations (tools/conv_trace.py, A/B probes)
-    const bool traced = (abl & 64) != 0;
-    auto kern = conv_pipe_kernel<0>;
-    int ki = 0;
-    switch (abl) {
-        case 1: kern = conv_pipe_kernel<1>; ki = 1; break;       // no s_setprio
-        case 2: kern = conv_pipe_kernel<2>; ki = 2; break;       // no stagger
-        case 4: kern = conv_pipe_kernel<4>; ki = 6; break;       // no sched_group_barrier interleave hint
-        case 8: kern = conv_pipe_kernel<8>; ki = 7; break;       // no weight DMA
-        case 16: kern = conv_pipe_kernel<16>; ki = 8; break;     // no fragment reads
-        case 32: kern = conv_pipe_kernel<32>; ki = 9; break;     // no MFMA
-        case 24: kern = conv_pipe_kernel<24>; ki = 10; break;    // no DMA, no fragment reads
-        case 48: kern = conv_pipe_kernel<48>; ki = 11; break;    // no fragment reads, no MFMA
-        case 56: kern = conv_pipe_kernel<56>; ki = 12; break;    // barriers + bookkeeping only
-        case 64: kern = conv_pipe_kernel<64>; ki = 3; break;     // wave timeline stamps
-        case 65: kern = conv_pipe_kernel<65>; ki = 4; break;
-        case 66: kern = conv_pipe_kernel<66>; ki = 5; break;
-        default: break;
-    }
-    static bool attr_set[13] = {};
-    if (!attr_set[ki]) {
-        STORM_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES));
-        attr_set[ki] = true;
+    typedef PCfg<WAVES_M, WAVES_N> Cfg;
+    auto kern = conv_pipe_kernel<WAVES_M, WAVES_N, ABL>;
+    static bool attr_set = false;                       // per instantiation; benign race (idempotent)
+    if (!attr_set) {
+        STORM_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, Cfg::LDS_BYTES));
+        attr_set = true;
     }
     const int tiles_x = cdiv(a.W, TILE_W);
     const int tiles_per_img = tiles_x * cdiv(a.H, TILE_H);
@@ -594,14 +704,43 @@ int launch_conv_pipe(const storm_conv_args& a, hipStream_t st) {
     const long long grid = 8LL * tiles_per_xcd * n_ct;
     STORM_CHECK(grid > 0 && grid < (1LL << 31), "storm_conv: grid %lld out of range", grid);
     ConvParams prm = make_params(a);
-    if (traced) {
+    if (ABL & 64) {                                     // profiling: device buffer address handed over by tools/conv_trace.py
         const char* tp = getenv("STORM_CONV_TRACE_PTR");
         prm.trace = tp ? reinterpret_cast<unsigned long long*>(strtoull(tp, nullptr, 0)) : nullptr;
     }
-    hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(THREADS), LDS_BYTES, st, prm, n_ct, tiles_per_xcd, (int)ntiles,
+    hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(Cfg::THREADS), Cfg::LDS_BYTES, st, prm, n_ct, tiles_per_xcd, (int)ntiles,
                        tiles_x, tiles_per_img);
     STORM_LAUNCH_CHECK();
     return STORM_OK;
+}
+
+// layout 1: one wave per SIMD (4 x 128x128); layout 2: ping-pong pairs (8 x 64x128).  STORM_CONV_ABLATE selects
+// profiling instantiations (tools/conv_trace.py, A/B probes); never set in production.
+int launch_conv_pipe(const storm_conv_args& a, hipStream_t st, int layout) {
+    const char* abl_env = getenv("STORM_CONV_ABLATE");
+    const int abl = abl_env ? atoi(abl_env) : 0;
+    if (layout == 2) {
+        switch (abl) {
+            case 1: return launch_pipe<4, 2, 1>(a, st);         // no s_setprio
+            case 2: return launch_pipe<4, 2, 2>(a, st);         // no stagger
+            case 4: return launch_pipe<4, 2, 4>(a, st);         // no sched_group_barrier interleave hint
+            case 8: return launch_pipe<4, 2, 8>(a, st);         // no weight DMA
+            case 16: return launch_pipe<4, 2, 16>(a, st);       // no fragment reads
+            case 32: return launch_pipe<4, 2, 32>(a, st);       // no MFMA
+            case 56: return launch_pipe<4, 2, 56>(a, st);       // barriers + bookkeeping only
+            case 64: return launch_pipe<4, 2, 64>(a, st);       // wave timeline stamps
+            default: return launch_pipe<4, 2, 0>(a, st);
+        }
+    }
+    switch (abl) {
+        case 4: return launch_pipe<2, 2, 4>(a, st);
+        case 8: return launch_pipe<2, 2, 8>(a, st);
+        case 16: return launch_pipe<2, 2, 16>(a, st);
+        case 32: return launch_pipe<2, 2, 32>(a, st);
+        case 24: return launch_pipe<2, 2, 24>(a, st);
+        case 56: return launch_pipe<2, 2, 56>(a, st);
+        default: return launch_pipe<2, 2, 0>(a, st);
+    }
 }
 
 }  // namespace storm

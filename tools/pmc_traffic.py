@@ -22,8 +22,8 @@ def main(fetch_csv, write_csv, out_json):
     f, w = per_kernel(fetch_csv, "FETCH_SIZE"), per_kernel(write_csv, "WRITE_SIZE")
     out = {}
     for name in f:
-        m = re.search(r"conv_igemm_kernel<(.*?)>\(", name)
-        key = m.group(1).replace(" ", "") if m else name.split("(")[0]
+        m = re.search(r"(conv_\w+_kernel<.*?>)\(", name)
+        key = m.group(1).replace(" ", "").replace("storm::", "") if m else name.split("(")[0]
         fetch_kib, n = f[name]
         write_kib = w.get(name, (0.0, 0))[0]
         out[key] = {"launches": n, "fetch_kib_raw": fetch_kib, "write_kib_raw": write_kib,
