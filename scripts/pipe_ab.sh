@@ -1,4 +1,5 @@
 #!/bin/bash
-for abl in 0 4 8 16 32 24 48 56; do
-  echo "pipe ablate $abl: $(STORM_CONV_VARIANT=3 STORM_CONV_ABLATE=$abl python tools/conv_probe.py --reps 5 2>&1 | grep -E '^c' | tr '\n' ' ')"
-done
+for i in 1 2; do for v in 0 3; do
+  echo "variant $v: $(STORM_CONV_VARIANT=$v python tools/conv_probe.py --reps 5 2>&1 | grep -E '^c' | tr '\n' ' ')"
+done; done
+timeout 600 python tools/conv_check.py 2>&1 | grep -v "^ok" | tail -3

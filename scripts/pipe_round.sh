@@ -5,6 +5,6 @@ timeout 600 python tools/conv_check.py 2>&1 | grep -v "^ok" | tail -8
 for v in 0 3 4; do
   echo "variant $v: $(STORM_CONV_VARIANT=$v python tools/conv_probe.py --reps 5 2>&1 | grep -E '^c' | tr '\n' ' ')"
 done
-for abl in 4 8 16 32 24 56; do
-  echo "variant 4 ablate $abl: $(STORM_CONV_VARIANT=4 STORM_CONV_ABLATE=$abl python tools/conv_probe.py --reps 5 2>&1 | grep -E '^c' | tr '\n' ' ')"
+for abl in 1 8 16 32 56; do
+  echo "variant 3 ablate $abl: $(STORM_CONV_VARIANT=3 STORM_CONV_ABLATE=$abl python tools/conv_probe.py --reps 5 2>&1 | grep -E '^c' | tr '\n' ' ')"
 done

@@ -75,6 +75,11 @@ template <int WAVES_M_, int WAVES_N_> struct PCfg {
 // LDS byte offset of 16-B slot s (0..3) of row `row` of a weight phase tile: the 16 lanes of a ds_read_b128
 // group hit 16 distinct 16-B bank groups.
 STORM_HD int w_off(int row, int s) { return row * WROW + ((s ^ ((row >> 2) & 3)) << 4); }
+// Patch image: pixel (py, px) of the haloed 10 x 34 patch is row py * PW + px, 128 B; its eight 16-B slots are
+// XOR-swizzled by the COLUMN ((px >> 1) & 7).  16 lanes of a fragment read are 16 consecutive px -> 16 distinct
+// bank groups; and because the swizzle does not depend on py, a tap's row offset, the wave's pixel rows and the
+// patch buffer are plain additions (scalar / instruction-immediate), so a k-group's four reads share one VGPR.
+STORM_HD int p_swz(int px, int slot) { return (slot ^ ((px >> 1) & 7)) << 4; }
 
 // Raw buffer resource (stride 0): reads past num_records return zeros (and write zeros to LDS).
 __device__ __forceinline__ u32x4 make_srd(const void* base, uint32_t bytes) {
@@ -96,9 +101,9 @@ __device__ __forceinline__ void dma16(u32x4 srd, uint32_t voff, uint32_t soff, c
 #if defined(__HIP_DEVICE_COMPILE__)
     (void)lane;
     const uint32_t la = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)lds_wave);
-    uint32_t keep;
-    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %4\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds\n\ts_mov_b32 m0, %0"
-                 : "=&s"(keep) : "v"(voff), "s"(srd), "s"(soff), "s"(la) : "memory");
+    // M0 is written and consumed inside this one statement (the compiler keeps nothing live in M0 in this kernel)
+    asm volatile("s_mov_b32 m0, %3\n\ts_nop 0\n\tbuffer_load_dwordx4 %0, %1, %2 offen lds"
+                 :: "v"(voff), "s"(srd), "s"(soff), "s"(la) : "memory");
 #else
     const uint64_t off = (uint64_t)voff + soff;
     const char* base = reinterpret_cast<const char*>(((uint64_t)srd[1] << 32) | srd[0]);
@@ -261,8 +266,8 @@ void conv_pipe_kernel(const ConvParams a, const int n_ct, const int tiles_per_xc
             int k = wave + i * NWAVES;                           // piece: patch rows 8k .. 8k+7
             if (k >= PPIECES) k -= NWAVES;                       // surplus slot: same piece again (keeps the VMEM count uniform)
             const int row = k * 8 + (lane >> 3);
-            const int slot = (lane & 7) ^ ((row >> 1) & 7);      // logical 16-B slot that lands in physical slot lane & 7
             const int py = row / PW, px = row - py * PW;
+            const int slot = (lane & 7) ^ ((px >> 1) & 7);       // logical 16-B slot that lands in physical slot lane & 7
             const int gy = ty0 + py - 1, gx = tx0 + px - 1;
             const bool ok = row < NPIX && slot * 8 < c.cvalid && gy >= 0 && gy < a.H && gx >= 0 && gx < a.W;
             dma16(c.srd, ok ? (uint32_t)((gy * a.W + gx) * c.C + slot * 8) * 2u : OOB, so, dst + k * 1024, lane);
@@ -277,7 +282,7 @@ void conv_pipe_kernel(const ConvParams a, const int n_ct, const int tiles_per_xc
             const int k = wave + i * NWAVES;
             if (k < PPIECES && ((pmask >> i) & 1u)) {
                 const int row = k * 8 + (lane >> 3);
-                const int slot = (lane & 7) ^ ((row >> 1) & 7);
+                const int slot = (lane & 7) ^ (((row % PW) >> 1) & 7);
                 uint4* const q = reinterpret_cast<uint4*>(dst + k * 1024 + lane * 16);
                 float ss[16];
                 const float* t = reinterpret_cast<const float*>(smem + OFF_SS + parity * SS_BYTES) + 16 * slot;
@@ -292,15 +297,18 @@ void conv_pipe_kernel(const ConvParams a, const int n_ct, const int tiles_per_xc
     };
 
     // ---- fragment reads ----------------------------------------------------------------------------------
-    const int aoff = w_off(wm * WM * 32 + (lane & 31), lane >> 5);   // row of mi = 1 is +32 rows = +2048 B, same swizzle
-    const int prow0 = (wn * WN) * PW + (lane & 31);                 // patch pixel of ni = 0 under tap (0, 0)
-    int pbase[WN];                             // patch offsets of the tap being read, k-group 0 of the chunk
-    auto set_tap = [&](int parity, int tapoff) {   // tapoff = dy * PW + dx
+    const int aoff = w_off(wm * WM * 32 + (lane & 31), lane >> 5);   // row of mi is +32 mi rows = +2048 mi B, same swizzle
+    const int aoff1 = aoff ^ 32;                                   // second k-group of a phase
+    const int pv0 = ((wn * WN) * PW + (lane & 31)) * PIX_BYTES;    // this lane's pixel of ni = 0 under tap (0, 0)
+    int psw[3];                                                    // swizzle term of k-group 0 for tap column dx
 #pragma unroll
-        for (int ni = 0; ni < WN; ++ni)
-            pbase[ni] = parity * PATCH_BYTES + lds_off(prow0 + ni * PW + tapoff, lane >> 5);
+    for (int d = 0; d < 3; ++d) psw[d] = p_swz((lane & 31) + d, lane >> 5);
+    // byte offset (k-group 0, ni = 0) of the tap at pixel offset tapoff = dy * PW + dx in patch buffer `parity`
+    auto tap_base = [&](int parity, int tapoff, int dx) {
+        return pv0 + parity * PATCH_BYTES + tapoff * PIX_BYTES + (dx == 0 ? psw[0] : dx == 1 ? psw[1] : psw[2]);
     };
-    // k-group kg (0..3) of the chunk = k-group (kg & 1) of ring phase q
+    int pcur = 0;                              // tap_base of the tap being read
+    // k-group kg (0..3) of the chunk = k-group (kg & 1) of ring phase q; pixel rows are immediate offsets
     auto read_frags = [&](Frag (&fa)[WM], Frag (&fb)[WN], int q, int kg) {
         if ((ABL & 16) && q > 0) {                          // (profiling: no fragment reads after the first phase)
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -311,11 +319,12 @@ void conv_pipe_kernel(const ConvParams a, const int n_ct, const int tiles_per_xc
 #endif
             return;
         }
-        const char* wb = smem + OFF_RING + (q & (RING - 1)) * WPHASE_BYTES + (aoff ^ ((kg & 1) << 5));
+        const char* wb = smem + OFF_RING + (q & (RING - 1)) * WPHASE_BYTES + ((kg & 1) ? aoff1 : aoff);
 #pragma unroll
         for (int mi = 0; mi < WM; ++mi) fa[mi] = *reinterpret_cast<const Frag*>(wb + mi * 32 * WROW);
+        const char* pp = smem + (pcur ^ (kg << 5));
 #pragma unroll
-        for (int ni = 0; ni < WN; ++ni) fb[ni] = *reinterpret_cast<const Frag*>(smem + (pbase[ni] ^ (kg << 5)));
+        for (int ni = 0; ni < WN; ++ni) fb[ni] = *reinterpret_cast<const Frag*>(pp + ni * PW * PIX_BYTES);
     };
     auto mma = [&](const Frag (&fa)[WM], const Frag (&fb)[WN]) {
         if (ABL & 32) {                                     // (profiling: no MFMAs; operands stay live)
@@ -349,7 +358,7 @@ void conv_pipe_kernel(const ConvParams a, const int n_ct, const int tiles_per_xc
 
         // ---- main loop: one iteration = one tap-step = phases P (half 0) and P+1 (half 1) ------------------
         int P = 0, tp = 0, step = 0, steps_left = pin(total_steps);
-        bool has_nc, commit_pending = false, issued_prev = false;
+        bool has_nc, commit_pending = false;
         Chunk nxt = cur;
         {
             int nr = r, nc = ch + 1;
@@ -359,42 +368,43 @@ void conv_pipe_kernel(const ConvParams a, const int n_ct, const int tiles_per_xc
         }
         int ntaps = pin(cur.ntaps), par = 0;
         int tapoff = ntaps == 9 ? 0 : PW + 1, tapdx = 0;          // LDS pixel offset of the current tap, its column
-        set_tap(0, tapoff);
-        // Interleave hint for an MFMA interval: the fragment reads first, then one MFMA : a few VALU / SALU of the
-        // bookkeeping placed in the same region (it rides in the MFMA issue gaps instead of lengthening a staging interval).
-        auto interleave = [&]() {
-    #if defined(__HIP_DEVICE_COMPILE__)
-            __builtin_amdgcn_sched_group_barrier(0x100, 6, 0);        // 6 DS reads
-    #pragma unroll
-            for (int i = 0; i < 16; ++i) {
-                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);    // 1 MFMA
-                __builtin_amdgcn_sched_group_barrier(0x002, 3, 0);    // <= 3 VALU
-                __builtin_amdgcn_sched_group_barrier(0x004, 2, 0);    // <= 2 SALU
-            }
-    #endif
-        };
+        pcur = tap_base(0, tapoff, ntaps == 9 ? 0 : 1);
+        // Staging intervals start with the fragment reads (their LDS latency then hides under the interval's own
+        // bookkeeping), MFMA intervals contain nothing but the second k-group's reads and the 16 MFMAs.
         while (true) {
-            // ================= phase P (half 0) =================
+            // ================= S(P), half 0 =================
             stamp(4 + 16 * step);
-            w_issue(P + 2, 0);
             read_frags(fa0, fb0, P, 0);
+            if (P > 0) {                                        // weight cursor -> the step whose halves are issued next
+                const int adv = --w_left > 0 ? 1 : 0;           // past the end it stays (harmless re-load)
+                const int wtn = w_tp + adv;
+                if (wtn < w_ntaps) { w_soff += adv ? w_tapbytes : 0; w_tp = wtn; }
+                else {                                          // next chunk of the run, or the next run
+                    w_tp = 0; ++w_ch;
+                    if (w_ch < w_nch) w_soff = w_ch * (2 * WROW);
+                    else { ++w_r; w_enter_run(w_r); }
+                }
+            }
+            w_issue(P + 2, 0);
             stamp(6 + 16 * step);
-            if (issued_prev) vm_wait<2 + NP>(); else vm_wait<2>();
+            vm_wait<2>();                                       // (also retires a patch issued last phase: once per chunk)
             raw_barrier();
+            // ================= C(P) =================
             stamp(8 + 16 * step);
             __builtin_amdgcn_sched_barrier(0);
             if (!(ABL & 1)) prio(1);
             read_frags(fa1, fb1, P, 1);
+            __builtin_amdgcn_sched_barrier(0);                  // all six reads in flight before the first MFMA
             mma(fa0, fb0);
             mma(fa1, fb1);
-            if (!(ABL & 4)) interleave();
             __builtin_amdgcn_sched_barrier(0);
             if (!(ABL & 1)) prio(0);
             stamp(10 + 16 * step);
             raw_barrier();
             stamp(11 + 16 * step);
-            // ================= phase P+1 (half 1) =================
-            if (commit_pending && tp == 1) {                        // 9-tap chunk: the patch was issued two phases ago
+            // ================= S(P+1), half 1 =================
+            read_frags(fa0, fb0, P + 1, 2);
+            if (commit_pending && tp == 1) {                    // 9-tap chunk: the patch was issued two phases ago
                 if (nxt.gn) { vm_wait<2>(); patch_commit(nxt, par ^ 1); }
                 commit_pending = false;
             }
@@ -403,49 +413,37 @@ void conv_pipe_kernel(const ConvParams a, const int n_ct, const int tiles_per_xc
             // leading group's S(P0): the DMA into it starts in the chunk's SECOND phase.
             const bool issue_now = tp == 0 && has_nc;
             if (issue_now) { patch_issue(nxt, par ^ 1); commit_pending = ntaps != 1; }
-            read_frags(fa0, fb0, P + 1, 2);
+            const bool last = --steps_left == 0;
+            const int tpn = tp + 1;
+            const bool wrap = tpn == ntaps;
+            const bool row_end = tapdx == 2;                    // 3x3 taps in raster order: offset dy * PW + dx
+            const int nxt_first = nxt.ntaps == 9 ? 0 : PW + 1;
+            tapoff = wrap ? nxt_first : (ntaps == 9 ? tapoff + (row_end ? PW - 2 : 1) : PW + 1);
+            tapdx = (row_end || wrap) ? 0 : tapdx + 1;
+            const int par_n = wrap ? par ^ 1 : par, dx_n = wrap ? (nxt.ntaps == 9 ? 0 : 1) : (ntaps == 9 ? tapdx : 1);
             stamp(12 + 16 * step);
-            if (issue_now && ntaps == 1) {                          // two-phase chunk: the next phase already reads the patch
+            if (issue_now && ntaps == 1) {                      // two-phase chunk: the next phase already reads the patch
                 vm_wait<0>();
                 if (nxt.gn) patch_commit(nxt, par ^ 1);
             } else if (issue_now) vm_wait<2 + NP>(); else vm_wait<2>();
-            issued_prev = issue_now;
             raw_barrier();
+            // ================= C(P+1) =================
             stamp(13 + 16 * step);
             __builtin_amdgcn_sched_barrier(0);
             if (!(ABL & 1)) prio(1);
             read_frags(fa1, fb1, P + 1, 3);
-            // Bookkeeping for the next step rides in this MFMA interval, branch-free so that it stays in the MFMAs'
-            // basic block (common case: next tap of the same chunk / same run); chunk and run changes are fixed
-            // up after the interval's barrier.
-            const int adv = --w_left > 0 ? 1 : 0;                   // weight cursor: past the end it stays (harmless re-load)
-            const int wtn = w_tp + adv;
-            const bool w_slow = wtn >= w_ntaps;
-            w_soff += (adv && !w_slow) ? w_tapbytes : 0;
-            w_tp = w_slow ? w_tp : wtn;
-            P += 2; ++step;
-            const bool last = --steps_left == 0;
-            const int tpn = tp + 1;
-            const bool wrap = tpn == ntaps;
-            tp = wrap ? 0 : tpn;
-            const bool row_end = tapdx == 2;                        // 3x3 taps in raster order: offset dy * PW + dx
-            tapoff = ntaps == 9 ? (wrap ? 0 : tapoff + (row_end ? PW - 2 : 1)) : PW + 1;
-            tapdx = (row_end || wrap) ? 0 : tapdx + 1;
-            set_tap(par, tapoff);                                   // (re-done below when the chunk changes)
+            __builtin_amdgcn_sched_barrier(0);
             mma(fa0, fb0);
             mma(fa1, fb1);
-            if (!(ABL & 4)) interleave();
+            pcur = tap_base(par_n, tapoff, dx_n);               // next tap-step's patch offsets (a handful of VALU)
             __builtin_amdgcn_sched_barrier(0);
             if (!(ABL & 1)) prio(0);
-            stamp(14 + 16 * step - 16);
+            stamp(14 + 16 * step);
             raw_barrier();
-            stamp(15 + 16 * step - 16);
+            stamp(15 + 16 * step);
+            P += 2; ++step;
             if (last) break;
-            if (w_slow) {                                           // next chunk of the run, or the next run
-                w_tp = 0; ++w_ch;
-                if (w_ch < w_nch) w_soff = w_ch * (2 * WROW);
-                else { ++w_r; w_enter_run(w_r); }
-            }
+            tp = wrap ? 0 : tpn;
             if (wrap) {
                 int nr = r, nc = ch + 1;
                 if (nc == nch_r) { nc = 0; ++nr; }
@@ -456,8 +454,6 @@ void conv_pipe_kernel(const ConvParams a, const int n_ct, const int tiles_per_xc
                 has_nc = nr < nruns;
                 nxt = get_chunk(has_nc ? nr : r, has_nc ? nc : ch);
                 ntaps = pin(cur.ntaps); par = ci & 1;
-                tapoff = ntaps == 9 ? 0 : PW + 1; tapdx = 0;
-                set_tap(par, tapoff);
             }
         }
         if (grp == 0) raw_barrier();                        // balance the stagger: every wave has executed the same barriers
@@ -486,7 +482,7 @@ void conv_pipe_kernel(const ConvParams a, const int n_ct, const int tiles_per_xc
         }
         int ntaps = pin(cur.ntaps), par = 0;
         int tapoff = ntaps == 9 ? 0 : PW + 1, tapdx = 0;
-        set_tap(0, tapoff);
+        pcur = tap_base(0, tapoff, ntaps == 9 ? 0 : 1);
         read_frags(fa0, fb0, 0, 0);
         auto interleave1 = [&]() {                              // scheduling hint for one k-group region
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -551,7 +547,7 @@ void conv_pipe_kernel(const ConvParams a, const int n_ct, const int tiles_per_xc
             tapoff = wrap ? nxt_first : (ntaps == 9 ? tapoff + (row_end ? PW - 2 : 1) : PW + 1);
             tapdx = (row_end || wrap) ? 0 : tapdx + 1;
             const int par_n = wrap ? par ^ 1 : par;
-            set_tap(par_n, tapoff);
+            pcur = tap_base(par_n, tapoff, wrap ? (nxt.ntaps == 9 ? 0 : 1) : (ntaps == 9 ? tapdx : 1));
             mma(fa0, fb0);
             if (!(ABL & 4)) interleave1();
             __builtin_amdgcn_sched_barrier(0);

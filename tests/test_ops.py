@@ -62,6 +62,60 @@ def test_conv_persistent_tile_loop(dev, dtype, k, monkeypatch):
     assert torch.allclose(st, sref, rtol=rtol, atol=rtol * float(sref.abs().max()))
 
 
+@pytest.mark.parametrize("variant", [3, 4])
+@pytest.mark.parametrize("case", ["plain", "block_tail", "gn_fused", "ragged"])
+def test_conv_pipelined_kernels(dev, variant, case, monkeypatch):
+    """conv_pipe.hip (LDS-DMA pipelined 256-cout kernels, both wave layouts) on shapes the default dispatch would give
+    to conv_igemm.hip: plain 3x3, fused 1x1 shortcut over a concat, fused GroupNorm-apply operand, ragged sizes."""
+    from storm_amd import ops
+    monkeypatch.setenv("STORM_CONV_VARIANT", str(variant))
+    dtype = torch.bfloat16
+    g = torch.Generator().manual_seed(31)
+    if case == "plain":
+        B, Cin, Cout, H, W = 2, 72, 288, 19, 45
+        x = torch.randn(B, Cin, H, W, generator=g); w = torch.randn(Cout, Cin, 3, 3, generator=g) * 0.1
+        b = torch.randn(Cout, generator=g)
+        y, part = ops.conv([ops.Seg(nhwc(x).to(dtype).to(dev), ops.pack_conv_weight(w.to(dev), dtype), 9)], Cout,
+                           bias=b.to(dev), gn_partials=True)
+        ref = F.conv2d(q(x, dtype), q(w, dtype), b, padding=1)
+        assert rel_l2(nchw(y.float().cpu())[:, :Cout], ref) < 6e-3
+        st, sref = ops.gn_finalize(part).cpu(), ops.gn_stats(y).cpu()
+        assert torch.allclose(st, sref, rtol=2e-3, atol=2e-3 * float(sref.abs().max()))
+    elif case == "block_tail":
+        B, H, W, Ca, Cb, Co = 2, 9, 35, 72, 16, 136
+        h = torch.randn(B, Co, H, W, generator=g)
+        xa, xb = torch.randn(B, Ca, H, W, generator=g), torch.randn(B, Cb, H, W, generator=g)
+        w1 = torch.randn(Co, Co, 3, 3, generator=g) * 0.05; w2 = torch.randn(Co, Ca + Cb, 1, 1, generator=g) * 0.2
+        bias, tb = torch.randn(Co, generator=g), torch.randn(B, 200, generator=g)
+        segs = [ops.Seg(nhwc(h).to(dtype).to(dev), ops.pack_conv_weight(w1.to(dev), dtype), 9),
+                ops.Seg(nhwc(xa).to(dtype).to(dev), ops.pack_conv_weight(w2.to(dev), dtype), 1, src_b=nhwc(xb).to(dtype).to(dev))]
+        tbd = tb.to(dev)
+        y = ops.conv(segs, Co, bias=bias.to(dev), tbias=tbd[:, 8:], scale=1 / math.sqrt(2)).float().cpu()
+        ref = (F.conv2d(q(h, dtype), q(w1, dtype), padding=1) + F.conv2d(q(torch.cat([xa, xb], 1), dtype), q(w2, dtype))
+               + bias[None, :, None, None] + tb[:, 8:8 + Co, None, None]) / math.sqrt(2)
+        assert rel_l2(nchw(y), ref) < 6e-3
+    elif case == "gn_fused":
+        B, C0, Ca, Cb, Co, H, W = 2, 8, 72, 56, 40, 10, 36
+        x0 = torch.randn(B, C0, H, W, generator=g)
+        wa, wb = torch.randn(Ca, C0, 3, 3, generator=g) * 0.4, torch.randn(Cb, C0, 1, 1, generator=g) * 0.7
+        w = torch.randn(Co, Ca + Cb, 3, 3, generator=g) * 0.1
+        gam, bet = 1 + 0.1 * torch.randn(Ca + Cb, generator=g), 0.1 * torch.randn(Ca + Cb, generator=g)
+        x0d = nhwc(x0).to(dtype).to(dev)
+        xa, pa = ops.conv([ops.Seg(x0d, ops.pack_conv_weight(wa.to(dev), dtype), 9)], Ca, gn_partials=True)
+        xb, pb = ops.conv([ops.Seg(x0d, ops.pack_conv_weight(wb.to(dev), dtype), 1)], Cb, gn_partials=True)
+        st, ss = ops.gn_finalize(pa, pb, gamma=gam.to(dev), beta=bet.to(dev), count=H * W)
+        y = ops.conv([ops.Seg(xa, ops.pack_conv_weight(w.to(dev), dtype), 9, src_b=xb, gn_ss=ss, gn_silu=True)], Co)
+        xcat = torch.cat([nchw(xa.float().cpu()), nchw(xb.float().cpu())], 1)
+        a = NR.silu(NR.group_norm(xcat, gam, bet))
+        ref = F.conv2d(q(a, dtype), q(w, dtype), padding=1)
+        assert rel_l2(nchw(y.float().cpu()), ref) < 1e-2
+    else:
+        B, Cin, Cout, H, W = 1, 24, 8 * 5, 5, 7                       # less than one pixel tile, Cout far below the tile
+        x = torch.randn(B, Cin, H, W, generator=g); w = torch.randn(Cout, Cin, 3, 3, generator=g) * 0.2
+        y = ops.conv([ops.Seg(nhwc(x).to(dtype).to(dev), ops.pack_conv_weight(w.to(dev), dtype), 9)], Cout).float().cpu()
+        assert rel_l2(nchw(y)[:, :Cout], F.conv2d(q(x, dtype), q(w, dtype), padding=1)) < 6e-3
+
+
 @pytest.mark.parametrize("dtype", DTYPES)
 def test_conv_fused_block_tail(dev, dtype):
     """Conv_1 3x3 over h + Conv_2 1x1 over cat[xa, xb] + bias + temb bias, rescaled (layerspp.py:266-274)."""
