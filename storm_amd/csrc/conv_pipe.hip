@@ -40,27 +40,29 @@ using namespace cidx;
 namespace pipe {
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 
-constexpr int BN = 256;
 constexpr int PW = Geo<9>::PW, NPIX = Geo<9>::NPIX;
-constexpr int PATCH_ROWS = (NPIX + 7) / 8 * 8;                // 344: whole 8-row (1 KiB) LDS-DMA pieces
-constexpr int PATCH_BYTES = PATCH_ROWS * PIX_BYTES;           // 44032
-constexpr int PPIECES = PATCH_ROWS / 8;                       // 43 wave-instructions cover a patch
-constexpr int WROW = 64;                                      // bytes per weight row and phase
-constexpr int WPHASE_BYTES = BN * WROW;                       // 16 KiB
+constexpr int WROW = 64;                                      // bytes per weight row and phase (two k-groups)
 constexpr int RING = 4;
-constexpr int OFF_RING = 2 * PATCH_BYTES;
-constexpr int OFF_SS = OFF_RING + RING * WPHASE_BYTES;
-constexpr int SS_BYTES = 1024;                                // one wave-instruction: 64 channels x (scale, shift) + pad
-constexpr int MAIN_BYTES = OFF_SS + 2 * SS_BYTES;             // 155648
+constexpr int SS_BYTES = 1024;                                // one wave-instruction: (scale, shift) of a chunk's channels + pad
 constexpr int PR = 2;                                         // pixel rows (of 32 px) staged per epilogue pass and wave
 constexpr uint32_t OOB = 0x80000000u;                         // per-lane offset that is out of range of every buffer here
 
-// Two wave layouts of the 256-cout x 256-pixel tile:
-//   <4, 2>: 8 waves (2 / SIMD, 256 registers each), 64 x 128 per wave, the two waves of a SIMD ping-pong
-//   <2, 2>: 4 waves (1 / SIMD, 512 registers), 128 x 128 per wave: half the barriers and LDS fragment reads per
-//           MFMA; everything else rides in the wave's own MFMA issue gaps
-template <int WAVES_M_, int WAVES_N_> struct PCfg {
+// Kernel geometry.  BN output channels x (8 x 32) pixels per workgroup; PIXB bytes of channels per pixel and K-chunk.
+//   <256, 128, 4, 2>: 8 waves (2 / SIMD, 256 registers each), 64 x 128 per wave, the two waves of a SIMD ping-pong
+//   <256, 128, 2, 2>: 4 waves (1 / SIMD, 512 registers), 128 x 128 per wave
+// (A <128, 64, 2, 2> geometry - 64-byte K-chunks, two workgroups per CU for the <= 128-cout layers - was built and
+//  measured in round 1: no faster than conv_igemm's 128-cout tile, so it is not instantiated.)
+template <int BN_, int PIXB_, int WAVES_M_, int WAVES_N_> struct PCfg {
+    static constexpr int BN = BN_, PIXB = PIXB_, KC = PIXB / 2, SLOTS = PIXB / 16;
     static constexpr int WAVES_M = WAVES_M_, WAVES_N = WAVES_N_, NWAVES = WAVES_M * WAVES_N, THREADS = 64 * NWAVES;
+    static constexpr int RPP = 1024 / PIXB;                   // patch rows per 1-KiB LDS-DMA piece
+    static constexpr int PATCH_ROWS = (NPIX + RPP - 1) / RPP * RPP;
+    static constexpr int PATCH_BYTES = PATCH_ROWS * PIXB;
+    static constexpr int PPIECES = PATCH_ROWS / RPP;
+    static constexpr int WPHASE_BYTES = BN * WROW;
+    static constexpr int OFF_RING = 2 * PATCH_BYTES;
+    static constexpr int OFF_SS = OFF_RING + RING * WPHASE_BYTES;
+    static constexpr int MAIN_BYTES = OFF_SS + 2 * SS_BYTES;
     static constexpr int WM = BN / 32 / WAVES_M;              // 32-cout tiles per wave
     static constexpr int WN = TILE_H / WAVES_N;               // pixel rows (32 px) per wave
     static constexpr int PU = (PPIECES + NWAVES - 1) / NWAVES;   // patch pieces per wave (the surplus re-issues a piece)
@@ -68,8 +70,10 @@ template <int WAVES_M_, int WAVES_N_> struct PCfg {
     static constexpr int NWD = BN / 16 / NWAVES;              // weight DMA instructions per wave and phase (16 rows each)
     static constexpr int STAGE_BYTES = NWAVES * 32 * PR * WM * 128;
     static constexpr int LDS_BYTES = MAIN_BYTES > STAGE_BYTES ? MAIN_BYTES : STAGE_BYTES;
+    static constexpr int BLOCKS_PER_CU = 2 * LDS_BYTES <= 160 * 1024 ? 2 : 1;
     static_assert(LDS_BYTES <= 160 * 1024, "LDS budget");
     static_assert(PU * NWAVES - PPIECES < NWAVES && PU <= 31, "patch pieces");
+    static_assert(PATCH_BYTES % 256 == 0, "k-group XOR must stay inside the slot field");
 };
 
 // LDS byte offset of 16-B slot s (0..3) of row `row` of a weight phase tile: the 16 lanes of a ds_read_b128
@@ -79,7 +83,9 @@ STORM_HD int w_off(int row, int s) { return row * WROW + ((s ^ ((row >> 2) & 3))
 // XOR-swizzled by the COLUMN ((px >> 1) & 7).  16 lanes of a fragment read are 16 consecutive px -> 16 distinct
 // bank groups; and because the swizzle does not depend on py, a tap's row offset, the wave's pixel rows and the
 // patch buffer are plain additions (scalar / instruction-immediate), so a k-group's four reads share one VGPR.
-STORM_HD int p_swz(int px, int slot) { return (slot ^ ((px >> 1) & 7)) << 4; }
+template <int PIXB> STORM_HD int p_swz(int px, int slot) {
+    return PIXB == 128 ? (slot ^ ((px >> 1) & 7)) << 4 : (slot ^ ((px >> 2) & 3)) << 4;     // 64-B rows: 4 slots
+}
 
 // Raw buffer resource (stride 0): reads past num_records return zeros (and write zeros to LDS).
 __device__ __forceinline__ u32x4 make_srd(const void* base, uint32_t bytes) {
@@ -144,15 +150,17 @@ __device__ __forceinline__ int pin(int x) {
 }  // namespace pipe
 using namespace pipe;
 
-template <int WAVES_M, int WAVES_N, int ABL>
-__global__ __launch_bounds__((pipe::PCfg<WAVES_M, WAVES_N>::THREADS), (pipe::PCfg<WAVES_M, WAVES_N>::NWAVES / 4))
+template <int BN, int PIXB, int WAVES_M, int WAVES_N, int ABL>
+__global__ __launch_bounds__((pipe::PCfg<BN, PIXB, WAVES_M, WAVES_N>::THREADS),
+                             (pipe::PCfg<BN, PIXB, WAVES_M, WAVES_N>::NWAVES * pipe::PCfg<BN, PIXB, WAVES_M, WAVES_N>::BLOCKS_PER_CU / 4))
 void conv_pipe_kernel(const ConvParams a, const int n_ct, const int tiles_per_xcd,
                       const int ntiles, const int tiles_x, const int tiles_per_img) {
-    typedef PCfg<WAVES_M, WAVES_N> Cfg;
+    typedef PCfg<BN, PIXB, WAVES_M, WAVES_N> Cfg;
     constexpr int NWAVES = Cfg::NWAVES, WM = Cfg::WM, WN = Cfg::WN, PU = Cfg::PU, NP = Cfg::NP, NWD = Cfg::NWD;
+    constexpr int KC = Cfg::KC, SLOTS = Cfg::SLOTS, RPP = Cfg::RPP, PATCH_BYTES = Cfg::PATCH_BYTES, PPIECES = Cfg::PPIECES;
+    constexpr int WPHASE_BYTES = Cfg::WPHASE_BYTES, OFF_RING = Cfg::OFF_RING, OFF_SS = Cfg::OFF_SS;
     typedef bf16_t T;
     typedef bf16x8 Frag;
-    constexpr int KC = 64;                                      // channels per K-chunk (128 B)
     extern __shared__ __attribute__((aligned(16))) char smem[];
 
     const BlockMap bm = block_map(blockIdx.x, n_ct, tiles_per_xcd);
@@ -250,7 +258,7 @@ void conv_pipe_kernel(const ConvParams a, const int n_ct, const int tiles_per_xc
             if (w_tp < w_ntaps) w_soff += w_tapbytes;
             else {
                 w_tp = 0; ++w_ch;
-                if (w_ch < w_nch) w_soff = w_ch * (2 * WROW);
+                if (w_ch < w_nch) w_soff = w_ch * PIXB;
                 else { ++w_r; w_enter_run(w_r); }
             }
         }
@@ -265,9 +273,9 @@ void conv_pipe_kernel(const ConvParams a, const int n_ct, const int tiles_per_xc
         for (int i = 0; i < PU; ++i) {
             int k = wave + i * NWAVES;                           // piece: patch rows 8k .. 8k+7
             if (k >= PPIECES) k -= NWAVES;                       // surplus slot: same piece again (keeps the VMEM count uniform)
-            const int row = k * 8 + (lane >> 3);
+            const int row = k * RPP + lane / SLOTS;
             const int py = row / PW, px = row - py * PW;
-            const int slot = (lane & 7) ^ ((px >> 1) & 7);       // logical 16-B slot that lands in physical slot lane & 7
+            const int slot = p_swz<PIXB>(px, lane % SLOTS) >> 4;  // logical 16-B slot that lands in physical slot lane % SLOTS
             const int gy = ty0 + py - 1, gx = tx0 + px - 1;
             const bool ok = row < NPIX && slot * 8 < c.cvalid && gy >= 0 && gy < a.H && gx >= 0 && gx < a.W;
             dma16(c.srd, ok ? (uint32_t)((gy * a.W + gx) * c.C + slot * 8) * 2u : OOB, so, dst + k * 1024, lane);
@@ -281,8 +289,8 @@ void conv_pipe_kernel(const ConvParams a, const int n_ct, const int tiles_per_xc
         for (int i = 0; i < PU; ++i) {
             const int k = wave + i * NWAVES;
             if (k < PPIECES && ((pmask >> i) & 1u)) {
-                const int row = k * 8 + (lane >> 3);
-                const int slot = (lane & 7) ^ (((row % PW) >> 1) & 7);
+                const int row = k * RPP + lane / SLOTS;
+                const int slot = p_swz<PIXB>(row % PW, lane % SLOTS) >> 4;
                 uint4* const q = reinterpret_cast<uint4*>(dst + k * 1024 + lane * 16);
                 float ss[16];
                 const float* t = reinterpret_cast<const float*>(smem + OFF_SS + parity * SS_BYTES) + 16 * slot;
@@ -299,13 +307,13 @@ void conv_pipe_kernel(const ConvParams a, const int n_ct, const int tiles_per_xc
     // ---- fragment reads ----------------------------------------------------------------------------------
     const int aoff = w_off(wm * WM * 32 + (lane & 31), lane >> 5);   // row of mi is +32 mi rows = +2048 mi B, same swizzle
     const int aoff1 = aoff ^ 32;                                   // second k-group of a phase
-    const int pv0 = ((wn * WN) * PW + (lane & 31)) * PIX_BYTES;    // this lane's pixel of ni = 0 under tap (0, 0)
+    const int pv0 = ((wn * WN) * PW + (lane & 31)) * PIXB;         // this lane's pixel of ni = 0 under tap (0, 0)
     int psw[3];                                                    // swizzle term of k-group 0 for tap column dx
 #pragma unroll
-    for (int d = 0; d < 3; ++d) psw[d] = p_swz((lane & 31) + d, lane >> 5);
+    for (int d = 0; d < 3; ++d) psw[d] = p_swz<PIXB>((lane & 31) + d, lane >> 5);
     // byte offset (k-group 0, ni = 0) of the tap at pixel offset tapoff = dy * PW + dx in patch buffer `parity`
     auto tap_base = [&](int parity, int tapoff, int dx) {
-        return pv0 + parity * PATCH_BYTES + tapoff * PIX_BYTES + (dx == 0 ? psw[0] : dx == 1 ? psw[1] : psw[2]);
+        return pv0 + parity * PATCH_BYTES + tapoff * PIXB + (dx == 0 ? psw[0] : dx == 1 ? psw[1] : psw[2]);
     };
     int pcur = 0;                              // tap_base of the tap being read
     // k-group kg (0..3) of the chunk = k-group (kg & 1) of ring phase q; pixel rows are immediate offsets
@@ -324,7 +332,7 @@ void conv_pipe_kernel(const ConvParams a, const int n_ct, const int tiles_per_xc
         for (int mi = 0; mi < WM; ++mi) fa[mi] = *reinterpret_cast<const Frag*>(wb + mi * 32 * WROW);
         const char* pp = smem + (pcur ^ (kg << 5));
 #pragma unroll
-        for (int ni = 0; ni < WN; ++ni) fb[ni] = *reinterpret_cast<const Frag*>(pp + ni * PW * PIX_BYTES);
+        for (int ni = 0; ni < WN; ++ni) fb[ni] = *reinterpret_cast<const Frag*>(pp + ni * PW * PIXB);
     };
     auto mma = [&](const Frag (&fa)[WM], const Frag (&fb)[WN]) {
         if (ABL & 32) {                                     // (profiling: no MFMAs; operands stay live)
@@ -381,7 +389,7 @@ void conv_pipe_kernel(const ConvParams a, const int n_ct, const int tiles_per_xc
                 if (wtn < w_ntaps) { w_soff += adv ? w_tapbytes : 0; w_tp = wtn; }
                 else {                                          // next chunk of the run, or the next run
                     w_tp = 0; ++w_ch;
-                    if (w_ch < w_nch) w_soff = w_ch * (2 * WROW);
+                    if (w_ch < w_nch) w_soff = w_ch * PIXB;
                     else { ++w_r; w_enter_run(w_r); }
                 }
             }
@@ -523,7 +531,7 @@ void conv_pipe_kernel(const ConvParams a, const int n_ct, const int tiles_per_xc
             __builtin_amdgcn_sched_barrier(0);
             if (w_slow) {                                       // next chunk of the run, or the next run
                 w_tp = 0; ++w_ch;
-                if (w_ch < w_nch) w_soff = w_ch * (2 * WROW);
+                if (w_ch < w_nch) w_soff = w_ch * PIXB;
                 else { ++w_r; w_enter_run(w_r); }
             }
             // ================= phase P+1 (half 1) =================
@@ -682,11 +690,11 @@ bool conv_pipe_supports(const storm_conv_args& a) {
     return true;
 }
 
-template <int WAVES_M, int WAVES_N, int ABL>
+template <int BN, int PIXB, int WAVES_M, int WAVES_N, int ABL>
 static int launch_pipe(const storm_conv_args& a, hipStream_t st) {
     using namespace pipe;
-    typedef PCfg<WAVES_M, WAVES_N> Cfg;
-    auto kern = conv_pipe_kernel<WAVES_M, WAVES_N, ABL>;
+    typedef PCfg<BN, PIXB, WAVES_M, WAVES_N> Cfg;
+    auto kern = conv_pipe_kernel<BN, PIXB, WAVES_M, WAVES_N, ABL>;
     static bool attr_set = false;                       // per instantiation; benign race (idempotent)
     if (!attr_set) {
         STORM_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, Cfg::LDS_BYTES));
@@ -717,25 +725,21 @@ int launch_conv_pipe(const storm_conv_args& a, hipStream_t st, int layout) {
     const int abl = abl_env ? atoi(abl_env) : 0;
     if (layout == 2) {
         switch (abl) {
-            case 1: return launch_pipe<4, 2, 1>(a, st);         // no s_setprio
-            case 2: return launch_pipe<4, 2, 2>(a, st);         // no stagger
-            case 4: return launch_pipe<4, 2, 4>(a, st);         // no sched_group_barrier interleave hint
-            case 8: return launch_pipe<4, 2, 8>(a, st);         // no weight DMA
-            case 16: return launch_pipe<4, 2, 16>(a, st);       // no fragment reads
-            case 32: return launch_pipe<4, 2, 32>(a, st);       // no MFMA
-            case 56: return launch_pipe<4, 2, 56>(a, st);       // barriers + bookkeeping only
-            case 64: return launch_pipe<4, 2, 64>(a, st);       // wave timeline stamps
-            default: return launch_pipe<4, 2, 0>(a, st);
+            case 1: return launch_pipe<256, 128, 4, 2, 1>(a, st);         // no s_setprio
+            case 2: return launch_pipe<256, 128, 4, 2, 2>(a, st);         // no stagger
+            case 8: return launch_pipe<256, 128, 4, 2, 8>(a, st);         // no weight DMA
+            case 16: return launch_pipe<256, 128, 4, 2, 16>(a, st);       // no fragment reads
+            case 32: return launch_pipe<256, 128, 4, 2, 32>(a, st);       // no MFMA
+            case 56: return launch_pipe<256, 128, 4, 2, 56>(a, st);       // barriers + bookkeeping only
+            case 64: return launch_pipe<256, 128, 4, 2, 64>(a, st);       // wave timeline stamps
+            default: return launch_pipe<256, 128, 4, 2, 0>(a, st);
         }
     }
     switch (abl) {
-        case 4: return launch_pipe<2, 2, 4>(a, st);
-        case 8: return launch_pipe<2, 2, 8>(a, st);
-        case 16: return launch_pipe<2, 2, 16>(a, st);
-        case 32: return launch_pipe<2, 2, 32>(a, st);
-        case 24: return launch_pipe<2, 2, 24>(a, st);
-        case 56: return launch_pipe<2, 2, 56>(a, st);
-        default: return launch_pipe<2, 2, 0>(a, st);
+        case 4: return launch_pipe<256, 128, 2, 2, 4>(a, st);
+        case 32: return launch_pipe<256, 128, 2, 2, 32>(a, st);
+        case 56: return launch_pipe<256, 128, 2, 2, 56>(a, st);
+        default: return launch_pipe<256, 128, 2, 2, 0>(a, st);
     }
 }
 

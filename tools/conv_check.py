@@ -53,13 +53,23 @@ for B, cin, cout, H, W, cshort in cases:
         fn = lambda: ops.conv(sg, cout, bias=bias, gn_partials=True, scale=0.7)  # noqa: E731
         y0, p0 = run(0, fn)
         for variant in VARIANTS:
+            yfirst = None
             for rep in range(5):
                 y3, p3 = run(variant, fn)
-                same = torch.equal(y0, y3) and torch.allclose(p0, p3, rtol=1e-4, atol=1e-3 * float(p0.abs().max()))   # partial sums: other order per layout
+                if variant == 5:        # 32-channel chunks: another summation order -> close, and bit-identical between repetitions
+                    d = (y0.float() - y3.float()).norm() / y0.float().norm()
+                    same = float(d) < 4e-3 and (yfirst is None or torch.equal(yfirst, y3))
+                    yfirst = y3 if yfirst is None else yfirst
+                else:
+                    same = torch.equal(y0, y3)
+                same = same and torch.allclose(p0, p3, rtol=1e-4, atol=2e-4 * float(p0.abs().max()))   # partial sums: other order per layout
                 if not same:
                     bad += 1
                     d = (y0.float() - y3.float()).abs()
-                    print(f"MISMATCH variant {variant} B{B} cin{cin} cout{cout} {H}x{W} short{cshort} fused{fused} rep{rep}: max {float(d.max()):.4g} n {int((d > 0).sum())}")
+                    dp = (p0 - p3).abs()
+                    print(f"MISMATCH variant {variant} B{B} cin{cin} cout{cout} {H}x{W} short{cshort} fused{fused} rep{rep}: max {float(d.max()):.4g} n {int((d > 0).sum())}"
+                          f" rel {float(d.norm() / y0.float().norm()):.3g} partials max diff {float(dp.max()):.4g} of {float(p0.abs().max()):.4g}"
+                          f" repeat-equal {yfirst is None or bool(torch.equal(yfirst, y3))}")
                     break
             else:
                 print(f"ok variant {variant} B{B} cin{cin} cout{cout} {H}x{W} short{cshort} fused{fused}")

@@ -23,6 +23,9 @@ def rnd(*s):
 
 
 cases = [("c256_128x256", 256, 256, 128, 256), ("c128_256x512", 128, 128, 256, 512), ("c512_64x128", 512, 256, 64, 128)]
+import os  # noqa: E402
+if os.environ.get("PROBE_KSWEEP"):      # fixed output tile work, growing K: separates per-tile from per-phase cost
+    cases = [(f"k{c}_256_128x256", c, 256, 128, 256) for c in (64, 128, 256, 512)] + [(f"k{c}_128_256x512", c, 128, 256, 512) for c in (32, 64, 128, 256)]
 for name, cin, cout, H, W in cases:
     x = rnd(args.B, H, W, cin).to(dt).to(dev)
     w = ops.pack_conv_weight((rnd(cout, cin, 3, 3) * 0.05).to(dev), dt)
