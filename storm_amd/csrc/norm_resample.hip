@@ -214,22 +214,24 @@ void gn_apply_resample_kernel(const T* __restrict__ xa, int Ca, const T* __restr
     const bool cvalid = c < C;
     const int OH = RESAMPLE == 1 ? 2 * H : H / 2, OW = RESAMPLE == 1 ? 2 * W : W / 2;
     const int iy0 = ty * 8 - 1, ix0 = tx * 16 - 1;  // input tile origin (core starts at ty*8, tx*16)
-    // per-thread GN parameters of its PER16 channels
-    float pm[PER16], pa[PER16], pb[PER16];
+    // GN parameters of the workgroup's CG channels: one thread per channel does the fp64 statistics math once
+    // (scale, shift with y = x * scale + shift), everyone else reads the LDS table after the tile loads are in flight
+    __shared__ float gtab[2 * CG];
     const int gs = C / G;
-    const double n = (double)gs * H * W;
-#pragma unroll
-    for (int e = 0; e < PER16; ++e) {
-        pm[e] = 0.f; pa[e] = 0.f; pb[e] = 0.f;
-        if (cvalid) {
-            const int g = (c + e) / gs;
+    if (tid < CG) {
+        const int cc = cg * CG + tid;
+        float sc = 0.f, sh = 0.f;
+        if (cc < C) {
+            const double n = (double)gs * H * W;
+            const int g = cc / gs;
             const double m = stats[((long long)b * G + g) * 2] / n;
             double var = stats[((long long)b * G + g) * 2 + 1] / n - m * m;
             if (var < 0.0) var = 0.0;
-            pm[e] = (float)m;
-            pa[e] = (float)(1.0 / sqrt(var + (double)eps)) * gamma[c + e];
-            pb[e] = beta[c + e];
+            const float pm = (float)m;
+            sc = (float)(1.0 / sqrt(var + (double)eps)) * gamma[cc];
+            sh = beta[cc] - pm * sc;
         }
+        gtab[2 * tid] = sc; gtab[2 * tid + 1] = sh;
     }
     const long long ibase = (long long)b * H * W;
     // ---- stage: raw + activated input tile -> LDS (zeros outside the image) ----
@@ -251,6 +253,10 @@ void gn_apply_resample_kernel(const T* __restrict__ xa, int Ca, const T* __restr
             rawv[k] = *reinterpret_cast<const uint4*>(src);
         }
     }
+    __syncthreads();                                   // gtab visible (the tile loads above are already in flight)
+    float pa[PER16], pb[PER16];
+#pragma unroll
+    for (int e = 0; e < PER16; ++e) { pa[e] = gtab[2 * (slot * PER16 + e)]; pb[e] = gtab[2 * (slot * PER16 + e) + 1]; }
 #pragma unroll
     for (int k = 0; k < NU; ++k) {
         const int u = tid + k * 256;
@@ -262,7 +268,7 @@ void gn_apply_resample_kernel(const T* __restrict__ xa, int Ca, const T* __restr
         if (okv[k]) {
 #pragma unroll
             for (int e = 0; e < PER16; ++e) {
-                float y = (to_f32(raw[e]) - pm[e]) * pa[e] + pb[e];
+                float y = fmaf(to_f32(raw[e]), pa[e], pb[e]);
                 if (silu) y = (sizeof(T) == 2) ? fast_silu(y) : silu_f(y);
                 from_f32(act[e], y);
             }
