@@ -13,6 +13,7 @@ namespace storm {
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
 typedef __attribute__((ext_vector_type(16))) float f32x16;
 typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef __attribute__((ext_vector_type(2))) float f32x2;
 
 struct bf16_t { uint16_t v; };   // storage type for bf16 activations / weights
 

@@ -610,9 +610,16 @@ void conv_pipe_kernel(const ConvParams a, const int n_ct, const int tiles_per_xc
     }
     const bool co_ok = co < a.outC;
     const T* const skip_b = reinterpret_cast<const T*>(a.skip) + (long long)b * a.skip_bstride;
-    float gsum[8], gsq[8];
+    // out = (acc + bias + temb bias + skip) * scale, evaluated as packed fma: (acc [+ skip]) * scale + (bias * scale);
+    // channel pairs stay in adjacent registers from the staging read to the bf16 pack (v_pk_fma_f32 / v_pk_add_f32)
+    f32x2 badd2[4], gsum2[4], gsq2[4];
+    const f32x2 scale2 = {a.scale, a.scale};
 #pragma unroll
-    for (int e = 0; e < 8; ++e) { gsum[e] = 0.f; gsq[e] = 0.f; }
+    for (int i = 0; i < 4; ++i) {
+        badd2[i] = f32x2{badd[2 * i] * a.scale, badd[2 * i + 1] * a.scale};
+        gsum2[i] = f32x2{0.f, 0.f}; gsq2[i] = f32x2{0.f, 0.f};
+    }
+    float gsum[8], gsq[8];
 #pragma unroll
     for (int pass = 0; pass < WN / PR; ++pass) {
         if (pass > 0) wave_sync();
@@ -633,22 +640,25 @@ void conv_pipe_kernel(const ConvParams a, const int n_ct, const int tiles_per_xc
             const int row = it * RPI + lane / LPR;
             const float4 v0 = *reinterpret_cast<const float4*>(stage + stage_off<WM>(row, 2 * c8));
             const float4 v1 = *reinterpret_cast<const float4*>(stage + stage_off<WM>(row, 2 * c8 + 1));
-            float v[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
+            f32x2 v2[4] = {f32x2{v0.x, v0.y}, f32x2{v0.z, v0.w}, f32x2{v1.x, v1.y}, f32x2{v1.z, v1.w}};
             const int trow = wn * WN + pass * PR + (row >> 5), n = row & 31;
             const int gy = ty0 + trow, gx = tx0 + n;
             const bool ok = gy < a.H && gx < a.W;
             const int pix = gy * a.W + gx;
             if (ok && co_ok) {
-#pragma unroll
-                for (int e = 0; e < 8; ++e) v[e] += badd[e];
                 if (a.skip) {
                     float sk[8];
                     load8(skip_b + (uint32_t)(pix * skipC + co), sk);
 #pragma unroll
-                    for (int e = 0; e < 8; ++e) v[e] += sk[e];
+                    for (int i = 0; i < 4; ++i) v2[i] += f32x2{sk[2 * i], sk[2 * i + 1]};
                 }
 #pragma unroll
-                for (int e = 0; e < 8; ++e) { v[e] *= a.scale; gsum[e] += v[e]; gsq[e] = fmaf(v[e], v[e], gsq[e]); }
+                for (int i = 0; i < 4; ++i) {
+                    v2[i] = __builtin_elementwise_fma(v2[i], scale2, badd2[i]);
+                    gsum2[i] += v2[i];
+                    gsq2[i] = __builtin_elementwise_fma(v2[i], v2[i], gsq2[i]);
+                }
+                const float v[8] = {v2[0].x, v2[0].y, v2[1].x, v2[1].y, v2[2].x, v2[2].y, v2[3].x, v2[3].y};
                 const uint32_t o = (uint32_t)(pix * a.outC + co);
                 if (a.out_f32) store8(reinterpret_cast<float*>(a.out) + (long long)b * a.out_bstride + o, v);
                 else store8(reinterpret_cast<T*>(a.out) + (long long)b * a.out_bstride + o, v);
@@ -657,6 +667,8 @@ void conv_pipe_kernel(const ConvParams a, const int n_ct, const int tiles_per_xc
     }
     stamp_tail(502);
     if (ABL & 64) { vm_wait<0>(); stamp_tail(503); }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { gsum[2 * i] = gsum2[i].x; gsum[2 * i + 1] = gsum2[i].y; gsq[2 * i] = gsq2[i].x; gsq[2 * i + 1] = gsq2[i].y; }
     if (a.gn_part != nullptr) {
 #pragma unroll
         for (int off = LPR; off < 64; off <<= 1)
