@@ -202,7 +202,7 @@ def main():
         for r in rows:
             if r["code"] == 4 and r["big"] and 9 in r["taps"]:
                 v2 = r["Cout"] > 128 and args.batch * ((r["H"] * r["W"] + 255) // 256) >= 512
-                key = ("storm::conv_pipe_kernel<4, 2, 0>" if v2 and args.precision == "bf16"
+                key = ("storm::conv_pipe_kernel<256, 128, 4, 2, 0>" if v2 and args.precision == "bf16"
                        else f"storm::conv_igemm_kernel<{tname}, 9, 2, 4, 2, true, false, 0>" if v2
                        else f"storm::conv_igemm_kernel<{tname}, 9, 2, 2, 2, false, false, 0>")
                 groups.setdefault(key, []).append(r)
