@@ -201,26 +201,25 @@ __device__ __forceinline__ void conv_tile(const ConvParams& a, const int vblock,
             if (u < Cfg::NPIX * 8) {
                 uint4 v = preg[i];
                 if (c.gn_ss != nullptr && (pmask >> i) & 1u) v = gn_act_slot(v, ss, c.gn_silu, (T*)nullptr);
-                *reinterpret_cast<uint4*>(dst + lds_off(u >> 3, u & 7)) = v;
+                *reinterpret_cast<uint4*>(dst + patch_off(u >> 3, (u >> 3) % PW, u & 7)) = v;
             }
         }
     };
 
-    // per-lane fragment rows (tap independent parts)
-    int arow[WM];
-#pragma unroll
-    for (int mi = 0; mi < WM; ++mi) arow[mi] = (wm * WM + mi) * 32 + (lane & 31);
+    // per-lane fragment offsets: weights rows of mi are +32 rows (same swizzle) -> one VGPR + immediates; k-group j
+    // flips bits 5-6 of the slot field (slot = 2j + lane / 32)
+    const int abase = lds_off(wm * WM * 32 + (lane & 31), lane >> 5);
 
     auto compute = [&](const char* patch, const char* wb, int dy, int dx, int nk) {
-        int prow[WN];
-#pragma unroll
-        for (int ni = 0; ni < WN; ++ni) prow[ni] = patch_pixel<TAPS>(lane, wn * WN + ni, dy, dx);
+        const int px = (lane & 31) + dx;
+        const int pb = patch_off((wn * WN + dy) * PW + px, px, lane >> 5);       // pixel row ni: + ni * PW rows
         auto load_frags = [&](int j, Frag (&fa)[WM], Frag (&fb)[WN]) {
-            const int slot = frag_slot(lane, j);
+            const char* wa = wb + (abase ^ (j << 5));
+            const char* pp = patch + (pb ^ (j << 5));
 #pragma unroll
-            for (int mi = 0; mi < WM; ++mi) fa[mi] = *reinterpret_cast<const Frag*>(wb + lds_off(arow[mi], slot));
+            for (int mi = 0; mi < WM; ++mi) fa[mi] = *reinterpret_cast<const Frag*>(wa + mi * 32 * PIX_BYTES);
 #pragma unroll
-            for (int ni = 0; ni < WN; ++ni) fb[ni] = *reinterpret_cast<const Frag*>(patch + lds_off(prow[ni], slot));
+            for (int ni = 0; ni < WN; ++ni) fb[ni] = *reinterpret_cast<const Frag*>(pp + ni * PW * PIX_BYTES);
         };
         auto mma = [&](const Frag (&fa)[WM], const Frag (&fb)[WN]) {
 #pragma unroll

@@ -23,6 +23,11 @@ template <> struct Geo<1> { static constexpr int PH = TILE_H, PW = TILE_W, NPIX 
 // XOR swizzle: 16 consecutive rows read at one slot hit 16 distinct 16-B bank groups.
 STORM_HD int lds_off(int row, int slot) { return row * PIX_BYTES + ((slot ^ ((row >> 1) & 7)) << 4); }
 
+// Patch image (activations): pixel `pix` = py * PW + px of the staged patch; its slots are swizzled by the COLUMN
+// px, so 16 consecutive px of a fragment read still hit 16 distinct bank groups (row parity == px parity, PW even)
+// while a tap's row offset / a wave's pixel rows become plain byte offsets (instruction immediates).
+STORM_HD int patch_off(int pix, int px, int slot) { return pix * PIX_BYTES + ((slot ^ ((px >> 1) & 7)) << 4); }
+
 // MFMA 32x32 accumulator layout (all dtypes): lane holds column (lane & 31) and, for
 // register r in [0,16), row  (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5).
 STORM_HD int acc_row(int lane, int r) { return (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5); }
