@@ -117,6 +117,7 @@ __device__ __forceinline__ void conv_tile(const ConvParams& a, const int vblock,
     // ---- per-chunk scalars (one K-chunk = 128 B of channels of one run) ----------------------------
     struct Chunk {
         const T* src; const T* w; const float* gn_ss;
+        BufRsrc sb, wb;                                // buffer views of src / w: out-of-range reads are zeros
         int C, cbeg, cvalid, CinP, w_rows, ntaps, kbeg, klim, gn_silu;
         long long w_tapstride;
     };
@@ -125,6 +126,8 @@ __device__ __forceinline__ void conv_tile(const ConvParams& a, const int vblock,
         Chunk c;
         c.src = reinterpret_cast<const T*>(R.src) + (long long)b * R.src_bstride;
         c.w = reinterpret_cast<const T*>(R.w) + (long long)b * R.w_bstride + R.wc0;
+        c.sb = make_buf(c.src, (uint32_t)((long long)a.H * a.W * R.C * sizeof(T)));
+        c.wb = make_buf(c.w, (uint32_t)(((long long)R.ntaps * R.w_tapstride - R.wc0) * sizeof(T)));
         c.C = R.C; c.cbeg = R.c0 + ch * KC; c.cvalid = min(KC, R.cn - ch * KC);
         c.CinP = R.CinP; c.w_rows = R.w_rows; c.ntaps = R.ntaps; c.w_tapstride = R.w_tapstride;
         c.kbeg = ch * KC; c.klim = R.CinP - R.wc0;
@@ -137,14 +140,14 @@ __device__ __forceinline__ void conv_tile(const ConvParams& a, const int vblock,
     // ---- loaders --------------------------------------------------------------------------------
     uint4 wreg[Cfg::WU];
     auto load_w = [&](const Chunk& c, int tp) {
-        const T* wbase = c.w + (long long)tp * c.w_tapstride;
+        const uint32_t wsoff = (uint32_t)((long long)tp * c.w_tapstride * sizeof(T));
 #pragma unroll
         for (int i = 0; i < Cfg::WU; ++i) {
             const int u = tid + i * THREADS;
             const int row = u >> 3, slot = u & 7;
             const int co = cout0 + row, k = c.kbeg + slot * PER16;
             uint4 v = make_uint4(0u, 0u, 0u, 0u);
-            if (co < c.w_rows && k < c.klim) v = ld16(wbase, (uint32_t)(co * c.CinP + k) * (uint32_t)sizeof(T));
+            v = buf_load16(c.wb, (co < c.w_rows && k < c.klim) ? (uint32_t)(co * c.CinP + k) * (uint32_t)sizeof(T) : BUF_OOB, wsoff);
             wreg[i] = v;
         }
     };
@@ -178,7 +181,7 @@ __device__ __forceinline__ void conv_tile(const ConvParams& a, const int vblock,
                 ok = ok && pix < (int)npix;
             }
             uint4 v = make_uint4(0u, 0u, 0u, 0u);
-            if (ok) v = ld16(c.src, (uint32_t)(pix * c.C + c.cbeg + slot * PER16) * (uint32_t)sizeof(T));
+            v = buf_load16(c.sb, ok ? (uint32_t)(pix * c.C + c.cbeg + slot * PER16) * (uint32_t)sizeof(T) : BUF_OOB, 0u);
             preg[i] = v;
             pmask = ok ? (pmask | (1u << i)) : (pmask & ~(1u << i));
         }

@@ -29,6 +29,37 @@ __device__ __forceinline__ uint4 ld16(const void* base, uint32_t byte_off) {
     return *reinterpret_cast<const uint4*>(static_cast<const char*>(base) + byte_off);
 }
 
+// Raw buffer resource (stride 0): a 16-byte load whose offset lies past `bytes` returns zeros.  Padding pixels,
+// ragged channel counts and rows past a matrix become an out-of-range OFFSET instead of a branch around the load.
+constexpr uint32_t BUF_OOB = 0x80000000u;
+struct BufRsrc {
+#if defined(STORM_HOST_SIM)
+    const char* base; uint32_t bytes;
+#else
+    __amdgpu_buffer_rsrc_t r;
+#endif
+};
+__device__ __forceinline__ BufRsrc make_buf(const void* base, uint32_t bytes) {
+    BufRsrc b;
+#if defined(STORM_HOST_SIM)
+    b.base = static_cast<const char*>(base); b.bytes = bytes;
+#else
+    b.r = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, (int)bytes, 0x00020000);
+#endif
+    return b;
+}
+__device__ __forceinline__ uint4 buf_load16(const BufRsrc& b, uint32_t voff, uint32_t soff) {
+#if defined(STORM_HOST_SIM)
+    uint4 v = make_uint4(0u, 0u, 0u, 0u);
+    if ((uint64_t)voff + soff + 16 <= b.bytes) memcpy(&v, b.base + voff + soff, 16);
+    return v;
+#else
+    typedef uint32_t u32x4_ __attribute__((ext_vector_type(4)));
+    const u32x4_ v = __builtin_amdgcn_raw_buffer_load_b128(b.r, (int)voff, (int)soff, 0);
+    return make_uint4(v[0], v[1], v[2], v[3]);
+#endif
+}
+
 // y = act(x * scale + shift) on the 16-byte slot held in `v` (GroupNorm-apply + SiLU fused into the
 // operand load: the normalised tensor is never written to HBM).
 __device__ __forceinline__ uint4 gn_act_slot(uint4 v, const float (&ss)[16], int silu, bf16_t*) {
