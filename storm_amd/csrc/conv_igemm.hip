@@ -270,6 +270,7 @@ __device__ __forceinline__ void conv_tile(const ConvParams& a, const int vblock,
             for (int j = 0; j < nk; ++j) {
                 Frag fa[WM], fb[WN];
                 load_frags(j, fa, fb);
+                __builtin_amdgcn_sched_barrier(0);      // every fragment read of the k-group in flight before its first MFMA
                 mma(fa, fb);
             }
         }
