@@ -4,7 +4,7 @@
     python enhancement.py --test_dir noisy/ --enhanced_dir out/ --ckpt model.ckpt --mode storm \
         [--corrector ald --corrector-steps 1 --snr 0.5 --N 50]
 
-Additions: --precision {fp32,bf16}, --batch (equal-length utterances per sampler call) and multi-GPU
+Additions: --precision {fp32,bf16}, --batch (equal-length utterances per sampler call), --seed and multi-GPU
 sharding when launched with torchrun (one process per GPU, files dealt by length; no collectives in the
 sampler).  WAV I/O uses scipy.io.wavfile (torchaudio is not required)."""
 import glob
@@ -47,6 +47,7 @@ def main():
     p.add_argument("--N", type=int, default=50)
     p.add_argument("--precision", choices=("fp32", "bf16"), default="fp32")
     p.add_argument("--batch", type=int, default=16)
+    p.add_argument("--seed", type=int, default=None, help="Philox seed of the sampler noise (default: drawn from torch's RNG, as the reference)")
     args = p.parse_args()
 
     from storm_amd import distributed as D
@@ -74,7 +75,8 @@ def main():
         if args.mode == "denoiser-only":
             outs = [model.enhance(wavs[i]) for i in ids]
         else:
-            x_hat = model.enhance_batch(y, corrector=args.corrector, N=args.N, corrector_steps=args.corrector_steps, snr=args.snr)
+            kw = {} if args.seed is None else dict(seed=args.seed + ids[0])     # distinct, reproducible draws per batch
+            x_hat = model.enhance_batch(y, corrector=args.corrector, N=args.N, corrector_steps=args.corrector_steps, snr=args.snr, **kw)
             outs = list(x_hat)
         for i, x in zip(ids, outs):
             write_wav(os.path.join(args.enhanced_dir, os.path.basename(files[i])), x.float().reshape(-1), 16000)
