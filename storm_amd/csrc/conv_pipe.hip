@@ -383,16 +383,6 @@ void conv_pipe_kernel(const ConvParams a, const int n_ct, const int tiles_per_xc
             // ================= S(P), half 0 =================
             stamp(4 + 16 * step);
             read_frags(fa0, fb0, P, 0);
-            if (P > 0) {                                        // weight cursor -> the step whose halves are issued next
-                const int adv = --w_left > 0 ? 1 : 0;           // past the end it stays (harmless re-load)
-                const int wtn = w_tp + adv;
-                if (wtn < w_ntaps) { w_soff += adv ? w_tapbytes : 0; w_tp = wtn; }
-                else {                                          // next chunk of the run, or the next run
-                    w_tp = 0; ++w_ch;
-                    if (w_ch < w_nch) w_soff = w_ch * PIXB;
-                    else { ++w_r; w_enter_run(w_r); }
-                }
-            }
             w_issue(P + 2, 0);
             stamp(6 + 16 * step);
             vm_wait<2>();                                       // (also retires a patch issued last phase: once per chunk)
@@ -452,7 +442,17 @@ void conv_pipe_kernel(const ConvParams a, const int n_ct, const int tiles_per_xc
             P += 2; ++step;
             if (last) break;
             tp = wrap ? 0 : tpn;
-            if (wrap) {
+            {                                                   // weight cursor -> the step whose halves are issued next
+                const int adv = --w_left > 0 ? 1 : 0;           // past the end it stays (harmless re-load)
+                const int wtn = w_tp + adv;
+                if (__builtin_expect(wtn < w_ntaps, 1)) { w_soff += adv ? w_tapbytes : 0; w_tp = wtn; }
+                else {                                          // next chunk of the run, or the next run (rare)
+                    w_tp = 0; ++w_ch;
+                    if (w_ch < w_nch) w_soff = w_ch * PIXB;
+                    else { ++w_r; w_enter_run(w_r); }
+                }
+            }
+            if (__builtin_expect(wrap, 0)) {
                 int nr = r, nc = ch + 1;
                 if (nc == nch_r) { nc = 0; ++nr; }
                 if (nr != r) nch_r = chunks_of(nr);
