@@ -33,16 +33,21 @@ template <int TAPS, int WM, int WAVES_M, int WAVES_N, bool PF, bool FP = false, 
 struct ConvCfg {
     static constexpr int ABL = ABL_;           // profiling-only ablation mask (separate instantiations)
     static constexpr bool PREFETCH = PF;       // double-buffered patch, next chunk fetched under the MFMAs
-    static constexpr bool FRAG_PIPE = FP;      // two fragment sets, hand software-pipelined k-loop
+    static constexpr bool DMA = FP;            // operands staged by LDS-DMA (buffer_load ... lds) instead of registers
     static constexpr int NWAVES = WAVES_M * WAVES_N;
     static constexpr int THREADS = 64 * NWAVES;
     static constexpr int WN = TILE_H / WAVES_N;          // pixel tile rows (of 32 px) per wave
     static constexpr int BN = WAVES_M * WM * 32;          // output channels per workgroup
     static constexpr int NPIX = Geo<TAPS>::NPIX;
-    static constexpr int PATCH_BYTES = NPIX * PIX_BYTES;
+    static constexpr int PATCH_BYTES = (FP ? (NPIX + 7) / 8 * 8 : NPIX) * PIX_BYTES;     // DMA: whole 8-row (1 KiB) pieces
     static constexpr int WBUF_BYTES = BN * PIX_BYTES;
     static constexpr int NPBUF = PF ? 2 : 1;
-    static constexpr int MAIN_BYTES = NPBUF * PATCH_BYTES + 2 * WBUF_BYTES;
+    static constexpr int SS_BYTES = FP ? 1024 : 0;                                      // DMA: (scale, shift) table of a chunk
+    static constexpr int OFF_SS = NPBUF * PATCH_BYTES + 2 * WBUF_BYTES;
+    static constexpr int MAIN_BYTES = OFF_SS + SS_BYTES;
+    static constexpr int PPIECES = PATCH_BYTES / 1024;                                   // DMA pieces of a patch
+    static constexpr int PUD = (PPIECES + NWAVES - 1) / NWAVES;                          // ... per wave
+    static constexpr int WUD = BN / 8 / NWAVES;                                          // weight DMA pieces per wave and tap
     static constexpr int PR = (WN >= 2 && NWAVES * 64 * WM * 128 <= MAIN_BYTES) ? 2 : 1;   // pixel rows staged per epilogue pass
     static constexpr int STAGE_BYTES = NWAVES * 32 * PR * WM * 128;
     static constexpr int LDS_BYTES = MAIN_BYTES > STAGE_BYTES ? MAIN_BYTES : STAGE_BYTES;
@@ -118,6 +123,7 @@ __device__ __forceinline__ void conv_tile(const ConvParams& a, const int vblock,
     struct Chunk {
         const T* src; const T* w; const float* gn_ss;
         BufRsrc sb, wb;                                // buffer views of src / w: out-of-range reads are zeros
+        u32x4 ssrd, wsrd, tsrd;                        // (DMA staging) raw descriptors of src, w and the GN (scale, shift) pairs
         int C, cbeg, cvalid, CinP, w_rows, ntaps, kbeg, klim, gn_silu;
         long long w_tapstride;
     };
@@ -128,11 +134,16 @@ __device__ __forceinline__ void conv_tile(const ConvParams& a, const int vblock,
         c.w = reinterpret_cast<const T*>(R.w) + (long long)b * R.w_bstride + R.wc0;
         c.sb = make_buf(c.src, (uint32_t)((long long)a.H * a.W * R.C * sizeof(T)));
         c.wb = make_buf(c.w, (uint32_t)(((long long)R.ntaps * R.w_tapstride - R.wc0) * sizeof(T)));
+        if (Cfg::DMA) {
+            c.ssrd = make_srd(c.src, (uint32_t)((long long)a.H * a.W * R.C * sizeof(T)));
+            c.wsrd = make_srd(c.w, (uint32_t)(((long long)R.ntaps * R.w_tapstride - R.wc0) * sizeof(T)));
+        }
         c.C = R.C; c.cbeg = R.c0 + ch * KC; c.cvalid = min(KC, R.cn - ch * KC);
         c.CinP = R.CinP; c.w_rows = R.w_rows; c.ntaps = R.ntaps; c.w_tapstride = R.w_tapstride;
         c.kbeg = ch * KC; c.klim = R.CinP - R.wc0;
         c.gn_ss = R.gn_ss ? R.gn_ss + 2 * ((long long)b * R.gn_C + R.wc0 + ch * KC) : nullptr;
         c.gn_silu = R.gn_silu;
+        if (Cfg::DMA) c.tsrd = make_srd(c.gn_ss ? static_cast<const void*>(c.gn_ss) : static_cast<const void*>(c.src), c.gn_ss ? (uint32_t)c.cvalid * 8u : 0u);
         return c;
     };
     auto chunks_of = [&](int r) { return (a.run[r].cn + KC - 1) / KC; };
@@ -209,6 +220,66 @@ __device__ __forceinline__ void conv_tile(const ConvParams& a, const int vblock,
         }
     };
 
+    // ---- LDS-DMA staging (Cfg::DMA): the same LDS images, filled by `buffer_load_dwordx4 ... lds` -------------
+    // An instruction's LDS image is lane-linear (1 KiB = 8 rows), so the bank swizzle goes on the per-lane SOURCE
+    // offset; padding / ragged channels / rows past the matrix are out-of-range offsets = hardware zeros.  No
+    // staging registers, no ds_write pass; the fused GroupNorm transform rewrites a lane's own units in place.
+    const int wave_u = tid >> 6;
+    auto w_dma = [&](const Chunk& c, int tp, int buf) {
+        char* dst = wbuf + buf * Cfg::WBUF_BYTES + wave_u * (Cfg::WUD * 1024);
+        const uint32_t wsoff = (uint32_t)((long long)tp * c.w_tapstride * sizeof(T));
+#pragma unroll
+        for (int j = 0; j < Cfg::WUD; ++j) {
+            const int row = (wave_u * Cfg::WUD + j) * 8 + (lane >> 3);
+            const int slot = (lane & 7) ^ ((row >> 1) & 7);
+            const int co = cout0 + row, k = c.kbeg + slot * PER16;
+            dma16(c.wsrd, (co < c.w_rows && k < c.klim) ? (uint32_t)(co * c.CinP + k) * (uint32_t)sizeof(T) : BUF_OOB, wsoff, dst + j * 1024, lane);
+        }
+    };
+    uint32_t dmask = 0;                          // bit i: DMA unit i of this lane is real input (gets the GN transform)
+    auto patch_dma = [&](const Chunk& c, char* dst) {
+#pragma unroll
+        for (int i = 0; i < Cfg::PUD; ++i) {
+            int k = wave_u + i * Cfg::NWAVES;                     // piece: patch rows 8k .. 8k+7
+            if (k >= Cfg::PPIECES) k -= Cfg::NWAVES;               // surplus slot: the same piece again
+            const int p = k * 8 + (lane >> 3);
+            const int py = p / PW, px = p - py * PW;
+            const int slot = (lane & 7) ^ ((px >> 1) & 7);
+            int pix;
+            bool ok = p < Cfg::NPIX && slot * PER16 < c.cvalid;
+            if (TAPS == 9) {
+                const int gy = ty0 + py - 1, gx = tx0 + px - 1;
+                ok = ok && gy >= 0 && gy < a.H && gx >= 0 && gx < a.W;
+                pix = gy * a.W + gx;
+            } else {
+                pix = (int)lin0 + p;
+                ok = ok && pix < (int)npix;
+            }
+            dma16(c.ssrd, ok ? (uint32_t)(pix * c.C + c.cbeg + slot * PER16) * (uint32_t)sizeof(T) : BUF_OOB, 0u, dst + k * 1024, lane);
+            dmask = ok ? (dmask | (1u << i)) : (dmask & ~(1u << i));
+        }
+        dma16(c.tsrd, (uint32_t)lane * 16u, 0u, smem + Cfg::OFF_SS, lane);
+    };
+    auto patch_fixup = [&](const Chunk& c, char* dst) {          // fused GroupNorm-apply (+ SiLU), in place, own units
+#pragma unroll
+        for (int i = 0; i < Cfg::PUD; ++i) {
+            const int k = wave_u + i * Cfg::NWAVES;
+            if (k < Cfg::PPIECES && ((dmask >> i) & 1u)) {
+                const int p = k * 8 + (lane >> 3);
+                const int slot = (lane & 7) ^ (((p % PW) >> 1) & 7);
+                uint4* const q = reinterpret_cast<uint4*>(dst + k * 1024 + lane * 16);
+                float ss[16];
+                const float* t = reinterpret_cast<const float*>(smem + Cfg::OFF_SS) + 2 * PER16 * slot;
+#pragma unroll
+                for (int j = 0; j < 2 * PER16; j += 4) {
+                    const float4 t4 = *reinterpret_cast<const float4*>(t + j);
+                    ss[j] = t4.x; ss[j + 1] = t4.y; ss[j + 2] = t4.z; ss[j + 3] = t4.w;
+                }
+                *q = gn_act_slot(*q, ss, c.gn_silu, (T*)nullptr);
+            }
+        }
+    };
+
     // per-lane fragment offsets: weights rows of mi are +32 rows (same swizzle) -> one VGPR + immediates; k-group j
     // flips bits 5-6 of the slot field (slot = 2j + lane / 32)
     const int abase = lds_off(wm * WM * 32 + (lane & 31), lane >> 5);
@@ -231,25 +302,8 @@ __device__ __forceinline__ void conv_tile(const ConvParams& a, const int vblock,
                 for (int ni = 0; ni < WN; ++ni) Mma<T>::run(fa[mi], fb[ni], acc[mi][ni]);
         };
         // ONE rolled loop (a second, unrolled copy of the MFMA code makes the register allocator keep two
-        // homes for the accumulators).  Two fragment sets, software pipelined by hand: the LDS reads of
-        // k-group j+1 are issued BEFORE the 8 MFMAs of group j (sched_barrier pins that order), so a wave's
-        // MFMA stream does not stop for its own LDS latency.  An odd nk runs one group on zero slots.
-        if (Cfg::FRAG_PIPE) {
-            Frag fa0[WM], fb0[WN], fa1[WM], fb1[WN];
-            load_frags(0, fa0, fb0);
-            const int npair = (nk + 1) >> 1;
-#pragma unroll 1
-            for (int jj = 0; jj < npair; ++jj) {
-                load_frags(2 * jj + 1, fa1, fb1);
-                __builtin_amdgcn_sched_barrier(0);
-                mma(fa0, fb0);
-                __builtin_amdgcn_sched_barrier(0);
-                load_frags(min(2 * jj + 2, 3), fa0, fb0);     // (re-reads a valid group on the last pass; unused)
-                __builtin_amdgcn_sched_barrier(0);
-                mma(fa1, fb1);
-                __builtin_amdgcn_sched_barrier(0);
-            }
-        } else if (ABL & 3) {                          // profiling ablations (own instantiations, never dispatched in production)
+        // homes for the accumulators).
+        if (ABL & 3) {                          // profiling ablations (own instantiations, never dispatched in production)
             Frag fa[WM], fb[WN];
             load_frags(0, fa, fb);
 #pragma unroll 1
@@ -285,8 +339,8 @@ __device__ __forceinline__ void conv_tile(const ConvParams& a, const int vblock,
         patch_issue(cur, 0, Cfg::PU);
         patch_commit(cur, pbuf, 0, Cfg::PU);
     }
-    load_w(cur, 0);
-    store_w(0);
+    if (Cfg::DMA) w_dma(cur, 0, 0);
+    else { load_w(cur, 0); store_w(0); }
     stamp(2);
     while (true) {
         int nr = r, nc = ch + 1;
@@ -297,9 +351,15 @@ __device__ __forceinline__ void conv_tile(const ConvParams& a, const int vblock,
             stamp(400 + 4 * ci);
             __syncthreads();                       // every wave finished reading the previous patch
             stamp(401 + 4 * ci);
-            patch_issue(cur, 0, HALF); patch_commit(cur, pbuf, 0, HALF);
-            stamp(402 + 4 * ci);
-            patch_issue(cur, HALF, Cfg::PU); patch_commit(cur, pbuf, HALF, Cfg::PU);
+            if (Cfg::DMA) {                                 // one memory round trip, no registers, no ds_write pass
+                patch_dma(cur, pbuf);
+                vm_wait<0>();                               // (also the weight tile issued before this stage)
+                if (cur.gn_ss != nullptr) patch_fixup(cur, pbuf);
+            } else {
+                patch_issue(cur, 0, HALF); patch_commit(cur, pbuf, 0, HALF);
+                stamp(402 + 4 * ci);
+                patch_issue(cur, HALF, Cfg::PU); patch_commit(cur, pbuf, HALF, Cfg::PU);
+            }
             stamp(403 + 4 * ci);
         }
         const char* const patch = pbuf + (PF ? (ci & 1) * Cfg::PATCH_BYTES : 0);
@@ -310,7 +370,7 @@ __device__ __forceinline__ void conv_tile(const ConvParams& a, const int vblock,
             // Both fly during the MFMAs below and are written to LDS after them.
             const bool more_taps = tp + 1 < ntaps;
             const bool has_next = more_taps || has_nc;
-            if (!(ABL & (4 | 16))) {
+            if (!Cfg::DMA && !(ABL & (4 | 16))) {
                 if (more_taps) load_w(cur, tp + 1);
                 else if (has_nc) load_w(nxt, 0);
             }
@@ -318,6 +378,10 @@ __device__ __forceinline__ void conv_tile(const ConvParams& a, const int vblock,
             if (pf_now) patch_issue(nxt, 0, Cfg::PU);
             stamp(4 + 4 * step);
             __syncthreads();                       // patch + wbuf[step&1] visible; ring slots of step-1 free
+            if (Cfg::DMA && has_next) {            // next tile straight into the other ring slot: lands under the MFMAs
+                if (more_taps) w_dma(cur, tp + 1, (step + 1) & 1);
+                else w_dma(nxt, 0, (step + 1) & 1);
+            }
             stamp(5 + 4 * step);
             int dy = 0, dx = 0;
             if (TAPS == 9) {
@@ -325,7 +389,8 @@ __device__ __forceinline__ void conv_tile(const ConvParams& a, const int vblock,
             }
             compute(patch, wbuf + (step & 1) * Cfg::WBUF_BYTES, dy, dx, nk);
             stamp(6 + 4 * step);
-            if (has_next) store_w((step + 1) & 1);
+            if (Cfg::DMA) vm_wait<0>();            // own share of the next weight tile landed before the next barrier
+            else if (has_next) store_w((step + 1) & 1);
             if (pf_now) patch_commit(nxt, pbuf + ((ci + 1) & 1) * Cfg::PATCH_BYTES, 0, Cfg::PU);
             stamp(7 + 4 * step);
             ++step;
@@ -555,7 +620,8 @@ static int dispatch_conv(const storm_conv_args& a, hipStream_t st) {
     for (int s = 0; s < a.nseg; ++s) any9 = any9 || a.seg[s].ntaps == 9;
     const bool small = a.outC <= 32;
     // Tile variants (STORM_CONV_VARIANT overrides the choice, for A/B runs):
-    //   0: 128 cout x 256 px, 4 waves (64x128 each), 2 workgroups / CU overlap each other's staging
+    //   0: 128 cout x 256 px, 4 waves (64x128 each), 2 workgroups / CU overlap each other's staging; operands by
+    //      LDS-DMA (STORM_CONV_DMA=0: through registers)
     //   1: 128 cout x 256 px, 8 waves (64x64 each), 2 workgroups / CU
     //   2: 256 cout x 256 px, 8 waves (64x128 each), 1 workgroup / CU, patch double-buffered and the
     //      next K-chunk prefetched under the MFMAs (one patch load + GN transform per 256 couts)
@@ -563,7 +629,8 @@ static int dispatch_conv(const storm_conv_args& a, hipStream_t st) {
     //   4: conv_pipe.hip, same tile, 4 waves of 128x128 (one per SIMD)
     const char* forced_env = getenv("STORM_CONV_VARIANT");          // read per launch: tests and probes switch it at run time
     const int forced = forced_env ? atoi(forced_env) : -1;
-    static const bool frag_pipe = getenv("STORM_FRAG_PIPE") ? atoi(getenv("STORM_FRAG_PIPE")) != 0 : false;
+    const char* dma_env = getenv("STORM_CONV_DMA");                 // A/B switch: 0 = register staging in the 128-cout kernel
+    const bool dma = dma_env ? atoi(dma_env) != 0 : true;
     const long long px_tiles = (long long)a.B * cdiv((long long)a.H * a.W, TILE_H * TILE_W);
     const int variant = forced >= 0 ? forced : ((a.outC > 128 && px_tiles >= 512) ? (any9 && conv_pipe_supports(a) ? 3 : 2) : 0);
     const char* abl_env = getenv("STORM_CONV_ABLATE");
@@ -589,7 +656,7 @@ static int dispatch_conv(const storm_conv_args& a, hipStream_t st) {
         if ((variant == 3 || variant == 4) && conv_pipe_supports(a)) return launch_conv_pipe(a, st, variant == 4 ? 1 : 2);
         if (variant == 2) return launch_conv<T, 9, 2, 4, 2, true>(a, st);
         if (variant == 1) return launch_conv<T, 9, 2, 2, 4, false>(a, st);
-        return frag_pipe ? launch_conv<T, 9, 2, 2, 2, false, true>(a, st) : launch_conv<T, 9, 2, 2, 2, false, false>(a, st);
+        return dma ? launch_conv<T, 9, 2, 2, 2, false, true>(a, st) : launch_conv<T, 9, 2, 2, 2, false, false>(a, st);
     }
     if (small) return launch_conv<T, 1, 1, 1, 4, false>(a, st);
     if (variant == 2) return launch_conv<T, 1, 2, 4, 2, true>(a, st);

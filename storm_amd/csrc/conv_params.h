@@ -60,6 +60,54 @@ __device__ __forceinline__ uint4 buf_load16(const BufRsrc& b, uint32_t voff, uin
 #endif
 }
 
+// ---- LDS-DMA primitives shared by the convolution kernels ------------------------------------------------
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+// Raw buffer resource (stride 0): reads past num_records return zeros (and write zeros to LDS).
+__device__ __forceinline__ u32x4 make_srd(const void* base, uint32_t bytes) {
+    const uint64_t p = reinterpret_cast<uint64_t>(base);
+    u32x4 r;
+#if defined(__HIP_DEVICE_COMPILE__)
+    r[0] = __builtin_amdgcn_readfirstlane((uint32_t)p);
+    r[1] = __builtin_amdgcn_readfirstlane((uint32_t)(p >> 32) & 0xffffu);
+    r[2] = __builtin_amdgcn_readfirstlane(bytes);
+    r[3] = 0x00020000u;
+#else
+    r[0] = (uint32_t)p; r[1] = (uint32_t)(p >> 32); r[2] = bytes; r[3] = 0;
+#endif
+    return r;
+}
+// ---- asynchronous copy (inline asm on the device; synchronous on the host simulator) --------------------
+// 16 B per lane: buffer (srd) at voff + soff  ->  LDS at (uniform lds_wave + 16 * lane).
+__device__ __forceinline__ void dma16(u32x4 srd, uint32_t voff, uint32_t soff, char* lds_wave, int lane) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    (void)lane;
+    const uint32_t la = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)lds_wave);
+    // M0 is written and consumed inside this one statement (the compiler keeps nothing live in M0 in this kernel)
+    asm volatile("s_mov_b32 m0, %3\n\ts_nop 0\n\tbuffer_load_dwordx4 %0, %1, %2 offen lds"
+                 :: "v"(voff), "s"(srd), "s"(soff), "s"(la) : "memory");
+#else
+    const uint64_t off = (uint64_t)voff + soff;
+    const char* base = reinterpret_cast<const char*>(((uint64_t)srd[1] << 32) | srd[0]);
+    if (off + 16 <= srd[2]) memcpy(lds_wave + 16 * lane, base + off, 16);
+    else memset(lds_wave + 16 * lane, 0, 16);
+#endif
+}
+template <int N> __device__ __forceinline__ void vm_wait() {
+#if defined(__HIP_DEVICE_COMPILE__)
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+#elif defined(STORM_HOST_SIM)
+    simrt::wave_rendezvous();          // simulator lanes are not in lockstep: every lane's copy is done past this point
+#endif
+}
+// workgroup barrier WITHOUT a vmcnt drain: LDS traffic of this wave retired (lgkmcnt), loads keep flying
+__device__ __forceinline__ void raw_barrier() {
+#if defined(__HIP_DEVICE_COMPILE__)
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+#else
+    __syncthreads();
+#endif
+}
+
 // y = act(x * scale + shift) on the 16-byte slot held in `v` (GroupNorm-apply + SiLU fused into the
 // operand load: the normalised tensor is never written to HBM).
 __device__ __forceinline__ uint4 gn_act_slot(uint4 v, const float (&ss)[16], int silu, bf16_t*) {

@@ -38,14 +38,13 @@ namespace storm {
 using namespace cidx;
 
 namespace pipe {
-typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 
 constexpr int PW = Geo<9>::PW, NPIX = Geo<9>::NPIX;
 constexpr int WROW = 64;                                      // bytes per weight row and phase (two k-groups)
 constexpr int RING = 4;
 constexpr int SS_BYTES = 1024;                                // one wave-instruction: (scale, shift) of a chunk's channels + pad
 constexpr int PR = 2;                                         // pixel rows (of 32 px) staged per epilogue pass and wave
-constexpr uint32_t OOB = 0x80000000u;                         // per-lane offset that is out of range of every buffer here
+constexpr uint32_t OOB = BUF_OOB;                             // per-lane offset that is out of range of every buffer here
 
 // Kernel geometry.  BN output channels x (8 x 32) pixels per workgroup; PIXB bytes of channels per pixel and K-chunk.
 //   <256, 128, 4, 2>: 8 waves (2 / SIMD, 256 registers each), 64 x 128 per wave, the two waves of a SIMD ping-pong
@@ -87,51 +86,6 @@ template <int PIXB> STORM_HD int p_swz(int px, int slot) {
     return PIXB == 128 ? (slot ^ ((px >> 1) & 7)) << 4 : (slot ^ ((px >> 2) & 3)) << 4;     // 64-B rows: 4 slots
 }
 
-// Raw buffer resource (stride 0): reads past num_records return zeros (and write zeros to LDS).
-__device__ __forceinline__ u32x4 make_srd(const void* base, uint32_t bytes) {
-    const uint64_t p = reinterpret_cast<uint64_t>(base);
-    u32x4 r;
-#if defined(__HIP_DEVICE_COMPILE__)
-    r[0] = __builtin_amdgcn_readfirstlane((uint32_t)p);
-    r[1] = __builtin_amdgcn_readfirstlane((uint32_t)(p >> 32) & 0xffffu);
-    r[2] = __builtin_amdgcn_readfirstlane(bytes);
-    r[3] = 0x00020000u;
-#else
-    r[0] = (uint32_t)p; r[1] = (uint32_t)(p >> 32); r[2] = bytes; r[3] = 0;
-#endif
-    return r;
-}
-// ---- asynchronous copy (inline asm on the device; synchronous on the host simulator) --------------------
-// 16 B per lane: buffer (srd) at voff + soff  ->  LDS at (uniform lds_wave + 16 * lane).
-__device__ __forceinline__ void dma16(u32x4 srd, uint32_t voff, uint32_t soff, char* lds_wave, int lane) {
-#if defined(__HIP_DEVICE_COMPILE__)
-    (void)lane;
-    const uint32_t la = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)lds_wave);
-    // M0 is written and consumed inside this one statement (the compiler keeps nothing live in M0 in this kernel)
-    asm volatile("s_mov_b32 m0, %3\n\ts_nop 0\n\tbuffer_load_dwordx4 %0, %1, %2 offen lds"
-                 :: "v"(voff), "s"(srd), "s"(soff), "s"(la) : "memory");
-#else
-    const uint64_t off = (uint64_t)voff + soff;
-    const char* base = reinterpret_cast<const char*>(((uint64_t)srd[1] << 32) | srd[0]);
-    if (off + 16 <= srd[2]) memcpy(lds_wave + 16 * lane, base + off, 16);
-    else memset(lds_wave + 16 * lane, 0, 16);
-#endif
-}
-template <int N> __device__ __forceinline__ void vm_wait() {
-#if defined(__HIP_DEVICE_COMPILE__)
-    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
-#elif defined(STORM_HOST_SIM)
-    simrt::wave_rendezvous();          // simulator lanes are not in lockstep: every lane's copy is done past this point
-#endif
-}
-// workgroup barrier WITHOUT a vmcnt drain: LDS traffic of this wave retired (lgkmcnt), loads keep flying
-__device__ __forceinline__ void raw_barrier() {
-#if defined(__HIP_DEVICE_COMPILE__)
-    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-#else
-    __syncthreads();
-#endif
-}
 __device__ __forceinline__ void prio(int p) {
 #if defined(__HIP_DEVICE_COMPILE__)
     if (p) __builtin_amdgcn_s_setprio(1); else __builtin_amdgcn_s_setprio(0);
