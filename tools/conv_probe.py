@@ -26,6 +26,8 @@ cases = [("c256_128x256", 256, 256, 128, 256), ("c128_256x512", 128, 128, 256, 5
 import os  # noqa: E402
 if os.environ.get("PROBE_SMALL"):       # the low-resolution layers: fewer tiles than CUs x 2
     cases = [("c256_32x64", 256, 256, 32, 64), ("c512_32x64", 512, 256, 32, 64), ("c256_64x128", 256, 256, 64, 128)]
+if os.environ.get("PROBE_NARROW"):      # the output-pyramid convolutions (4 output channels): HBM-bound
+    cases = [("c128to4_256x512", 128, 4, 256, 512), ("c256to4_128x256", 256, 4, 128, 256), ("c8to128_256x512", 8, 128, 256, 512)]
 if os.environ.get("PROBE_KSWEEP"):      # fixed output tile work, growing K: separates per-tile from per-phase cost
     cases = [(f"k{c}_256_128x256", c, 256, 128, 256) for c in (64, 128, 256, 512)] + [(f"k{c}_128_256x512", c, 128, 256, 512) for c in (32, 64, 128, 256)]
 for name, cin, cout, H, W in cases:

@@ -1,0 +1,40 @@
+#!/usr/bin/env python
+"""Race screen at the bench shape: the full 27.8 M-parameter score network (batch 16, 256 x 512, bf16) is evaluated
+repeatedly on the same input; any timing-dependent hazard in the LDS-DMA / counted-vmcnt pipelines shows up as a
+bitwise difference between repetitions.  Also repeats a seeded 2-step sampler run."""
+import sys
+
+import torch
+
+sys.path.insert(0, ".")
+from oracle import ncsnpp_ref as NR  # noqa: E402  (test infrastructure: seeded weights only)
+from storm_amd.model import ScoreModel  # noqa: E402
+
+reps = int(sys.argv[1]) if len(sys.argv) > 1 else 10
+dev = torch.device("cuda:0")
+m = ScoreModel(backbone="ncsnpp", sde="ouve", theta=1.5, sigma_min=0.05, sigma_max=0.5, spec_factor=0.15, spec_abs_exponent=0.5)
+m.dnn.load_state_dict(NR.seeded_state_dict(NR.NCSNppConfig(), seed=7))
+m._error_loading_ema = True
+m = m.eval().to(dev)
+m.set_precision("bf16")
+g = torch.Generator().manual_seed(0)
+x = torch.randn(16, 1, 256, 512, dtype=torch.complex64, generator=g).to(dev)
+y = torch.randn(16, 1, 256, 512, dtype=torch.complex64, generator=g).to(dev)
+t = torch.linspace(0.1, 0.9, 16).to(dev)
+bad = 0
+with torch.no_grad():
+    ref = m(x, t, y).clone()
+    for i in range(reps):
+        out = m(x, t, y)
+        if not torch.equal(out, ref):
+            bad += 1
+            print("forward repetition", i, "differs: max", float((out - ref).abs().max()))
+    wav = (0.1 * torch.randn(16, 32000, generator=g)).to(dev)
+    w0 = m.enhance_batch(wav, N=2, corrector="ald", snr=0.5, seed=11).clone()
+    for i in range(max(2, reps // 5)):
+        w1 = m.enhance_batch(wav, N=2, corrector="ald", snr=0.5, seed=11)
+        if not torch.equal(w0, w1):
+            bad += 1
+            print("sampler repetition", i, "differs: max", float((w0 - w1).abs().max()))
+print("finite:", bool(torch.isfinite(ref.abs()).all()), " RESULT", "FAIL" if bad else "PASS")
+sys.exit(1 if bad else 0)
