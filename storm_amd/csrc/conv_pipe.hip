@@ -304,6 +304,11 @@ void conv_pipe_kernel(const ConvParams a, const int n_ct, const int tiles_per_xc
             for (int ni = 0; ni < WN; ++ni) Mma<T>::run(fa[mi], fb[ni], acc[mi][ni]);
     };
 
+    auto mma_part = [&](const Frag (&fa)[WM], const Frag (&fb)[WN], int lo, int hi) {   // MFMAs lo..hi-1 of the k-group's WM x WN
+#pragma unroll
+        for (int i = 0; i < WM * WN; ++i)
+            if (i >= lo && i < hi) Mma<T>::run(fa[i / WN], fb[i % WN], acc[i / WN][i % WN]);
+    };
     int r = 0, ch = 0, nch_r = chunks_of(0), ci = 0;
     Chunk cur = get_chunk(0, 0);
     Frag fa0[WM], fb0[WN], fa1[WM], fb1[WN];
@@ -345,9 +350,11 @@ void conv_pipe_kernel(const ConvParams a, const int n_ct, const int tiles_per_xc
             stamp(8 + 16 * step);
             __builtin_amdgcn_sched_barrier(0);
             if (!(ABL & 1)) prio(1);
-            read_frags(fa1, fb1, P, 1);
-            __builtin_amdgcn_sched_barrier(0);                  // all six reads in flight before the first MFMA
-            mma(fa0, fb0);
+            mma_part(fa0, fb0, 0, 2);                           // the matrix pipe starts at once (operands were read in S) ...
+            __builtin_amdgcn_sched_barrier(0);
+            read_frags(fa1, fb1, P, 1);                         // ... the second k-group's reads issue in its shadow
+            __builtin_amdgcn_sched_barrier(0);
+            mma_part(fa0, fb0, 2, WM * WN);
             mma(fa1, fb1);
             __builtin_amdgcn_sched_barrier(0);
             if (!(ABL & 1)) prio(0);
@@ -383,9 +390,11 @@ void conv_pipe_kernel(const ConvParams a, const int n_ct, const int tiles_per_xc
             stamp(13 + 16 * step);
             __builtin_amdgcn_sched_barrier(0);
             if (!(ABL & 1)) prio(1);
+            mma_part(fa0, fb0, 0, 2);
+            __builtin_amdgcn_sched_barrier(0);
             read_frags(fa1, fb1, P + 1, 3);
             __builtin_amdgcn_sched_barrier(0);
-            mma(fa0, fb0);
+            mma_part(fa0, fb0, 2, WM * WN);
             mma(fa1, fb1);
             pcur = tap_base(par_n, tapoff, dx_n);               // next tap-step's patch offsets (a handful of VALU)
             __builtin_amdgcn_sched_barrier(0);

@@ -72,31 +72,23 @@ print(f"variant {variant}: {ms:.3f} ms, {nb} workgroups x {nwaves} waves, span {
 if variant == 3:
     raw = t[:, :, 4:4 + 16 * 30].reshape(nb, nwaves, 30, 16)
     steps = int((raw[0, 0, :, 0] > 0).sum())
-    st = raw[:, :, :steps, :12]
+    idx = [0, 2, 4, 6, 7, 8, 9, 10, 11]       # stamps written per tap-step (slot 4 + 16 * step + idx)
+    st = raw[:, :, :steps][..., idx]
     us3 = lambda d: d * tick_ns / 1e3  # noqa: E731
-    names = ["h0 S: weight DMA issue", "h0 S: tap offsets + k-group 0 reads issue", "h0 S: vmcnt wait", "h0 S: lgkmcnt + barrier",
-             "h0 C: k-group 1 reads + 8 MFMA", "h0 C: 8 MFMA", "h0 C: lgkmcnt + barrier",
-             "h1 S: [commit] DMA issue, cursor, [patch DMA]", "h1 S: reads, vmcnt, lgkmcnt + barrier", "h1 C: reads + 16 MFMA",
-             "h1 C: lgkmcnt + barrier"]
+    names = ["S(h0): reads, weight DMA issue, vmcnt", "S(h0): lgkmcnt + barrier", "C(h0): reads + 16 MFMA", "C(h0): lgkmcnt + barrier",
+             "S(h1): reads, [commit], DMA issue, tap bookkeeping", "S(h1): vmcnt + lgkmcnt + barrier", "C(h1): reads + 16 MFMA",
+             "C(h1): lgkmcnt + barrier"]
     print(f"per wave, first {steps} tap-steps (us; tick->us calibrated on the launch; every stamp costs ~0.09 us itself):")
     for gname, sel in (("g0 (waves 0-3)", slice(0, 4)), ("g1 (waves 4-7)", slice(4, 8))):
         print(f" {gname}: tile total {us3((t[:, sel, 503] - t[:, sel, 1]).mean()):.2f}, prologue {us3((t[:, sel, 2] - t[:, sel, 1]).mean()):.2f}")
         for i, nm in enumerate(names):
             d = us3((st[:, sel, :, i + 1] - st[:, sel, :, i]).astype(np.float64))
-            print(f"   {nm:48s} mean/step {d.mean():7.3f}   p10 {np.percentile(d, 10):7.3f}   p90 {np.percentile(d, 90):7.3f}")
-        adv = us3((st[:, sel, 1:, 0] - st[:, sel, :-1, 11]).astype(np.float64))
-        print(f"   {'loop advance (to next step)':48s} mean/step {adv.mean():7.3f}   p10 {np.percentile(adv, 10):7.3f}   p90 {np.percentile(adv, 90):7.3f}")
+            print(f"   {nm:52s} mean/step {d.mean():7.3f}   p10 {np.percentile(d, 10):7.3f}   p90 {np.percentile(d, 90):7.3f}")
+        adv = us3((st[:, sel, 1:, 0] - st[:, sel, :-1, 8]).astype(np.float64))
+        print(f"   {'loop tail (cursor, chunk change) -> next step':52s} mean/step {adv.mean():7.3f}   p10 {np.percentile(adv, 10):7.3f}   p90 {np.percentile(adv, 90):7.3f}")
         whole = us3((st[:, sel, 1:, 0] - st[:, sel, :-1, 0]).astype(np.float64))
-        print(f"   {'whole step':48s} mean      {whole.mean():7.3f}")
+        print(f"   {'whole step':52s} mean      {whole.mean():7.3f}")
     print(f" epilogue: drain+barrier {us3((t[:, :, 501] - t[:, :, 500]).mean()):.2f}, transpose+stores {us3((t[:, :, 502] - t[:, :, 501]).mean()):.2f}, store drain {us3((t[:, :, 503] - t[:, :, 502]).mean()):.2f}")
-    order = np.argsort(t[:, 0, 503] - t[:, 0, 1])
-    mid = order[len(order) // 2]
-    print(f"median workgroup (index {mid}), wave 0 | wave 4, steps 2..13: the 11 segments above + advance")
-    for s_ in range(2, min(steps - 1, 14)):
-        a_, b_ = st[mid, 0], st[mid, 4]
-        fa = " ".join("%5.2f" % us3(a_[s_, i + 1] - a_[s_, i]) for i in range(11)) + " %5.2f" % us3(a_[s_ + 1, 0] - a_[s_, 11])
-        fb = " ".join("%5.2f" % us3(b_[s_, i + 1] - b_[s_, i]) for i in range(11)) + " %5.2f" % us3(b_[s_ + 1, 0] - b_[s_, 11])
-        print(f"  {s_:2d}: {fa} | {fb}")
     sys.exit(0)
 steps = int(((t[0, 0, 4:400].reshape(-1, 4)[:, 0]) > 0).sum())
 nchunks = int((t[0, 0, 400:500].reshape(-1, 4)[:, 0] > 0).sum())
