@@ -219,14 +219,22 @@ void conv_pipe_kernel(const ConvParams a, const int n_ct, const int tiles_per_xc
     };
 
     // ---- patch staging ---------------------------------------------------------------------------------
+    // Who fetches patches: in the ping-pong layout only the LAGGING group (waves 4-7).  Its staging interval S(P0) of a
+    // chunk's first phase is the first interval in which the other patch buffer is free (the group itself read it last,
+    // one interval earlier), so the DMA starts a whole phase earlier than the leading group could start it - which
+    // is what hides the latency for two-phase (1x1 shortcut) chunks.
+    constexpr int PW0 = NWAVES == 8 ? 4 : 0, PNW = NWAVES == 8 ? 4 : NWAVES;
+    constexpr int PUU = (PPIECES + PNW - 1) / PNW, NPP = PUU + 1;        // pieces / VMEM instructions per fetching wave
+    static_assert(PUU * PNW - PPIECES < PNW && PUU <= 31, "patch pieces");
+    const bool patcher = wave >= PW0;
     uint32_t pmask = 0;                        // bit i: unit i of this lane is real input (needs the GN transform)
     auto patch_issue = [&](const Chunk& c, int parity) {
         char* dst = smem + parity * PATCH_BYTES;
         const uint32_t so = (uint32_t)c.cbeg * 2u;
 #pragma unroll
-        for (int i = 0; i < PU; ++i) {
-            int k = wave + i * NWAVES;                           // piece: patch rows 8k .. 8k+7
-            if (k >= PPIECES) k -= NWAVES;                       // surplus slot: same piece again (keeps the VMEM count uniform)
+        for (int i = 0; i < PUU; ++i) {
+            int k = (wave - PW0) + i * PNW;                      // piece: patch rows 8k .. 8k+7
+            if (k >= PPIECES) k -= PNW;                          // surplus slot: same piece again (keeps the VMEM count uniform)
             const int row = k * RPP + lane / SLOTS;
             const int py = row / PW, px = row - py * PW;
             const int slot = p_swz<PIXB>(px, lane % SLOTS) >> 4;  // logical 16-B slot that lands in physical slot lane % SLOTS
@@ -240,8 +248,8 @@ void conv_pipe_kernel(const ConvParams a, const int n_ct, const int tiles_per_xc
     auto patch_commit = [&](const Chunk& c, int parity) {   // only with a fused GroupNorm: in place, own units
         char* dst = smem + parity * PATCH_BYTES;
 #pragma unroll
-        for (int i = 0; i < PU; ++i) {
-            const int k = wave + i * NWAVES;
+        for (int i = 0; i < PUU; ++i) {
+            const int k = (wave - PW0) + i * PNW;
             if (k < PPIECES && ((pmask >> i) & 1u)) {
                 const int row = k * RPP + lane / SLOTS;
                 const int slot = p_swz<PIXB>(row % PW, lane % SLOTS) >> 4;
@@ -315,9 +323,9 @@ void conv_pipe_kernel(const ConvParams a, const int n_ct, const int tiles_per_xc
     if constexpr (NWAVES == 8) {
         // ---- prologue: first patch, first step's weights --------------------------------------------------
         w_issue(0, 0); w_issue(1, 1); w_advance();
-        patch_issue(cur, 0);
+        if (patcher) patch_issue(cur, 0);
         vm_wait<0>();
-        if (cur.gn) patch_commit(cur, 0);
+        if (patcher && cur.gn) patch_commit(cur, 0);
         raw_barrier();
         const int grp = (ABL & 2) ? 0 : wave >> 2;        // (ABL & 2: profiling variant without the stagger)
         if (grp == 1) raw_barrier();
@@ -325,7 +333,7 @@ void conv_pipe_kernel(const ConvParams a, const int n_ct, const int tiles_per_xc
 
         // ---- main loop: one iteration = one tap-step = phases P (half 0) and P+1 (half 1) ------------------
         int P = 0, tp = 0, step = 0, steps_left = pin(total_steps);
-        bool has_nc, commit_pending = false;
+        bool has_nc;
         Chunk nxt = cur;
         {
             int nr = r, nc = ch + 1;
@@ -343,8 +351,11 @@ void conv_pipe_kernel(const ConvParams a, const int n_ct, const int tiles_per_xc
             stamp(4 + 16 * step);
             read_frags(fa0, fb0, P, 0);
             w_issue(P + 2, 0);
+            if (patcher && tp == 0 && has_nc) {                 // first phase of a chunk: fetch the next chunk's patch
+                patch_issue(nxt, par ^ 1);
+                vm_wait<2 + NPP>();
+            } else vm_wait<2>();
             stamp(6 + 16 * step);
-            vm_wait<2>();                                       // (also retires a patch issued last phase: once per chunk)
             raw_barrier();
             // ================= C(P) =================
             stamp(8 + 16 * step);
@@ -363,15 +374,7 @@ void conv_pipe_kernel(const ConvParams a, const int n_ct, const int tiles_per_xc
             stamp(11 + 16 * step);
             // ================= S(P+1), half 1 =================
             read_frags(fa0, fb0, P + 1, 2);
-            if (commit_pending && tp == 1) {                    // 9-tap chunk: the patch was issued two phases ago
-                if (nxt.gn) { vm_wait<2>(); patch_commit(nxt, par ^ 1); }
-                commit_pending = false;
-            }
             w_issue(P + 3, 1);
-            // The other patch buffer was read until the lagging group's C(P0 - 1), which shares its interval with the
-            // leading group's S(P0): the DMA into it starts in the chunk's SECOND phase.
-            const bool issue_now = tp == 0 && has_nc;
-            if (issue_now) { patch_issue(nxt, par ^ 1); commit_pending = ntaps != 1; }
             const bool last = --steps_left == 0;
             const int tpn = tp + 1;
             const bool wrap = tpn == ntaps;
@@ -381,10 +384,8 @@ void conv_pipe_kernel(const ConvParams a, const int n_ct, const int tiles_per_xc
             tapdx = (row_end || wrap) ? 0 : tapdx + 1;
             const int par_n = wrap ? par ^ 1 : par, dx_n = wrap ? (nxt.ntaps == 9 ? 0 : 1) : (ntaps == 9 ? tapdx : 1);
             stamp(12 + 16 * step);
-            if (issue_now && ntaps == 1) {                      // two-phase chunk: the next phase already reads the patch
-                vm_wait<0>();
-                if (nxt.gn) patch_commit(nxt, par ^ 1);
-            } else if (issue_now) vm_wait<2 + NP>(); else vm_wait<2>();
+            vm_wait<2>();                                       // this phase's successor weights AND a patch fetched in S(P) have landed
+            if (patcher && tp == 0 && has_nc && nxt.gn) patch_commit(nxt, par ^ 1);   // fused GroupNorm: in place, own units
             raw_barrier();
             // ================= C(P+1) =================
             stamp(13 + 16 * step);

@@ -28,8 +28,27 @@ if os.environ.get("PROBE_SMALL"):       # the low-resolution layers: fewer tiles
     cases = [("c256_32x64", 256, 256, 32, 64), ("c512_32x64", 512, 256, 32, 64), ("c256_64x128", 256, 256, 64, 128)]
 if os.environ.get("PROBE_NARROW"):      # the output-pyramid convolutions (4 output channels): HBM-bound
     cases = [("c128to4_256x512", 128, 4, 256, 512), ("c256to4_128x256", 256, 4, 128, 256), ("c8to128_256x512", 8, 128, 256, 512)]
+if os.environ.get("PROBE_SHORTCUT"):    # Conv_1 of a BigGAN block: 3x3 over h + fused 1x1 shortcut over x (two-phase K-chunks)
+    cases = []
 if os.environ.get("PROBE_KSWEEP"):      # fixed output tile work, growing K: separates per-tile from per-phase cost
     cases = [(f"k{c}_256_128x256", c, 256, 128, 256) for c in (64, 128, 256, 512)] + [(f"k{c}_128_256x512", c, 128, 256, 512) for c in (32, 64, 128, 256)]
+if os.environ.get("PROBE_SHORTCUT"):
+    for name, cin, cout, H, W in [("sc256_128x256", 256, 256, 128, 256), ("sc256_256x512", 256, 256, 256, 512)]:
+        x = rnd(args.B, H, W, cin).to(dt).to(dev); xs = rnd(args.B, H, W, cin).to(dt).to(dev)
+        w = ops.pack_conv_weight((rnd(cout, cin, 3, 3) * 0.05).to(dev), dt)
+        ws = ops.pack_conv_weight((rnd(cout, cin, 1, 1) * 0.05).to(dev), dt)
+        b = rnd(cout).to(dev)
+        segs = [ops.Seg(x, w, 9), ops.Seg(xs, ws, 1)]
+        for _ in range(args.reps):
+            y = ops.conv(segs, cout, bias=b)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(args.reps):
+            y = ops.conv(segs, cout, bias=b)
+        torch.cuda.synchronize()
+        ms = (time.perf_counter() - t0) / args.reps * 1e3
+        fl = 2 * args.B * H * W * cout * cin * 10
+        print(f"{name}: {ms:.3f} ms  {fl / ms / 1e9:.0f} TF")
 for name, cin, cout, H, W in cases:
     x = rnd(args.B, H, W, cin).to(dt).to(dev)
     w = ops.pack_conv_weight((rnd(cout, cin, 3, 3) * 0.05).to(dev), dt)
