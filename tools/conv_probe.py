@@ -38,17 +38,22 @@ if os.environ.get("PROBE_SHORTCUT"):
         w = ops.pack_conv_weight((rnd(cout, cin, 3, 3) * 0.05).to(dev), dt)
         ws = ops.pack_conv_weight((rnd(cout, cin, 1, 1) * 0.05).to(dev), dt)
         b = rnd(cout).to(dev)
-        segs = [ops.Seg(x, w, 9), ops.Seg(xs, ws, 1)]
-        for _ in range(args.reps):
-            y = ops.conv(segs, cout, bias=b)
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        for _ in range(args.reps):
-            y = ops.conv(segs, cout, bias=b)
-        torch.cuda.synchronize()
-        ms = (time.perf_counter() - t0) / args.reps * 1e3
-        fl = 2 * args.B * H * W * cout * cin * 10
-        print(f"{name}: {ms:.3f} ms  {fl / ms / 1e9:.0f} TF")
+        _, part = ops.conv([ops.Seg(x, ops.pack_conv_weight(torch.eye(cin).reshape(cin, cin, 1, 1).to(dev), dt), 1)], cin, gn_partials=True)
+        _, ss = ops.gn_finalize(part, gamma=(1 + 0.1 * rnd(cin)).to(dev), beta=(0.1 * rnd(cin)).to(dev), count=H * W)
+        for tag, segs, kw in [("plain", [ops.Seg(x, w, 9), ops.Seg(xs, ws, 1)], {}),
+                              ("gn", [ops.Seg(x, w, 9, gn_ss=ss, gn_silu=True), ops.Seg(xs, ws, 1)], {}),
+                              ("gn+stats", [ops.Seg(x, w, 9, gn_ss=ss, gn_silu=True), ops.Seg(xs, ws, 1)], dict(gn_partials=True, scale=0.7)),
+                              ("gn+stats, no shortcut", [ops.Seg(x, w, 9, gn_ss=ss, gn_silu=True)], dict(gn_partials=True, scale=0.7))]:
+            for _ in range(args.reps):
+                y = ops.conv(segs, cout, bias=b, **kw)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(args.reps):
+                y = ops.conv(segs, cout, bias=b, **kw)
+            torch.cuda.synchronize()
+            ms = (time.perf_counter() - t0) / args.reps * 1e3
+            fl = 2 * args.B * H * W * cout * cin * (9 + (len(segs) - 1))
+            print(f"{name} [{tag}]: {ms:.3f} ms  {fl / ms / 1e9:.0f} TF")
 for name, cin, cout, H, W in cases:
     x = rnd(args.B, H, W, cin).to(dt).to(dev)
     w = ops.pack_conv_weight((rnd(cout, cin, 3, 3) * 0.05).to(dev), dt)
