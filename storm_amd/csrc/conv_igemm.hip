@@ -10,9 +10,14 @@
 //     16-byte contiguous along the channel (K) axis -> ds_read_b128 fragments, no transposes.
 //   * per K-chunk (128 B of channels per pixel) the haloed 10x34 input patch is staged ONCE in
 //     LDS and reused by all nine taps (9x fewer L2->LDS bytes than im2col);  weight tiles
-//     [BN][chunk] stream per tap through a 2-deep LDS ring, prefetched into registers during
-//     the MFMAs of the previous tap (one barrier per tap).
-//   * LDS rows are XOR-swizzled (conv_index.h) so every ds_read_b128 group is conflict free.
+//     [BN][chunk] stream per tap through a 2-deep LDS ring (one barrier per tap).
+//   * staging: the main 3x3 instantiation copies both operands global -> LDS with `buffer_load ... lds`
+//     (LDS-DMA: bank swizzle on the per-lane source offset, out-of-range offsets = hardware zero fill, the next
+//     weight tile lands under the MFMAs of the current tap, one memory round trip per patch, fused GroupNorm
+//     = in-place rewrite of a lane's own units); the other instantiations (1x1 / GEMM, prefetching 256-cout
+//     tile, fp32 parity path through STORM_CONV_DMA=0) stage through registers with branch-free raw-buffer loads.
+//   * LDS rows are XOR-swizzled (conv_index.h) so every ds_read_b128 group is conflict free; the patch image is
+//     swizzled by pixel COLUMN, so a k-group's fragment addresses are ONE VGPR plus instruction immediates.
 //   * ~75 KB LDS and <=256 VGPR per workgroup -> 2 workgroups / CU so one group's staging
 //     overlaps the other's MFMA phase; block ids are mapped so each XCD's L2 sees a contiguous
 //     run of pixel tiles and both cout halves of a tile.

@@ -11,25 +11,32 @@
 //     moving part - tap, chunk, half - is the scalar offset) and again on the fragment read.
 //   * the haloed 10 x 34 pixel patch of a K-chunk is double buffered and fetched the same way, raw, straight into
 //     the other buffer; padding pixels / channels past the run are out-of-range buffer reads = hardware zeros.
-//     With a fused GroupNorm-apply + SiLU every lane then rewrites the 16-byte units it fetched itself in place
-//     (scale / shift table fetched to LDS alongside).
+//     The patch image is swizzled by pixel COLUMN, so a tap / pixel row / buffer change is a scalar or instruction
+//     immediate add: one address VGPR per k-group.  With a fused GroupNorm-apply + SiLU every lane then rewrites the
+//     16-byte units it fetched itself in place (scale / shift table fetched to LDS alongside).
 //   * all VMEM of the main loop is inline asm, so the counted `s_waitcnt vmcnt(N)` below are the only waits and
 //     loads stay in flight across the raw s_barriers (a compiler-visible load would drain the queue with
 //     vmcnt(0) at every barrier).  Counting rule: N = number of VMEM instructions this wave issued AFTER the one
 //     that must have landed (they return in order).
 //   * ping-pong: waves 4-7 (the second wave of every SIMD) run one barrier interval behind waves 0-3, so one
 //     group's MFMA interval C coincides with the other's staging interval S and the matrix pipe of a SIMD always
-//     has a wave feeding it.  The hot loop is hand-thinned to ~70 non-MFMA instructions per phase: a SIMD hides
-//     about five of them per MFMA.
+//     has a wave feeding it.  Staging intervals start with the fragment reads and stay well under the 16-MFMA
+//     length of an MFMA interval (a SIMD hides about five non-MFMA instructions per MFMA).
+//   * patches are fetched by the LAGGING group only: its S of a chunk's first phase is the first interval in which
+//     the other patch buffer is free, a whole phase before the leading group could touch it - enough to cover the
+//     DMA latency even for the two-phase chunks of a fused 1x1 shortcut.
 //
-// Phase P = (chunk, tap, half), two k-groups, 16 MFMAs per wave:
-//   S(P): [patch commit]  DMA weights of phase P+2 -> ring slot (P+2)&3  [DMA next chunk's patch]
-//         read k-group 0 of P | vmcnt: own share of phase P+1 landed | barrier
-//   C(P): read k-group 1 | 16 MFMAs | barrier
+// Phase P = (chunk, tap, half), two k-groups, 16 MFMAs per wave; a tap-step = phases (half 0, half 1):
+//   S(P):   read k-group 0 of P | DMA weights of phase P+2 -> ring slot (P+2)&3
+//           [lagging group, first phase of a chunk: DMA the next chunk's patch] | vmcnt | barrier
+//   C(P):   2 MFMAs | read k-group 1 | 14 MFMAs | barrier
+//   S(P+1): as S(P) [lagging group, first tap-step: GroupNorm rewrite of the fetched patch after the vmcnt]
+//   C(P+1): as C(P), plus the next tap's patch offset
 // LDS lifetimes (intervals counted in barriers; group 1 lags by one): phase P's ring slot is read in intervals
 // 2P..2P+2; slot (P+2)&3 = (P-2)&3 was last read in interval 2P-2 -> free in S(P).  The other patch buffer was
-// last read in the interval of S(P0) itself (by the lagging group), P0 = first phase of a chunk -> the DMA into it
-// starts in S(P0+1).
+// last read by the lagging group's C(P0-1) (interval 2P0, P0 = first phase of a chunk), so the lagging group's
+// S(P0) (interval 2P0+1) may overwrite it; the new patch is waited for in its S(P0+1) (interval 2P0+3), i.e. visible
+// from interval 2P0+4 = the leading group's S(P0+2), the first possible reader (two-phase chunk).
 #include <cstdlib>
 #include <cstring>
 #include "conv_params.h"
