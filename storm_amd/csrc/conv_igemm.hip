@@ -15,7 +15,8 @@
 //     (LDS-DMA: bank swizzle on the per-lane source offset, out-of-range offsets = hardware zero fill, the next
 //     weight tile lands under the MFMAs of the current tap, one memory round trip per patch, fused GroupNorm
 //     = in-place rewrite of a lane's own units); the other instantiations (1x1 / GEMM, prefetching 256-cout
-//     tile, fp32 parity path through STORM_CONV_DMA=0) stage through registers with branch-free raw-buffer loads.
+//     tile, and the register-staged build kept behind STORM_CONV_DMA=0) stage through registers with branch-free
+//     raw-buffer loads.
 //   * LDS rows are XOR-swizzled (conv_index.h) so every ds_read_b128 group is conflict free; the patch image is
 //     swizzled by pixel COLUMN, so a k-group's fragment addresses are ONE VGPR plus instruction immediates.
 //   * ~75 KB LDS and <=256 VGPR per workgroup -> 2 workgroups / CU so one group's staging
