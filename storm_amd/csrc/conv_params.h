@@ -2,6 +2,10 @@
 // MFMA wrappers and the fused GroupNorm-apply slot transform.
 #pragma once
 #include <cstring>
+#if defined(STORM_HOST_SIM)
+#include <cstdlib>
+#include <vector>
+#endif
 #include "common.h"
 #include "conv_index.h"
 
@@ -60,6 +64,29 @@ __device__ __forceinline__ uint4 buf_load16(const BufRsrc& b, uint32_t voff, uin
 #endif
 }
 
+#if defined(STORM_HOST_SIM)
+// Host simulation of the asynchronous LDS-DMA queue (test infrastructure).  Two extremes bracket the hardware:
+//   STORM_SIM_DMA unset : a copy lands the moment it is issued  -> exposes write-after-read hazards (a DMA issued
+//                         while another wave may still read the destination);
+//   STORM_SIM_DMA=late  : a copy lands only when the issuing lane's counted vm_wait<N> retires it (in issue order,
+//                         leaving the N newest in flight)        -> exposes read-after-write hazards (a fragment read
+//                         before the wait + barrier that publishes the data).
+namespace simdma {
+struct Entry { char* dst; char data[16]; };
+inline bool late() { static const bool v = [] { const char* e = getenv("STORM_SIM_DMA"); return e && e[0] == 'l'; }(); return v; }
+inline std::vector<Entry>& queue() {                     // per simulated thread (fibers of a workgroup share an OS thread)
+    static thread_local std::vector<std::vector<Entry>> q(1024);
+    return q[threadIdx.x];
+}
+inline void retire(int keep) {
+    std::vector<Entry>& q = queue();
+    const size_t n = q.size() > (size_t)keep ? q.size() - (size_t)keep : 0;
+    for (size_t i = 0; i < n; ++i) memcpy(q[i].dst, q[i].data, 16);
+    q.erase(q.begin(), q.begin() + (long)n);
+}
+}  // namespace simdma
+#endif
+
 // ---- LDS-DMA primitives shared by the convolution kernels ------------------------------------------------
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 // Raw buffer resource (stride 0): reads past num_records return zeros (and write zeros to LDS).
@@ -85,17 +112,23 @@ __device__ __forceinline__ void dma16(u32x4 srd, uint32_t voff, uint32_t soff, c
     // M0 is written and consumed inside this one statement (the compiler keeps nothing live in M0 in this kernel)
     asm volatile("s_mov_b32 m0, %3\n\ts_nop 0\n\tbuffer_load_dwordx4 %0, %1, %2 offen lds"
                  :: "v"(voff), "s"(srd), "s"(soff), "s"(la) : "memory");
-#else
+#elif defined(STORM_HOST_SIM)
     const uint64_t off = (uint64_t)voff + soff;
     const char* base = reinterpret_cast<const char*>(((uint64_t)srd[1] << 32) | srd[0]);
-    if (off + 16 <= srd[2]) memcpy(lds_wave + 16 * lane, base + off, 16);
-    else memset(lds_wave + 16 * lane, 0, 16);
+    simdma::Entry e;
+    e.dst = lds_wave + 16 * lane;
+    if (off + 16 <= srd[2]) memcpy(e.data, base + off, 16); else memset(e.data, 0, 16);
+    if (simdma::late()) simdma::queue().push_back(e);        // lands at the latest legal moment (see simdma)
+    else memcpy(e.dst, e.data, 16);                          // lands at once
+#else
+    (void)srd; (void)voff; (void)soff; (void)lds_wave; (void)lane;     // (host pass of the device build: never called)
 #endif
 }
 template <int N> __device__ __forceinline__ void vm_wait() {
 #if defined(__HIP_DEVICE_COMPILE__)
     asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
 #elif defined(STORM_HOST_SIM)
+    simdma::retire(N);
     simrt::wave_rendezvous();          // simulator lanes are not in lockstep: every lane's copy is done past this point
 #endif
 }

@@ -396,3 +396,20 @@ def test_conv_fused_groupnorm_apply(dev, dtype):
     a = NR.silu(NR.group_norm(xcat, gam, bet))
     ref = F.conv2d(q(a, dtype), q(w, dtype), padding=1)
     assert rel_l2(nchw(y.float().cpu()), ref) < tol(dtype, 5e-6, 1e-2)
+
+
+def test_conv_wait_placement_under_late_dma_landing():
+    """The LDS-DMA kernels again, with the simulator's DMA queue in its 'late' mode: a copy becomes visible only when
+    the issuing lane's counted vm_wait retires it, so a fragment read placed before the wait + barrier that publishes
+    its data reads stale LDS and fails parity.  (The default mode lands copies at once, which exposes the opposite,
+    write-after-read, class of hazards.)  Runs in a subprocess: the mode is fixed per loaded simulator library."""
+    import os
+    import subprocess
+    import sys
+    if os.environ.get("STORM_SIM_DMA") == "late":
+        pytest.skip("already inside the late-landing run")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, STORM_SIM_DMA="late", PYTHONPATH=root)
+    r = subprocess.run([sys.executable, "-m", "pytest", os.path.join(root, "tests", "test_ops.py"), "-q", "-x", "-m", "not gpu",
+                        "-k", "conv and not late_dma", "-p", "no:cacheprovider"], env=env, capture_output=True, text=True, timeout=1500)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-1000:]
