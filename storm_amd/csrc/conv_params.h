@@ -141,6 +141,15 @@ __device__ __forceinline__ void raw_barrier() {
 #endif
 }
 
+// issue priority of this wave (raised around MFMA clusters: the partner wave on the SIMD is staging then)
+__device__ __forceinline__ void prio(int p) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    if (p) __builtin_amdgcn_s_setprio(1); else __builtin_amdgcn_s_setprio(0);
+#else
+    (void)p;
+#endif
+}
+
 // y = act(x * scale + shift) on the 16-byte slot held in `v` (GroupNorm-apply + SiLU fused into the
 // operand load: the normalised tensor is never written to HBM).
 __device__ __forceinline__ uint4 gn_act_slot(uint4 v, const float (&ss)[16], int silu, bf16_t*) {

@@ -93,13 +93,6 @@ template <int PIXB> STORM_HD int p_swz(int px, int slot) {
     return PIXB == 128 ? (slot ^ ((px >> 1) & 7)) << 4 : (slot ^ ((px >> 2) & 3)) << 4;     // 64-B rows: 4 slots
 }
 
-__device__ __forceinline__ void prio(int p) {
-#if defined(__HIP_DEVICE_COMPILE__)
-    if (p) __builtin_amdgcn_s_setprio(1); else __builtin_amdgcn_s_setprio(0);
-#else
-    (void)p;
-#endif
-}
 // keep a wave-uniform value in an SGPR: stops the compiler re-loading it from the kernarg segment (an s_load +
 // lgkmcnt(0) in the hot loop drains the LDS queue as well)
 __device__ __forceinline__ int pin(int x) {
