@@ -50,6 +50,8 @@ def parse():
     p.add_argument("--no-roofline", action="store_true")
     p.add_argument("--profile-nfe", type=int, default=2, help="score evaluations profiled with per-op HIP events")
     p.add_argument("--ops-json", default=None, help="write the per-op timing table of the profiled pass here")
+    p.add_argument("--selftest-cpu", action="store_true",
+                   help="(tests) run the launch / sharding / timing skeleton with a stand-in step on CPU ranks (gloo)")
     return p.parse_args()
 
 
@@ -70,8 +72,9 @@ def randomize(model, seed):
                 p.copy_(0.05 * torch.randn(p.shape, generator=g))
 
 
-def cpu_baseline(backbone, seconds):
-    """One score evaluation of one utterance with the CPU oracle (PyTorch fp32, all host cores)."""
+def cpu_baseline(backbone, seconds, reps=3):
+    """Score evaluations of one utterance with the CPU oracle (PyTorch fp32, all host cores): one warm-up, then the
+    median of `reps`."""
     from oracle import ncsnpp_ref as NR
     cfg = NR.NCSNppConfig(**NR.NAMED_CONFIGS[backbone], input_channels=4)
     sd = NR.seeded_state_dict(cfg, seed=0)
@@ -79,11 +82,15 @@ def cpu_baseline(backbone, seconds):
     g = torch.Generator().manual_seed(0)
     x = torch.randn(1, 2, 256, T, dtype=torch.complex64, generator=g) * 0.3
     t = torch.tensor([0.5])
+    times = []
     with torch.no_grad():
-        t0 = time.perf_counter()
-        NR.ncsnpp_forward(sd, cfg, x, t)
-        dt = time.perf_counter() - t0
-    return dt, torch.get_num_threads()
+        NR.ncsnpp_forward(sd, cfg, x, t)                   # warm-up (allocator, thread pool, page-in)
+        for _ in range(reps):
+            t0 = time.perf_counter()
+            NR.ncsnpp_forward(sd, cfg, x, t)
+            times.append(time.perf_counter() - t0)
+    times.sort()
+    return times[len(times) // 2], times, torch.get_num_threads()
 
 
 def profile_ops(net, Y, nfe_count):
@@ -127,11 +134,53 @@ def profile_ops(net, Y, nfe_count):
     return rows, prog
 
 
+def conv_kernel_names(prog, code):
+    """Kernel name per conv op of a planned program, asked of the LAUNCHER (storm_program_kernel_name): the roofline then
+    names the kernel that really ran instead of a copy of the dispatch rule."""
+    from storm_amd import _lib as L
+    names = {}
+    for k, op in enumerate(prog.ops):
+        if op.code == 4:
+            names[k] = L.lib().storm_program_kernel_name(prog.op_array, k, code).decode()
+    return names
+
+
+def selftest_cpu(args, rank, world):
+    """Launch / sharding / timing skeleton on CPU ranks (gloo) with a stand-in step: what tests/test_distributed.py runs."""
+    import torch.distributed as dist
+    from storm_amd import distributed as D
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+        assert dist.get_world_size() == args.gpus, (dist.get_world_size(), args.gpus)
+    mine = D.shard_indices(args.batch * world, rank, world)
+
+    def step(i):
+        time.sleep(0.02 * (1 + rank))                      # ranks differ: the reported time must be the slowest rank's
+        return len(mine)
+
+    elapsed, per_rank, n = D.timed_steps(step, args.steps, args.warmup)
+    if rank == 0:
+        print(json.dumps({"metric": METRIC, "value": args.batch * world * args.steps / elapsed, "unit": "utterances/s",
+                          "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps,
+                          "selftest": True, "per_rank_s": per_rank, "utterances_per_rank": n}))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
 def main():
     args = parse()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # started without a launcher (`python bench.py --gpus N`): become N ranks of this node, one per GPU
+        from storm_amd.distributed import self_launch
+        self_launch(args.gpus, os.path.abspath(__file__), sys.argv[1:])
     rank = int(os.environ.get("RANK", 0))
     world = int(os.environ.get("WORLD_SIZE", 1))
     local = int(os.environ.get("LOCAL_RANK", 0))
+    assert world == args.gpus, f"--gpus {args.gpus} but the launcher started {world} rank(s)"
+    if args.selftest_cpu:
+        return selftest_cpu(args, rank, world)
     assert torch.cuda.is_available(), "bench.py needs a GPU (no CPU fallback)"
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
@@ -140,7 +189,9 @@ def main():
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        assert dist.get_world_size() == args.gpus
 
+    from storm_amd import distributed as D
     from storm_amd.model import ScoreModel
     model = ScoreModel(backbone=args.backbone, sde="ouve", theta=1.5, sigma_min=0.05, sigma_max=0.5,
                        spec_factor=0.15, spec_abs_exponent=0.5)
@@ -158,54 +209,37 @@ def main():
         return model.enhance_batch(wav, predictor="reverse_diffusion", corrector=args.corrector, N=args.N,
                                    corrector_steps=args.corrector_steps, snr=0.5, seed=1000 * rank + i, return_nfe=True)
 
-    def barrier():
-        torch.cuda.synchronize()
-        if dist is not None:
-            dist.barrier()
-        torch.cuda.synchronize()
-
-    nfe = None
-    for i in range(args.warmup):
-        _, nfe = step(i)
-    barrier()
-    t0 = time.perf_counter()
-    for i in range(args.steps):
-        out, nfe = step(args.warmup + i)
-    barrier()
-    elapsed = time.perf_counter() - t0
-    if dist is not None:
-        tt = torch.tensor([elapsed], device=dev, dtype=torch.float64)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        elapsed = float(tt.item())
+    elapsed, per_rank, (out, nfe) = D.timed_steps(step, args.steps, args.warmup, sync=torch.cuda.synchronize)
     assert torch.isfinite(out).all(), "non-finite output"
     value = args.batch * world * args.steps / elapsed
 
+    cfg_name = {("ncsnpp", 4.0, 30): "configs[1]" if world == 1 else "configs[2]", ("ncsnpplarge", 8.0, 50): "configs[3]"}.get(
+        (args.backbone, float(args.seconds), args.N), "custom")
     result = {
         "metric": METRIC, "value": value, "unit": "utterances/s", "n_gpus": world, "steps": args.steps,
         "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True,
         "scaling": "weak", "vs_baseline": None, "dtype": args.precision, "data": "synthetic",
-        "config": {"workload": f"configs[1]: {args.backbone} batch={args.batch}x{args.seconds:g} s@16 kHz per GPU, "
+        "config": {"workload": f"{cfg_name}: {args.backbone} batch={args.batch}x{args.seconds:g} s@16 kHz per GPU, "
                                f"{args.N}-step PC sampler (reverse_diffusion + {args.corrector} x{args.corrector_steps}), "
-                               f"{args.precision} operands, wav->wav incl. STFT/iSTFT",
+                               f"{args.precision} operands, wav->wav incl. STFT/iSTFT, inputs resident in HBM "
+                               f"(H2D + D2H of {2 * args.batch * L * 4 / 1e6:.1f} MB per step would add < 0.01 %)",
                    "batch_per_gpu": args.batch, "global_batch": args.batch * world, "seconds": args.seconds,
                    "pc_steps": args.N, "nfe_per_utterance": nfe, "parallelism": f"utterance-sharded x{world}"},
         "nfe_per_s": value * nfe, "ms_per_nfe_batch": 1e3 * elapsed / args.steps / nfe,
+        "per_rank_s": [round(t, 4) for t in per_rank],
     }
 
     if rank == 0 and not args.no_roofline:
+        from storm_amd import _lib as LL
         Y, _, _ = model._prepare(wav)
         rows, prog = profile_ops(model.dnn, Y, args.profile_nfe)
-        # the 3x3 implicit-GEMM convolution has two kernels (dispatch rule of conv_igemm.hip): the pipelined
-        #   256 cout x 256 px kernel of conv_pipe.hip when outC > 128 and >= 512 pixel tiles, else 128 cout x 256 px
-        tname = "storm::bf16_t" if args.precision == "bf16" else "float"
-        groups = {}
+        knames = conv_kernel_names(prog, LL.dt(model.dnn.compute_dtype))
+        groups = {}                                        # 3x3 convolutions on the matrix cores, by the kernel the launcher picked
         for r in rows:
-            if r["code"] == 4 and r["big"] and 9 in r["taps"]:
-                v2 = r["Cout"] > 128 and args.batch * ((r["H"] * r["W"] + 255) // 256) >= 512
-                key = ("storm::conv_pipe_kernel<256, 128, 4, 2, 0>" if v2 and args.precision == "bf16"
-                       else f"storm::conv_igemm_kernel<{tname}, 9, 2, 4, 2, true, false, 0>" if v2
-                       else f"storm::conv_igemm_kernel<{tname}, 9, 2, 2, 2, false, false, 0>")
-                groups.setdefault(key, []).append(r)
+            if r["code"] == 4:
+                r["kernel"] = knames[r["idx"]]
+                if r["big"] and 9 in r["taps"]:
+                    groups.setdefault(r["kernel"], []).append(r)
         kname, big = max(groups.items(), key=lambda kv: sum(r["ms"] for r in kv[1]))
         flops, ms = sum(r["flops"] for r in big), sum(r["ms"] for r in big)
         total_ms = sum(r["ms"] for r in rows)
@@ -214,34 +248,43 @@ def main():
         peak = BF16_MFMA_PEAK_TFLOPS if args.precision == "bf16" else F32_MFMA_PEAK_TFLOPS
         ach = flops / (ms * 1e-3) / 1e12
         names = {0: "memset", 1: "pack_input", 2: "temb", 3: "dense", 4: "conv", 5: "gn_stats", 6: "gn_apply",
-                 7: "fir_up", 8: "fir_down", 9: "softmax", 10: "output_head", 11: "gn_finalize"}
+                 7: "fir_up", 8: "fir_down", 9: "softmax", 10: "output_head", 11: "gn_finalize", 12: "attention"}
         by_kind = {}
         for r in rows:
-            by_kind[names[r["code"]]] = by_kind.get(names[r["code"]], 0.0) + r["ms"]
-        traffic = None
-        tpath = os.path.join(ROOT, "profiles", "conv_traffic.json")     # PMC pass (scripts/pmc_round.sh), per launch
+            by_kind[names.get(r["code"], str(r["code"]))] = by_kind.get(names.get(r["code"], str(r["code"])), 0.0) + r["ms"]
+        traffic, tsrc = None, None
+        tpath = os.path.join(ROOT, "profiles", "conv_traffic.json")     # PMC passes of scripts/pmc_bench.sh, per launch
         if os.path.exists(tpath):
-            traffic = json.load(open(tpath)).get(kname.replace("storm::", "").replace(" ", ""), {}).get("hbm_bytes_per_launch")
+            tj = json.load(open(tpath))
+            traffic = tj.get(kname.replace("storm::", "").replace(" ", ""), {}).get("hbm_bytes_per_launch")
+            tsrc = "profiles/conv_traffic.json: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes, FETCH_SIZE x2 per the " \
+                   "gfx950 correction) over this bench command, average per launch of this kernel; not re-measured in this run"
+        by_kernel = {k: {"launches_per_nfe": len(v), "ms_per_nfe": round(sum(r["ms"] for r in v), 3),
+                         "tflops": round(sum(r["flops"] for r in v) / (sum(r["ms"] for r in v) * 1e-3) / 1e12, 1)}
+                     for k, v in groups.items()}
         result["roofline"] = {
             "bound": "mfma", "kernel": kname,
-            "achieved": ach, "peak": peak, "unit": "TFLOP/s", "frac": ach / peak, "traffic": traffic,
+            "achieved": ach, "peak": peak, "unit": "TFLOP/s", "frac": ach / peak, "traffic": traffic, "traffic_source": tsrc,
             "launches_per_nfe": len(big), "avg_launch_ms": ms / len(big), "avg_launch_gflop": flops / len(big) / 1e9,
             "nfe_ms_profiled": total_ms, "ms_by_op_kind": {k: round(v, 3) for k, v in by_kind.items()},
+            "conv3x3_by_kernel": by_kernel,
             "all_3x3_tflops": sum(r["flops"] for r in all3) / (sum(r["ms"] for r in all3) * 1e-3) / 1e12,
             "all_conv_tflops": sum(r["flops"] for r in all_conv) / (sum(r["ms"] for r in all_conv) * 1e-3) / 1e12,
             "method": f"HIP events per op on the launch stream (storm_program_run_timed) over {args.profile_nfe} score "
-                      f"evaluations at batch {args.batch}; algorithmic FLOPs = 2*B*H*W*Cout*Cin*taps per launch",
+                      f"evaluations at batch {args.batch}; algorithmic FLOPs = 2*B*H*W*Cout*Cin*taps per launch; kernel names from "
+                      f"the launcher (storm_program_kernel_name)",
         }
         if args.ops_json:
             with open(args.ops_json, "w") as f:
                 json.dump(rows, f, indent=0)
 
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        dt, cores = cpu_baseline(args.backbone, args.seconds)
+        dt, times, cores = cpu_baseline(args.backbone, args.seconds)
         result["cpu_baseline"] = {
             "value": 1.0 / (dt * nfe), "unit": "utterances/s", "cores": cores, "kind": "port",
-            "sample": f"1 score evaluation (of {nfe}) of one {args.seconds:g}-s utterance with the CPU oracle "
-                      f"(PyTorch fp32): {dt:.1f} s, extrapolated x{nfe}",
+            "sample": f"score evaluations (1 of the {nfe} per utterance each) of one {args.seconds:g}-s utterance with the CPU oracle "
+                      f"(PyTorch fp32): 1 warm-up + median of {len(times)} = {dt:.1f} s "
+                      f"(runs: {', '.join(f'{t:.1f}' for t in times)} s), extrapolated x{nfe}",
             "s_per_nfe": dt,
         }
 

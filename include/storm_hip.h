@@ -106,6 +106,9 @@ typedef struct storm_conv_args {
 int storm_conv(const storm_conv_args* a, storm_stream_t s);
 /* number of pixel tiles per batch item the kernel will use for this call (size of gn_part) */
 int storm_conv_tiles(const storm_conv_args* a);
+/* name (as rocprofv3 prints it) of the kernel storm_conv launches for these arguments: lets a profiler or
+ * bench.py's roofline name the kernel the launcher really picked; static storage */
+const char* storm_conv_kernel_name(const storm_conv_args* a);
 
 /* ------------------------------------------------------------------------------------------
  * GroupNorm(min(C/4,32) groups, eps) [+ SiLU] [+ FIR x2 up / down of BOTH the activated and
@@ -260,6 +263,8 @@ int storm_program_run(const storm_op* ops, int n_ops, void* const* bufs, int n_b
  * elapsed milliseconds of each op to the HOST array ms[n_ops] (bench.py's roofline leg).    */
 int storm_program_run_timed(const storm_op* ops, int n_ops, void* const* bufs, int n_bufs,
                             int dtype, storm_stream_t s, float* ms);
+/* name of the kernel op k of a program launches (STORM_OP_CONV ops; "" otherwise), see storm_conv_kernel_name */
+const char* storm_program_kernel_name(const storm_op* ops, int k, int dtype);
 
 #ifdef __cplusplus
 }

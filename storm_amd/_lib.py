@@ -11,7 +11,8 @@ import os
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "csrc", "libstorm_hip.so")
+# STORM_LIB: tools/ point this at the profiling build (libstorm_hip_prof.so, python -m storm_amd.build --profiling)
+LIB_PATH = os.environ.get("STORM_LIB") or os.path.join(_HERE, "csrc", "libstorm_hip.so")
 
 F32, BF16 = 0, 1
 _TORCH2DT = {torch.float32: F32, torch.bfloat16: BF16}
@@ -61,6 +62,7 @@ _SIGNATURES = {
     "storm_pack_matrix": ([_vp, _vp, _i, _i, _i, _i, _i, _i, _vp], C.c_int),
     "storm_conv": ([C.POINTER(ConvArgs), _vp], C.c_int),
     "storm_conv_tiles": ([C.POINTER(ConvArgs)], C.c_int),
+    "storm_conv_kernel_name": ([C.POINTER(ConvArgs)], C.c_char_p),
     "storm_gn_finalize": ([_vp, _i, _i, _vp, _i, _i, _i, _i, _vp, _vp], C.c_int),
     "storm_gn_finalize_ss": ([_vp, _i, _i, _vp, _i, _i, _i, _i, _ll, _vp, _vp, _f, _vp, _vp, _vp], C.c_int),
     "storm_gn_stats": ([_vp, _i, _vp, _i, _i, _i, _i, _vp, _i, _vp], C.c_int),
@@ -83,6 +85,7 @@ _SIGNATURES = {
     "storm_stft": ([_vp, _vp, _vp, _vp, _vp, _i, _ll, _ll, _i, _i, _i, _i, _f, _f, _vp], C.c_int),
     "storm_istft": ([_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _ll, _ll, _i, _i, _f, _f, _vp], C.c_int),
     "storm_program_run": ([C.POINTER(Op), _i, C.POINTER(_vp), _i, _i, _vp], C.c_int),
+    "storm_program_kernel_name": ([C.POINTER(Op), _i, _i], C.c_char_p),
     "storm_program_run_timed": ([C.POINTER(Op), _i, C.POINTER(_vp), _i, _i, _vp, C.POINTER(C.c_float)], C.c_int),
 }
 EXPORTS = ["storm_last_error"] + list(_SIGNATURES)

@@ -31,16 +31,23 @@ def up_to_date():
     return all(os.path.getmtime(d) <= t for d in deps)
 
 
-def build(force=False, verbose=False):
-    if not force and up_to_date():
+PROF_OUT = os.path.join(CSRC, "libstorm_hip_prof.so")
+
+
+def build(force=False, verbose=False, profiling=False):
+    """profiling=True builds libstorm_hip_prof.so with -DSTORM_PROFILING: the same library plus wave-timeline stamps and
+    work-skipping kernel instantiations for tools/ (selected through STORM_LIB=<path>); never loaded by the product."""
+    out = PROF_OUT if profiling else OUT
+    if not profiling and not force and up_to_date():
         return OUT
     cc = hipcc()
-    bdir = os.path.join(CSRC, "build")
+    bdir = os.path.join(CSRC, "build_prof" if profiling else "build")
     os.makedirs(bdir, exist_ok=True)
+    flags = FLAGS + (["-DSTORM_PROFILING"] if profiling else [])
 
     def compile_one(s):
         src, obj = os.path.join(CSRC, s + ".hip"), os.path.join(bdir, s + ".o")
-        cmd = [cc] + FLAGS + ["-c", src, "-o", obj]
+        cmd = [cc] + flags + ["-c", src, "-o", obj]
         r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)
         if r.returncode != 0:
             raise RuntimeError(f"hipcc failed on {s}.hip:\n{r.stdout.decode()}")
@@ -50,12 +57,12 @@ def build(force=False, verbose=False):
 
     with ThreadPoolExecutor(max_workers=4) as ex:
         objs = list(ex.map(compile_one, SOURCES))
-    r = subprocess.run([cc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", OUT] + objs,
+    r = subprocess.run([cc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", out] + objs,
                        stdout=subprocess.PIPE, stderr=subprocess.STDOUT)
     if r.returncode != 0:
         raise RuntimeError(f"link failed:\n{r.stdout.decode()}")
-    return OUT
+    return out
 
 
 if __name__ == "__main__":
-    print(build(force="--force" in sys.argv, verbose=True))
+    print(build(force="--force" in sys.argv, verbose=True, profiling="--profiling" in sys.argv))

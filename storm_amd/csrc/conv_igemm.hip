@@ -610,14 +610,37 @@ static int launch_conv(const storm_conv_args& a, hipStream_t st) {
         if (grid > resident) grid = resident;
     }
     ConvParams prm = make_params(a);
-    if (ABL & 64) {                                              // profiling: device buffer address handed over by the probe tool
+#if defined(STORM_PROFILING)
+    if (ABL & 64) {                                              // device buffer address handed over by tools/conv_trace.py
         const char* tp = getenv("STORM_CONV_TRACE_PTR");
         prm.trace = tp ? reinterpret_cast<unsigned long long*>(strtoull(tp, nullptr, 0)) : nullptr;
     }
+#endif
     hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(Cfg::THREADS), Cfg::LDS_BYTES, st, prm, n_ct,
                        tiles_per_xcd, (int)ntiles, tiles_x, tiles_per_img, (int)vblocks);
     STORM_LAUNCH_CHECK();
     return STORM_OK;
+}
+
+// Environment switches (A/B runs and forced-variant tests only; never set in production).  STORM_CONV_VARIANT is read
+// per launch because the tests switch it at run time; it costs one getenv per conv launch.
+static int env_int(const char* name, int dflt) {
+    const char* v = getenv(name);
+    return v ? atoi(v) : dflt;
+}
+
+// Which kernel a convolution runs on (exported as storm_conv_kernel_name, so that bench.py's roofline names the
+// kernel the launcher really picked instead of re-deriving the rule).
+//   0: conv_igemm 128 cout x 256 px, 4 waves (64x128 each), 2 workgroups / CU overlap each other's staging; LDS-DMA
+//   1: conv_igemm 128 cout x 256 px, 8 waves (64x64 each), 2 workgroups / CU
+//   2: conv_igemm 256 cout x 256 px, 8 waves, 1 workgroup / CU, patch double-buffered through registers
+//   3: conv_pipe.hip, 256 cout x 256 px, 8 waves in two ping-pong groups, chunk-unrolled LDS-DMA pipeline (bf16 3x3)
+static int choose_variant(const storm_conv_args& a, bool any9) {
+    const int forced = env_int("STORM_CONV_VARIANT", -1);
+    if (forced >= 0) return forced;
+    const long long px_tiles = (long long)a.B * cdiv((long long)a.H * a.W, TILE_H * TILE_W);
+    if (a.outC > 128 && px_tiles >= 512) return any9 && conv_pipe_supports(a) ? 3 : 2;
+    return 0;
 }
 
 template <typename T>
@@ -625,41 +648,28 @@ static int dispatch_conv(const storm_conv_args& a, hipStream_t st) {
     bool any9 = false;
     for (int s = 0; s < a.nseg; ++s) any9 = any9 || a.seg[s].ntaps == 9;
     const bool small = a.outC <= 32;
-    // Tile variants (STORM_CONV_VARIANT overrides the choice, for A/B runs):
-    //   0: 128 cout x 256 px, 4 waves (64x128 each), 2 workgroups / CU overlap each other's staging; operands by
-    //      LDS-DMA (STORM_CONV_DMA=0: through registers)
-    //   1: 128 cout x 256 px, 8 waves (64x64 each), 2 workgroups / CU
-    //   2: 256 cout x 256 px, 8 waves (64x128 each), 1 workgroup / CU, patch double-buffered and the
-    //      next K-chunk prefetched under the MFMAs (one patch load + GN transform per 256 couts)
-    //   3: conv_pipe.hip, 256 cout x 256 px, 8 waves in two ping-pong groups, operands by LDS-DMA (bf16 3x3 only)
-    //   4: conv_pipe.hip, same tile, 4 waves of 128x128 (one per SIMD)
-    const char* forced_env = getenv("STORM_CONV_VARIANT");          // read per launch: tests and probes switch it at run time
-    const int forced = forced_env ? atoi(forced_env) : -1;
-    const char* dma_env = getenv("STORM_CONV_DMA");                 // A/B switch: 0 = register staging in the 128-cout kernel
-    const bool dma = dma_env ? atoi(dma_env) != 0 : true;
-    const long long px_tiles = (long long)a.B * cdiv((long long)a.H * a.W, TILE_H * TILE_W);
-    const int variant = forced >= 0 ? forced : ((a.outC > 128 && px_tiles >= 512) ? (any9 && conv_pipe_supports(a) ? 3 : 2) : 0);
-    const char* abl_env = getenv("STORM_CONV_ABLATE");
-    const int abl = abl_env ? atoi(abl_env) : 0;
-    if (any9 && !small && abl && variant != 3 && variant != 4) {        // profiling only
+    static const bool dma = env_int("STORM_CONV_DMA", 1) != 0;        // A/B switch: 0 = register staging in the 128-cout kernel
+    const int variant = choose_variant(a, any9);
+#if defined(STORM_PROFILING)
+    // work-skipping instantiations for tools/ (no MFMA, no fragment reads, ...): profiling build only
+    const int abl = env_int("STORM_CONV_ABLATE", 0);
+    if (any9 && !small && abl && variant != 3) {
         const bool v2 = variant == 2;
         switch (abl) {
             case 1: return v2 ? launch_conv<T, 9, 2, 4, 2, true, false, 1>(a, st) : launch_conv<T, 9, 2, 2, 2, false, false, 1>(a, st);
             case 2: return v2 ? launch_conv<T, 9, 2, 4, 2, true, false, 2>(a, st) : launch_conv<T, 9, 2, 2, 2, false, false, 2>(a, st);
             case 4: return v2 ? launch_conv<T, 9, 2, 4, 2, true, false, 4>(a, st) : launch_conv<T, 9, 2, 2, 2, false, false, 4>(a, st);
             case 8: return v2 ? launch_conv<T, 9, 2, 4, 2, true, false, 8>(a, st) : launch_conv<T, 9, 2, 2, 2, false, false, 8>(a, st);
-            case 6: return v2 ? launch_conv<T, 9, 2, 4, 2, true, false, 6>(a, st) : launch_conv<T, 9, 2, 2, 2, false, false, 6>(a, st);
-            case 5: return v2 ? launch_conv<T, 9, 2, 4, 2, true, false, 5>(a, st) : launch_conv<T, 9, 2, 2, 2, false, false, 5>(a, st);
             case 16: return v2 ? launch_conv<T, 9, 2, 4, 2, true, false, 16>(a, st) : launch_conv<T, 9, 2, 2, 2, false, false, 16>(a, st);
             case 32: return v2 ? launch_conv<T, 9, 2, 4, 2, true, false, 32>(a, st) : launch_conv<T, 9, 2, 2, 2, false, false, 32>(a, st);
             case 64: return v2 ? launch_conv<T, 9, 2, 4, 2, true, false, 64>(a, st) : launch_conv<T, 9, 2, 2, 2, false, false, 64>(a, st);
-            case 40: return v2 ? launch_conv<T, 9, 2, 4, 2, true, false, 40>(a, st) : launch_conv<T, 9, 2, 2, 2, false, false, 40>(a, st);
             default: break;
         }
     }
+#endif
     if (any9) {
         if (small) return launch_conv<T, 9, 1, 1, 4, false>(a, st);
-        if ((variant == 3 || variant == 4) && conv_pipe_supports(a)) return launch_conv_pipe(a, st, variant == 4 ? 1 : 2);
+        if (variant == 3 && conv_pipe_supports(a)) return launch_conv_pipe(a, st, 256);
         if (variant == 2) return launch_conv<T, 9, 2, 4, 2, true>(a, st);
         if (variant == 1) return launch_conv<T, 9, 2, 2, 4, false>(a, st);
         return dma ? launch_conv<T, 9, 2, 2, 2, false, true>(a, st) : launch_conv<T, 9, 2, 2, 2, false, false>(a, st);
@@ -667,6 +677,25 @@ static int dispatch_conv(const storm_conv_args& a, hipStream_t st) {
     if (small) return launch_conv<T, 1, 1, 1, 4, false>(a, st);
     if (variant == 2) return launch_conv<T, 1, 2, 4, 2, true>(a, st);
     return variant == 1 ? launch_conv<T, 1, 2, 2, 4, false>(a, st) : launch_conv<T, 1, 2, 2, 2, false>(a, st);
+}
+
+// Name of the kernel storm_conv launches for these arguments (as rocprofv3 prints it).
+static const char* kernel_name_of(const storm_conv_args& a) {
+    bool any9 = false;
+    for (int s = 0; s < a.nseg; ++s) any9 = any9 || a.seg[s].ntaps == 9;
+    const bool bf = a.dtype == STORM_BF16;
+    if (a.outC <= 32) return any9 ? (bf ? "storm::conv_igemm_kernel<storm::bf16_t, 9, 1, 1, 4, false, false, 0>" : "storm::conv_igemm_kernel<float, 9, 1, 1, 4, false, false, 0>")
+                                  : (bf ? "storm::conv_igemm_kernel<storm::bf16_t, 1, 1, 1, 4, false, false, 0>" : "storm::conv_igemm_kernel<float, 1, 1, 1, 4, false, false, 0>");
+    const int variant = choose_variant(a, any9);
+    if (any9) {
+        if (variant == 3 && conv_pipe_supports(a)) return conv_pipe_kernel_name(256);
+        if (variant == 2) return bf ? "storm::conv_igemm_kernel<storm::bf16_t, 9, 2, 4, 2, true, false, 0>" : "storm::conv_igemm_kernel<float, 9, 2, 4, 2, true, false, 0>";
+        if (variant == 1) return bf ? "storm::conv_igemm_kernel<storm::bf16_t, 9, 2, 2, 4, false, false, 0>" : "storm::conv_igemm_kernel<float, 9, 2, 2, 4, false, false, 0>";
+        return bf ? "storm::conv_igemm_kernel<storm::bf16_t, 9, 2, 2, 2, false, true, 0>" : "storm::conv_igemm_kernel<float, 9, 2, 2, 2, false, true, 0>";
+    }
+    if (variant == 2) return bf ? "storm::conv_igemm_kernel<storm::bf16_t, 1, 2, 4, 2, true, false, 0>" : "storm::conv_igemm_kernel<float, 1, 2, 4, 2, true, false, 0>";
+    if (variant == 1) return bf ? "storm::conv_igemm_kernel<storm::bf16_t, 1, 2, 2, 4, false, false, 0>" : "storm::conv_igemm_kernel<float, 1, 2, 2, 4, false, false, 0>";
+    return bf ? "storm::conv_igemm_kernel<storm::bf16_t, 1, 2, 2, 2, false, false, 0>" : "storm::conv_igemm_kernel<float, 1, 2, 2, 2, false, false, 0>";
 }
 
 }  // namespace storm
@@ -701,4 +730,8 @@ extern "C" int storm_conv(const storm_conv_args* ap, storm_stream_t s) {
     if (a.dtype == STORM_BF16) return dispatch_conv<bf16_t>(a, st);
     if (a.dtype == STORM_F32) return dispatch_conv<float>(a, st);
     STORM_CHECK(false, "storm_conv: dtype %d", a.dtype);
+}
+
+extern "C" const char* storm_conv_kernel_name(const storm_conv_args* ap) {
+    return ap ? storm::kernel_name_of(*ap) : "";
 }

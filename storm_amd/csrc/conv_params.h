@@ -228,8 +228,43 @@ static inline ConvParams make_params(const storm_conv_args& a) {
     return p;
 }
 
-// defined in conv_pipe.hip: software-pipelined 256-cout x 256-pixel 3x3 kernel (bf16)
+// ---- conv_pipe.hip: the K loop as a host-built list of chunk descriptors -----------------------------------
+// One chunk = 64 channels (128 B per pixel) of one run under all its taps.  Everything that does not depend on the
+// workgroup's batch index is computed on the host, so the kernel's chunk boundary is two scalar loads and a few
+// scalar adds - no per-tap or per-chunk address arithmetic is left in the pipelined loop.
+namespace pipe {
+constexpr int MAX_CHUNKS = 36;
+struct ChunkDesc {                    // 64 bytes
+    unsigned long long src;           // the run's source tensor (batch 0)
+    unsigned long long bstride;       // its batch stride in bytes
+    unsigned long long ss;            // (scale, shift) pairs of this chunk's channels for batch 0 (fused GroupNorm), or 0
+    unsigned int ss_bstride;          // bytes
+    unsigned int src_bytes;           // one batch image in bytes (= num_records; 0 in the terminator: every read is zero)
+    int C2, cbeg2;                    // pixel stride / this chunk's first channel, in bytes
+    int cvalid, ntaps;                // channels of this chunk (<= 64); 9 or 1
+    int silu, wrun;                   // SiLU after the fused affine; index of the weight run
+    int w_soff, new_wrun;             // byte offset of the chunk's first weight column inside a weight row; run changes here
+};
+struct WRunDesc {                     // 32 bytes: the weight matrix of a run, [tap][row][CinP] bf16
+    unsigned long long w;             // first element of column wc0
+    unsigned int bytes;               // num_records
+    int CinP2, rows, tapbytes, pad0_, pad1_;
+};
+struct PipeParams {
+    ChunkDesc chunk[MAX_CHUNKS + 1];  // [nchunks] = terminator (prefetch target of the last chunk)
+    WRunDesc wrun[4];
+    int nchunks, nchunks9, B, H, W, pad_;   // nchunks9: the leading nine-tap chunks (one-tap chunks follow)
+    void* out; int outC, Cout; long long out_bstride;
+    const float* bias; const float* tbias; int tbias_stride, out_f32;
+    const void* skip; long long skip_bstride; float scale; int pad2_;
+    float* gn_part;
+    unsigned long long* trace;        // profiling build (-DSTORM_PROFILING) only
+};
+}  // namespace pipe
+
+// defined in conv_pipe.hip: software-pipelined 3x3 kernels (bf16): 256 or 128 output channels per workgroup
 bool conv_pipe_supports(const storm_conv_args& a);
-int launch_conv_pipe(const storm_conv_args& a, hipStream_t st, int layout);
+int launch_conv_pipe(const storm_conv_args& a, hipStream_t st, int bn);
+const char* conv_pipe_kernel_name(int bn);
 
 }  // namespace storm

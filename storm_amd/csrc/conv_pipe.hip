@@ -1,44 +1,54 @@
-// Software-pipelined 3x3 implicit-GEMM convolution for the wide layers (bf16, >128 output channels).
+// Software-pipelined 3x3 implicit-GEMM convolution (bf16): the kernel behind every wide 3x3 layer of NCSN++
+// (layers.py:119-126 ddpm_conv3x3, with the fused pieces of layerspp.py:242-274 listed in include/storm_hip.h).
 //
-// Same math, arguments and epilogue as conv_igemm.hip (see there and include/storm_hip.h); what differs is the
-// staging pipeline, built for ONE 8-wave workgroup per CU (2 waves / SIMD, 256 registers each):
-//   * tile: 256 output channels x (8 x 32) pixels; wave grid 4 (cout) x 2 (pixel rows), 64 x 128 per wave
-//     = 8 accumulator tiles of v_mfma_f32_32x32x16_bf16.
+// Same math, arguments and epilogue as conv_igemm.hip; what differs is the K loop, built for ONE 8-wave workgroup
+// per CU (2 waves / SIMD, 256 registers each) and for an instruction stream in which nothing but MFMAs, fragment
+// reads and DMA issues is left:
+//   * tile: BN output channels x (TH x 32) pixels; every wave owns 64 couts x (4 x 32) pixels = 8 accumulator tiles
+//     of v_mfma_f32_32x32x16_bf16.   <256, 8>: wave grid 4 (cout) x 2 (pixel rows);  <128, 16>: 2 x 4.
+//   * the K dimension is a HOST-BUILT list of chunk descriptors (conv_params.h: 64 channels of one source tensor
+//     under all of its taps), and the body of a chunk is compile-time unrolled over its taps (two bodies: nine taps,
+//     one tap).  Tap offsets, pixel rows and k-groups are instruction immediates; the per-phase scalar work is one
+//     ring-slot rotation and one weight-offset add.  (Round 1 walked taps / chunks / runs with a run-time cursor:
+//     its bookkeeping alone - no MFMA, no DMA, no fragment reads - took 58 % of the kernel's time.)
 //   * nothing asynchronous ever targets a VGPR.  Weights: every "phase" (half a tap of one 128-byte K-chunk:
-//     256 rows x 64 B = 16 KiB) is copied global -> LDS by two `buffer_load_dwordx4 ... lds` per wave into a
-//     4-slot ring, issued two phases before use.  The LDS image of such an instruction is lane-linear, so the
-//     bank swizzle is applied to the per-lane SOURCE offset (constant for a whole run of the K dimension; the
-//     moving part - tap, chunk, half - is the scalar offset) and again on the fragment read.
-//   * the haloed 10 x 34 pixel patch of a K-chunk is double buffered and fetched the same way, raw, straight into
-//     the other buffer; padding pixels / channels past the run are out-of-range buffer reads = hardware zeros.
-//     The patch image is swizzled by pixel COLUMN, so a tap / pixel row / buffer change is a scalar or instruction
-//     immediate add: one address VGPR per k-group.  With a fused GroupNorm-apply + SiLU every lane then rewrites the
-//     16-byte units it fetched itself in place (scale / shift table fetched to LDS alongside).
-//   * all VMEM of the main loop is inline asm, so the counted `s_waitcnt vmcnt(N)` below are the only waits and
-//     loads stay in flight across the raw s_barriers (a compiler-visible load would drain the queue with
-//     vmcnt(0) at every barrier).  Counting rule: N = number of VMEM instructions this wave issued AFTER the one
-//     that must have landed (they return in order).
-//   * ping-pong: waves 4-7 (the second wave of every SIMD) run one barrier interval behind waves 0-3, so one
-//     group's MFMA interval C coincides with the other's staging interval S and the matrix pipe of a SIMD always
-//     has a wave feeding it.  Staging intervals start with the fragment reads and stay well under the 16-MFMA
-//     length of an MFMA interval (a SIMD hides about five non-MFMA instructions per MFMA).
-//   * patches are fetched by the LAGGING group only: its S of a chunk's first phase is the first interval in which
-//     the other patch buffer is free, a whole phase before the leading group could touch it - enough to cover the
-//     DMA latency even for the two-phase chunks of a fused 1x1 shortcut.
+//     BN rows x 64 B) is copied global -> LDS by `buffer_load_dwordx4 ... lds` into a 4-slot ring, issued two phases
+//     before use.  The LDS image of such an instruction is lane-linear, so the bank swizzle is applied to the per-lane
+//     SOURCE offset (constant for a whole run; tap / chunk / half ride in the scalar offset) and again on the read.
+//   * the haloed (TH+2) x 34 pixel patch of the NEXT chunk is fetched the same way into the other patch buffer, ONE
+//     1-KiB piece per wave and phase, and - with a fused GroupNorm-apply + SiLU - rewritten in place by the lane that
+//     fetched it, one piece per phase, six phases later.  Padding pixels / ragged channels are out-of-range buffer
+//     reads = hardware zeros.  The patch image is swizzled by pixel COLUMN, so a tap / pixel row change is an
+//     instruction immediate.  A one-tap chunk (the fused 1x1 shortcut) uses a compact TH x 32 image (no halo).
+//   * ping-pong with ROLES: waves 4-7 (the second wave of every SIMD, "lagging") run one barrier interval behind waves
+//     0-3 ("leading"), so one group's MFMA interval C coincides with the other's staging interval S.  vmcnt retires in
+//     order, so a wave that waits for L2-resident weights every phase would also wait for every HBM patch piece it
+//     issued since: the LEADING group therefore streams all weights (4 pieces per wave and phase, waited for one
+//     phase later) and the LAGGING group fetches and transforms all patches with lazy waits (a piece is waited for six
+//     phases after its issue; the whole patch two phases before the chunk ends).
+//   * fragment reads live in the MFMA intervals only: C(P) reads its second k-group under its first MFMAs and, once the
+//     first k-group's MFMAs are issued, the FIRST k-group of phase P+1 into the registers they free - a staging
+//     interval is DMA issue + wait + barrier, and the matrix pipe starts the moment a barrier opens.
+//   * all VMEM of the loop is inline asm, so the counted `s_waitcnt vmcnt(N)` are the only waits and loads stay in
+//     flight across the raw s_barriers (N = VMEM instructions this wave issued AFTER the one that must have landed).
 //
-// Phase P = (chunk, tap, half), two k-groups, 16 MFMAs per wave; a tap-step = phases (half 0, half 1):
-//   S(P):   read k-group 0 of P | DMA weights of phase P+2 -> ring slot (P+2)&3
-//           [lagging group, first phase of a chunk: DMA the next chunk's patch] | vmcnt | barrier
-//   C(P):   2 MFMAs | read k-group 1 | 14 MFMAs | barrier
-//   S(P+1): as S(P) [lagging group, first tap-step: GroupNorm rewrite of the fetched patch after the vmcnt]
-//   C(P+1): as C(P), plus the next tap's patch offset
-// LDS lifetimes (intervals counted in barriers; group 1 lags by one): phase P's ring slot is read in intervals
-// 2P..2P+2; slot (P+2)&3 = (P-2)&3 was last read in interval 2P-2 -> free in S(P).  The other patch buffer was
-// last read by the lagging group's C(P0-1) (interval 2P0, P0 = first phase of a chunk), so the lagging group's
-// S(P0) (interval 2P0+1) may overwrite it; the new patch is waited for in its S(P0+1) (interval 2P0+3), i.e. visible
-// from interval 2P0+4 = the leading group's S(P0+2), the first possible reader (two-phase chunk).
+// Phase = (tap, half), two k-groups, 16 MFMAs per wave:
+//   S(P):  leading: DMA weights of phase P+2 -> ring slot (P+2)&3 | vmcnt: weights of P+1 landed
+//          lagging: DMA one patch piece of the next chunk | vmcnt: the piece issued six phases ago | transform it
+//          barrier
+//   C(P):  2 MFMAs | read k-group 1 | 6 MFMAs | read k-group 0 of P+1 | 8 MFMAs | barrier
+// Interval numbering (barriers): leading group S(P) = 2P, C(P) = 2P+1; lagging group one later.
+// LDS lifetimes: ring slot (P+2)&3 = (P-2)&3 was last read in C(P-2) (lagging: interval 2P-2) -> free in the leading
+// S(P) (2P); the weights of P+1 are waited for in the leading S(P) and visible from 2P+1 = the leading C(P), which
+// pre-reads them.  The other patch buffer was last read by the lagging C(P0-1) (interval 2P0, P0 = first phase of the
+// chunk): the lagging group issues from its S(P0) (2P0+1) on, transforms until its S(P0+16) (2P0+33), and the first
+// reader is the leading C(P0+17) (2P0+35).  A ONE-tap chunk is fetched whole in the lagging S(P0) and waited for in its
+// S(P0+1) (2P0+3): its successor's first k-group is therefore read at the START of the successor's S(0) (2P0+4), not
+// pre-read.
 #include <cstdlib>
 #include <cstring>
+#include <type_traits>
+#include <utility>
 #include "conv_params.h"
 
 namespace storm {
@@ -46,677 +56,777 @@ using namespace cidx;
 
 namespace pipe {
 
-constexpr int PW = Geo<9>::PW, NPIX = Geo<9>::NPIX;
+constexpr int PW = TILE_W + 2;
+constexpr int PIXB = 128, KC = 64, SLOTS = 8;                 // bytes / channels / 16-B slots per pixel and K-chunk
 constexpr int WROW = 64;                                      // bytes per weight row and phase (two k-groups)
-constexpr int RING = 4;
-constexpr int SS_BYTES = 1024;                                // one wave-instruction: (scale, shift) of a chunk's channels + pad
-constexpr int PR = 2;                                         // pixel rows (of 32 px) staged per epilogue pass and wave
+constexpr int PR = 1;                                         // pixel rows (of 32 px) staged per epilogue pass and wave
 constexpr uint32_t OOB = BUF_OOB;                             // per-lane offset that is out of range of every buffer here
+constexpr int NWAVES = 8, THREADS = 512;
 
-// Kernel geometry.  BN output channels x (8 x 32) pixels per workgroup; PIXB bytes of channels per pixel and K-chunk.
-//   <256, 128, 4, 2>: 8 waves (2 / SIMD, 256 registers each), 64 x 128 per wave, the two waves of a SIMD ping-pong
-//   <256, 128, 2, 2>: 4 waves (1 / SIMD, 512 registers), 128 x 128 per wave
-// (A <128, 64, 2, 2> geometry - 64-byte K-chunks, two workgroups per CU for the <= 128-cout layers - was built and
-//  measured in round 1: no faster than conv_igemm's 128-cout tile, so it is not instantiated.)
-template <int BN_, int PIXB_, int WAVES_M_, int WAVES_N_> struct PCfg {
-    static constexpr int BN = BN_, PIXB = PIXB_, KC = PIXB / 2, SLOTS = PIXB / 16;
-    static constexpr int WAVES_M = WAVES_M_, WAVES_N = WAVES_N_, NWAVES = WAVES_M * WAVES_N, THREADS = 64 * NWAVES;
-    static constexpr int RPP = 1024 / PIXB;                   // patch rows per 1-KiB LDS-DMA piece
-    static constexpr int PATCH_ROWS = (NPIX + RPP - 1) / RPP * RPP;
-    static constexpr int PATCH_BYTES = PATCH_ROWS * PIXB;
-    static constexpr int PPIECES = PATCH_ROWS / RPP;
-    static constexpr int WPHASE_BYTES = BN * WROW;
+template <int BN_, int TH_> struct PCfg {
+    static constexpr int BN = BN_, TH = TH_;
+    static constexpr int WAVES_M = BN / 64, WAVES_N = NWAVES / WAVES_M;
+    static constexpr int WM = 2, WN = TH / WAVES_N;           // 32-cout tiles / pixel rows (32 px) per wave
+    static constexpr int NPIX = (TH + 2) * PW;
+    static constexpr int PPIECES = (NPIX + 7) / 8;            // 1-KiB DMA pieces (8 rows) of a haloed patch
+    static constexpr int PATCH_BYTES = PPIECES * 1024;
+    static constexpr int CPIECES = TH * 4;                    // pieces of a compact (one-tap) patch
+    static constexpr int NLAG = 4;                            // patch-fetching (lagging) waves
+    static constexpr int NSLOT = (PPIECES + NLAG - 1) / NLAG; // haloed pieces per lagging wave (one per phase)
+    static constexpr int NSLOT1 = CPIECES / NLAG;             // compact pieces per lagging wave
+    static constexpr int LAZY = 6;                            // phases between a piece's issue and its wait / transform
+    static constexpr int WPHASE = BN * WROW, RINGB = 4 * WPHASE;
+    static constexpr int NWD = BN / 16 / 4;                   // weight DMA instructions per LEADING wave and phase (16 rows each)
     static constexpr int OFF_RING = 2 * PATCH_BYTES;
-    static constexpr int OFF_SS = OFF_RING + RING * WPHASE_BYTES;
-    static constexpr int MAIN_BYTES = OFF_SS + 2 * SS_BYTES;
-    static constexpr int WM = BN / 32 / WAVES_M;              // 32-cout tiles per wave
-    static constexpr int WN = TILE_H / WAVES_N;               // pixel rows (32 px) per wave
-    static constexpr int PU = (PPIECES + NWAVES - 1) / NWAVES;   // patch pieces per wave (the surplus re-issues a piece)
-    static constexpr int NP = PU + 1;                         // VMEM instructions of one patch issue (+ the table)
-    static constexpr int NWD = BN / 16 / NWAVES;              // weight DMA instructions per wave and phase (16 rows each)
+    static constexpr int OFF_SS = OFF_RING + RINGB;
+    static constexpr int MAIN_BYTES = OFF_SS + 2 * 1024;
     static constexpr int STAGE_BYTES = NWAVES * 32 * PR * WM * 128;
     static constexpr int LDS_BYTES = MAIN_BYTES > STAGE_BYTES ? MAIN_BYTES : STAGE_BYTES;
-    static constexpr int BLOCKS_PER_CU = 2 * LDS_BYTES <= 160 * 1024 ? 2 : 1;
+    static_assert(WN == 4, "wave tile is 64 couts x 4 pixel rows");
     static_assert(LDS_BYTES <= 160 * 1024, "LDS budget");
-    static_assert(PU * NWAVES - PPIECES < NWAVES && PU <= 31, "patch pieces");
+    static_assert((WPHASE & (WPHASE - 1)) == 0, "ring rotation by mask");
     static_assert(PATCH_BYTES % 256 == 0, "k-group XOR must stay inside the slot field");
+    static_assert(NSLOT * NLAG - PPIECES < NLAG, "at most one surplus slot per wave");
+    static_assert(CPIECES % NLAG == 0 && NSLOT1 <= NSLOT, "compact pieces fit the same slots");
+    static_assert(NSLOT - 1 + LAZY <= 16, "the whole patch is transformed two phases before a nine-tap chunk ends");
 };
 
 // LDS byte offset of 16-B slot s (0..3) of row `row` of a weight phase tile: the 16 lanes of a ds_read_b128
 // group hit 16 distinct 16-B bank groups.
 STORM_HD int w_off(int row, int s) { return row * WROW + ((s ^ ((row >> 2) & 3)) << 4); }
-// Patch image: pixel (py, px) of the haloed 10 x 34 patch is row py * PW + px, 128 B; its eight 16-B slots are
-// XOR-swizzled by the COLUMN ((px >> 1) & 7).  16 lanes of a fragment read are 16 consecutive px -> 16 distinct
-// bank groups; and because the swizzle does not depend on py, a tap's row offset, the wave's pixel rows and the
-// patch buffer are plain additions (scalar / instruction-immediate), so a k-group's four reads share one VGPR.
-template <int PIXB> STORM_HD int p_swz(int px, int slot) {
-    return PIXB == 128 ? (slot ^ ((px >> 1) & 7)) << 4 : (slot ^ ((px >> 2) & 3)) << 4;     // 64-B rows: 4 slots
+// Patch image: pixel row r, 128 B; its eight 16-B slots are XOR-swizzled by the pixel COLUMN ((px >> 1) & 7).
+// 16 lanes of a fragment read are 16 consecutive px -> 16 distinct bank groups; and because the swizzle does not
+// depend on the pixel row, taps / wave rows / buffers are plain additions.
+STORM_HD int p_swz(int px, int slot) { return (slot ^ ((px >> 1) & 7)) << 4; }
+
+template <int N> using IC = std::integral_constant<int, N>;
+template <typename F, int... Is> __device__ __forceinline__ void static_for_impl(F&& f, std::integer_sequence<int, Is...>) {
+    (f(IC<Is>{}), ...);
+}
+template <int N, typename F> __device__ __forceinline__ void static_for(F&& f) {
+    static_for_impl(f, std::make_integer_sequence<int, N>{});
 }
 
-// keep a wave-uniform value in an SGPR: stops the compiler re-loading it from the kernarg segment (an s_load +
-// lgkmcnt(0) in the hot loop drains the LDS queue as well)
+// keep a wave-uniform value in an SGPR (stops re-materialisation from the kernarg segment inside the loop)
 __device__ __forceinline__ int pin(int x) {
 #if defined(__HIP_DEVICE_COMPILE__)
     asm volatile("" : "+s"(x));
 #endif
     return x;
 }
+__device__ __forceinline__ int uniform(int x) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __builtin_amdgcn_readfirstlane(x);
+#else
+    return x;
+#endif
+}
 }  // namespace pipe
 using namespace pipe;
 
-template <int BN, int PIXB, int WAVES_M, int WAVES_N, int ABL>
-__global__ __launch_bounds__((pipe::PCfg<BN, PIXB, WAVES_M, WAVES_N>::THREADS),
-                             (pipe::PCfg<BN, PIXB, WAVES_M, WAVES_N>::NWAVES * pipe::PCfg<BN, PIXB, WAVES_M, WAVES_N>::BLOCKS_PER_CU / 4))
-void conv_pipe_kernel(const ConvParams a, const int n_ct, const int tiles_per_xcd,
-                      const int ntiles, const int tiles_x, const int tiles_per_img) {
-    typedef PCfg<BN, PIXB, WAVES_M, WAVES_N> Cfg;
-    constexpr int NWAVES = Cfg::NWAVES, WM = Cfg::WM, WN = Cfg::WN, PU = Cfg::PU, NP = Cfg::NP, NWD = Cfg::NWD;
-    constexpr int KC = Cfg::KC, SLOTS = Cfg::SLOTS, RPP = Cfg::RPP, PATCH_BYTES = Cfg::PATCH_BYTES, PPIECES = Cfg::PPIECES;
-    constexpr int WPHASE_BYTES = Cfg::WPHASE_BYTES, OFF_RING = Cfg::OFF_RING, OFF_SS = Cfg::OFF_SS;
+// ABL: profiling-only instantiations (built with -DSTORM_PROFILING into libstorm_hip_prof.so, never in the product
+// library): 8 no weight DMA after the prologue, 16 no fragment reads, 32 no MFMAs, 128 no patch DMA / transform,
+// 64 wave-timeline stamps (tools/conv_trace.py).
+template <int BN, int TH, int ABL>
+__global__ __launch_bounds__(pipe::THREADS, 2)
+void conv_pipe_kernel(const PipeParams a, const int n_ct, const int tiles_per_xcd,
+                      const int ntiles, const int tiles_x, const int tiles_per_img, const int total_vblocks) {
+    typedef PCfg<BN, TH> Cfg;
+    constexpr bool TRACE = (ABL & 64) != 0;
+    constexpr int WM = Cfg::WM, WN = Cfg::WN, WAVES_M = Cfg::WAVES_M, WAVES_N = Cfg::WAVES_N, NWD = Cfg::NWD;
+    constexpr int PATCH_BYTES = Cfg::PATCH_BYTES, PPIECES = Cfg::PPIECES, CPIECES = Cfg::CPIECES;
+    constexpr int NSLOT = Cfg::NSLOT, NSLOT1 = Cfg::NSLOT1, WPHASE = Cfg::WPHASE, RINGB = Cfg::RINGB;
+    constexpr int OFF_RING = Cfg::OFF_RING, OFF_SS = Cfg::OFF_SS;
     typedef bf16_t T;
     typedef bf16x8 Frag;
     extern __shared__ __attribute__((aligned(16))) char smem[];
-
-    const BlockMap bm = block_map(blockIdx.x, n_ct, tiles_per_xcd);
-    if (bm.tile >= ntiles) return;
-    const int b = bm.tile / tiles_per_img;
-    const int trem = bm.tile - b * tiles_per_img;
-    const int ty0 = (trem / tiles_x) * TILE_H;
-    const int tx0 = (trem % tiles_x) * TILE_W;
-    const int cout0 = bm.ct * BN;
-
-    const int tid = threadIdx.x, lane = tid & 63;
+    // The parameter block is read through the kernarg segment pointer (PipeParams is the first argument, offset 0),
+    // re-laundered at every tile and before every epilogue: otherwise every scalar load of the block is hoisted out of
+    // the tile loop and the live SGPRs spill.
 #if defined(__HIP_DEVICE_COMPILE__)
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    typedef const PipeParams __attribute__((address_space(4)))* KArgPtr;   // (the constant address space keeps the loads scalar)
+    KArgPtr ap = (KArgPtr)__builtin_amdgcn_kernarg_segment_ptr();
+    (void)a;
+#define STORM_RELAUNDER() asm volatile("" : "+s"(ap))
 #else
-    const int wave = tid >> 6;
+    const PipeParams* ap = &a;
+#define STORM_RELAUNDER() ((void)0)
 #endif
+
+    // Persistent workgroups: at most one per CU, each walking the virtual block ids blockIdx.x, + gridDim.x, ... (gridDim.x
+    // is a multiple of 8, so a workgroup stays on its XCD's tile range).  The first patch and weights of the NEXT tile are
+    // issued before this tile's epilogue, whose stores then drain under the next tile's main loop.
+    int vb = blockIdx.x;
+    while (vb < total_vblocks && block_map(vb, n_ct, tiles_per_xcd).tile >= ntiles) vb += gridDim.x;   // (padding ids of the XCD map)
+    if (vb >= total_vblocks) return;
+    int tile, b, ty0, tx0, cout0;                           // the tile whose loads are being ISSUED (= computed, until the hand-over)
+    auto decode = [&](int v) {
+        const BlockMap bm = block_map(v, n_ct, tiles_per_xcd);
+        tile = bm.tile;
+        b = bm.tile / tiles_per_img;
+        const int trem = bm.tile - b * tiles_per_img;
+        ty0 = (trem / tiles_x) * TH;
+        tx0 = (trem % tiles_x) * TILE_W;
+        cout0 = bm.ct * BN;
+    };
+    decode(vb);
+    const int imgH = pin(ap->H), imgW = pin(ap->W);         // (two SGPRs for the whole kernel: read in the pipelined loop)
+
+    const int tid = threadIdx.x;
+    int lane = tid & 63;                                    // re-laundered at every chunk (see relaunder())
+    const int wave = uniform(tid >> 6);
     const int wm = wave % WAVES_M, wn = wave / WAVES_M;
+    const int grp = wave >> 2;                              // 0: leading, 1: lagging (one barrier interval behind)
 
 #if defined(__HIP_DEVICE_COMPILE__)
-    unsigned long long* const trace_rec = (ABL & 64) && a.trace ? a.trace + ((long long)blockIdx.x * NWAVES + wave) * TRACE_SLOTS : nullptr;
-    auto stamp = [&](int idx) {                  // profiling instantiation only (tools/conv_trace.py)
-        if ((ABL & 64) && trace_rec && idx < 496) {
+    unsigned long long* const trace_rec = TRACE && ap->trace ? ap->trace + ((long long)blockIdx.x * NWAVES + wave) * TRACE_SLOTS : nullptr;
+    auto stamp = [&](int idx) {                             // profiling build only (tools/conv_trace.py)
+        if (TRACE && trace_rec && idx < TRACE_SLOTS) {
             const unsigned long long t = __builtin_amdgcn_s_memtime();
             if (lane == 0) trace_rec[idx] = t;
         }
     };
-    auto stamp_tail = [&](int idx) {
-        if ((ABL & 64) && trace_rec) { const unsigned long long t = __builtin_amdgcn_s_memtime(); if (lane == 0) trace_rec[idx] = t; }
-    };
-    if ((ABL & 64) && trace_rec && lane == 0)
+    if (TRACE && trace_rec && lane == 0)
         trace_rec[0] = (unsigned long long)__builtin_amdgcn_s_getreg((31 << 11) | 4) | ((unsigned long long)__builtin_amdgcn_s_getreg((31 << 11) | 20) << 32);
 #else
     auto stamp = [&](int) {};
-    auto stamp_tail = [&](int) {};
 #endif
     stamp(1);
 
     f32x16 acc[WM][WN];
-#pragma unroll
-    for (int mi = 0; mi < WM; ++mi)
-#pragma unroll
-        for (int ni = 0; ni < WN; ++ni)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[mi][ni][r] = 0.0f;
 
-    // ---- K-chunk descriptors (wave-uniform; built at chunk boundaries only) --------------------------
-    struct Chunk {
-        u32x4 srd;                   // the batch image of the run's source tensor
-        u32x4 ss_srd;                // this chunk's (scale, shift) pairs, or an empty buffer
-        int C, cbeg, cvalid, ntaps, gn_silu, gn;
-    };
-    auto get_chunk = [&](int r, int ch) {
-        const ConvRun& R = a.run[r];
-        Chunk c;
-        c.C = R.C; c.cbeg = R.c0 + ch * KC; c.cvalid = min(KC, R.cn - ch * KC);
-        c.ntaps = R.ntaps; c.gn_silu = R.gn_silu; c.gn = R.gn_ss != nullptr;
-        c.srd = make_srd(reinterpret_cast<const T*>(R.src) + (long long)b * R.src_bstride, (uint32_t)a.H * a.W * R.C * 2u);
-        const float* ssp = R.gn_ss ? R.gn_ss + 2 * ((long long)b * R.gn_C + R.wc0 + ch * KC) : reinterpret_cast<const float*>(R.src);
-        c.ss_srd = make_srd(ssp, R.gn_ss ? (uint32_t)c.cvalid * 8u : 0u);
-        return c;
-    };
-    auto chunks_of = [&](int r) { return (a.run[r].cn + KC - 1) / KC; };
-    const int nruns = a.nruns;
-    int total_steps = 0;                                   // tap-steps (two phases each) of the whole K loop
-    for (int r = 0; r < nruns; ++r) total_steps += chunks_of(r) * a.run[r].ntaps;
+    // ---- lane constants -----------------------------------------------------------------------------------
+    // weights: row of mi is +32 rows = +2048 B (same swizzle); the second k-group of a phase flips slot bit 1
+    const int aoff = OFF_RING + w_off(wm * WM * 32 + (lane & 31), lane >> 5);
+    const int aoff1 = aoff ^ 32;
+    // patch: this lane's pixel of ni = 0 under tap (0, 0) + the k-group-0 swizzle term of tap column dx
+    // (all other parts of a fragment address are instruction immediates; the buffer parity is added at a chunk change)
+    int pbase[3];
+#pragma unroll
+    for (int d = 0; d < 3; ++d) pbase[d] = ((wn * WN) * PW + (lane & 31)) * PIXB + p_swz((lane & 31) + d, lane >> 5);
+    const int cdelta = wn * WN * (PW - TILE_W) * PIXB;      // haloed row index - compact row index of this wave's pixels (uniform)
 
-    // ---- weight stream: cursor over tap-steps, one step ahead of the MFMAs --------------------------
-    // per run: buffer resource + this lane's two row offsets (swizzled slot included); per step: scalar offset
-    u32x4 w_srd; uint32_t w_voff[NWD];
-    int w_r = 0, w_ch = 0, w_tp = 0, w_soff = 0, w_tapbytes, w_ntaps, w_nch, w_left = total_steps;
-    auto w_enter_run = [&](int r) {
-        const ConvRun& R = a.run[r];
-        const T* base = reinterpret_cast<const T*>(R.w) + (long long)b * R.w_bstride + R.wc0;
-        w_tapbytes = (int)R.w_tapstride * 2; w_ntaps = R.ntaps; w_nch = (R.cn + KC - 1) / KC;
-        w_srd = make_srd(base, (uint32_t)(R.ntaps * (int)R.w_tapstride - R.wc0) * 2u);
+    // ---- role registers ---------------------------------------------------------------------------------------
+    // leading waves: R[j] = per-lane source offset of weight piece j of the current run;
+    // lagging waves: R[i] = haloed patch piece lw + 4 i of this wave (issued in phase i of a nine-tap chunk):
+    //   (pixel index << 3) | logical 16-B slot that lands in this lane's physical slot, or -1 (padding / past the
+    //   patch: hardware zero fill).
+    const int lw = wave & 3;
+    uint32_t R[NSLOT];
+    static_assert(NWD <= NSLOT, "role registers");
+    auto patch_table = [&]() {                              // (lagging waves) for the tile (ty0, tx0)
+        if (grp == 1) {
 #pragma unroll
-        for (int j = 0; j < NWD; ++j) {
-            const int row = (wave * NWD + j) * 16 + (lane >> 2);
-            const int co = cout0 + row;                          // rows past the matrix: zeros (never stored)
-            w_voff[j] = co < R.w_rows ? (uint32_t)(co * R.CinP + ((lane & 3) ^ ((row >> 2) & 3)) * 8) * 2u : OOB;
-        }
-        w_soff = 0; w_ch = 0; w_tp = 0;
-    };
-    w_enter_run(0);
-    auto w_issue = [&](int q, int h) {                     // half h of the cursor's step -> ring slot q & 3
-        if ((ABL & 8) && q > 1) return;                     // (profiling: no weight DMA after the prologue)
-        char* dst = smem + OFF_RING + (q & (RING - 1)) * WPHASE_BYTES + wave * (NWD * 1024);
-        const uint32_t so = (uint32_t)(w_soff + h * WROW);
-#pragma unroll
-        for (int j = 0; j < NWD; ++j) dma16(w_srd, w_voff[j], so, dst + j * 1024, lane);
-    };
-    auto w_advance = [&]() {                               // past the end the cursor stays (harmless re-load)
-        if (--w_left > 0) {
-            ++w_tp;
-            if (w_tp < w_ntaps) w_soff += w_tapbytes;
-            else {
-                w_tp = 0; ++w_ch;
-                if (w_ch < w_nch) w_soff = w_ch * PIXB;
-                else { ++w_r; w_enter_run(w_r); }
+            for (int i = 0; i < NSLOT; ++i) {
+                const int k = lw + Cfg::NLAG * i;                  // (k >= PPIECES: surplus slot, never used as a piece)
+                const int row = k * 8 + (lane >> 3);
+                const int py = row / PW, px = row - py * PW;
+                const int slot = (lane & 7) ^ ((px >> 1) & 7);
+                const int gy = ty0 + py - 1, gx = tx0 + px - 1;
+                const bool ok = row < Cfg::NPIX && gy >= 0 && gy < imgH && gx >= 0 && gx < imgW;
+                R[i] = ok ? (uint32_t)(((gy * imgW + gx) << 3) | slot) : 0xffffffffu;
             }
         }
     };
 
-    // ---- patch staging ---------------------------------------------------------------------------------
-    // Who fetches patches: in the ping-pong layout only the LAGGING group (waves 4-7).  Its staging interval S(P0) of a
-    // chunk's first phase is the first interval in which the other patch buffer is free (the group itself read it last,
-    // one interval earlier), so the DMA starts a whole phase earlier than the leading group could start it - which
-    // is what hides the latency for two-phase (1x1 shortcut) chunks.
-    constexpr int PW0 = NWAVES == 8 ? 4 : 0, PNW = NWAVES == 8 ? 4 : NWAVES;
-    constexpr int PUU = (PPIECES + PNW - 1) / PNW, NPP = PUU + 1;        // pieces / VMEM instructions per fetching wave
-    static_assert(PUU * PNW - PPIECES < PNW && PUU <= 31, "patch pieces");
-    const bool patcher = wave >= PW0;
-    uint32_t pmask = 0;                        // bit i: unit i of this lane is real input (needs the GN transform)
-    auto patch_issue = [&](const Chunk& c, int parity) {
-        char* dst = smem + parity * PATCH_BYTES;
-        const uint32_t so = (uint32_t)c.cbeg * 2u;
-#pragma unroll
-        for (int i = 0; i < PUU; ++i) {
-            int k = (wave - PW0) + i * PNW;                      // piece: patch rows 8k .. 8k+7
-            if (k >= PPIECES) k -= PNW;                          // surplus slot: same piece again (keeps the VMEM count uniform)
-            const int row = k * RPP + lane / SLOTS;
-            const int py = row / PW, px = row - py * PW;
-            const int slot = p_swz<PIXB>(px, lane % SLOTS) >> 4;  // logical 16-B slot that lands in physical slot lane % SLOTS
-            const int gy = ty0 + py - 1, gx = tx0 + px - 1;
-            const bool ok = row < NPIX && slot * 8 < c.cvalid && gy >= 0 && gy < a.H && gx >= 0 && gx < a.W;
-            dma16(c.srd, ok ? (uint32_t)((gy * a.W + gx) * c.C + slot * 8) * 2u : OOB, so, dst + k * 1024, lane);
-            pmask = ok ? (pmask | (1u << i)) : (pmask & ~(1u << i));
-        }
-        dma16(c.ss_srd, (uint32_t)lane * 16u, 0u, smem + OFF_SS + parity * SS_BYTES, lane);
+    // ---- issue-side state: the NEXT chunk's patch source and the weight stream ----------------------------------
+    u32x4 nx_srd, nx_ss_srd, w_srd;
+    const int nchunks_k = pin(ap->nchunks);                   // index of the terminator descriptor
+    int nx_C2 = 0, nx_cbeg2 = 0, nx_cvalid = 0, nx_ntaps = 9, nx_gn = 0, nx_silu = 0, nx_wrun = 0, nx_wsoff = 0, nx_neww = 0;
+    int w_soff = 0, w_tapbytes = 0;
+    auto load_next = [&](int i) {                           // descriptor i -> nx_* (scalar loads from the kernarg segment)
+        const ChunkDesc& d = ap->chunk[i < nchunks_k ? i : nchunks_k];
+        nx_srd = make_srd(reinterpret_cast<const char*>(d.src + (unsigned long long)b * d.bstride), d.src_bytes);
+        nx_gn = d.ss != 0ull;
+        nx_ss_srd = make_srd(reinterpret_cast<const char*>(nx_gn ? d.ss + (unsigned long long)b * d.ss_bstride : d.src),
+                             nx_gn ? (uint32_t)d.cvalid * 8u : 0u);
+        nx_C2 = d.C2; nx_cbeg2 = d.cbeg2; nx_cvalid = d.cvalid; nx_ntaps = d.ntaps; nx_silu = d.silu;
+        nx_wrun = d.wrun; nx_wsoff = d.w_soff; nx_neww = d.new_wrun;
     };
-    auto patch_commit = [&](const Chunk& c, int parity) {   // only with a fused GroupNorm: in place, own units
-        char* dst = smem + parity * PATCH_BYTES;
+    auto enter_wrun = [&](int r) {                          // (leading waves: R = weight piece offsets)
+        const WRunDesc& W = ap->wrun[r];
+        w_srd = make_srd(reinterpret_cast<const char*>(W.w), W.bytes);
+        w_tapbytes = W.tapbytes;
+        if (grp == 0) {
 #pragma unroll
-        for (int i = 0; i < PUU; ++i) {
-            const int k = (wave - PW0) + i * PNW;
-            if (k < PPIECES && ((pmask >> i) & 1u)) {
-                const int row = k * RPP + lane / SLOTS;
-                const int slot = p_swz<PIXB>(row % PW, lane % SLOTS) >> 4;
-                uint4* const q = reinterpret_cast<uint4*>(dst + k * 1024 + lane * 16);
+            for (int j = 0; j < NWD; ++j) {
+                const int row = (lw * NWD + j) * 16 + (lane >> 2);
+                const int co = cout0 + row;                      // rows past the matrix: zeros (never stored)
+                R[j] = co < W.rows ? (uint32_t)(co * W.CinP2 + ((lane & 3) ^ ((row >> 2) & 3)) * 16) : OOB;
+            }
+        }
+    };
+    int ring_rd = 0;                                        // byte offset of the ring slot of the phase being read
+    auto w_issue = [&](int half) {                          // (leading) half of the stream's tap -> the slot two phases ahead
+        if (ABL & 8) return;
+        char* dst = smem + OFF_RING + (ring_rd ^ (2 * WPHASE)) + lw * (NWD * 1024);
+        const uint32_t so = (uint32_t)(w_soff + half * WROW);
+#pragma unroll
+        for (int j = 0; j < NWD; ++j) dma16(w_srd, R[j], so, dst + j * 1024, lane);
+    };
+    auto ring_next = [&]() { ring_rd = (ring_rd + WPHASE) & (RINGB - 1); };
+
+    int par = 0;                                            // patch buffer of the chunk being read
+    // (lagging) the (scale, shift) table of the next chunk: every lagging wave fetches its own copy (identical bytes), so
+    // that its own vmcnt orders it before the transforms
+    auto issue_table = [&](int into) { dma16(nx_ss_srd, (uint32_t)lane * 16u, 0u, smem + OFF_SS + into * 1024, lane); };
+    // (lagging) haloed piece i of this wave -> the other buffer
+    auto issue_slot = [&](int i, int into) {
+        const int k = lw + Cfg::NLAG * i;
+        if (k >= PPIECES) { issue_table(into); return; }     // surplus slot: identical table bytes again - harmless whenever
+                                                             // they land (a repeated PIECE could land on its transformed image)
+        const uint32_t v = R[i];
+        const bool ok = (int)v >= 0 && (int)(v & 7u) * 8 < nx_cvalid;
+        dma16(nx_srd, ok ? (v >> 3) * (uint32_t)nx_C2 + (v & 7u) * 16u : OOB, (uint32_t)nx_cbeg2,
+              smem + into * PATCH_BYTES + k * 1024, lane);
+    };
+    // (lagging) one compact piece (one-tap chunk: TH x 32 pixels, no halo): piece k = pixel row k >> 2, columns 8 (k & 3) ..
+    auto issue_compact = [&](int k, int into) {
+        const int trow = k >> 2, n = (k & 3) * 8 + (lane >> 3);
+        const int slot = (lane & 7) ^ ((n >> 1) & 7);
+        const int gy = ty0 + trow, gx = tx0 + n;
+        const bool ok = gy < imgH && gx < imgW && slot * 8 < nx_cvalid;
+        dma16(nx_srd, ok ? (uint32_t)(gy * imgW + gx) * (uint32_t)nx_C2 + (uint32_t)slot * 16u : OOB, (uint32_t)nx_cbeg2,
+              smem + into * PATCH_BYTES + k * 1024, lane);
+    };
+    auto issue_any = [&](int i, int into) {                 // (lagging) slot i, in the next chunk's layout
+        if (nx_ntaps == 9) issue_slot(i, into);
+        else if (i < NSLOT1) issue_compact(lw + Cfg::NLAG * i, into);
+        else issue_table(into);                              // surplus slot (keeps the VMEM count uniform)
+    };
+    // (lagging) fused GroupNorm-apply (+ SiLU): in place, by the lane that fetched the unit (haloed layout only)
+    auto commit_slot = [&](int i, int into) {
+        const int k = lw + Cfg::NLAG * i;
+        if (k < PPIECES) {
+            const uint32_t v = R[i];
+            if ((int)v >= 0 && (int)(v & 7u) * 8 < nx_cvalid) {
+                uint4* const q = reinterpret_cast<uint4*>(smem + into * PATCH_BYTES + k * 1024 + lane * 16);
                 float ss[16];
-                const float* t = reinterpret_cast<const float*>(smem + OFF_SS + parity * SS_BYTES) + 16 * slot;
+                const float* t = reinterpret_cast<const float*>(smem + OFF_SS + into * 1024) + 16 * (v & 7u);
 #pragma unroll
                 for (int j = 0; j < 16; j += 4) {
                     const float4 t4 = *reinterpret_cast<const float4*>(t + j);
                     ss[j] = t4.x; ss[j + 1] = t4.y; ss[j + 2] = t4.z; ss[j + 3] = t4.w;
                 }
-                *q = gn_act_slot(*q, ss, c.gn_silu, (T*)nullptr);
+                *q = gn_act_slot(*q, ss, nx_silu, (T*)nullptr);
             }
         }
     };
 
-    // ---- fragment reads ----------------------------------------------------------------------------------
-    const int aoff = w_off(wm * WM * 32 + (lane & 31), lane >> 5);   // row of mi is +32 mi rows = +2048 mi B, same swizzle
-    const int aoff1 = aoff ^ 32;                                   // second k-group of a phase
-    const int pv0 = ((wn * WN) * PW + (lane & 31)) * PIXB;         // this lane's pixel of ni = 0 under tap (0, 0)
-    int psw[3];                                                    // swizzle term of k-group 0 for tap column dx
-#pragma unroll
-    for (int d = 0; d < 3; ++d) psw[d] = p_swz<PIXB>((lane & 31) + d, lane >> 5);
-    // byte offset (k-group 0, ni = 0) of the tap at pixel offset tapoff = dy * PW + dx in patch buffer `parity`
-    auto tap_base = [&](int parity, int tapoff, int dx) {
-        return pv0 + parity * PATCH_BYTES + tapoff * PIXB + (dx == 0 ? psw[0] : dx == 1 ? psw[1] : psw[2]);
-    };
-    int pcur = 0;                              // tap_base of the tap being read
-    // k-group kg (0..3) of the chunk = k-group (kg & 1) of ring phase q; pixel rows are immediate offsets
-    auto read_frags = [&](Frag (&fa)[WM], Frag (&fb)[WN], int q, int kg) {
-        if ((ABL & 16) && q > 0) {                          // (profiling: no fragment reads after the first phase)
+    // ---- fragment reads / MFMAs --------------------------------------------------------------------------------
+    // k-group kg (0..3) of the chunk = k-group (kg & 1) of the ring phase at byte offset `ring`; POFF = byte offset of
+    // the tap inside the patch image; PROW = bytes between consecutive pixel rows of the image (haloed: PW, compact: 32 px)
+    auto read_frags = [&](Frag (&fa)[WM], Frag (&fb)[WN], int ring, int pb, auto kg_, auto poff_, auto prow_) {
+        constexpr int kg = decltype(kg_)::value, POFF = decltype(poff_)::value, PROW = decltype(prow_)::value;
 #if defined(__HIP_DEVICE_COMPILE__)
+        if (ABL & 16) {                                      // operands stay whatever the prologue left in the registers
 #pragma unroll
             for (int mi = 0; mi < WM; ++mi) asm volatile("" : "+v"(fa[mi]));
 #pragma unroll
             for (int ni = 0; ni < WN; ++ni) asm volatile("" : "+v"(fb[ni]));
-#endif
             return;
         }
-        const char* wb = smem + OFF_RING + (q & (RING - 1)) * WPHASE_BYTES + ((kg & 1) ? aoff1 : aoff);
+#endif
+        const char* wb = smem + ring + ((kg & 1) ? aoff1 : aoff);
 #pragma unroll
         for (int mi = 0; mi < WM; ++mi) fa[mi] = *reinterpret_cast<const Frag*>(wb + mi * 32 * WROW);
-        const char* pp = smem + (pcur ^ (kg << 5));
+        const char* pp = smem + (pb ^ (kg << 5)) + POFF;
 #pragma unroll
-        for (int ni = 0; ni < WN; ++ni) fb[ni] = *reinterpret_cast<const Frag*>(pp + ni * PW * PIXB);
+        for (int ni = 0; ni < WN; ++ni) fb[ni] = *reinterpret_cast<const Frag*>(pp + ni * PROW);
     };
-    auto mma = [&](const Frag (&fa)[WM], const Frag (&fb)[WN]) {
-        if (ABL & 32) {                                     // (profiling: no MFMAs; operands stay live)
+    auto read_a = [&](Frag& f, int ring, auto kg_, auto mi_) {           // one weight fragment
+        constexpr int kg = decltype(kg_)::value, mi = decltype(mi_)::value;
 #if defined(__HIP_DEVICE_COMPILE__)
+        if (ABL & 16) { asm volatile("" : "+v"(f)); return; }
+#endif
+        f = *reinterpret_cast<const Frag*>(smem + ring + ((kg & 1) ? aoff1 : aoff) + mi * 32 * WROW);
+    };
+    auto read_b = [&](Frag& f, int pb, auto kg_, auto poff_, auto prow_, auto ni_) {   // one pixel fragment
+        constexpr int kg = decltype(kg_)::value, POFF = decltype(poff_)::value, PROW = decltype(prow_)::value, ni = decltype(ni_)::value;
+#if defined(__HIP_DEVICE_COMPILE__)
+        if (ABL & 16) { asm volatile("" : "+v"(f)); return; }
+#endif
+        f = *reinterpret_cast<const Frag*>(smem + (pb ^ (kg << 5)) + POFF + ni * PROW);
+    };
+    auto mma_part = [&](const Frag (&fa)[WM], const Frag (&fb)[WN], int lo, int hi) {   // MFMAs lo..hi-1 of the k-group's WM x WN
+#if defined(__HIP_DEVICE_COMPILE__)
+        if (ABL & 32) {
 #pragma unroll
             for (int mi = 0; mi < WM; ++mi) asm volatile("" ::"v"(fa[mi]));
 #pragma unroll
             for (int ni = 0; ni < WN; ++ni) asm volatile("" ::"v"(fb[ni]));
-#endif
             return;
         }
-#pragma unroll
-        for (int mi = 0; mi < WM; ++mi)
-#pragma unroll
-            for (int ni = 0; ni < WN; ++ni) Mma<T>::run(fa[mi], fb[ni], acc[mi][ni]);
-    };
-
-    auto mma_part = [&](const Frag (&fa)[WM], const Frag (&fb)[WN], int lo, int hi) {   // MFMAs lo..hi-1 of the k-group's WM x WN
+#endif
 #pragma unroll
         for (int i = 0; i < WM * WN; ++i)
             if (i >= lo && i < hi) Mma<T>::run(fa[i / WN], fb[i % WN], acc[i / WN][i % WN]);
     };
-    int r = 0, ch = 0, nch_r = chunks_of(0), ci = 0;
-    Chunk cur = get_chunk(0, 0);
     Frag fa0[WM], fb0[WN], fa1[WM], fb1[WN];
-    if constexpr (NWAVES == 8) {
-        // ---- prologue: first patch, first step's weights --------------------------------------------------
-        w_issue(0, 0); w_issue(1, 1); w_advance();
-        if (patcher) patch_issue(cur, 0);
-        vm_wait<0>();
-        if (patcher && cur.gn) patch_commit(cur, 0);
-        raw_barrier();
-        const int grp = (ABL & 2) ? 0 : wave >> 2;        // (ABL & 2: profiling variant without the stagger)
-        if (grp == 1) raw_barrier();
-        stamp(2);
+    int tstep = 0;                                          // (profiling) tap-steps stamped so far
+    typedef IC<PW * PIXB> Prow9; typedef IC<TILE_W * PIXB> Prow1;
 
-        // ---- main loop: one iteration = one tap-step = phases P (half 0) and P+1 (half 1) ------------------
-        int P = 0, tp = 0, step = 0, steps_left = pin(total_steps);
-        bool has_nc;
-        Chunk nxt = cur;
-        {
-            int nr = r, nc = ch + 1;
-            if (nc == nch_r) { nc = 0; ++nr; }
-            has_nc = nr < nruns;
-            nxt = get_chunk(has_nc ? nr : r, has_nc ? nc : ch);
+    // ---- one tap-step (two phases) of a chunk with NT taps; TP = tap index ------------------------------------------
+    auto tap_step = [&](auto t_, auto nt_) {
+        constexpr int TP = decltype(t_)::value, NT = decltype(nt_)::value;
+        constexpr int DX = NT == 9 ? TP % 3 : 0;
+        constexpr int POFF = NT == 9 ? ((TP / 3) * PW + DX) * PIXB : 0;
+        constexpr int DXN = NT == 9 ? (TP + 1) % 3 : 0;                          // the next tap of the chunk
+        constexpr int POFFN = NT == 9 ? (((TP + 1) / 3) * PW + DXN) * PIXB : 0;
+        typedef IC<POFF> Poff; typedef IC<POFFN> PoffN;
+        typedef std::conditional_t<NT == 9, Prow9, Prow1> Prow;
+        const int pb = NT == 9 ? pbase[DX] : pbase[0] - cdelta;
+        const int into = par ^ 1;
+        const int sb = tstep < 30 ? 4 + 16 * tstep : 4096;   // (profiling: the first 30 tap-steps are stamped)
+        // the weight stream moves to the next tap (last tap: to the first tap of the next chunk)
+        if constexpr (TP == NT - 1) {
+            if (nx_neww) enter_wrun(nx_wrun);
+            w_soff = nx_wsoff;
+        } else {
+            w_soff += w_tapbytes;
         }
-        int ntaps = pin(cur.ntaps), par = 0;
-        int tapoff = ntaps == 9 ? 0 : PW + 1, tapdx = 0;          // LDS pixel offset of the current tap, its column
-        pcur = tap_base(0, tapoff, ntaps == 9 ? 0 : 1);
-        // Staging intervals start with the fragment reads (their LDS latency then hides under the interval's own
-        // bookkeeping), MFMA intervals contain nothing but the second k-group's reads and the 16 MFMAs.
-        while (true) {
-            // ================= S(P), half 0 =================
-            stamp(4 + 16 * step);
-            read_frags(fa0, fb0, P, 0);
-            w_issue(P + 2, 0);
-            if (patcher && tp == 0 && has_nc) {                 // first phase of a chunk: fetch the next chunk's patch
-                patch_issue(nxt, par ^ 1);
-                vm_wait<2 + NPP>();
-            } else vm_wait<2>();
-            stamp(6 + 16 * step);
+        static_for<2>([&](auto h_) {
+            constexpr int h = decltype(h_)::value;
+            constexpr int p = 2 * TP + h;                    // phase of the chunk
+            constexpr bool pdma = !(ABL & 128);
+            // ================= S =================
+            stamp(sb + (h ? 7 : 0));
+            if constexpr (NT == 1 && h == 0) read_frags(fa0, fb0, ring_rd, pb, IC<0>{}, Poff{}, Prow{});   // (not pre-read: see top)
+            if (grp == 0) {
+                w_issue(h);
+                stamp(sb + (h ? 12 : 1));
+                vm_wait<(ABL & 8) ? 0 : NWD>();                  // the weights of the next phase have landed
+            } else if constexpr (pdma && NT == 9) {
+                if constexpr (p == 0) issue_table(into);
+                if constexpr (p < NSLOT) issue_any(p, into);
+                stamp(sb + (h ? 12 : 1));
+                if constexpr (p >= Cfg::LAZY && p - Cfg::LAZY < NSLOT) {
+                    constexpr int i = p - Cfg::LAZY;             // this piece has had LAZY phases to arrive
+                    vm_wait<(p < NSLOT ? p : NSLOT - 1) - i>();
+                    if (nx_gn) commit_slot(i, into);
+                }
+            } else if constexpr (pdma) {                         // one-tap chunk: the whole compact patch of the next chunk
+                if constexpr (h == 0) {
+#pragma unroll
+                    for (int i = 0; i < NSLOT1; ++i) issue_compact(lw + Cfg::NLAG * i, into);
+                } else vm_wait<0>();
+                stamp(sb + (h ? 12 : 1));
+            }
+            stamp(sb + (h ? 8 : 2));
             raw_barrier();
-            // ================= C(P) =================
-            stamp(8 + 16 * step);
+            // ================= C =================
+            stamp(sb + (h ? 9 : 4));
             __builtin_amdgcn_sched_barrier(0);
-            if (!(ABL & 1)) prio(1);
-            mma_part(fa0, fb0, 0, 2);                           // the matrix pipe starts at once (operands were read in S) ...
+            prio(1);
+            if constexpr (!(ABL & 256)) {
+                // ONE fragment read per MFMA gap (an in-order wave cannot issue its next MFMA behind a burst of reads that
+                // queue for the LDS): MFMA i of k-group 0 uses fa0[i / 4], fb0[i % 4]; the second k-group's six fragments
+                // arrive under MFMAs 1-6, then the first k-group of the NEXT phase refills fa0 / fb0 as the MFMAs release them
+                const int rn = (ring_rd + WPHASE) & (RINGB - 1);
+                auto next_a = [&](auto mi_) {                    // fa0[mi] <- first k-group of the next phase
+                    constexpr int mi = decltype(mi_)::value;
+                    if constexpr (h == 0) read_a(fa0[mi], rn, IC<2>{}, mi_);
+                    else if constexpr (TP < NT - 1) read_a(fa0[mi], rn, IC<0>{}, mi_);
+                    else if constexpr (NT == 9) { if (nx_ntaps == 9) read_a(fa0[mi], rn, IC<0>{}, mi_); }
+                };
+                auto next_b = [&](auto ni_) {
+                    constexpr int ni = decltype(ni_)::value;
+                    if constexpr (h == 0) read_b(fb0[ni], pb, IC<2>{}, Poff{}, Prow{}, ni_);
+                    else if constexpr (TP < NT - 1) read_b(fb0[ni], pbase[DXN], IC<0>{}, PoffN{}, Prow{}, ni_);
+                    else if constexpr (NT == 9) { if (nx_ntaps == 9) read_b(fb0[ni], pbase[0] + (par ? -PATCH_BYTES : PATCH_BYTES), IC<0>{}, IC<0>{}, Prow9{}, ni_); }
+                };
+                typedef IC<2 * h + 1> K1;
+#define STORM_SB() __builtin_amdgcn_sched_barrier(0)
+                // fragment registers are refilled as early as the MFMAs release them, so that every LDS read of the interval
+                // has returned by MFMA 12: the wave then ARRIVES at the interval barrier and issues its last four MFMAs behind
+                // it - the barrier's latency (~95 cycles) and the partner group's start-up hide under them
+                mma_part(fa0, fb0, 0, 1); read_a(fa1[0], ring_rd, K1{}, IC<0>{}); read_b(fb1[0], pb, K1{}, Poff{}, Prow{}, IC<0>{}); STORM_SB();
+                mma_part(fa0, fb0, 1, 2); read_b(fb1[1], pb, K1{}, Poff{}, Prow{}, IC<1>{}); read_b(fb1[2], pb, K1{}, Poff{}, Prow{}, IC<2>{}); STORM_SB();
+                mma_part(fa0, fb0, 2, 3); read_b(fb1[3], pb, K1{}, Poff{}, Prow{}, IC<3>{}); read_a(fa1[1], ring_rd, K1{}, IC<1>{}); STORM_SB();
+                mma_part(fa0, fb0, 3, 4); STORM_SB();
+                mma_part(fa0, fb0, 4, 5); next_a(IC<0>{}); STORM_SB();          // fa0[0]: last used by MFMA 3
+                mma_part(fa0, fb0, 5, 6); next_b(IC<0>{}); STORM_SB();          // fb0[0]: last used by MFMA 4
+                mma_part(fa0, fb0, 6, 7); next_b(IC<1>{}); STORM_SB();
+                mma_part(fa0, fb0, 7, 8); next_b(IC<2>{}); STORM_SB();
+                mma_part(fa1, fb1, 0, 1); next_b(IC<3>{}); next_a(IC<1>{}); STORM_SB();   // fb0[3], fa0[1]: last used by MFMA 7
+                if constexpr ((ABL & 512) != 0) {                // (profiling A/B: arrive at the barrier before the last four MFMAs)
+                    mma_part(fa1, fb1, 1, 4); STORM_SB();
+                    stamp(sb + (h ? 10 : 6));
+                    raw_barrier();                               // (lgkmcnt(0): this interval's reads are complete)
+                    STORM_SB();
+                    mma_part(fa1, fb1, 4, WM * WN);
+                } else {
+                    mma_part(fa1, fb1, 1, WM * WN); STORM_SB();
+                    stamp(sb + (h ? 10 : 6));
+                    raw_barrier();
+                }
+#undef STORM_SB
+            } else {
+            mma_part(fa0, fb0, 0, 2);                            // the matrix pipe starts at once (operands were pre-read)
             __builtin_amdgcn_sched_barrier(0);
-            read_frags(fa1, fb1, P, 1);                         // ... the second k-group's reads issue in its shadow
+            read_frags(fa1, fb1, ring_rd, pb, IC<2 * h + 1>{}, Poff{}, Prow{});
             __builtin_amdgcn_sched_barrier(0);
             mma_part(fa0, fb0, 2, WM * WN);
-            mma(fa1, fb1);
             __builtin_amdgcn_sched_barrier(0);
-            if (!(ABL & 1)) prio(0);
-            stamp(10 + 16 * step);
-            raw_barrier();
-            stamp(11 + 16 * step);
-            // ================= S(P+1), half 1 =================
-            read_frags(fa0, fb0, P + 1, 2);
-            w_issue(P + 3, 1);
-            const bool last = --steps_left == 0;
-            const int tpn = tp + 1;
-            const bool wrap = tpn == ntaps;
-            const bool row_end = tapdx == 2;                    // 3x3 taps in raster order: offset dy * PW + dx
-            const int nxt_first = nxt.ntaps == 9 ? 0 : PW + 1;
-            tapoff = wrap ? nxt_first : (ntaps == 9 ? tapoff + (row_end ? PW - 2 : 1) : PW + 1);
-            tapdx = (row_end || wrap) ? 0 : tapdx + 1;
-            const int par_n = wrap ? par ^ 1 : par, dx_n = wrap ? (nxt.ntaps == 9 ? 0 : 1) : (ntaps == 9 ? tapdx : 1);
-            stamp(12 + 16 * step);
-            vm_wait<2>();                                       // this phase's successor weights AND a patch fetched in S(P) have landed
-            if (patcher && tp == 0 && has_nc && nxt.gn) patch_commit(nxt, par ^ 1);   // fused GroupNorm: in place, own units
-            raw_barrier();
-            // ================= C(P+1) =================
-            stamp(13 + 16 * step);
-            __builtin_amdgcn_sched_barrier(0);
-            if (!(ABL & 1)) prio(1);
-            mma_part(fa0, fb0, 0, 2);
-            __builtin_amdgcn_sched_barrier(0);
-            read_frags(fa1, fb1, P + 1, 3);
-            __builtin_amdgcn_sched_barrier(0);
-            mma_part(fa0, fb0, 2, WM * WN);
-            mma(fa1, fb1);
-            pcur = tap_base(par_n, tapoff, dx_n);               // next tap-step's patch offsets (a handful of VALU)
-            __builtin_amdgcn_sched_barrier(0);
-            if (!(ABL & 1)) prio(0);
-            stamp(14 + 16 * step);
-            raw_barrier();
-            stamp(15 + 16 * step);
-            P += 2; ++step;
-            if (last) break;
-            tp = wrap ? 0 : tpn;
-            {                                                   // weight cursor -> the step whose halves are issued next
-                const int adv = --w_left > 0 ? 1 : 0;           // past the end it stays (harmless re-load)
-                const int wtn = w_tp + adv;
-                if (__builtin_expect(wtn < w_ntaps, 1)) { w_soff += adv ? w_tapbytes : 0; w_tp = wtn; }
-                else {                                          // next chunk of the run, or the next run (rare)
-                    w_tp = 0; ++w_ch;
-                    if (w_ch < w_nch) w_soff = w_ch * PIXB;
-                    else { ++w_r; w_enter_run(w_r); }
+            {   // first k-group of the NEXT phase into the registers the MFMAs above have consumed
+                const int rn = (ring_rd + WPHASE) & (RINGB - 1);
+                if constexpr (h == 0) read_frags(fa0, fb0, rn, pb, IC<2>{}, Poff{}, Prow{});
+                else if constexpr (TP < NT - 1) read_frags(fa0, fb0, rn, pbase[DXN], IC<0>{}, PoffN{}, Prow{});
+                else if constexpr (NT == 9) {                    // next chunk: the other buffer (a one-tap chunk reads in its own S)
+                    if (nx_ntaps == 9) read_frags(fa0, fb0, rn, pbase[0] + (par ? -PATCH_BYTES : PATCH_BYTES), IC<0>{}, IC<0>{}, Prow9{});
                 }
             }
-            if (__builtin_expect(wrap, 0)) {
-                int nr = r, nc = ch + 1;
-                if (nc == nch_r) { nc = 0; ++nr; }
-                if (nr != r) nch_r = chunks_of(nr);
-                cur = nxt; r = nr; ch = nc; ++ci;
-                nr = r; nc = ch + 1;
-                if (nc == nch_r) { nc = 0; ++nr; }
-                has_nc = nr < nruns;
-                nxt = get_chunk(has_nc ? nr : r, has_nc ? nc : ch);
-                ntaps = pin(cur.ntaps); par = ci & 1;
+            __builtin_amdgcn_sched_barrier(0);
+            mma_part(fa1, fb1, 0, WM * WN);
+            stamp(sb + (h ? 10 : 6));
+            raw_barrier();
             }
+            __builtin_amdgcn_sched_barrier(0);
+            prio(0);
+            ring_next();
+        });
+        stamp(sb + 11);
+        if (TRACE) ++tstep;
+    };
+
+    // ---- tile start, part A: issue the first chunk's patch (lagging waves) and the first tap's weights (leading waves)
+    // into patch buffer 0 / ring slots 0, 1 / table 0 (regions the previous tile's epilogue staging does not touch)
+    auto tile_issue = [&]() {
+        patch_table();
+        load_next(0);
+        enter_wrun(nx_wrun);
+        w_soff = nx_wsoff;
+        if (grp == 0) {                                     // phases 0 and 1 -> ring slots 0 and 1
+            char* dst = smem + OFF_RING + lw * (NWD * 1024);
+#pragma unroll
+            for (int h = 0; h < 2; ++h)
+#pragma unroll
+                for (int j = 0; j < NWD; ++j) dma16(w_srd, R[j], (uint32_t)(w_soff + h * WROW), dst + h * WPHASE + j * 1024, lane);
+        } else {
+            issue_table(0);
+#pragma unroll
+            for (int i = 0; i < NSLOT; ++i) issue_slot(i, 0);
+        }
+    };
+    const int nchunks = pin(ap->nchunks), n9 = pin(ap->nchunks9);
+    // chunk change: the fetched buffer becomes current; descriptor of the chunk after the next.  Lane-derived address
+    // math is re-laundered so that none of it is hoisted out of the loops and kept in registers.
+    auto chunk_change = [&](int ci) {
+        par ^= 1;
+        const int dlt = par ? PATCH_BYTES : -PATCH_BYTES;
+#pragma unroll
+        for (int d = 0; d < 3; ++d) pbase[d] += dlt;
+        load_next(ci + 1);
+#if defined(__HIP_DEVICE_COMPILE__)
+        asm volatile("" : "+v"(lane));
+#endif
+    };
+    tile_issue();
+    bool first = true;
+    while (true) {
+        // ---- tile start, part B: everything issued has landed; fused GroupNorm transform of the first patch ----------
+        STORM_RELAUNDER();
+        vm_wait<0>();
+        if (grp == 1 && nx_gn) {
+#pragma unroll
+            for (int i = 0; i < NSLOT; ++i) commit_slot(i, 0);
+        }
+        load_next(1);
+        raw_barrier();
+        read_frags(fa0, fb0, 0, pbase[0], IC<0>{}, IC<0>{}, Prow9{});   // first k-group of phase 0
+        if (grp == 1) raw_barrier();                        // the lagging group starts one interval later
+#pragma unroll
+        for (int mi = 0; mi < WM; ++mi)
+#pragma unroll
+            for (int ni = 0; ni < WN; ++ni)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[mi][ni][r] = 0.0f;
+        if (first) stamp(2);
+
+        // ---- main loops: the nine-tap chunks, then the one-tap chunks of a fused 1x1 shortcut ---------------------------
+        // (two loops in sequence, not one loop with two bodies: the accumulators then have one home per loop)
+        int ci = 0;
+        for (; ci < n9; ++ci) {
+            static_for<9>([&](auto t) { tap_step(t, IC<9>{}); });
+            chunk_change(ci + 1);
+        }
+        for (; ci < nchunks; ++ci) {
+            tap_step(IC<0>{}, IC<1>{});
+            chunk_change(ci + 1);
         }
         if (grp == 0) raw_barrier();                        // balance the stagger: every wave has executed the same barriers
 
-    } else {
-        // =========================== one wave per SIMD (4 waves, 128 x 128 each) ===========================
-        // No partner wave: every phase is ONE straight-line block in which the staging instructions ride in the
-        // MFMA issue gaps (sched_group_barrier), one barrier per phase, fragments read one k-group ahead.
-        //   phase P:  vmcnt: own share of phase P+1's weights landed | barrier (reads of P-1 retired everywhere)
-        //             DMA weights of phase P+3 -> slot (P+3)&3   [first phase of a chunk: DMA the next chunk's patch]
-        //             read k-group 1 | 16 MFMA (k-group 0) | read k-group 0 of phase P+1 | 16 MFMA (k-group 1)
-        w_issue(0, 0); w_issue(1, 1); w_advance(); w_issue(2, 0);
-        patch_issue(cur, 0);
-        vm_wait<0>();
-        if (cur.gn) patch_commit(cur, 0);
-        raw_barrier();
-        stamp(2);
-        int P = 0, tp = 0, step = 0, steps_left = pin(total_steps);
-        bool has_nc, issued_prev = false;
-        Chunk nxt = cur;
-        {
-            int nr = r, nc = ch + 1;
-            if (nc == nch_r) { nc = 0; ++nr; }
-            has_nc = nr < nruns;
-            nxt = get_chunk(has_nc ? nr : r, has_nc ? nc : ch);
-        }
-        int ntaps = pin(cur.ntaps), par = 0;
-        int tapoff = ntaps == 9 ? 0 : PW + 1, tapdx = 0;
-        pcur = tap_base(0, tapoff, ntaps == 9 ? 0 : 1);
-        read_frags(fa0, fb0, 0, 0);
-        auto interleave1 = [&]() {                              // scheduling hint for one k-group region
+        // ---- hand-over: this tile's coordinates go to the epilogue; the next tile's first loads are issued -----------------
+        if (first) stamp(500);
+        vm_wait<0>();                                       // trailing ring / patch re-loads landed ...
+        raw_barrier();                                      // ... and every wave is done reading: all of LDS is free
+        if (first) stamp(501);
+        const int e_tile = tile, e_b = b, e_ty0 = ty0, e_tx0 = tx0, e_cout0 = cout0;
+        STORM_RELAUNDER();
+        int nvb = vb + gridDim.x;
+        while (nvb < total_vblocks && block_map(nvb, n_ct, tiles_per_xcd).tile >= ntiles) nvb += gridDim.x;
+        const bool has_next = nvb < total_vblocks;
+        if (has_next) {
+            vb = nvb;
+            decode(vb);
+            if (par) {                                      // the next tile starts in patch buffer 0 / ring slot 0
+                par = 0;
+#pragma unroll
+                for (int d = 0; d < 3; ++d) pbase[d] -= PATCH_BYTES;
+            }
+            ring_rd = 0;
 #if defined(__HIP_DEVICE_COMPILE__)
-            __builtin_amdgcn_sched_group_barrier(0x100, WM + WN, 0);      // the fragment reads first
-#pragma unroll
-            for (int i = 0; i < WM * WN; ++i) {
-                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);        // 1 MFMA
-                __builtin_amdgcn_sched_group_barrier(0x002, 2, 0);        // <= 2 VALU
-                __builtin_amdgcn_sched_group_barrier(0x004, 2, 0);        // <= 2 SALU
-            }
+            asm volatile("" : "+v"(lane));
 #endif
-        };
-        while (true) {
-            // ================= phase P (half 0) =================
-            const bool issue_now = tp == 0 && has_nc;           // P is the chunk's first phase
-            if (issued_prev) vm_wait<NWD + NP>(); else vm_wait<NWD>();
-            raw_barrier();
-            __builtin_amdgcn_sched_barrier(0);
-            w_issue(P + 3, 1);
-            const int adv = --w_left > 0 ? 1 : 0;               // weight cursor -> next tap-step (branch-free common case)
-            const int wtn = w_tp + adv;
-            const bool w_slow = wtn >= w_ntaps;
-            w_soff += (adv && !w_slow) ? w_tapbytes : 0;
-            w_tp = w_slow ? w_tp : wtn;
-            if (issue_now) patch_issue(nxt, par ^ 1);
-            if (tp == 1 && ntaps != 1 && nxt.gn && has_nc) {    // long chunk: patch issued two phases ago
-                vm_wait<2 * NWD>();
-                patch_commit(nxt, par ^ 1);
-            }
-            __builtin_amdgcn_sched_barrier(0);
-            read_frags(fa1, fb1, P, 1);
-            mma(fa0, fb0);
-            if (!(ABL & 4)) interleave1();
-            __builtin_amdgcn_sched_barrier(0);
-            read_frags(fa0, fb0, P + 1, 2);
-            mma(fa1, fb1);
-            if (!(ABL & 4)) interleave1();
-            __builtin_amdgcn_sched_barrier(0);
-            if (w_slow) {                                       // next chunk of the run, or the next run
-                w_tp = 0; ++w_ch;
-                if (w_ch < w_nch) w_soff = w_ch * PIXB;
-                else { ++w_r; w_enter_run(w_r); }
-            }
-            // ================= phase P+1 (half 1) =================
-            if (issue_now && ntaps == 1) {                      // two-phase chunk: this phase already reads the new patch
-                vm_wait<0>();
-                if (nxt.gn) patch_commit(nxt, par ^ 1);
-            } else if (issue_now) vm_wait<NWD + NP>(); else vm_wait<NWD>();
-            issued_prev = issue_now;
-            raw_barrier();
-            __builtin_amdgcn_sched_barrier(0);
-            w_issue(P + 4, 0);
-            read_frags(fa1, fb1, P + 1, 3);
-            // next tap (branch-free; a chunk change is completed after the MFMAs)
-            P += 2; ++step;
-            const bool last = --steps_left == 0;
-            const int tpn = tp + 1;
-            const bool wrap = tpn == ntaps;
-            tp = wrap ? 0 : tpn;
-            const bool row_end = tapdx == 2;
-            const int nxt_first = nxt.ntaps == 9 ? 0 : PW + 1;
-            tapoff = wrap ? nxt_first : (ntaps == 9 ? tapoff + (row_end ? PW - 2 : 1) : PW + 1);
-            tapdx = (row_end || wrap) ? 0 : tapdx + 1;
-            const int par_n = wrap ? par ^ 1 : par;
-            pcur = tap_base(par_n, tapoff, wrap ? (nxt.ntaps == 9 ? 0 : 1) : (ntaps == 9 ? tapdx : 1));
-            mma(fa0, fb0);
-            if (!(ABL & 4)) interleave1();
-            __builtin_amdgcn_sched_barrier(0);
-            read_frags(fa0, fb0, P, 0);
-            mma(fa1, fb1);
-            if (!(ABL & 4)) interleave1();
-            __builtin_amdgcn_sched_barrier(0);
-            if (last) break;
-            if (wrap) {
-                int nr = r, nc = ch + 1;
-                if (nc == nch_r) { nc = 0; ++nr; }
-                if (nr != r) nch_r = chunks_of(nr);
-                cur = nxt; r = nr; ch = nc; ++ci;
-                nr = r; nc = ch + 1;
-                if (nc == nch_r) { nc = 0; ++nr; }
-                has_nc = nr < nruns;
-                nxt = get_chunk(has_nc ? nr : r, has_nc ? nc : ch);
-                ntaps = pin(cur.ntaps); par = ci & 1;
-            }
+            tile_issue();
         }
-    }
 
-    // ---- epilogue: LDS transpose -> (bias, temb bias, skip, scale) -> wide stores (as conv_igemm.hip) ------
-    stamp_tail(500);
-    vm_wait<0>();                                       // trailing ring re-loads landed: LDS is free to reuse
-    raw_barrier();
-    stamp_tail(501);
-    constexpr int SROWS = 32 * PR;
-    char* const stage = smem + wave * (SROWS * WM * 128);
-    constexpr int LPR = WM * 4;                 // lanes per staged row (8 couts each)
-    constexpr int RPI = 64 / LPR;               // rows per read iteration
-    const int skipC = a.outC;
-    const int c8 = lane % LPR;
-    const int co = cout0 + wm * WM * 32 + c8 * 8;
-    float badd[8];
+            STORM_RELAUNDER();
+    // ---- epilogue: LDS transpose -> (bias, temb bias, skip, scale) -> wide stores (as conv_igemm.hip).  Staging lives in
+        // patch buffer 1 (waves 0-4) and ring slots 2, 3 (waves 5-7): the next tile's first loads are landing in buffer 0 /
+        // slots 0, 1 meanwhile.
+        constexpr int SROWS = 32 * PR;
+        constexpr int WSTAGE = SROWS * WM * 128;
+        static_assert(5 * WSTAGE <= PATCH_BYTES && 3 * WSTAGE + WAVES_N * BN * 8 <= 2 * WPHASE, "epilogue staging beside the next tile's loads");
+        char* const stage = smem + (wave < 5 ? PATCH_BYTES + wave * WSTAGE : OFF_RING + 2 * WPHASE + (wave - 5) * WSTAGE);
+        constexpr int LPR = WM * 4;                 // lanes per staged row (8 couts each)
+        constexpr int RPI = 64 / LPR;               // rows per read iteration
+        const int skipC = ap->outC;
+        const int c8 = lane % LPR;
+        const int co = e_cout0 + wm * WM * 32 + c8 * 8;
+        float badd[8];
 #pragma unroll
-    for (int e = 0; e < 8; ++e) badd[e] = 0.f;
-    if (co + 8 <= a.Cout) {
-        if (a.bias) { float bb[8]; load8(a.bias + co, bb);
+        for (int e = 0; e < 8; ++e) badd[e] = 0.f;
+        if (co + 8 <= ap->Cout) {
+            if (ap->bias) { float bb[8]; load8(ap->bias + co, bb);
 #pragma unroll
-            for (int e = 0; e < 8; ++e) badd[e] += bb[e]; }
-        if (a.tbias) { float bb[8]; load8(a.tbias + (long long)b * a.tbias_stride + co, bb);
+                for (int e = 0; e < 8; ++e) badd[e] += bb[e]; }
+            if (ap->tbias) { float bb[8]; load8(ap->tbias + (long long)e_b * ap->tbias_stride + co, bb);
 #pragma unroll
-            for (int e = 0; e < 8; ++e) badd[e] += bb[e]; }
-    } else {
+                for (int e = 0; e < 8; ++e) badd[e] += bb[e]; }
+        } else {
 #pragma unroll
-        for (int e = 0; e < 8; ++e)
-            if (co + e < a.Cout) {
-                if (a.bias) badd[e] += a.bias[co + e];
-                if (a.tbias) badd[e] += a.tbias[(long long)b * a.tbias_stride + co + e];
-            }
-    }
-    const bool co_ok = co < a.outC;
-    const T* const skip_b = reinterpret_cast<const T*>(a.skip) + (long long)b * a.skip_bstride;
-    // out = (acc + bias + temb bias + skip) * scale, evaluated as packed fma: (acc [+ skip]) * scale + (bias * scale);
-    // channel pairs stay in adjacent registers from the staging read to the bf16 pack (v_pk_fma_f32 / v_pk_add_f32)
-    f32x2 badd2[4], gsum2[4], gsq2[4];
-    const f32x2 scale2 = {a.scale, a.scale};
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        badd2[i] = f32x2{badd[2 * i] * a.scale, badd[2 * i + 1] * a.scale};
-        gsum2[i] = f32x2{0.f, 0.f}; gsq2[i] = f32x2{0.f, 0.f};
-    }
-    float gsum[8], gsq[8];
-#pragma unroll
-    for (int pass = 0; pass < WN / PR; ++pass) {
-        if (pass > 0) wave_sync();
-#pragma unroll
-        for (int nn = 0; nn < PR; ++nn)
-#pragma unroll
-            for (int mi = 0; mi < WM; ++mi)
-#pragma unroll
-                for (int g = 0; g < 4; ++g) {
-                    const int row = nn * 32 + (lane & 31);
-                    const f32x16& c = acc[mi][pass * PR + nn];
-                    *reinterpret_cast<float4*>(stage + stage_off<WM>(row, stage_wslot(lane, mi, g))) =
-                        make_float4(c[4 * g], c[4 * g + 1], c[4 * g + 2], c[4 * g + 3]);
+            for (int e = 0; e < 8; ++e)
+                if (co + e < ap->Cout) {
+                    if (ap->bias) badd[e] += ap->bias[co + e];
+                    if (ap->tbias) badd[e] += ap->tbias[(long long)e_b * ap->tbias_stride + co + e];
                 }
-        wave_sync();
+        }
+        const bool co_ok = co < ap->outC;
+        const T* const skip_b = reinterpret_cast<const T*>(ap->skip) + (long long)e_b * ap->skip_bstride;
+        // out = (acc + bias + temb bias + skip) * scale, evaluated as packed fma: (acc [+ skip]) * scale + (bias * scale);
+        // channel pairs stay in adjacent registers from the staging read to the bf16 pack (v_pk_fma_f32 / v_pk_add_f32)
+        f32x2 badd2[4], gsum2[4], gsq2[4];
+        const f32x2 scale2 = {ap->scale, ap->scale};
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            badd2[i] = f32x2{badd[2 * i] * ap->scale, badd[2 * i + 1] * ap->scale};
+            gsum2[i] = f32x2{0.f, 0.f}; gsq2[i] = f32x2{0.f, 0.f};
+        }
+        float gsum[8], gsq[8];
+#pragma unroll
+        for (int pass = 0; pass < WN / PR; ++pass) {
+            if (pass > 0) wave_sync();
+#pragma unroll
+            for (int nn = 0; nn < PR; ++nn)
+#pragma unroll
+                for (int mi = 0; mi < WM; ++mi)
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) {
+                        const int row = nn * 32 + (lane & 31);
+                        const f32x16& c = acc[mi][pass * PR + nn];
+                        *reinterpret_cast<float4*>(stage + stage_off<WM>(row, stage_wslot(lane, mi, g))) =
+                            make_float4(c[4 * g], c[4 * g + 1], c[4 * g + 2], c[4 * g + 3]);
+                    }
+            wave_sync();
 #pragma unroll 4
-        for (int it = 0; it < SROWS / RPI; ++it) {
-            const int row = it * RPI + lane / LPR;
-            const float4 v0 = *reinterpret_cast<const float4*>(stage + stage_off<WM>(row, 2 * c8));
-            const float4 v1 = *reinterpret_cast<const float4*>(stage + stage_off<WM>(row, 2 * c8 + 1));
-            f32x2 v2[4] = {f32x2{v0.x, v0.y}, f32x2{v0.z, v0.w}, f32x2{v1.x, v1.y}, f32x2{v1.z, v1.w}};
-            const int trow = wn * WN + pass * PR + (row >> 5), n = row & 31;
-            const int gy = ty0 + trow, gx = tx0 + n;
-            const bool ok = gy < a.H && gx < a.W;
-            const int pix = gy * a.W + gx;
-            if (ok && co_ok) {
-                if (a.skip) {
-                    float sk[8];
-                    load8(skip_b + (uint32_t)(pix * skipC + co), sk);
+            for (int it = 0; it < SROWS / RPI; ++it) {
+                const int row = it * RPI + lane / LPR;
+                const float4 v0 = *reinterpret_cast<const float4*>(stage + stage_off<WM>(row, 2 * c8));
+                const float4 v1 = *reinterpret_cast<const float4*>(stage + stage_off<WM>(row, 2 * c8 + 1));
+                f32x2 v2[4] = {f32x2{v0.x, v0.y}, f32x2{v0.z, v0.w}, f32x2{v1.x, v1.y}, f32x2{v1.z, v1.w}};
+                const int trow = wn * WN + pass * PR + (row >> 5), n = row & 31;
+                const int gy = e_ty0 + trow, gx = e_tx0 + n;
+                const bool ok = gy < imgH && gx < imgW;
+                const int pix = gy * imgW + gx;
+                if (ok && co_ok) {
+                    if (ap->skip) {
+                        float sk[8];
+                        load8(skip_b + (uint32_t)(pix * skipC + co), sk);
 #pragma unroll
-                    for (int i = 0; i < 4; ++i) v2[i] += f32x2{sk[2 * i], sk[2 * i + 1]};
-                }
+                        for (int i = 0; i < 4; ++i) v2[i] += f32x2{sk[2 * i], sk[2 * i + 1]};
+                    }
 #pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    v2[i] = __builtin_elementwise_fma(v2[i], scale2, badd2[i]);
-                    gsum2[i] += v2[i];
-                    gsq2[i] = __builtin_elementwise_fma(v2[i], v2[i], gsq2[i]);
+                    for (int i = 0; i < 4; ++i) {
+                        v2[i] = __builtin_elementwise_fma(v2[i], scale2, badd2[i]);
+                        gsum2[i] += v2[i];
+                        gsq2[i] = __builtin_elementwise_fma(v2[i], v2[i], gsq2[i]);
+                    }
+                    const float v[8] = {v2[0].x, v2[0].y, v2[1].x, v2[1].y, v2[2].x, v2[2].y, v2[3].x, v2[3].y};
+                    const uint32_t o = (uint32_t)(pix * ap->outC + co);
+                    if (ap->out_f32) store8(reinterpret_cast<float*>(ap->out) + (long long)e_b * ap->out_bstride + o, v);
+                    else store8(reinterpret_cast<T*>(ap->out) + (long long)e_b * ap->out_bstride + o, v);
                 }
-                const float v[8] = {v2[0].x, v2[0].y, v2[1].x, v2[1].y, v2[2].x, v2[2].y, v2[3].x, v2[3].y};
-                const uint32_t o = (uint32_t)(pix * a.outC + co);
-                if (a.out_f32) store8(reinterpret_cast<float*>(a.out) + (long long)b * a.out_bstride + o, v);
-                else store8(reinterpret_cast<T*>(a.out) + (long long)b * a.out_bstride + o, v);
             }
         }
-    }
-    stamp_tail(502);
-    if (ABL & 64) { vm_wait<0>(); stamp_tail(503); }
+        if (first) stamp(502);
 #pragma unroll
-    for (int i = 0; i < 4; ++i) { gsum[2 * i] = gsum2[i].x; gsum[2 * i + 1] = gsum2[i].y; gsq[2 * i] = gsq2[i].x; gsq[2 * i + 1] = gsq2[i].y; }
-    if (a.gn_part != nullptr) {
+        for (int i = 0; i < 4; ++i) { gsum[2 * i] = gsum2[i].x; gsum[2 * i + 1] = gsum2[i].y; gsq[2 * i] = gsq2[i].x; gsq[2 * i + 1] = gsq2[i].y; }
+        if (ap->gn_part != nullptr) {
 #pragma unroll
-        for (int off = LPR; off < 64; off <<= 1)
+            for (int off = LPR; off < 64; off <<= 1)
 #pragma unroll
-            for (int e = 0; e < 8; ++e) { gsum[e] += __shfl_xor(gsum[e], off, 64); gsq[e] += __shfl_xor(gsq[e], off, 64); }
-        __syncthreads();
-        float* red = reinterpret_cast<float*>(smem);      // [WAVES_N][BN][2]
-        if (lane < LPR) {
+                for (int e = 0; e < 8; ++e) { gsum[e] += __shfl_xor(gsum[e], off, 64); gsq[e] += __shfl_xor(gsq[e], off, 64); }
+            __syncthreads();
+            float* red = reinterpret_cast<float*>(smem + OFF_RING + 2 * WPHASE + 3 * WSTAGE);   // [WAVES_N][BN][2]
+            if (lane < LPR) {
 #pragma unroll
-            for (int e = 0; e < 8; ++e) {
-                const int chl = wm * WM * 32 + lane * 8 + e;
-                red[(wn * BN + chl) * 2] = gsum[e];
-                red[(wn * BN + chl) * 2 + 1] = gsq[e];
+                for (int e = 0; e < 8; ++e) {
+                    const int chl = wm * WM * 32 + lane * 8 + e;
+                    red[(wn * BN + chl) * 2] = gsum[e];
+                    red[(wn * BN + chl) * 2 + 1] = gsq[e];
+                }
+            }
+            __syncthreads();
+            if (tid < BN && e_cout0 + tid < ap->outC) {
+                float s0 = 0.f, s1 = 0.f;
+#pragma unroll
+                for (int w = 0; w < WAVES_N; ++w) { s0 += red[(w * BN + tid) * 2]; s1 += red[(w * BN + tid) * 2 + 1]; }
+                float* dst = ap->gn_part + ((long long)e_tile * ap->outC + e_cout0 + tid) * 2;
+                dst[0] = s0; dst[1] = s1;
             }
         }
-        __syncthreads();
-        if (tid < BN && cout0 + tid < a.outC) {
-            float s0 = 0.f, s1 = 0.f;
-#pragma unroll
-            for (int w = 0; w < WAVES_N; ++w) { s0 += red[(w * BN + tid) * 2]; s1 += red[(w * BN + tid) * 2 + 1]; }
-            float* dst = a.gn_part + ((long long)bm.tile * a.outC + cout0 + tid) * 2;
-            dst[0] = s0; dst[1] = s1;
-        }
+        if (!has_next) break;
+        first = false;
+        __syncthreads();                                    // the statistics scratch / staging of this tile is free again
     }
+    if (TRACE) { vm_wait<0>(); stamp(503); }
 }
 
-bool conv_pipe_supports(const storm_conv_args& a) {
+#undef STORM_RELAUNDER
+
+// ---- host side ---------------------------------------------------------------------------------------------------
+// The K loop as chunk descriptors.  Returns false when the convolution is outside what the pipelined kernel covers.
+static bool build_pipe_params(const storm_conv_args& a, PipeParams& p) {
+    memset(&p, 0, sizeof(p));
     if (a.dtype != STORM_BF16 || a.nseg < 1 || a.seg[0].ntaps != 9) return false;
-    for (int s = 0; s < a.nseg; ++s)
-        if ((a.seg[s].w_tapstride >> 31) != 0) return false;
+    int n = 0, nw = 0;
+    for (int s = 0; s < a.nseg; ++s) {
+        const storm_conv_seg& g = a.seg[s];
+        if ((g.ntaps != 9 && g.ntaps != 1) || g.w_bstride != 0) return false;
+        if (g.ntaps == 1 && g.gn_ss != nullptr) return false;
+        if (s > 0 && g.ntaps == 9) return false;                       // nine-tap chunks first (a one-tap chunk never precedes one)
+        for (int part = 0; part < 2; ++part) {
+            if (part == 1 && g.Cb == 0) break;
+            if (nw >= 4) return false;
+            const int C = part == 0 ? g.Ca : g.Cb, wc0 = part == 0 ? 0 : g.Ca;
+            const long long bstride = part == 0 ? g.bstride_a : g.bstride_b;
+            const long long img_bytes = (long long)a.H * a.W * C * 2;
+            const long long w_bytes = ((long long)g.ntaps * g.w_tapstride - wc0) * 2;
+            if (img_bytes >= (1LL << 31) || w_bytes >= (1LL << 31) || g.w_tapstride * 2 >= (1LL << 31)) return false;
+            WRunDesc& R = p.wrun[nw];
+            R.w = (unsigned long long)(reinterpret_cast<const char*>(g.w) + 2LL * wc0);
+            R.bytes = (unsigned int)w_bytes; R.CinP2 = g.CinP * 2; R.rows = g.w_rows; R.tapbytes = (int)(g.w_tapstride * 2);
+            const int nch = (C + KC - 1) / KC;
+            for (int ch = 0; ch < nch; ++ch) {
+                if (n >= MAX_CHUNKS) return false;
+                ChunkDesc& d = p.chunk[n++];
+                d.src = (unsigned long long)(part == 0 ? g.src_a : g.src_b);
+                d.bstride = (unsigned long long)(bstride * 2);
+                d.src_bytes = (unsigned int)img_bytes;
+                d.C2 = C * 2; d.cbeg2 = ch * PIXB; d.cvalid = C - ch * KC < KC ? C - ch * KC : KC;
+                d.ntaps = g.ntaps; d.silu = g.gn_silu;
+                if (g.gn_ss) {
+                    d.ss = (unsigned long long)(g.gn_ss + 2 * (wc0 + ch * KC));
+                    d.ss_bstride = (unsigned int)((g.Ca + g.Cb) * 8);
+                }
+                d.wrun = nw; d.w_soff = ch * PIXB; d.new_wrun = ch == 0;
+            }
+            ++nw;
+        }
+    }
+    ChunkDesc& t = p.chunk[n];                                         // terminator: the last chunk's prefetch target
+    t = p.chunk[n - 1];
+    t.src_bytes = 0; t.ss = 0; t.ntaps = 9; t.new_wrun = 0; t.cvalid = 0;
+    p.nchunks = n; p.nchunks9 = 0;
+    for (int i = 0; i < n; ++i) p.nchunks9 += p.chunk[i].ntaps == 9;
+    p.B = a.B; p.H = a.H; p.W = a.W;
+    p.out = a.out; p.outC = a.outC; p.Cout = a.Cout; p.out_bstride = a.out_bstride;
+    p.bias = a.bias; p.tbias = a.tbias; p.tbias_stride = a.tbias_stride; p.out_f32 = a.out_f32;
+    p.skip = a.skip; p.skip_bstride = a.skip_bstride; p.scale = a.scale;
+    p.gn_part = a.gn_part;
+    p.trace = nullptr;
     return true;
 }
 
-template <int BN, int PIXB, int WAVES_M, int WAVES_N, int ABL>
+bool conv_pipe_supports(const storm_conv_args& a) {
+    PipeParams p;
+    return build_pipe_params(a, p);
+}
+
+template <int BN, int TH, int ABL>
 static int launch_pipe(const storm_conv_args& a, hipStream_t st) {
-    using namespace pipe;
-    typedef PCfg<BN, PIXB, WAVES_M, WAVES_N> Cfg;
-    auto kern = conv_pipe_kernel<BN, PIXB, WAVES_M, WAVES_N, ABL>;
+    typedef PCfg<BN, TH> Cfg;
+    auto kern = conv_pipe_kernel<BN, TH, ABL>;
     static bool attr_set = false;                       // per instantiation; benign race (idempotent)
     if (!attr_set) {
         STORM_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, Cfg::LDS_BYTES));
         attr_set = true;
     }
+    PipeParams prm;
+    STORM_CHECK(build_pipe_params(a, prm), "storm_conv: convolution outside the pipelined kernel's coverage");
     const int tiles_x = cdiv(a.W, TILE_W);
-    const int tiles_per_img = tiles_x * cdiv(a.H, TILE_H);
+    const int tiles_per_img = tiles_x * cdiv(a.H, TH);
     const long long ntiles = (long long)a.B * tiles_per_img;
     const int n_ct = cdiv(a.outC, BN);
     const int tiles_per_xcd = cdiv(ntiles, 8);
-    const long long grid = 8LL * tiles_per_xcd * n_ct;
-    STORM_CHECK(grid > 0 && grid < (1LL << 31), "storm_conv: grid %lld out of range", grid);
-    ConvParams prm = make_params(a);
-    if (ABL & 64) {                                     // profiling: device buffer address handed over by tools/conv_trace.py
+    const long long vblocks = 8LL * tiles_per_xcd * n_ct;
+    STORM_CHECK(vblocks > 0 && vblocks < (1LL << 31), "storm_conv: grid %lld out of range", vblocks);
+    static int n_cu = 0;
+    if (n_cu == 0) {
+        int dev = 0; hipDeviceProp_t prop;
+        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) n_cu = prop.multiProcessorCount;
+        if (n_cu <= 0) n_cu = 256;
+    }
+    const char* cus_env = getenv("STORM_CONV_CUS");                    // test hook: pretend the device has this many CUs
+    const long long resident = ((cus_env ? atoi(cus_env) : n_cu) + 7) / 8 * 8;   // one workgroup per CU; a multiple of 8
+    const long long grid = vblocks < resident ? vblocks : resident;
+#if defined(STORM_PROFILING)
+    if (ABL & 64) {   // device buffer address handed over by tools/conv_trace.py
         const char* tp = getenv("STORM_CONV_TRACE_PTR");
         prm.trace = tp ? reinterpret_cast<unsigned long long*>(strtoull(tp, nullptr, 0)) : nullptr;
     }
-    hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(Cfg::THREADS), Cfg::LDS_BYTES, st, prm, n_ct, tiles_per_xcd, (int)ntiles,
-                       tiles_x, tiles_per_img);
+#endif
+    hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(THREADS), Cfg::LDS_BYTES, st, prm, n_ct, tiles_per_xcd, (int)ntiles,
+                       tiles_x, tiles_per_img, (int)vblocks);
     STORM_LAUNCH_CHECK();
     return STORM_OK;
 }
 
-// layout 1: one wave per SIMD (4 x 128x128); layout 2: ping-pong pairs (8 x 64x128).  STORM_CONV_ABLATE selects
-// profiling instantiations (tools/conv_trace.py, A/B probes); never set in production.
-int launch_conv_pipe(const storm_conv_args& a, hipStream_t st, int layout) {
+int launch_conv_pipe(const storm_conv_args& a, hipStream_t st, int bn) {
+    (void)bn;
+#if defined(STORM_PROFILING)
     const char* abl_env = getenv("STORM_CONV_ABLATE");
-    const int abl = abl_env ? atoi(abl_env) : 0;
-    if (layout == 2) {
-        switch (abl) {
-            case 1: return launch_pipe<256, 128, 4, 2, 1>(a, st);         // no s_setprio
-            case 2: return launch_pipe<256, 128, 4, 2, 2>(a, st);         // no stagger
-            case 8: return launch_pipe<256, 128, 4, 2, 8>(a, st);         // no weight DMA
-            case 16: return launch_pipe<256, 128, 4, 2, 16>(a, st);       // no fragment reads
-            case 32: return launch_pipe<256, 128, 4, 2, 32>(a, st);       // no MFMA
-            case 56: return launch_pipe<256, 128, 4, 2, 56>(a, st);       // barriers + bookkeeping only
-            case 64: return launch_pipe<256, 128, 4, 2, 64>(a, st);       // wave timeline stamps
-            default: return launch_pipe<256, 128, 4, 2, 0>(a, st);
-        }
+    switch (abl_env ? atoi(abl_env) : 0) {
+        case 8: return launch_pipe<256, 8, 8>(a, st);
+        case 16: return launch_pipe<256, 8, 16>(a, st);
+        case 32: return launch_pipe<256, 8, 32>(a, st);
+        case 128: return launch_pipe<256, 8, 128>(a, st);
+        case 184: return launch_pipe<256, 8, 184>(a, st);       // barriers + scalar skeleton only
+        case 136: return launch_pipe<256, 8, 136>(a, st);       // no DMA of either kind
+        case 152: return launch_pipe<256, 8, 152>(a, st);       // MFMAs + barriers only
+        case 64: return launch_pipe<256, 8, 64>(a, st);
+        case 256: return launch_pipe<256, 8, 256>(a, st);       // fragment reads in two bursts per MFMA interval
+        case 512: return launch_pipe<256, 8, 512>(a, st);       // barrier arrival before the last four MFMAs
+        default: break;
     }
-    switch (abl) {
-        case 4: return launch_pipe<256, 128, 2, 2, 4>(a, st);
-        case 32: return launch_pipe<256, 128, 2, 2, 32>(a, st);
-        case 56: return launch_pipe<256, 128, 2, 2, 56>(a, st);
-        default: return launch_pipe<256, 128, 2, 2, 0>(a, st);
-    }
+#endif
+    return launch_pipe<256, 8, 0>(a, st);
+}
+
+const char* conv_pipe_kernel_name(int bn) {
+    (void)bn;
+    return "storm::conv_pipe_kernel<256, 8, 0>";
 }
 
 }  // namespace storm

@@ -12,6 +12,32 @@ static inline void* resolve(const storm_ref& r, void* const* bufs, int n_bufs, b
     return static_cast<char*>(bufs[r.buf]) + r.off;
 }
 
+// storm_conv_args of a STORM_OP_CONV op (pointers resolved by the caller; NULL pointers when only the shape matters)
+static void conv_args_of(const storm_op& op, void* const* p, int dtype, storm_conv_args& a) {
+    const int64_t* i = op.i;
+    memset(&a, 0, sizeof(a));
+    a.nseg = (int)i[0]; a.B = (int)i[1]; a.H = (int)i[2]; a.W = (int)i[3];
+    a.outC = (int)i[4]; a.Cout = (int)i[5]; a.tbias_stride = (int)i[6]; a.out_f32 = (int)i[7];
+    const long long hw = (long long)a.H * a.W;
+    for (int g = 0; g < 2; ++g) {
+        storm_conv_seg& sgm = a.seg[g];
+        const int64_t* q = i + 8 + 7 * g;
+        sgm.src_a = p[3 * g]; sgm.src_b = p[3 * g + 1]; sgm.w = p[3 * g + 2];
+        sgm.Ca = (int)q[0]; sgm.Cb = (int)q[1]; sgm.CinP = (int)q[2]; sgm.w_rows = (int)q[3];
+        sgm.ntaps = (int)q[4]; sgm.w_bstride = q[5]; sgm.w_tapstride = q[6];
+        sgm.bstride_a = hw * sgm.Ca; sgm.bstride_b = hw * sgm.Cb;
+    }
+    if (i[22] >= 0) a.seg[0].bstride_a = i[22];
+    a.out = p[6]; a.bias = (const float*)p[7]; a.tbias = (const float*)p[8]; a.skip = p[9];
+    a.out_bstride = i[23] >= 0 ? i[23] : hw * a.outC;
+    a.skip_bstride = hw * a.outC;
+    a.scale = op.f[0];
+    a.dtype = dtype;
+    a.gn_part = (float*)p[10];
+    a.seg[0].gn_ss = (const float*)p[11];
+    a.seg[0].gn_silu = op.f[1] != 0.f;
+}
+
 static int run_ops(const storm_op* ops, int n_ops, void* const* bufs, int n_bufs, int dtype, storm_stream_t s,
                    hipEvent_t* ev) {
     STORM_CHECK(ops && bufs && n_ops >= 0, "storm_program_run: bad arguments");
@@ -44,27 +70,7 @@ static int run_ops(const storm_op* ops, int n_ops, void* const* bufs, int n_bufs
                 break;
             case STORM_OP_CONV: {
                 storm_conv_args a;
-                memset(&a, 0, sizeof(a));
-                a.nseg = (int)i[0]; a.B = (int)i[1]; a.H = (int)i[2]; a.W = (int)i[3];
-                a.outC = (int)i[4]; a.Cout = (int)i[5]; a.tbias_stride = (int)i[6]; a.out_f32 = (int)i[7];
-                const long long hw = (long long)a.H * a.W;
-                for (int g = 0; g < 2; ++g) {
-                    storm_conv_seg& sgm = a.seg[g];
-                    const int64_t* q = i + 8 + 7 * g;
-                    sgm.src_a = p[3 * g]; sgm.src_b = p[3 * g + 1]; sgm.w = p[3 * g + 2];
-                    sgm.Ca = (int)q[0]; sgm.Cb = (int)q[1]; sgm.CinP = (int)q[2]; sgm.w_rows = (int)q[3];
-                    sgm.ntaps = (int)q[4]; sgm.w_bstride = q[5]; sgm.w_tapstride = q[6];
-                    sgm.bstride_a = hw * sgm.Ca; sgm.bstride_b = hw * sgm.Cb;
-                }
-                if (i[22] >= 0) a.seg[0].bstride_a = i[22];
-                a.out = p[6]; a.bias = (const float*)p[7]; a.tbias = (const float*)p[8]; a.skip = p[9];
-                a.out_bstride = i[23] >= 0 ? i[23] : hw * a.outC;
-                a.skip_bstride = hw * a.outC;
-                a.scale = op.f[0];
-                a.dtype = dtype;
-                a.gn_part = (float*)p[10];
-                a.seg[0].gn_ss = (const float*)p[11];
-                a.seg[0].gn_silu = op.f[1] != 0.f;
+                conv_args_of(op, p, dtype, a);
                 rc = storm_conv(&a, s);
                 break;
             }
@@ -129,4 +135,15 @@ extern "C" int storm_program_run_timed(const storm_op* ops, int n_ops, void* con
     for (int k = 0; k < created; ++k) hipEventDestroy(ev[k]);
     delete[] ev;
     return rc;
+}
+
+// Name of the kernel op k of the program launches (conv ops; "" otherwise): the dispatch decision depends on shapes, dtype
+// and which optional pointers are present, not on their values.
+extern "C" const char* storm_program_kernel_name(const storm_op* ops, int k, int dtype) {
+    if (ops == nullptr || k < 0 || ops[k].code != STORM_OP_CONV) return "";
+    void* p[STORM_OP_NPTR];
+    for (int j = 0; j < STORM_OP_NPTR; ++j) p[j] = ops[k].p[j].buf >= 0 ? reinterpret_cast<void*>(uintptr_t(16)) : nullptr;
+    storm_conv_args a;
+    conv_args_of(ops[k], p, dtype, a);
+    return storm_conv_kernel_name(&a);
 }

@@ -19,6 +19,54 @@ def init(backend=None):
     return rank, world, local
 
 
+def self_launch(n_procs, script, argv):
+    """Re-execute `script` as `n_procs` ranks of ONE node under torch.distributed.run (one process per GPU; rendezvous on
+    127.0.0.1 with a free port).  Used when a tool is started as plain `python tool.py --gpus N` without a launcher:
+    replaces the current process, never returns."""
+    import socket
+    import sys
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n_procs}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), script] + list(argv)
+    os.execv(sys.executable, cmd)
+
+
+def timed_steps(step, steps, warmup, sync=None, group_ready=True):
+    """The bench contract's timed region: `warmup` untimed steps, then EXACTLY `steps` steps bracketed by
+    (device sync, barrier, device sync) on both sides; returns (seconds = MAX over ranks, last step's result).
+    `sync` = torch.cuda.synchronize on a GPU rank, None on CPU."""
+    import time
+    import torch.distributed as dist
+    multi = group_ready and dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
+
+    def fence():
+        if sync is not None:
+            sync()
+        if multi:
+            dist.barrier()
+        if sync is not None:
+            sync()
+
+    out = None
+    for i in range(warmup):
+        out = step(i)
+    fence()
+    t0 = time.perf_counter()
+    for i in range(steps):
+        out = step(warmup + i)
+    fence()
+    elapsed = time.perf_counter() - t0
+    per_rank = [elapsed]
+    if multi:
+        per_rank = [None] * dist.get_world_size()
+        dist.all_gather_object(per_rank, elapsed)
+        elapsed = max(per_rank)
+    return elapsed, per_rank, out
+
+
 def shard_indices(n_items, rank, world, lengths=None):
     """Indices of the utterances rank `rank` processes.  With `lengths`, items are dealt longest-first in
     a serpentine order so every rank gets a similar amount of audio (tail effect of ragged batches)."""

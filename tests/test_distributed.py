@@ -71,3 +71,30 @@ def test_shard_helpers():
     parts = [D.shard_indices(7, r, 3, [5, 9, 1, 7, 3, 8, 2]) for r in range(3)]
     assert sorted(i for p in parts for i in p) == list(range(7))
     assert D.group_by_length([4, 8, 4, 4, 8], 2) == [[0, 2], [3], [1, 4]]
+
+
+def test_bench_self_launch_two_ranks():
+    """`python bench.py --gpus 2` with no launcher must become two ranks itself (the driver starts it exactly like that),
+    shard the batch, time the SLOWEST rank between barriers and print one JSON line with n_gpus == 2.  Run here on CPU
+    ranks (gloo) with a stand-in step: the launch / rendezvous / timing skeleton is bench.py's own code."""
+    import json
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1",
+                          "--selftest-cpu"], capture_output=True, text=True, timeout=300, env=env, cwd=ROOT)
+    assert out.returncode == 0, out.stderr[-2000:]
+    line = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(line) == 1                                   # rank 0 only
+    r = json.loads(line[0])
+    assert r["n_gpus"] == 2 and r["steps"] == 3 and r["warmup"] == 1 and r["utterances_per_rank"] == 16
+    assert len(r["per_rank_s"]) == 2
+    # rank 1's stand-in step is twice as slow: the reported time is at least its 3 x 40 ms
+    assert r["ms_per_step"] >= 39.0
+    assert abs(r["value"] - 32 * 3 / (r["ms_per_step"] * 3e-3)) < 1e-6 * r["value"]
+
+
+def test_bench_gpus_flag_must_match_the_launcher():
+    """A launcher that started a different number of ranks than --gpus says is an error, not a silently mislabelled line."""
+    env = dict(os.environ, RANK="0", WORLD_SIZE="1", LOCAL_RANK="0")
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--selftest-cpu"], capture_output=True,
+                         text=True, timeout=120, env=env, cwd=ROOT)
+    assert out.returncode != 0 and "--gpus 2" in out.stderr

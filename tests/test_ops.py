@@ -62,13 +62,18 @@ def test_conv_persistent_tile_loop(dev, dtype, k, monkeypatch):
     assert torch.allclose(st, sref, rtol=rtol, atol=rtol * float(sref.abs().max()))
 
 
-@pytest.mark.parametrize("variant", [3, 4])
-@pytest.mark.parametrize("case", ["plain", "block_tail", "gn_fused", "ragged"])
+@pytest.mark.parametrize("variant", [3])
+@pytest.mark.parametrize("case", ["plain", "block_tail", "gn_fused", "ragged", "deep_k", "plain@8", "block_tail@8", "gn_fused@8"])
 def test_conv_pipelined_kernels(dev, variant, case, monkeypatch):
-    """conv_pipe.hip (LDS-DMA pipelined 256-cout kernels, both wave layouts) on shapes the default dispatch would give
-    to conv_igemm.hip: plain 3x3, fused 1x1 shortcut over a concat, fused GroupNorm-apply operand, ragged sizes."""
+    """conv_pipe.hip (chunk-unrolled LDS-DMA pipeline, 256-cout tile) on shapes the default dispatch would give
+    to conv_igemm.hip: plain 3x3, fused 1x1 shortcut over a concat, fused GroupNorm-apply operand, ragged sizes, many
+    K-chunks; "@8": as if the device had 8 CUs, so every persistent workgroup walks several tiles (next-tile prefetch
+    before the epilogue, staging beside the landing loads)."""
     from storm_amd import ops
     monkeypatch.setenv("STORM_CONV_VARIANT", str(variant))
+    if case.endswith("@8"):
+        monkeypatch.setenv("STORM_CONV_CUS", "8")
+        case = case[:-2]
     dtype = torch.bfloat16
     g = torch.Generator().manual_seed(31)
     if case == "plain":
@@ -109,6 +114,29 @@ def test_conv_pipelined_kernels(dev, variant, case, monkeypatch):
         a = NR.silu(NR.group_norm(xcat, gam, bet))
         ref = F.conv2d(q(a, dtype), q(w, dtype), padding=1)
         assert rel_l2(nchw(y.float().cpu()), ref) < 1e-2
+    elif case == "deep_k":
+        # many chunks: 3 + 2 nine-tap chunks over a concat with a fused GroupNorm (last chunk of each run ragged), then 3 + 2
+        # one-tap chunks of the fused shortcut: every ring slot / patch-buffer parity / weight-run change is exercised
+        B, C0, Ca, Cb, Sa, Sb, Co, H, W = 1, 8, 136, 88, 136, 72, 264, 9, 33
+        x0 = torch.randn(B, C0, H, W, generator=g)
+        wa, wb = torch.randn(Ca, C0, 3, 3, generator=g) * 0.4, torch.randn(Cb, C0, 1, 1, generator=g) * 0.7
+        w = torch.randn(Co, Ca + Cb, 3, 3, generator=g) * 0.05
+        sa, sb = torch.randn(B, Sa, H, W, generator=g), torch.randn(B, Sb, H, W, generator=g)
+        w2 = torch.randn(Co, Sa + Sb, 1, 1, generator=g) * 0.1
+        bias = torch.randn(Co, generator=g)
+        gam, bet = 1 + 0.1 * torch.randn(Ca + Cb, generator=g), 0.1 * torch.randn(Ca + Cb, generator=g)
+        x0d = nhwc(x0).to(dtype).to(dev)
+        xa, pa = ops.conv([ops.Seg(x0d, ops.pack_conv_weight(wa.to(dev), dtype), 9)], Ca, gn_partials=True)
+        xb, pb = ops.conv([ops.Seg(x0d, ops.pack_conv_weight(wb.to(dev), dtype), 1)], Cb, gn_partials=True)
+        st, ss = ops.gn_finalize(pa, pb, gamma=gam.to(dev), beta=bet.to(dev), count=H * W)
+        y = ops.conv([ops.Seg(xa, ops.pack_conv_weight(w.to(dev), dtype), 9, src_b=xb, gn_ss=ss, gn_silu=True),
+                      ops.Seg(nhwc(sa).to(dtype).to(dev), ops.pack_conv_weight(w2.to(dev), dtype), 1, src_b=nhwc(sb).to(dtype).to(dev))],
+                     Co, bias=bias.to(dev), scale=0.5)
+        xcat = torch.cat([nchw(xa.float().cpu()), nchw(xb.float().cpu())], 1)
+        a = NR.silu(NR.group_norm(xcat, gam, bet))
+        ref = (F.conv2d(q(a, dtype), q(w, dtype), padding=1) + F.conv2d(q(torch.cat([sa, sb], 1), dtype), q(w2, dtype))
+               + bias[None, :, None, None]) * 0.5
+        assert rel_l2(nchw(y.float().cpu())[:, :Co], ref) < 1e-2
     else:
         B, Cin, Cout, H, W = 1, 24, 8 * 5, 5, 7                       # less than one pixel tile, Cout far below the tile
         x = torch.randn(B, Cin, H, W, generator=g); w = torch.randn(Cout, Cin, 3, 3, generator=g) * 0.2

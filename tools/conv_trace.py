@@ -13,6 +13,8 @@ import numpy as np
 import torch
 
 os.environ["STORM_CONV_ABLATE"] = str(64 + int(os.environ.get("STORM_TRACE_EXTRA", "0")))
+# stamps exist only in the profiling build (python -m storm_amd.build --profiling)
+os.environ.setdefault("STORM_LIB", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "storm_amd", "csrc", "libstorm_hip_prof.so"))
 sys.path.insert(0, ".")
 from storm_amd import ops  # noqa: E402
 
@@ -28,7 +30,7 @@ args = p.parse_args()
 dev = torch.device("cuda:0")
 SLOTS = 512
 variant = int(os.environ.get("STORM_CONV_VARIANT", "0"))
-nwaves = 8 if variant in (1, 2, 3) else 4
+nwaves = 8 if variant in (1, 2, 3) else 4   # (variant 3 = conv_pipe.hip)
 bn = 256 if variant in (2, 3) else 128
 tiles = args.B * ((args.H + 7) // 8) * ((args.W + 31) // 32)
 n_ct = (args.cout + bn - 1) // bn
@@ -72,22 +74,29 @@ print(f"variant {variant}: {ms:.3f} ms, {nb} workgroups x {nwaves} waves, span {
 if variant == 3:
     raw = t[:, :, 4:4 + 16 * 30].reshape(nb, nwaves, 30, 16)
     steps = int((raw[0, 0, :, 0] > 0).sum())
-    idx = [0, 2, 4, 6, 7, 8, 9, 10, 11]       # stamps written per tap-step (slot 4 + 16 * step + idx)
+    # stamps per tap-step (slot 4 + 16 * step + idx), in time order
+    idx = [0, 1, 2, 4, 6, 7, 12, 8, 9, 10, 11]
     st = raw[:, :, :steps][..., idx]
     us3 = lambda d: d * tick_ns / 1e3  # noqa: E731
-    names = ["S(h0): reads, weight DMA issue, vmcnt", "S(h0): lgkmcnt + barrier", "C(h0): reads + 16 MFMA", "C(h0): lgkmcnt + barrier",
-             "S(h1): reads, [commit], DMA issue, tap bookkeeping", "S(h1): vmcnt + lgkmcnt + barrier", "C(h1): reads + 16 MFMA",
-             "C(h1): lgkmcnt + barrier"]
+    names = ["S(h0): fragment reads + weight DMA issue", "S(h0): [patch piece] vmcnt [transform]", "S(h0): lgkmcnt + barrier",
+             "C(h0): reads + 16 MFMA", "C(h0): lgkmcnt + barrier",
+             "S(h1): fragment reads + weight DMA issue", "S(h1): [patch piece] vmcnt [transform]", "S(h1): lgkmcnt + barrier",
+             "C(h1): reads + 16 MFMA", "C(h1): lgkmcnt + barrier"]
     print(f"per wave, first {steps} tap-steps (us; tick->us calibrated on the launch; every stamp costs ~0.09 us itself):")
     for gname, sel in (("g0 (waves 0-3)", slice(0, 4)), ("g1 (waves 4-7)", slice(4, 8))):
         print(f" {gname}: tile total {us3((t[:, sel, 503] - t[:, sel, 1]).mean()):.2f}, prologue {us3((t[:, sel, 2] - t[:, sel, 1]).mean()):.2f}")
         for i, nm in enumerate(names):
             d = us3((st[:, sel, :, i + 1] - st[:, sel, :, i]).astype(np.float64))
             print(f"   {nm:52s} mean/step {d.mean():7.3f}   p10 {np.percentile(d, 10):7.3f}   p90 {np.percentile(d, 90):7.3f}")
-        adv = us3((st[:, sel, 1:, 0] - st[:, sel, :-1, 8]).astype(np.float64))
-        print(f"   {'loop tail (cursor, chunk change) -> next step':52s} mean/step {adv.mean():7.3f}   p10 {np.percentile(adv, 10):7.3f}   p90 {np.percentile(adv, 90):7.3f}")
+        adv = us3((st[:, sel, 1:, 0] - st[:, sel, :-1, 10]).astype(np.float64))
+        print(f"   {'step end -> next step (chunk change every 9th)':52s} mean/step {adv.mean():7.3f}   p10 {np.percentile(adv, 10):7.3f}   p90 {np.percentile(adv, 90):7.3f}")
         whole = us3((st[:, sel, 1:, 0] - st[:, sel, :-1, 0]).astype(np.float64))
         print(f"   {'whole step':52s} mean      {whole.mean():7.3f}")
+        # per-step profile of S(h0) wait (vmcnt) and the chunk position
+        w0 = us3((st[:, sel, :, 2] - st[:, sel, :, 1]).astype(np.float64)).mean(axis=(0, 1))
+        w1 = us3((st[:, sel, :, 7] - st[:, sel, :, 6]).astype(np.float64)).mean(axis=(0, 1))
+        print("   vmcnt interval by tap-step, h0:", " ".join(f"{v:.2f}" for v in w0[:18]))
+        print("   vmcnt interval by tap-step, h1:", " ".join(f"{v:.2f}" for v in w1[:18]))
     print(f" epilogue: drain+barrier {us3((t[:, :, 501] - t[:, :, 500]).mean()):.2f}, transpose+stores {us3((t[:, :, 502] - t[:, :, 501]).mean()):.2f}, store drain {us3((t[:, :, 503] - t[:, :, 502]).mean()):.2f}")
     sys.exit(0)
 steps = int(((t[0, 0, 4:400].reshape(-1, 4)[:, 0]) > 0).sum())
