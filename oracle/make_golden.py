@@ -90,10 +90,54 @@ def gen_f7(ref):
     np.savez_compressed(os.path.join(OUT, "f7_ode.npz"), y=c2np(y), z=c2np(z), out=c2np(x), nfe=np.array(nfe))
 
 
+def seeded_input(shape, seed, scale, dtype=torch.complex64):
+    """Large fixture inputs are regenerated from a seed on both sides (their SHA-256 is stored)."""
+    return torch.randn(*shape, dtype=dtype, generator=torch.Generator().manual_seed(seed)) * scale
+
+
+def tensor_hash(x):
+    return hashlib.sha256(x.detach().contiguous().numpy().tobytes()).hexdigest()
+
+
+def gen_f8(ref):
+    """F8: the BENCH shape.  (a) `ncsnpp` (27.8 M, 4 input channels) forward of ONE 4-s utterance, [1,2,256,512]
+    (ncsnpp.py:281-450) - the shape at which the production kernel selection (pipelined 256-cout conv, L = 2048
+    attention) is active; (b) AttnBlockpp with 256 channels at 32 x 64 = 2048 positions (layerspp.py:60-91)."""
+    print("F8 bench-shape forward + L=2048 attention (about a minute)")
+    torch.set_num_threads(8)
+    f8 = {}
+    cfg = NR.NCSNppConfig(input_channels=4)
+    sd = NR.seeded_state_dict(cfg, seed=11)
+    net = ref_backbone(ref, cfg, sd)
+    xin = seeded_input((1, 2, 256, 512), 808, 0.5)
+    tt = torch.tensor([0.37])
+    with torch.no_grad():
+        y_ref = net(xin, tt)
+        y_or = NR.ncsnpp_forward(sd, cfg, xin, tt)
+    check("ncsnpp4 forward @ 256x512", y_or, y_ref, 5e-5)
+    f8.update(full4_y=c2np(y_ref), full4_xhash=np.array(tensor_hash(xin)), full4_sdhash=np.array(sd_hash(sd)),
+              t=np.array([0.37], dtype=np.float32))
+    C = 256
+    blk = ref["layerspp"].AttnBlockpp(channels=C, skip_rescale=True, init_scale=0.)
+    ga = torch.Generator().manual_seed(809)
+    sda = {k: (torch.randn(v.shape, generator=ga) * ((1.5 / C ** 0.5) if "NIN" in k and k.endswith("W") else 0.1)
+               + (1.0 if "GroupNorm_0.weight" in k else 0.0)) for k, v in blk.state_dict().items()}
+    blk.load_state_dict(sda)
+    xa = seeded_input((1, C, 32, 64), 810, 1.0, torch.float32)
+    with torch.no_grad():
+        ya = blk(xa)
+    check("attnblock L=2048", NR.attnblock(NR._SD(sda), xa), ya, 1e-5)
+    f8.update(attn_y=ya.numpy(), attn_xhash=np.array(tensor_hash(xa)), **{"attn_" + k: v.numpy() for k, v in sda.items()})
+    np.savez_compressed(os.path.join(OUT, "f8_bench_shape.npz"), **f8)
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
     if "--only-f7" in sys.argv:
         gen_f7(import_reference())
+        return
+    if "--only-f8" in sys.argv:
+        gen_f8(import_reference())
         return
     torch.set_num_threads(8)
     torch.manual_seed(0)
@@ -335,6 +379,7 @@ def main():
     np.savez_compressed(os.path.join(OUT, "f6_enhance.npz"), **f6)
 
     gen_f7(ref)
+    gen_f8(ref)
     for fn in sorted(os.listdir(OUT)):
         print(f"  {fn}: {os.path.getsize(os.path.join(OUT, fn))/1024:.0f} KiB")
     print("golden fixtures written to", OUT)

@@ -648,7 +648,7 @@ static int dispatch_conv(const storm_conv_args& a, hipStream_t st) {
     bool any9 = false;
     for (int s = 0; s < a.nseg; ++s) any9 = any9 || a.seg[s].ntaps == 9;
     const bool small = a.outC <= 32;
-    static const bool dma = env_int("STORM_CONV_DMA", 1) != 0;        // A/B switch: 0 = register staging in the 128-cout kernel
+    const bool dma = env_int("STORM_CONV_DMA", 1) != 0;               // A/B switch: 0 = register staging in the 128-cout kernel
     const int variant = choose_variant(a, any9);
 #if defined(STORM_PROFILING)
     // work-skipping instantiations for tools/ (no MFMA, no fragment reads, ...): profiling build only

@@ -86,3 +86,32 @@ def test_ode_sampler_vs_reference(dev, golden):
     x, nfe = sampler()
     assert abs(nfe - int(g["nfe"])) <= 12, (nfe, int(g["nfe"]))
     assert rel_l2(x.cpu(), g["out"]) < 1e-3
+
+
+@pytest.mark.gpu
+def test_bf16_sampler_drift_over_a_full_run():
+    """BASELINE.json configs[1] numerics: the FULL 30-step PC run (reverse_diffusion + 1 ald step = 60 score evaluations of
+    the 27.8 M network, 4-s utterances) in the bench precision (bf16 MFMA operands and activations) against the fp32 engine
+    (itself 1e-6 from the oracle) under the SAME noise (in-kernel Philox stream of the same seed): the error a score
+    evaluation makes (1e-2) is amplified by 1/t in the network head and re-enters 59 times.  wav rel-L2 <= 5e-2."""
+    import bench
+    from tests.backend import setup_backend
+    from storm_amd.model import ScoreModel
+    dev = setup_backend("hip")
+    model = ScoreModel(backbone="ncsnpp", sde="ouve", theta=1.5, sigma_min=0.05, sigma_max=0.5, spec_factor=0.15,
+                       spec_abs_exponent=0.5)
+    bench.randomize(model, seed=0)
+    model._error_loading_ema = True
+    model.eval()
+    model = model.to(dev)
+    wav = (0.1 * torch.randn(2, 64000, generator=torch.Generator().manual_seed(3))).to(dev)
+    outs = {}
+    for prec in ("fp32", "bf16"):
+        model.set_precision(prec)
+        x, nfe = model.enhance_batch(wav, predictor="reverse_diffusion", corrector="ald", N=30, corrector_steps=1, snr=0.5,
+                                     seed=7, return_nfe=True)
+        assert nfe == 60
+        outs[prec] = x.float().cpu()
+    err = rel_l2(outs["bf16"], outs["fp32"])
+    print(f"60-NFE PC run, bf16 vs fp32 engine under identical noise: wav rel-L2 {err:.3e}")
+    assert err < 5e-2
