@@ -197,10 +197,26 @@ int storm_ouve_predictor_step(float* x, float* x_mean, const float* score, const
 /* per-batch L2 norms of complex tensors: out[b] = ||v_b||  (correctors.py:53-54) */
 int storm_batch_l2norm(const float* v, float* out, int B, long long n, storm_stream_t s);
 /* Langevin corrector step; z must be given or generated beforehand (its norm is needed):
- * step = 2 (snr * mean_b||z_b|| / mean_b||score_b||)^2 from the two [B] norm arrays.      */
+ * step = 2 (snr * ||z|| / ||score||)^2 with the norms taken as
+ *   mode 0: means over the B rows (correctors.py:53-55 for the batch handed to the sampler),
+ *   mode 1: row b's own norms (B independent batch-1 calls: what the reference CLI computes per file),
+ *   mode 2: score_norms[0] / z_norms[0] = means over a larger batch (all-reduced over the ranks of a sharded run). */
 int storm_langevin_step(float* x, float* x_mean, const float* score, const float* z,
-                        const float* score_norms, const float* z_norms, int B, long long n,
-                        float snr, storm_stream_t s);
+                        const float* score_norms, const float* z_norms, int B, long long n, float snr, int mode,
+                        storm_stream_t s);
+/* drift of the probability-flow ODE, out = theta (y - x) - 1/2 g(t)^2 score  (sdes.py:92-121 with probability_flow, :203-207) */
+int storm_ouve_pf_drift(float* out, const float* x, const float* y, const float* score, const float* t, int B,
+                        long long n, storm_ouve p, storm_stream_t s);
+/* ---- probability-flow ODE sampler (sampling/__init__.py:71-141 hands the state to scipy's RK45 on the host) ----
+ * out = x + h * sum_{j<n_terms} coef[j] K[j]   (one Runge-Kutta stage; K = host array of device pointers, <= 7) */
+int storm_rk_combine(float* out, const float* x, const float* const* K, const float* coef, int n_terms, float h,
+                     long long n_complex, storm_stream_t s);
+/* out[0] = sum_c |v_c|^2 / (atol + max(|xa_c|, |xb_c|) rtol)^2 over the complex elements (scipy's scaled norms, squared
+ * and un-averaged): v = h * sum coef[j] K[j] (n_terms > 0: the embedded error), K[0] (n_terms = -1) or K[0] - K[1]
+ * (n_terms = -2).  xb may be NULL.  scratch: >= 2048 doubles; deterministic (fixed summation order). */
+int storm_rk_scaled_sumsq(double* out, double* scratch, int scratch_len, const float* xa, const float* xb,
+                          const float* const* K, const float* coef, int n_terms, float h, float atol, float rtol,
+                          long long n_complex, storm_stream_t s);
 /* fills z[B*n] complex with standard complex normal noise (Philox) */
 int storm_complex_randn(float* z, long long n_complex, uint64_t seed, uint64_t offset,
                         storm_stream_t s);

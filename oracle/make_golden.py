@@ -131,8 +131,58 @@ def gen_f8(ref):
     np.savez_compressed(os.path.join(OUT, "f8_bench_shape.npz"), **f8)
 
 
+def gen_f9(ref):
+    """F9: the remaining one-call surfaces of model.py - DiscriminativeModel.enhance (model.py:351-370) and
+    StochasticRegenerationModel.enhance with denoiser_only / return_stft (model.py:720-780) - on an 8000-sample input."""
+    print("F9 DiscriminativeModel.enhance, StoRM denoiser_only / return_stft")
+    f9 = {}
+    M = ref["model"]
+    DM = ref["data_module"].SpecsDataModule
+    ywav = torch.randn(1, 8000, generator=torch.Generator().manual_seed(909)) * 0.1
+    common = dict(sde="ouve", data_module_cls=DM, theta=1.5, sigma_min=0.05, sigma_max=0.5,
+                  spec_factor=0.15, spec_abs_exponent=0.5, nf=8)
+    m = M.DiscriminativeModel(backbone="ncsnpp", input_channels=2, discriminative=True, **common)
+    cfg_d = NR.NCSNppConfig(nf=8, input_channels=2, discriminative=True)
+    sd_d = NR.seeded_state_dict(cfg_d, seed=41)
+    m.dnn.load_state_dict(sd_d)
+    m.eval(no_ema=True)
+    with torch.no_grad():
+        xd_ref = m.enhance(ywav.clone())
+    Y, nfac, T0 = FR.wav_to_spec(ywav)
+    with torch.no_grad():
+        xd_or = FR.spec_to_wav(NR.ncsnpp_forward(sd_d, cfg_d, Y, None), nfac, T0)
+    check("DiscriminativeModel.enhance", xd_or, xd_ref, 1e-4)
+    f9.update(wav_in=ywav.numpy(), disc_out=xd_ref.numpy())
+    g = torch.Generator().manual_seed(910)
+    m = M.StochasticRegenerationModel(backbone_denoiser="ncsnpp", backbone_score="ncsnpp", condition="both", **dict(common))
+    cfg_s = NR.NCSNppConfig(nf=8, input_channels=6)
+    sd_d2, sd_s = NR.seeded_state_dict(cfg_d, seed=42), NR.seeded_state_dict(cfg_s, seed=43)
+    m.denoiser_net.load_state_dict(sd_d2)
+    m.score_net.load_state_dict(sd_s)
+    m.eval(no_ema=True)
+    with torch.no_grad():
+        x_do = m.enhance(ywav.clone(), denoiser_only=True)
+    f9.update(storm_denoiser_only=x_do.numpy())
+    N = 2
+    noises = [SR.complex_randn(Y.shape, g) for _ in range(1 + N)]
+    it = iter(noises)
+    orig = torch.randn_like
+    torch.randn_like = lambda x, *a, **k: next(it).to(x.dtype)
+    try:
+        with torch.no_grad():
+            sample, Yr, T_orig, nf_ = m.enhance(ywav.clone(), N=N, corrector="none", snr=0.5, return_stft=True)
+    finally:
+        torch.randn_like = orig
+    assert T_orig == 8000 and torch.equal(Yr, Y.squeeze())
+    f9.update(stft_noise=np.stack([c2np(n) for n in noises]), stft_sample=c2np(sample), stft_Y=c2np(Yr), stft_norm=np.array(nf_))
+    np.savez_compressed(os.path.join(OUT, "f9_surfaces.npz"), **f9)
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
+    if "--only-f9" in sys.argv:
+        gen_f9(import_reference())
+        return
     if "--only-f7" in sys.argv:
         gen_f7(import_reference())
         return
@@ -380,6 +430,7 @@ def main():
 
     gen_f7(ref)
     gen_f8(ref)
+    gen_f9(ref)
     for fn in sorted(os.listdir(OUT)):
         print(f"  {fn}: {os.path.getsize(os.path.join(OUT, fn))/1024:.0f} KiB")
     print("golden fixtures written to", OUT)

@@ -78,7 +78,10 @@ _SIGNATURES = {
     "storm_ouve_ald_step": ([_vp, _vp, _vp, _vp, _vp, _i, _ll, Ouve, _f, _u64, _u64, _vp], C.c_int),
     "storm_ouve_predictor_step": ([_vp, _vp, _vp, _vp, _vp, _vp, _i, _ll, Ouve, _i, _i, _u64, _u64, _vp], C.c_int),
     "storm_batch_l2norm": ([_vp, _vp, _i, _ll, _vp], C.c_int),
-    "storm_langevin_step": ([_vp, _vp, _vp, _vp, _vp, _vp, _i, _ll, _f, _vp], C.c_int),
+    "storm_langevin_step": ([_vp, _vp, _vp, _vp, _vp, _vp, _i, _ll, _f, _i, _vp], C.c_int),
+    "storm_ouve_pf_drift": ([_vp, _vp, _vp, _vp, _vp, _i, _ll, Ouve, _vp], C.c_int),
+    "storm_rk_combine": ([_vp, _vp, C.POINTER(_vp), C.POINTER(C.c_float), _i, _f, _ll, _vp], C.c_int),
+    "storm_rk_scaled_sumsq": ([_vp, _vp, _i, _vp, _vp, C.POINTER(_vp), C.POINTER(C.c_float), _i, _f, _f, _f, _ll, _vp], C.c_int),
     "storm_complex_randn": ([_vp, _ll, _u64, _u64, _vp], C.c_int),
     "storm_spec_transform": ([_vp, _vp, _ll, _f, _f, _i, _vp], C.c_int),
     "storm_peak_abs": ([_vp, _vp, _i, _ll, _ll, _vp], C.c_int),

@@ -131,16 +131,27 @@ __global__ void batch_l2norm_kernel(const float* __restrict__ v, float* __restri
     if (threadIdx.x == 0) out[b] = (float)sqrt(red[0] + red[1] + red[2] + red[3]);
 }
 
+// mode 0: step from the batch means of the B norms (the reference's semantics for the batch handed to the sampler,
+// correctors.py:53-55); mode 1: every row its own step (= B calls with batch 1, what the reference CLI does);
+// mode 2: snorm[0] / znorm[0] already hold the means over a LARGER batch (all-reduced over the ranks of a sharded run).
 __global__ void langevin_kernel(float* __restrict__ x, float* __restrict__ x_mean, const float* __restrict__ score,
                                 const float* __restrict__ z, const float* __restrict__ snorm,
-                                const float* __restrict__ znorm, int B, long long total, float snr) {
-    float gs = 0.f, gz = 0.f;
-    for (int b = 0; b < B; ++b) { gs += snorm[b]; gz += znorm[b]; }
-    gs /= (float)B; gz /= (float)B;
+                                const float* __restrict__ znorm, int B, long long n, float snr, int mode) {
+    const int b = blockIdx.y;
+    float gs, gz;
+    if (mode == 1) { gs = snorm[b]; gz = znorm[b]; }
+    else if (mode == 2) { gs = snorm[0]; gz = znorm[0]; }
+    else {
+        gs = 0.f; gz = 0.f;
+        for (int i = 0; i < B; ++i) { gs += snorm[i]; gz += znorm[i]; }
+        gs /= (float)B; gz /= (float)B;
+    }
     const float r = snr * gz / gs;
     const float step = r * r * 2.0f;                       // correctors.py:55
     const float nscale = sqrtf(step * 2.0f);
-    for (long long k = (long long)blockIdx.x * blockDim.x + threadIdx.x; k < total; k += (long long)gridDim.x * blockDim.x) {
+    const long long base = (long long)b * n;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+        const long long k = base + i;
         const float2 xx = reinterpret_cast<const float2*>(x)[k];
         const float2 s = reinterpret_cast<const float2*>(score)[k];
         const float2 zz = reinterpret_cast<const float2*>(z)[k];
@@ -153,6 +164,70 @@ __global__ void langevin_kernel(float* __restrict__ x, float* __restrict__ x_mea
 __global__ void complex_randn_kernel(float* __restrict__ z, long long n, uint64_t seed, uint64_t offset) {
     for (long long k = (long long)blockIdx.x * blockDim.x + threadIdx.x; k < n; k += (long long)gridDim.x * blockDim.x)
         reinterpret_cast<float2*>(z)[k] = complex_normal(seed, (uint64_t)k, offset);
+}
+
+// drift of the probability-flow ODE: theta (y - x) - 1/2 g(t)^2 score  (sdes.py:92-121 with probability_flow=True, :203-207)
+__global__ void ouve_pf_drift_kernel(float* __restrict__ out, const float* __restrict__ x, const float* __restrict__ y,
+                                     const float* __restrict__ score, const float* __restrict__ t, long long n, storm_ouve p) {
+    const int b = blockIdx.y;
+    const Ouve o = make_ouve(p);
+    const float g = ouve_g(o, (double)t[b]);
+    const float hg2 = 0.5f * g * g;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+        const long long k = (long long)b * n + i;
+        const float2 xx = reinterpret_cast<const float2*>(x)[k];
+        const float2 yy = reinterpret_cast<const float2*>(y)[k];
+        const float2 s = reinterpret_cast<const float2*>(score)[k];
+        reinterpret_cast<float2*>(out)[k] = make_float2(p.theta * (yy.x - xx.x) - hg2 * s.x, p.theta * (yy.y - xx.y) - hg2 * s.y);
+    }
+}
+
+// ---- probability-flow ODE (Dormand-Prince RK45, sampling/__init__.py:71-141 runs scipy's on the host) ----------------
+// out = x + h * sum_j coef[j] * K[j]  over n floats (one fused pass per stage instead of one pass per term)
+struct RkTerms { const float* k[7]; float c[7]; int n; };
+__global__ void rk_combine_kernel(float* __restrict__ out, const float* __restrict__ x, RkTerms t, float h, long long n4) {
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long long)gridDim.x * blockDim.x) {
+        float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+        for (int j = 0; j < 7; ++j)
+            if (j < t.n) {
+                const float4 k = reinterpret_cast<const float4*>(t.k[j])[i];
+                a.x = fmaf(t.c[j], k.x, a.x); a.y = fmaf(t.c[j], k.y, a.y); a.z = fmaf(t.c[j], k.z, a.z); a.w = fmaf(t.c[j], k.w, a.w);
+            }
+        const float4 xx = reinterpret_cast<const float4*>(x)[i];
+        reinterpret_cast<float4*>(out)[i] = make_float4(fmaf(h, a.x, xx.x), fmaf(h, a.y, xx.y), fmaf(h, a.z, xx.z), fmaf(h, a.w, xx.w));
+    }
+}
+// per-block partial of sum_c |v_c|^2 / (atol + max(|xa_c|, |xb_c|) rtol)^2 over complex elements c, where
+// v = h * sum_j coef[j] K[j] (t.n > 0) or v = K[0] - K[1] (t.n == -2) or v = K[0] (t.n == -1): scipy's scaled RMS norms
+__global__ void rk_scaled_sumsq_kernel(double* __restrict__ part, const float* __restrict__ xa, const float* __restrict__ xb,
+                                       RkTerms t, float h, float atol, float rtol, long long nc) {
+    __shared__ double red[4];
+    double acc = 0.0;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < nc; i += (long long)gridDim.x * blockDim.x) {
+        float2 v = make_float2(0.f, 0.f);
+        if (t.n > 0) {
+#pragma unroll
+            for (int j = 0; j < 7; ++j)
+                if (j < t.n) { const float2 k = reinterpret_cast<const float2*>(t.k[j])[i]; v.x = fmaf(t.c[j], k.x, v.x); v.y = fmaf(t.c[j], k.y, v.y); }
+            v.x *= h; v.y *= h;
+        } else {
+            v = reinterpret_cast<const float2*>(t.k[0])[i];
+            if (t.n == -2) { const float2 w = reinterpret_cast<const float2*>(t.k[1])[i]; v.x -= w.x; v.y -= w.y; }
+        }
+        const float2 a = reinterpret_cast<const float2*>(xa)[i];
+        float m = sqrtf(a.x * a.x + a.y * a.y);
+        if (xb) { const float2 b = reinterpret_cast<const float2*>(xb)[i]; m = fmaxf(m, sqrtf(b.x * b.x + b.y * b.y)); }
+        const double sc = (double)atol + (double)m * (double)rtol;
+        acc += ((double)v.x * v.x + (double)v.y * v.y) / (sc * sc);
+    }
+    acc = wave_sum_d(acc);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) part[blockIdx.x] = red[0] + red[1] + red[2] + red[3];
+}
+__global__ void sum_partials_kernel(const double* __restrict__ part, int n, double* __restrict__ out) {   // fixed order: deterministic
+    if (threadIdx.x == 0 && blockIdx.x == 0) { double s = 0.0; for (int i = 0; i < n; ++i) s += part[i]; out[0] = s; }
 }
 
 static inline int ew_blocks(long long n) { long long b = (n + 255) / 256; return (int)(b > 2048 ? 2048 : (b < 1 ? 1 : b)); }
@@ -196,9 +271,10 @@ extern "C" int storm_batch_l2norm(const float* v, float* out, int B, long long n
 }
 
 extern "C" int storm_langevin_step(float* x, float* x_mean, const float* score, const float* z, const float* score_norms,
-                                   const float* z_norms, int B, long long n, float snr, storm_stream_t s) {
+                                   const float* z_norms, int B, long long n, float snr, int mode, storm_stream_t s) {
     STORM_CHECK(x && score && z && score_norms && z_norms && B > 0 && n > 0, "storm_langevin_step: bad arguments");
-    hipLaunchKernelGGL(langevin_kernel, dim3(ew_blocks(n * B)), dim3(256), 0, (hipStream_t)s, x, x_mean, score, z, score_norms, z_norms, B, n * B, snr);
+    STORM_CHECK(mode >= 0 && mode <= 2, "storm_langevin_step: mode=%d", mode);
+    hipLaunchKernelGGL(langevin_kernel, dim3(ew_blocks(n), B), dim3(256), 0, (hipStream_t)s, x, x_mean, score, z, score_norms, z_norms, B, n, snr, mode);
     STORM_LAUNCH_CHECK();
     return STORM_OK;
 }
@@ -206,6 +282,48 @@ extern "C" int storm_langevin_step(float* x, float* x_mean, const float* score, 
 extern "C" int storm_complex_randn(float* z, long long n_complex, uint64_t seed, uint64_t offset, storm_stream_t s) {
     STORM_CHECK(z && n_complex > 0, "storm_complex_randn: bad arguments");
     hipLaunchKernelGGL(complex_randn_kernel, dim3(ew_blocks(n_complex)), dim3(256), 0, (hipStream_t)s, z, n_complex, seed, offset);
+    STORM_LAUNCH_CHECK();
+    return STORM_OK;
+}
+
+static int fill_terms(RkTerms& t, const float* const* K, const float* coef, int n_terms) {
+    STORM_CHECK(K && n_terms >= -2 && n_terms <= 7 && n_terms != 0, "storm_rk: n_terms=%d", n_terms);
+    const int np = n_terms > 0 ? n_terms : -n_terms;
+    STORM_CHECK(n_terms < 0 || coef, "storm_rk: null coefficients");
+    for (int j = 0; j < 7; ++j) { t.k[j] = j < np ? K[j] : nullptr; t.c[j] = (n_terms > 0 && j < np) ? coef[j] : 0.f; }
+    for (int j = 0; j < np; ++j) STORM_CHECK(K[j] != nullptr, "storm_rk: null stage %d", j);
+    t.n = n_terms;
+    return STORM_OK;
+}
+
+extern "C" int storm_rk_combine(float* out, const float* x, const float* const* K, const float* coef, int n_terms, float h,
+                                long long n_complex, storm_stream_t s) {
+    STORM_CHECK(out && x && n_complex > 0 && n_complex % 2 == 0 && n_terms > 0, "storm_rk_combine: bad arguments");
+    RkTerms t;
+    if (int rc = fill_terms(t, K, coef, n_terms)) return rc;
+    hipLaunchKernelGGL(rk_combine_kernel, dim3(ew_blocks(n_complex / 2)), dim3(256), 0, (hipStream_t)s, out, x, t, h, n_complex / 2);
+    STORM_LAUNCH_CHECK();
+    return STORM_OK;
+}
+
+extern "C" int storm_rk_scaled_sumsq(double* out, double* scratch, int scratch_len, const float* xa, const float* xb,
+                                     const float* const* K, const float* coef, int n_terms, float h, float atol, float rtol,
+                                     long long n_complex, storm_stream_t s) {
+    STORM_CHECK(out && scratch && xa && n_complex > 0 && scratch_len >= 1, "storm_rk_scaled_sumsq: bad arguments");
+    RkTerms t;
+    if (int rc = fill_terms(t, K, coef, n_terms)) return rc;
+    int nb = ew_blocks(n_complex);
+    if (nb > scratch_len) nb = scratch_len;
+    hipLaunchKernelGGL(rk_scaled_sumsq_kernel, dim3(nb), dim3(256), 0, (hipStream_t)s, scratch, xa, xb, t, h, atol, rtol, n_complex);
+    hipLaunchKernelGGL(sum_partials_kernel, dim3(1), dim3(64), 0, (hipStream_t)s, scratch, nb, out);
+    STORM_LAUNCH_CHECK();
+    return STORM_OK;
+}
+
+extern "C" int storm_ouve_pf_drift(float* out, const float* x, const float* y, const float* score, const float* t, int B,
+                                   long long n, storm_ouve p, storm_stream_t s) {
+    STORM_CHECK(out && x && y && score && t && B > 0 && n > 0, "storm_ouve_pf_drift: bad arguments");
+    hipLaunchKernelGGL(ouve_pf_drift_kernel, dim3(ew_blocks(n), B), dim3(256), 0, (hipStream_t)s, out, x, y, score, t, n, p);
     STORM_LAUNCH_CHECK();
     return STORM_OK;
 }

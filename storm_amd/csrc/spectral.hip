@@ -19,7 +19,9 @@ __global__ void peak_abs_kernel(const float* __restrict__ wav, float* __restrict
     m = wave_max(m);
     if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = m;
     __syncthreads();
-    if (threadIdx.x == 0) peak[b] = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+    // (an all-zero utterance: the reference divides 0 / 0 and fills the whole sampler with NaN, model.py:281-284; here its
+    // row stays zero - in a batch it would otherwise poison nothing but itself, silently)
+    if (threadIdx.x == 0) peak[b] = fmaxf(fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3])), 1e-20f);
 }
 
 __global__ void stft_kernel(const float* __restrict__ wav, const float* __restrict__ peak, float* __restrict__ spec,
@@ -33,7 +35,6 @@ __global__ void stft_kernel(const float* __restrict__ wav, const float* __restri
         for (int f = threadIdx.x; f < F; f += blockDim.x) out[(long long)f * Tpad + frame] = make_float2(0.f, 0.f);
         return;
     }
-    const float inv_peak = peak ? 1.0f / peak[b] : 1.0f;
     const float* x = wav + (long long)b * stride;
     const int pad = n_fft / 2;
     for (int k = threadIdx.x; k < n_fft; k += blockDim.x) {
@@ -44,7 +45,6 @@ __global__ void stft_kernel(const float* __restrict__ wav, const float* __restri
         xs[k] = v * window[k];
         tws[k] = reinterpret_cast<const float2*>(tw)[k];
     }
-    (void)inv_peak;
     __syncthreads();
     for (int f = threadIdx.x; f < F; f += blockDim.x) {
         double re = 0.0, im = 0.0;

@@ -228,9 +228,13 @@ class ScoreModel(_Base):
 
     def enhance_batch(self, y, sampler_type="pc", predictor="reverse_diffusion", corrector="ald", N=50,
                       corrector_steps=1, snr=0.5, return_nfe=False, **kwargs):
-        """B equal-length utterances y [B, L] in one sampler run; row b equals enhance(y[b:b+1])."""
+        """B equal-length utterances y [B, L] in one sampler run.  Every op on the path is per utterance and the Langevin
+        corrector runs with per-row step sizes, so with INJECTED noise (noise_fn) row b equals enhance(y[b:b+1]) for every
+        predictor / corrector; with the in-kernel Philox stream (seed=) rows are independent draws but not the draws a
+        batch-1 call with the same seed would make (the counter is the position in the batch)."""
         Y, peak, T_orig = self._prepare(y)
         if sampler_type == "pc":
+            kwargs.setdefault("langevin_per_row", True)
             sampler = self.get_pc_sampler(predictor, corrector, Y, N=N, corrector_steps=corrector_steps, snr=snr,
                                           intermediate=False, **kwargs)
         elif sampler_type == "ode":
@@ -321,8 +325,9 @@ class StochasticRegenerationModel(_Base):
             y, minibatch)
 
     def enhance_batch(self, y, sampler_type="pc", predictor="reverse_diffusion", corrector="none", N=30,
-                      corrector_steps=1, snr=0.5, denoiser_only=False, return_nfe=False, **kwargs):
+                      corrector_steps=1, snr=0.5, denoiser_only=False, return_nfe=False, return_stft=False, **kwargs):
         Y, peak, T_orig = self._prepare(y)
+        kwargs.setdefault("langevin_per_row", True)
         nfe = 0
         with torch.no_grad():
             Y_denoised = self.forward_denoiser(Y) if self.denoiser_net is not None else None
@@ -343,15 +348,20 @@ class StochasticRegenerationModel(_Base):
                 sample, nfe = sampler()
             else:
                 sample = Y_denoised
+        if return_stft:                                     # (model.py:766-767)
+            return sample.squeeze(), Y.squeeze(), T_orig, float(peak[0])
         x_hat = self.data_module.spec_to_wav(sample, T_orig, peak)
         return (x_hat, nfe) if return_nfe else x_hat
 
     def enhance(self, y, sampler_type="pc", predictor="reverse_diffusion", corrector="none", N=30, corrector_steps=1,
                 snr=0.5, timeit=False, scale_factor=None, return_stft=False, denoiser_only=False, **kwargs):
-        """model.py:720-780"""
+        """model.py:720-780; return_stft=True returns (sample, Y, T_orig, norm_factor) like the reference."""
         start = time.time()
-        x_hat, nfe = self.enhance_batch(y, sampler_type, predictor, corrector, N, corrector_steps, snr,
-                                        denoiser_only=denoiser_only, return_nfe=True, **kwargs)
+        out = self.enhance_batch(y, sampler_type, predictor, corrector, N, corrector_steps, snr,
+                                 denoiser_only=denoiser_only, return_nfe=True, return_stft=return_stft, **kwargs)
+        if return_stft:
+            return out
+        x_hat, nfe = out
         x_hat = x_hat.squeeze().cpu()
         end = time.time()
         if timeit:

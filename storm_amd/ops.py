@@ -214,6 +214,11 @@ def _r(z):
     return None if z is None else torch.view_as_real(z)
 
 
+def _t32(t):
+    """per-batch times as the kernels read them: contiguous float32 (a float64 / strided t would be read as garbage)"""
+    return t.to(torch.float32).contiguous()
+
+
 def _n_per_batch(x):
     return x.numel() // x.shape[0]
 
@@ -228,6 +233,7 @@ def ouve_prior(sde, y, z=None, seed=0, offset=0):
 def ouve_ald_step(sde, x, score, t, snr, z=None, seed=0, offset=0):
     """In place on x; returns (x, x_mean)."""
     xm = torch.empty_like(x)
+    t = _t32(t)
     L.check(L.lib().storm_ouve_ald_step(L.ptr(_r(x)), L.ptr(_r(xm)), L.ptr(_r(score)), L.ptr(_r(z)), L.ptr(t),
                                         x.shape[0], _n_per_batch(x), _ouve(sde), float(snr), seed, offset, L.stream()),
             "storm_ouve_ald_step")
@@ -235,7 +241,9 @@ def ouve_ald_step(sde, x, score, t, snr, z=None, seed=0, offset=0):
 
 
 def ouve_predictor_step(sde, x, score, y, t, kind=0, z=None, noise_free=False, seed=0, offset=0):
+    """In place on x; returns (x, x_mean)."""
     xm = torch.empty_like(x)
+    t = _t32(t)
     L.check(L.lib().storm_ouve_predictor_step(L.ptr(_r(x)), L.ptr(_r(xm)), L.ptr(_r(score)), L.ptr(_r(y)), L.ptr(_r(z)),
                                               L.ptr(t), x.shape[0], _n_per_batch(x), _ouve(sde), kind, int(noise_free),
                                               seed, offset, L.stream()), "storm_ouve_predictor_step")
@@ -248,12 +256,61 @@ def batch_l2norm(v):
     return out
 
 
-def langevin_step(x, score, z, snr):
+def langevin_step(x, score, z, snr, per_row=False, group=None):
+    """Langevin corrector update, IN PLACE on x (returns (x, x_mean)).  Step size from the batch-mean norms (reference
+    semantics, correctors.py:53-55), from every row's own norms (per_row: B independent batch-1 calls), or - with a
+    torch.distributed process group - from the means over the batches of all ranks (a 2-float all-reduce per step)."""
     xm = torch.empty_like(x)
     sn, zn = batch_l2norm(score), batch_l2norm(z)
+    mode = 1 if per_row else 0
+    if group is not None and not per_row:
+        tot = torch.stack([sn.sum(), zn.sum(), torch.tensor(float(x.shape[0]), device=x.device)])
+        group.all_reduce(tot)
+        sn, zn, mode = (tot[0:1] / tot[2]).contiguous(), (tot[1:2] / tot[2]).contiguous(), 2
     L.check(L.lib().storm_langevin_step(L.ptr(_r(x)), L.ptr(_r(xm)), L.ptr(_r(score)), L.ptr(_r(z)), L.ptr(sn), L.ptr(zn),
-                                        x.shape[0], _n_per_batch(x), float(snr), L.stream()), "storm_langevin_step")
+                                        x.shape[0], _n_per_batch(x), float(snr), mode, L.stream()), "storm_langevin_step")
     return x, xm
+
+
+def ouve_pf_drift(sde, x, y, score, t):
+    """theta (y - x) - 1/2 g(t)^2 score: the right-hand side of the probability-flow ODE in one pass."""
+    out = torch.empty_like(x)
+    t = _t32(t)                                             # (kept alive in a local: a temporary would be freed before the launch)
+    L.check(L.lib().storm_ouve_pf_drift(L.ptr(_r(out)), L.ptr(_r(x)), L.ptr(_r(y)), L.ptr(_r(score)), L.ptr(t), x.shape[0],
+                                        _n_per_batch(x), _ouve(sde), L.stream()), "storm_ouve_pf_drift")
+    return out
+
+
+_rk_scratch = {}
+
+
+def _kptrs(K):
+    arr = (C.c_void_p * len(K))(*[L.ptr(_r(k)) for k in K])
+    return arr
+
+
+def rk_combine(x, K, coef, h, out=None):
+    """out = x + h * sum_j coef[j] K[j] (one fused pass; complex64 tensors of one shape)."""
+    out = torch.empty_like(x) if out is None else out
+    cf = (C.c_float * len(K))(*[float(c) for c in coef])
+    L.check(L.lib().storm_rk_combine(L.ptr(_r(out)), L.ptr(_r(x)), _kptrs(K), cf, len(K), float(h), x.numel(), L.stream()),
+            "storm_rk_combine")
+    return out
+
+
+def rk_scaled_sumsq(xa, xb, K, coef, h, atol, rtol, mode=None):
+    """Device scalar (float64 tensor [1]) = sum over complex elements of |v|^2 / (atol + max(|xa|, |xb|) rtol)^2 with
+    v = h sum coef[j] K[j] (mode None), K[0] (mode -1) or K[0] - K[1] (mode -2); nothing is synchronised here."""
+    key = str(xa.device)
+    if key not in _rk_scratch:
+        _rk_scratch[key] = torch.empty(2048, dtype=torch.float64, device=xa.device)
+    out = torch.empty(1, dtype=torch.float64, device=xa.device)
+    n_terms = len(K) if mode is None else mode
+    cf = (C.c_float * max(1, len(K)))(*[float(c) for c in (coef if coef is not None else [0.0] * len(K))])
+    L.check(L.lib().storm_rk_scaled_sumsq(L.ptr(out), L.ptr(_rk_scratch[key]), 2048, L.ptr(_r(xa)), L.ptr(_r(xb)) if xb is not None else None,
+                                          _kptrs(K), cf, n_terms, float(h), float(atol), float(rtol), xa.numel(), L.stream()),
+            "storm_rk_scaled_sumsq")
+    return out
 
 
 def complex_randn(shape, device, seed, offset):

@@ -1,8 +1,9 @@
 """Predictor-corrector (and ODE) samplers — drop-in for sgmse/sampling/__init__.py.
 
 ``get_pc_sampler(...)`` keeps the reference signature and returns ``fn() -> (x, nfe)``.  Extra
-keyword-only knobs: ``noise_fn`` (inject the draws, for parity runs) and ``seed`` (in-kernel Philox
-stream for production runs)."""
+keyword-only knobs: ``noise_fn`` (inject the draws, for parity runs), ``seed`` (in-kernel Philox
+stream for production runs), ``langevin_per_row`` / ``langevin_group`` (how the Langevin corrector's batch-coupled
+step size is formed, see LangevinCorrector).  All update functions work IN PLACE on the state they are handed."""
 import torch
 
 from .correctors import Corrector, CorrectorRegistry
@@ -15,7 +16,7 @@ __all__ = ["PredictorRegistry", "CorrectorRegistry", "Predictor", "Corrector", "
 
 def get_pc_sampler(predictor_name, corrector_name, sde, score_fn, y, denoise=True, eps=3e-2, snr=0.1,
                    corrector_steps=1, probability_flow: bool = False, conditioning=None, intermediate=False,
-                   noise_fn=None, seed=None, **kwargs):
+                   noise_fn=None, seed=None, langevin_per_row=False, langevin_group=None, **kwargs):
     """PC sampler (sampling/__init__.py:27-68): prior draw, then N x (corrector, predictor) on the
     time grid linspace(T, eps, N); returns the last predictor mean and nfe = N (corrector_steps + 1)."""
     predictor_cls = PredictorRegistry.get_by_name(predictor_name)
@@ -28,7 +29,8 @@ def get_pc_sampler(predictor_name, corrector_name, sde, score_fn, y, denoise=Tru
     if corrector_name == "none":
         corrector = corrector_cls()
     else:
-        corrector = corrector_cls(sde, score_fn, snr=snr, n_steps=corrector_steps, noise=noise)
+        extra = dict(per_row=langevin_per_row, group=langevin_group) if corrector_name == "langevin" else {}
+        corrector = corrector_cls(sde, score_fn, snr=snr, n_steps=corrector_steps, noise=noise, **extra)
 
     def pc_sampler():
         with torch.no_grad():

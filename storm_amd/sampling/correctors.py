@@ -26,7 +26,17 @@ class Corrector(abc.ABC):
 
 @CorrectorRegistry.register(name="langevin")
 class LangevinCorrector(Corrector):
-    """step = 2 (snr * mean_b ||z_b|| / mean_b ||score_b||)^2 — batch-coupled (correctors.py:45-61)."""
+    """step = 2 (snr * mean_b ||z_b|| / mean_b ||score_b||)^2 — batch-coupled (correctors.py:45-61).
+
+    The coupling is over whatever batch the sampler was given.  `per_row=True` gives every row its own step size
+    (= B independent batch-1 runs, which is what the reference CLI computes per file: used by enhance_batch);
+    `group` = a torch.distributed process group: the means are taken over the batches of ALL its ranks (a 2-float
+    all-reduce per step), so a sharded run reproduces the unsharded batch-mean exactly.  Like every update_fn here it
+    updates x IN PLACE and returns (x, x_mean)."""
+
+    def __init__(self, sde, score_fn, snr, n_steps, noise=None, per_row=False, group=None):
+        super().__init__(sde, score_fn, snr, n_steps, noise)
+        self.per_row, self.group = per_row, group
 
     def update_fn(self, x, t, *args, **kwargs):
         x_mean = x
@@ -35,7 +45,8 @@ class LangevinCorrector(Corrector):
             z, seed, off = self.noise.next(x)
             if z is None:
                 z = ops.complex_randn(x.shape, x.device, seed, off)
-            x, x_mean = ops.langevin_step(x.contiguous(), grad.contiguous(), z.contiguous(), self.snr)
+            x, x_mean = ops.langevin_step(x.contiguous(), grad.contiguous(), z.contiguous(), self.snr, per_row=self.per_row,
+                                          group=self.group)
         return x, x_mean
 
 

@@ -6,6 +6,7 @@ import pytest
 import torch
 
 from oracle import ncsnpp_ref as NR
+from oracle import sde_ref as SR
 from tests.backend import dev  # noqa: F401
 from tests.util import rel_l2
 
@@ -138,3 +139,47 @@ def test_enhancement_cli(tmp_path):
     want = m.enhance_batch(torch.stack(wavs), corrector="ald", N=2, corrector_steps=1, snr=0.5, seed=123).cpu()
     for i in range(2):          # same Philox seed -> same noise -> same wav
         assert rel_l2(got[i], want[i].float()) < 1e-4
+
+
+def test_discriminative_and_storm_surfaces(dev, golden):
+    """DiscriminativeModel.enhance (model.py:351-370; the CLI's --mode denoiser-only) and StochasticRegenerationModel.enhance
+    with denoiser_only / return_stft (model.py:720-780) against the reference's outputs (fixture F9)."""
+    from storm_amd.model import DiscriminativeModel, StochasticRegenerationModel
+    g = golden["f9_surfaces"]
+    wav = torch.from_numpy(g["wav_in"])
+    m = DiscriminativeModel(backbone="ncsnpp", input_channels=2, discriminative=True, **dict(COMMON))
+    cfg_d = NR.NCSNppConfig(nf=8, input_channels=2, discriminative=True)
+    m.dnn.load_state_dict(NR.seeded_state_dict(cfg_d, seed=41))
+    m.eval(no_ema=True)
+    m = m.to(dev)
+    out = m.enhance(wav.to(dev)).cpu()
+    assert out.shape == (8000,) and rel_l2(out, g["disc_out"]) < 1e-3
+    s = StochasticRegenerationModel(backbone_denoiser="ncsnpp", backbone_score="ncsnpp", condition="both", **dict(COMMON))
+    s.denoiser_net.load_state_dict(NR.seeded_state_dict(cfg_d, seed=42))
+    s.score_net.load_state_dict(NR.seeded_state_dict(NR.NCSNppConfig(nf=8, input_channels=6), seed=43))
+    s.eval(no_ema=True)
+    s = s.to(dev)
+    assert rel_l2(s.enhance(wav.to(dev), denoiser_only=True), g["storm_denoiser_only"]) < 1e-3
+    it = iter([torch.from_numpy(n).to(dev) for n in g["stft_noise"]])
+    sample, Y, T_orig, norm = s.enhance(wav.to(dev), N=2, corrector="none", snr=0.5, return_stft=True, noise_fn=lambda: next(it))
+    assert T_orig == 8000 and abs(norm - float(g["stft_norm"])) < 1e-7 * float(g["stft_norm"])
+    assert rel_l2(Y.cpu(), g["stft_Y"]) < 1e-5 and rel_l2(sample.cpu(), g["stft_sample"]) < 1e-3
+
+
+def test_silent_utterance_does_not_poison_the_batch(dev):
+    """an all-zero file next to a normal one: the reference divides 0 / 0 (NaN through its whole sampler); here the silent row
+    comes out silent and the other row is what it is alone"""
+    from storm_amd.model import ScoreModel
+    m = ScoreModel(backbone="ncsnpp", **dict(COMMON))
+    m.dnn.load_state_dict(NR.seeded_state_dict(NR.NCSNppConfig(nf=8, input_channels=4), seed=5))
+    m.eval(no_ema=True)
+    m = m.to(dev)
+    w = 0.1 * torch.randn(1, 6000, generator=torch.Generator().manual_seed(2))
+    both = torch.cat([w, torch.zeros(1, 6000)], 0).to(dev)
+    noise = [SR.complex_randn((2, 1, 256, 64), torch.Generator().manual_seed(8)) for _ in range(1 + 2 * 2)]
+    it = iter([n.to(dev) for n in noise])
+    out = m.enhance_batch(both, N=2, corrector="ald", snr=0.5, noise_fn=lambda: next(it)).cpu()
+    it1 = iter([n[:1].to(dev) for n in noise])
+    alone = m.enhance_batch(w.to(dev), N=2, corrector="ald", snr=0.5, noise_fn=lambda: next(it1)).cpu()
+    assert torch.isfinite(out).all() and float(out[1].abs().max()) < 1e-12
+    assert rel_l2(out[0], alone[0]) < 1e-5
