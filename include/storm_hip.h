@@ -204,6 +204,10 @@ int storm_batch_l2norm(const float* v, float* out, int B, long long n, storm_str
 int storm_langevin_step(float* x, float* x_mean, const float* score, const float* z,
                         const float* score_norms, const float* z_norms, int B, long long n, float snr, int mode,
                         storm_stream_t s);
+/* Scale-invariant SDR in dB of B (clean s, estimate s_hat) waveform pairs, fp32 [B][>= n] with row strides (util/other.py:82-94:
+ * si_sdr with eps = 0, si_sdr_torch with eps = 1e-10; used by the evaluation loop, util/inference.py:20-72) */
+int storm_si_sdr(const float* s, const float* s_hat, float* out, int B, long long n, long long stride_s, long long stride_hat,
+                 float eps, storm_stream_t st);
 /* drift of the probability-flow ODE, out = theta (y - x) - 1/2 g(t)^2 score  (sdes.py:92-121 with probability_flow, :203-207) */
 int storm_ouve_pf_drift(float* out, const float* x, const float* y, const float* score, const float* t, int B,
                         long long n, storm_ouve p, storm_stream_t s);

@@ -79,6 +79,7 @@ _SIGNATURES = {
     "storm_ouve_predictor_step": ([_vp, _vp, _vp, _vp, _vp, _vp, _i, _ll, Ouve, _i, _i, _u64, _u64, _vp], C.c_int),
     "storm_batch_l2norm": ([_vp, _vp, _i, _ll, _vp], C.c_int),
     "storm_langevin_step": ([_vp, _vp, _vp, _vp, _vp, _vp, _i, _ll, _f, _i, _vp], C.c_int),
+    "storm_si_sdr": ([_vp, _vp, _vp, _i, _ll, _ll, _ll, _f, _vp], C.c_int),
     "storm_ouve_pf_drift": ([_vp, _vp, _vp, _vp, _vp, _i, _ll, Ouve, _vp], C.c_int),
     "storm_rk_combine": ([_vp, _vp, C.POINTER(_vp), C.POINTER(C.c_float), _i, _f, _ll, _vp], C.c_int),
     "storm_rk_scaled_sumsq": ([_vp, _vp, _i, _vp, _vp, C.POINTER(_vp), C.POINTER(C.c_float), _i, _f, _f, _f, _ll, _vp], C.c_int),

@@ -230,6 +230,38 @@ __global__ void sum_partials_kernel(const double* __restrict__ part, int n, doub
     if (threadIdx.x == 0 && blockIdx.x == 0) { double s = 0.0; for (int i = 0; i < n; ++i) s += part[i]; out[0] = s; }
 }
 
+// SI-SDR of B (reference, estimate) waveform pairs (util/other.py:82-94): alpha = <s_hat, s> / ||s||^2,
+// 10 log10((eps +) ||alpha s||^2 / (eps + ||alpha s - s_hat||^2)); sums in fp64, the residual formed per sample.
+__global__ void si_sdr_kernel(const float* __restrict__ s, const float* __restrict__ sh, float* __restrict__ out, long long n,
+                              long long stride_s, long long stride_h, float eps) {
+    __shared__ double red[2][4];
+    __shared__ double alpha_sh;
+    const int b = blockIdx.x;
+    const float* ps = s + (long long)b * stride_s;
+    const float* ph = sh + (long long)b * stride_h;
+    double dot = 0.0, ss = 0.0;
+    for (long long i = threadIdx.x; i < n; i += blockDim.x) { const double a = ps[i]; dot += a * (double)ph[i]; ss += a * a; }
+    dot = wave_sum_d(dot); ss = wave_sum_d(ss);
+    if ((threadIdx.x & 63) == 0) { red[0][threadIdx.x >> 6] = dot; red[1][threadIdx.x >> 6] = ss; }
+    __syncthreads();
+    if (threadIdx.x == 0) alpha_sh = (red[0][0] + red[0][1] + red[0][2] + red[0][3]) / (red[1][0] + red[1][1] + red[1][2] + red[1][3]);
+    __syncthreads();
+    const double alpha = alpha_sh;
+    double tgt = 0.0, res = 0.0;
+    for (long long i = threadIdx.x; i < n; i += blockDim.x) {
+        const double a = alpha * (double)ps[i], r = a - (double)ph[i];
+        tgt += a * a; res += r * r;
+    }
+    tgt = wave_sum_d(tgt); res = wave_sum_d(res);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) { red[0][threadIdx.x >> 6] = tgt; red[1][threadIdx.x >> 6] = res; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const double T = red[0][0] + red[0][1] + red[0][2] + red[0][3], R = red[1][0] + red[1][1] + red[1][2] + red[1][3];
+        out[b] = (float)(10.0 * log10((double)eps + T / ((double)eps + R)));
+    }
+}
+
 static inline int ew_blocks(long long n) { long long b = (n + 255) / 256; return (int)(b > 2048 ? 2048 : (b < 1 ? 1 : b)); }
 
 }  // namespace storm
@@ -324,6 +356,14 @@ extern "C" int storm_ouve_pf_drift(float* out, const float* x, const float* y, c
                                    long long n, storm_ouve p, storm_stream_t s) {
     STORM_CHECK(out && x && y && score && t && B > 0 && n > 0, "storm_ouve_pf_drift: bad arguments");
     hipLaunchKernelGGL(ouve_pf_drift_kernel, dim3(ew_blocks(n), B), dim3(256), 0, (hipStream_t)s, out, x, y, score, t, n, p);
+    STORM_LAUNCH_CHECK();
+    return STORM_OK;
+}
+
+extern "C" int storm_si_sdr(const float* s, const float* s_hat, float* out, int B, long long n, long long stride_s,
+                            long long stride_hat, float eps, storm_stream_t st) {
+    STORM_CHECK(s && s_hat && out && B > 0 && n > 0, "storm_si_sdr: bad arguments");
+    hipLaunchKernelGGL(si_sdr_kernel, dim3(B), dim3(256), 0, (hipStream_t)st, s, s_hat, out, n, stride_s, stride_hat, eps);
     STORM_LAUNCH_CHECK();
     return STORM_OK;
 }

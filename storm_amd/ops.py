@@ -272,6 +272,16 @@ def langevin_step(x, score, z, snr, per_row=False, group=None):
     return x, xm
 
 
+def si_sdr(s, s_hat, eps=0.0):
+    """SI-SDR in dB per row of two fp32 waveform batches [B, L] (rows may be strided views)."""
+    assert s.dim() == 2 and s_hat.dim() == 2 and s.shape[0] == s_hat.shape[0] and s.stride(1) == 1 and s_hat.stride(1) == 1
+    n = min(s.shape[1], s_hat.shape[1])
+    out = torch.empty(s.shape[0], dtype=torch.float32, device=s.device)
+    L.check(L.lib().storm_si_sdr(L.ptr_rows(s), L.ptr_rows(s_hat), L.ptr(out), s.shape[0], n, s.stride(0), s_hat.stride(0), float(eps),
+                                 L.stream()), "storm_si_sdr")
+    return out
+
+
 def ouve_pf_drift(sde, x, y, score, t):
     """theta (y - x) - 1/2 g(t)^2 score: the right-hand side of the probability-flow ODE in one pass."""
     out = torch.empty_like(x)

@@ -1,0 +1,69 @@
+"""Evaluation loop — drop-in for sgmse/util/inference.py:20-72 (`evaluate_model`), built for the batched engine.
+
+The reference enhances the first `num_eval_files` validation pairs ONE BY ONE (model.enhance) and averages PESQ,
+SI-SDR and ESTOI on the host.  Here the pairs are grouped into equal-length batches (every op of the path is per
+utterance, so a batched run equals the per-file runs), enhanced with `model.enhance_batch`, SI-SDR is one HIP launch
+per batch (storm_si_sdr), and PESQ / ESTOI are used when the `pesq` / `pystoi` packages are importable (they are CPU
+reference implementations of ITU-T P.862 / ESTOI; without them the two averages are NaN).
+
+Pairs come from `model.data_module.valid_set.__getitem__(i, raw=True)` like the reference, or from `pairs=` (a sequence
+of (clean [1, L], noisy [1, L]) tensors) since datasets are outside the hot path."""
+import math
+
+import torch
+
+from ..distributed import group_by_length
+from .other import si_sdr_batch
+
+# Settings of the reference's validation runs (util/inference.py:11-13)
+snr = 0.5
+N = 50
+corrector_steps = 1
+MAX_VIS_SAMPLES = 10
+
+
+def _optional(name, attr):
+    try:
+        return getattr(__import__(name), attr)
+    except Exception:
+        return None
+
+
+def evaluate_model(model, num_eval_files, spec=False, audio=False, discriminative=False, pairs=None, batch=16, **enhance_kwargs):
+    """Returns (pesq, si_sdr, estoi, [noisy, estimate, clean spectrograms] | None, [noisy, estimate, clean audio] | None),
+    the reference's tuple.  `discriminative` is accepted for signature parity (the model class decides the path)."""
+    model.eval()
+    pesq, stoi = _optional("pesq", "pesq"), _optional("pystoi", "stoi")
+    if pairs is None:
+        vs = model.data_module.valid_set
+        pairs = [vs.__getitem__(i, raw=True) for i in range(num_eval_files)]
+    pairs = [(x if x.dim() == 2 else x.unsqueeze(0), y if y.dim() == 2 else y.unsqueeze(0)) for x, y in list(pairs)[:num_eval_files]]
+    n = len(pairs)
+    dev = next(model.parameters()).device
+    est = [None] * n
+    sdr = torch.zeros(n, dtype=torch.float64)
+    for ids in group_by_length([p[1].shape[-1] for p in pairs], batch):
+        y = torch.cat([pairs[i][1][:1] for i in ids], 0).to(dev)          # first channel only (util/inference.py:44-47)
+        x = torch.cat([pairs[i][0][:1] for i in ids], 0).to(dev)
+        if hasattr(model, "enhance_batch") and not discriminative:
+            x_hat = model.enhance_batch(y, **enhance_kwargs)
+        else:
+            x_hat = torch.stack([model.enhance(y[k:k + 1]).reshape(-1) for k in range(len(ids))])
+        x_hat = x_hat.reshape(len(ids), -1).float()
+        sdr[ids] = si_sdr_batch(x.float().contiguous(), x_hat.contiguous()).double().cpu()
+        for k, i in enumerate(ids):
+            est[i] = x_hat[k].cpu()
+    _pesq = _estoi = float("nan")
+    if pesq is not None:
+        _pesq = sum(pesq(16000, pairs[i][0][0].numpy(), est[i].numpy(), "wb") for i in range(n)) / n
+    if stoi is not None:
+        _estoi = sum(stoi(pairs[i][0][0].numpy(), est[i].numpy(), 16000, extended=True) for i in range(n)) / n
+    specs = audios = None
+    if spec:
+        k = min(n, MAX_VIS_SAMPLES)
+        specs = [[model._stft(pairs[i][1][0]) for i in range(k)], [model._stft(est[i]) for i in range(k)],
+                 [model._stft(pairs[i][0][0]) for i in range(k)]]
+    if audio:
+        k = min(n, MAX_VIS_SAMPLES)
+        audios = [[pairs[i][1][0] for i in range(k)], [est[i] for i in range(k)], [pairs[i][0][0] for i in range(k)]]
+    return _pesq, float(sdr.mean()) if n else math.nan, _estoi, specs, audios
