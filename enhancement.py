@@ -69,15 +69,21 @@ def main():
         wavs.append(y[:1])
         lengths.append(y.shape[1])
     mine = D.shard_indices(len(files), rank, world, lengths)
-    for batch in D.group_by_length([lengths[i] for i in mine], args.batch):
+    # micro-batches of utterances that share a padded frame count (different lengths welcome): equal to per-file runs
+    for batch in D.bucket_by_frames([lengths[i] for i in mine], args.batch):
         ids = [mine[k] for k in batch]
-        y = torch.cat([wavs[i] for i in ids], 0)
+        lens = [lengths[i] for i in ids]
+        y = torch.zeros(len(ids), max(lens))
+        for k, i in enumerate(ids):
+            y[k, :lens[k]] = wavs[i][0]
+        ragged = None if len(set(lens)) == 1 else lens
         if args.mode == "denoiser-only":
             outs = [model.enhance(wavs[i]) for i in ids]
         else:
             kw = {} if args.seed is None else dict(seed=args.seed + ids[0])     # distinct, reproducible draws per batch
-            x_hat = model.enhance_batch(y, corrector=args.corrector, N=args.N, corrector_steps=args.corrector_steps, snr=args.snr, **kw)
-            outs = list(x_hat)
+            x_hat = model.enhance_batch(y, corrector=args.corrector, N=args.N, corrector_steps=args.corrector_steps, snr=args.snr,
+                                        lengths=ragged, **kw)
+            outs = [x_hat[k, :lens[k]] for k in range(len(ids))]
         for i, x in zip(ids, outs):
             write_wav(os.path.join(args.enhanced_dir, os.path.basename(files[i])), x.float().reshape(-1), 16000)
     D.barrier()

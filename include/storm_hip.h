@@ -235,15 +235,20 @@ int storm_complex_randn(float* z, long long n_complex, uint64_t seed, uint64_t o
  * (data_module.py:182-193): |z|^e e^{j angle z} * factor  /  its inverse.                  */
 int storm_spec_transform(const float* in, float* out, long long n_complex, float spec_factor,
                          float spec_abs_exponent, int inverse, storm_stream_t s);
-/* peak[b] = max |wav[b][:]|  (model.py:283) */
-int storm_peak_abs(const float* wav, float* peak, int B, long long L, long long stride,
+/* Ragged batches (micro-batching of utterances of different lengths that share ONE padded frame count, i.e.
+ * roundup(1 + L_b / hop, 64) equal for all rows): the three front / back end calls take row_len = device int32 [B] with
+ * every row's own sample count (NULL = all rows L); wav buffers are [B][L] with L = the longest row, zero filled past a
+ * row's length.  Row b then equals the single-utterance call with L_b (the reference pads per utterance,
+ * util/other.py:102-109, enhancement.py:66-72).
+ * peak[b] = max |wav[b][:L_b]|  (model.py:283) */
+int storm_peak_abs(const float* wav, float* peak, int B, long long L, long long stride, const int* row_len,
                    storm_stream_t s);
 /* wav [B][L] (row stride `stride`) -> spec complex [B][F][Tpad]; frames >= n_frames are zero.
  * spec = spec_fwd(stft(wav / peak[b])); peak may be NULL (no normalisation).
  * twiddle: fp32 [n_fft][2] = (cos, sin)(2 pi k / n_fft); window: fp32 [n_fft].            */
 int storm_stft(const float* wav, const float* peak, float* spec, const float* window,
                const float* twiddle, int B, long long L, long long stride, int n_fft, int hop,
-               int n_frames, int Tpad, float spec_factor, float spec_abs_exponent,
+               int n_frames, int Tpad, float spec_factor, float spec_abs_exponent, const int* row_len,
                storm_stream_t s);
 /* spec complex [B][F][T] (ALL T frames are inverted, as to_audio does, model.py:258-259,301)
  * -> wav [B][L] = istft(spec_back(spec), length=L) * peak[b].
@@ -251,7 +256,7 @@ int storm_stft(const float* wav, const float* peak, float* spec, const float* wi
 int storm_istft(const float* spec, const float* peak, float* wav, float* frames,
                 const float* window, const float* twiddle, int B, int T, long long L,
                 long long stride, int n_fft, int hop, float spec_factor, float spec_abs_exponent,
-                storm_stream_t s);
+                const int* row_len, storm_stream_t s);
 
 /* ------------------------------------------------------------------------------------------
  * Program interpreter: runs a whole NCSN++ forward (or any op list) with one host call.

@@ -85,9 +85,9 @@ _SIGNATURES = {
     "storm_rk_scaled_sumsq": ([_vp, _vp, _i, _vp, _vp, C.POINTER(_vp), C.POINTER(C.c_float), _i, _f, _f, _f, _ll, _vp], C.c_int),
     "storm_complex_randn": ([_vp, _ll, _u64, _u64, _vp], C.c_int),
     "storm_spec_transform": ([_vp, _vp, _ll, _f, _f, _i, _vp], C.c_int),
-    "storm_peak_abs": ([_vp, _vp, _i, _ll, _ll, _vp], C.c_int),
-    "storm_stft": ([_vp, _vp, _vp, _vp, _vp, _i, _ll, _ll, _i, _i, _i, _i, _f, _f, _vp], C.c_int),
-    "storm_istft": ([_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _ll, _ll, _i, _i, _f, _f, _vp], C.c_int),
+    "storm_peak_abs": ([_vp, _vp, _i, _ll, _ll, _vp, _vp], C.c_int),
+    "storm_stft": ([_vp, _vp, _vp, _vp, _vp, _i, _ll, _ll, _i, _i, _i, _i, _f, _f, _vp, _vp], C.c_int),
+    "storm_istft": ([_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _ll, _ll, _i, _i, _f, _f, _vp, _vp], C.c_int),
     "storm_program_run": ([C.POINTER(Op), _i, C.POINTER(_vp), _i, _i, _vp], C.c_int),
     "storm_program_kernel_name": ([C.POINTER(Op), _i, _i], C.c_char_p),
     "storm_program_run_timed": ([C.POINTER(Op), _i, C.POINTER(_vp), _i, _i, _vp, C.POINTER(C.c_float)], C.c_int),

@@ -10,9 +10,11 @@ namespace storm {
 
 constexpr int MAX_NFFT = 1024;
 
-__global__ void peak_abs_kernel(const float* __restrict__ wav, float* __restrict__ peak, long long L, long long stride) {
+__global__ void peak_abs_kernel(const float* __restrict__ wav, float* __restrict__ peak, long long L, long long stride,
+                                const int* __restrict__ row_len) {
     __shared__ float red[4];
     const int b = blockIdx.x;
+    if (row_len) L = row_len[b];
     const float* p = wav + (long long)b * stride;
     float m = 0.f;
     for (long long i = threadIdx.x; i < L; i += blockDim.x) m = fmaxf(m, fabsf(p[i]));
@@ -26,11 +28,12 @@ __global__ void peak_abs_kernel(const float* __restrict__ wav, float* __restrict
 
 __global__ void stft_kernel(const float* __restrict__ wav, const float* __restrict__ peak, float* __restrict__ spec,
                             const float* __restrict__ window, const float* __restrict__ tw, long long L,
-                            long long stride, int n_fft, int hop, int n_frames, int Tpad, float factor, float expo) {
+                            long long stride, int n_fft, int hop, int n_frames, int Tpad, float factor, float expo, const int* __restrict__ row_len) {
     __shared__ float xs[MAX_NFFT];
     __shared__ float2 tws[MAX_NFFT];
     const int frame = blockIdx.x, b = blockIdx.y, F = n_fft / 2 + 1;
     float2* out = reinterpret_cast<float2*>(spec) + (long long)b * F * Tpad;
+    if (row_len) { L = row_len[b]; n_frames = 1 + (int)(L / hop); }      // ragged batch: this row's own length / frame count
     if (frame >= n_frames) {                       // pad_spec: zero frames
         for (int f = threadIdx.x; f < F; f += blockDim.x) out[(long long)f * Tpad + frame] = make_float2(0.f, 0.f);
         return;
@@ -101,10 +104,11 @@ __global__ void istft_frames_kernel(const float* __restrict__ spec, float* __res
 
 __global__ void istft_ola_kernel(const float* __restrict__ frames, const float* __restrict__ window,
                                  const float* __restrict__ peak, float* __restrict__ wav, int T, long long L,
-                                 long long stride, int n_fft, int hop) {
+                                 long long stride, int n_fft, int hop, const int* __restrict__ row_len) {
     const int b = blockIdx.y;
     const long long n = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (n >= L) return;
+    if (row_len && n >= row_len[b]) { wav[(long long)b * stride + n] = 0.f; return; }   // ragged batch: istft(..., length = this row's)
     const long long m = n + n_fft / 2;
     long long t1 = m / hop; if (t1 > T - 1) t1 = T - 1;
     long long t0 = (m - n_fft + hop) / hop; if (m - n_fft + 1 <= 0) t0 = 0; if (t0 < 0) t0 = 0;
@@ -150,36 +154,37 @@ extern "C" int storm_spec_transform(const float* in, float* out, long long n_com
     return STORM_OK;
 }
 
-extern "C" int storm_peak_abs(const float* wav, float* peak, int B, long long L, long long stride, storm_stream_t s) {
+extern "C" int storm_peak_abs(const float* wav, float* peak, int B, long long L, long long stride, const int* row_len,
+                              storm_stream_t s) {
     STORM_CHECK(wav && peak && B > 0 && L > 0, "storm_peak_abs: bad arguments");
-    hipLaunchKernelGGL(peak_abs_kernel, dim3(B), dim3(256), 0, (hipStream_t)s, wav, peak, L, stride);
+    hipLaunchKernelGGL(peak_abs_kernel, dim3(B), dim3(256), 0, (hipStream_t)s, wav, peak, L, stride, row_len);
     STORM_LAUNCH_CHECK();
     return STORM_OK;
 }
 
 extern "C" int storm_stft(const float* wav, const float* peak, float* spec, const float* window, const float* twiddle,
                           int B, long long L, long long stride, int n_fft, int hop, int n_frames, int Tpad,
-                          float spec_factor, float spec_abs_exponent, storm_stream_t s) {
+                          float spec_factor, float spec_abs_exponent, const int* row_len, storm_stream_t s) {
     STORM_CHECK(wav && spec && window && twiddle && B > 0, "storm_stft: null pointer");
     STORM_CHECK(n_fft >= 2 && n_fft <= MAX_NFFT && hop > 0, "storm_stft: n_fft=%d hop=%d", n_fft, hop);
     STORM_CHECK(L > n_fft / 2, "storm_stft: signal too short for reflect padding (L=%lld)", L);
     STORM_CHECK(n_frames == 1 + (int)(L / hop) && Tpad >= n_frames, "storm_stft: n_frames=%d Tpad=%d L=%lld", n_frames, Tpad, L);
     hipLaunchKernelGGL(stft_kernel, dim3(Tpad, B), dim3(256), 0, (hipStream_t)s, wav, peak, spec, window, twiddle, L, stride,
-                       n_fft, hop, n_frames, Tpad, spec_factor, spec_abs_exponent);
+                       n_fft, hop, n_frames, Tpad, spec_factor, spec_abs_exponent, row_len);
     STORM_LAUNCH_CHECK();
     return STORM_OK;
 }
 
 extern "C" int storm_istft(const float* spec, const float* peak, float* wav, float* frames, const float* window,
                            const float* twiddle, int B, int T, long long L, long long stride, int n_fft, int hop,
-                           float spec_factor, float spec_abs_exponent, storm_stream_t s) {
+                           float spec_factor, float spec_abs_exponent, const int* row_len, storm_stream_t s) {
     STORM_CHECK(spec && wav && frames && window && twiddle && B > 0 && T > 0, "storm_istft: null pointer");
     STORM_CHECK(n_fft >= 2 && n_fft <= MAX_NFFT && hop > 0, "storm_istft: n_fft=%d hop=%d", n_fft, hop);
     STORM_CHECK(L > 0 && L <= (long long)n_fft + (long long)hop * (T - 1) - n_fft / 2, "storm_istft: length %lld not covered by %d frames", L, T);
     hipStream_t st = (hipStream_t)s;
     hipLaunchKernelGGL(istft_frames_kernel, dim3(T, B), dim3(256), 0, st, spec, frames, window, twiddle, T, n_fft, spec_factor, spec_abs_exponent);
     STORM_LAUNCH_CHECK();
-    hipLaunchKernelGGL(istft_ola_kernel, dim3(cdiv(L, 256), B), dim3(256), 0, st, frames, window, peak, wav, T, L, stride, n_fft, hop);
+    hipLaunchKernelGGL(istft_ola_kernel, dim3(cdiv(L, 256), B), dim3(256), 0, st, frames, window, peak, wav, T, L, stride, n_fft, hop, row_len);
     STORM_LAUNCH_CHECK();
     return STORM_OK;
 }

@@ -60,17 +60,27 @@ class SpecsDataModule:
         return w[0] if squeeze else w
 
     # ---- fused batched forms used by enhance() ---------------------------------------------------
-    def wav_to_spec(self, wav, pad_to=64):
-        """wav [B, L] -> (Y [B,1,F,Tpad] = pad_spec(spec_fwd(stft(wav / peak))), peak [B])  in two launches."""
-        peak = ops.peak_abs(wav)
+    def padded_frames(self, length, pad_to=64):
+        """frames of one utterance after pad_spec (util/other.py:102-109): utterances with equal values can share a batch"""
+        return ops.round_up(1 + int(length) // self.hop_length, pad_to)
+
+    def wav_to_spec(self, wav, pad_to=64, lengths=None):
+        """wav [B, L] -> (Y [B,1,F,Tpad] = pad_spec(spec_fwd(stft(wav / peak))), peak [B])  in two launches.
+        lengths: per-row sample counts of a ragged batch (rows zero filled past them, one padded frame count for all)."""
+        if lengths is not None:
+            tp = {self.padded_frames(v, pad_to) for v in lengths}
+            if len(tp) != 1 or max(int(v) for v in lengths) != wav.shape[1]:
+                raise ValueError(f"a ragged batch must share one padded frame count and be as wide as its longest row: {sorted(tp)}")
+        peak = ops.peak_abs(wav, lengths)
         Y = ops.stft(wav, peak, n_fft=self.n_fft, hop=self.hop_length, spec_factor=self.spec_factor,
-                     spec_abs_exponent=self.spec_abs_exponent, pad_to=pad_to, window=self.window_type)
+                     spec_abs_exponent=self.spec_abs_exponent, pad_to=pad_to, window=self.window_type, lengths=lengths)
         return Y.unsqueeze(1), peak
 
-    def spec_to_wav(self, spec, length, peak=None):
+    def spec_to_wav(self, spec, length, peak=None, lengths=None):
         """spec [B,1,F,T] -> wav [B, length] = istft(spec_back(spec), length) * peak."""
         return ops.istft(spec[:, 0].contiguous(), int(length), peak, n_fft=self.n_fft, hop=self.hop_length,
-                         spec_factor=self.spec_factor, spec_abs_exponent=self.spec_abs_exponent, window=self.window_type)
+                         spec_factor=self.spec_factor, spec_abs_exponent=self.spec_abs_exponent, window=self.window_type,
+                         lengths=lengths)
 
     @staticmethod
     def add_argparse_args(parser):

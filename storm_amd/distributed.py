@@ -97,6 +97,22 @@ def group_by_length(lengths, max_batch):
     return batches
 
 
+def bucket_by_frames(lengths, max_batch, hop=128, multiple=64):
+    """Micro-batches for utterances of DIFFERENT lengths: the reference pads every utterance's spectrogram to its own
+    multiple of 64 frames (util/other.py:102-109), and every op of the path is per utterance, so utterances whose padded
+    frame count roundup(1 + L // hop, multiple) is equal can share a batch and still equal their single-utterance runs
+    (2-10 s at 16 kHz: 17 buckets).  Returns index lists (at most max_batch long), longest bucket first."""
+    by_t = {}
+    for i, n in enumerate(lengths):
+        by_t.setdefault(-(-(1 + int(n) // hop) // multiple) * multiple, []).append(i)
+    batches = []
+    for t in sorted(by_t, reverse=True):
+        ids = sorted(by_t[t], key=lambda i: -int(lengths[i]))
+        for k in range(0, len(ids), max_batch):
+            batches.append(ids[k:k + max_batch])
+    return batches
+
+
 def gather_objects(obj, rank, world):
     """All ranks' python objects on rank 0 (None elsewhere)."""
     if world == 1:

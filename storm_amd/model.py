@@ -161,12 +161,13 @@ class _Base(nn.Module):
     def _istft(self, spec, length=None):
         return self.data_module.istft(spec, length)
 
-    def _prepare(self, y):
-        """model.py:282-286 for a batch: y [B, L] host/device -> (Y [B,1,F,Tpad], peak [B], L)."""
+    def _prepare(self, y, lengths=None):
+        """model.py:282-286 for a batch: y [B, L] host/device -> (Y [B,1,F,Tpad], peak [B], L).  lengths: the rows' own sample
+        counts when utterances of different lengths share the batch (same padded frame count; rows zero filled)."""
         if y.dim() != 2:
             raise ValueError("expected a waveform batch [B, L]")
         yd = y.to(device=self.device, dtype=torch.float32).contiguous()
-        Y, peak = self.data_module.wav_to_spec(yd, pad_to=64)
+        Y, peak = self.data_module.wav_to_spec(yd, pad_to=64, lengths=lengths)
         return Y, peak, y.size(1)
 
     def _sampler_minibatched(self, make, y, minibatch):
@@ -227,12 +228,14 @@ class ScoreModel(_Base):
         return self._sampler_minibatched(lambda sl: sampling.get_ode_sampler(sde, self, y=y[sl], **kwargs), y, minibatch)
 
     def enhance_batch(self, y, sampler_type="pc", predictor="reverse_diffusion", corrector="ald", N=50,
-                      corrector_steps=1, snr=0.5, return_nfe=False, **kwargs):
+                      corrector_steps=1, snr=0.5, return_nfe=False, lengths=None, **kwargs):
         """B equal-length utterances y [B, L] in one sampler run.  Every op on the path is per utterance and the Langevin
         corrector runs with per-row step sizes, so with INJECTED noise (noise_fn) row b equals enhance(y[b:b+1]) for every
         predictor / corrector; with the in-kernel Philox stream (seed=) rows are independent draws but not the draws a
-        batch-1 call with the same seed would make (the counter is the position in the batch)."""
-        Y, peak, T_orig = self._prepare(y)
+        batch-1 call with the same seed would make (the counter is the position in the batch).
+        lengths: ragged micro-batch - rows of different sample counts that share one padded frame count
+        (storm_amd.distributed.bucket_by_frames); y is zero filled to the longest row and so is the result."""
+        Y, peak, T_orig = self._prepare(y, lengths)
         if sampler_type == "pc":
             kwargs.setdefault("langevin_per_row", True)
             sampler = self.get_pc_sampler(predictor, corrector, Y, N=N, corrector_steps=corrector_steps, snr=snr,
@@ -242,7 +245,7 @@ class ScoreModel(_Base):
         else:
             raise ValueError("{} is not a valid sampler type!".format(sampler_type))
         sample, nfe = sampler()
-        x_hat = self.data_module.spec_to_wav(sample, T_orig, peak)
+        x_hat = self.data_module.spec_to_wav(sample, T_orig, peak, lengths=lengths)
         return (x_hat, nfe) if return_nfe else x_hat
 
     def enhance(self, y, sampler_type="pc", predictor="reverse_diffusion", corrector="ald", N=50, corrector_steps=1,
@@ -325,8 +328,9 @@ class StochasticRegenerationModel(_Base):
             y, minibatch)
 
     def enhance_batch(self, y, sampler_type="pc", predictor="reverse_diffusion", corrector="none", N=30,
-                      corrector_steps=1, snr=0.5, denoiser_only=False, return_nfe=False, return_stft=False, **kwargs):
-        Y, peak, T_orig = self._prepare(y)
+                      corrector_steps=1, snr=0.5, denoiser_only=False, return_nfe=False, return_stft=False, lengths=None,
+                      **kwargs):
+        Y, peak, T_orig = self._prepare(y, lengths)
         kwargs.setdefault("langevin_per_row", True)
         nfe = 0
         with torch.no_grad():
@@ -350,7 +354,7 @@ class StochasticRegenerationModel(_Base):
                 sample = Y_denoised
         if return_stft:                                     # (model.py:766-767)
             return sample.squeeze(), Y.squeeze(), T_orig, float(peak[0])
-        x_hat = self.data_module.spec_to_wav(sample, T_orig, peak)
+        x_hat = self.data_module.spec_to_wav(sample, T_orig, peak, lengths=lengths)
         return (x_hat, nfe) if return_nfe else x_hat
 
     def enhance(self, y, sampler_type="pc", predictor="reverse_diffusion", corrector="none", N=30, corrector_steps=1,

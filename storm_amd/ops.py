@@ -358,35 +358,48 @@ def spec_transform(spec, spec_factor, spec_abs_exponent, inverse):
     return out
 
 
-def peak_abs(wav):
+def _row_len(lengths, like):
+    """per-row sample counts of a ragged batch as the kernels read them (device int32 [B]) or None"""
+    if lengths is None:
+        return None
+    if isinstance(lengths, torch.Tensor):
+        return lengths.to(device=like.device, dtype=torch.int32).contiguous()
+    return torch.tensor([int(v) for v in lengths], dtype=torch.int32, device=like.device)
+
+
+def peak_abs(wav, lengths=None):
     B, Lw = wav.shape
     out = _alloc((B,), torch.float32, wav)
-    L.check(L.lib().storm_peak_abs(L.ptr(wav), L.ptr(out), B, Lw, wav.stride(0), L.stream()), "storm_peak_abs")
+    rl = _row_len(lengths, wav)
+    L.check(L.lib().storm_peak_abs(L.ptr(wav), L.ptr(out), B, Lw, wav.stride(0), L.ptr(rl), L.stream()), "storm_peak_abs")
     return out
 
 
-def stft(wav, peak=None, n_fft=510, hop=128, spec_factor=1.0, spec_abs_exponent=1.0, pad_to=1, window="hann"):
+def stft(wav, peak=None, n_fft=510, hop=128, spec_factor=1.0, spec_abs_exponent=1.0, pad_to=1, window="hann", lengths=None):
     """wav [B, L] fp32 -> complex64 [B, n_fft/2+1, Tpad] = spec_fwd(stft(wav / peak)), zero padded
-    in T to a multiple of `pad_to`."""
+    in T to a multiple of `pad_to`.  lengths: per-row sample counts of a ragged batch (rows zero filled past them)."""
     B, Lw = wav.shape
     n_frames = 1 + Lw // hop
     Tpad = round_up(n_frames, pad_to)
     win, tw = dft_tables(n_fft, wav.device, window)
     spec = torch.empty((B, n_fft // 2 + 1, Tpad), dtype=torch.complex64, device=wav.device)
+    rl = _row_len(lengths, wav)
     L.check(L.lib().storm_stft(L.ptr(wav), L.ptr(peak), L.ptr(_r(spec)), L.ptr(win), L.ptr(tw), B, Lw, wav.stride(0),
-                               n_fft, hop, n_frames, Tpad, float(spec_factor), float(spec_abs_exponent), L.stream()),
+                               n_fft, hop, n_frames, Tpad, float(spec_factor), float(spec_abs_exponent), L.ptr(rl), L.stream()),
             "storm_stft")
     return spec
 
 
-def istft(spec, length, peak=None, n_fft=510, hop=128, spec_factor=1.0, spec_abs_exponent=1.0, window="hann"):
-    """complex64 [B, F, T] -> wav [B, length] = istft(spec_back(spec)) * peak."""
+def istft(spec, length, peak=None, n_fft=510, hop=128, spec_factor=1.0, spec_abs_exponent=1.0, window="hann", lengths=None):
+    """complex64 [B, F, T] -> wav [B, length] = istft(spec_back(spec)) * peak; with `lengths`, row b is
+    istft(..., length=lengths[b]) and zero past it."""
     B, F, T = spec.shape
     spec = spec.contiguous()
     win, tw = dft_tables(n_fft, spec.device, window)
     wav = torch.empty((B, length), dtype=torch.float32, device=spec.device)
     frames = torch.empty((B, T, n_fft), dtype=torch.float32, device=spec.device)
+    rl = _row_len(lengths, spec)
     L.check(L.lib().storm_istft(L.ptr(_r(spec)), L.ptr(peak), L.ptr(wav), L.ptr(frames), L.ptr(win), L.ptr(tw), B, T,
-                                length, wav.stride(0), n_fft, hop, float(spec_factor), float(spec_abs_exponent),
+                                length, wav.stride(0), n_fft, hop, float(spec_factor), float(spec_abs_exponent), L.ptr(rl),
                                 L.stream()), "storm_istft")
     return wav

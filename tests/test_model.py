@@ -8,6 +8,7 @@ import torch
 
 from oracle import ncsnpp_ref as NR
 from oracle import sde_ref as SR
+from oracle import frontend_ref as FR
 from tests.backend import dev  # noqa: F401
 from tests.util import rel_l2
 
@@ -214,3 +215,41 @@ def test_si_sdr_and_evaluate_model(dev):
     assert specs is None and len(audios) == 3 and len(audios[1]) == 3 and audios[1][1].shape == (4000,)
     want = np.mean([O.si_sdr(pairs[i][0][0].numpy(), audios[1][i].numpy()) for i in range(3)])
     assert abs(sdr - want) < 1e-2 and math.isfinite(sdr)
+
+
+def test_ragged_micro_batch_equals_per_utterance_runs(dev):
+    """BASELINE.json configs[4] plumbing: utterances of different lengths whose spectrograms pad to the same frame count
+    share one batch (per-row lengths in STFT / peak / iSTFT) and every row equals its own single-utterance run
+    (<= 1e-5): front end, whole enhance_batch with injected noise, and the bucketing helper."""
+    from storm_amd import distributed as D
+    from storm_amd import ops
+    from storm_amd.model import ScoreModel
+    lens = [5003, 4500, 4225, 4100]                          # 40 / 36 / 34 / 33 frames -> all pad to 64
+    assert D.bucket_by_frames(lens + [9000], 3) == [[4], [0, 1, 2], [3]]
+    assert len(D.bucket_by_frames([32000 + 1000 * k for k in range(129)], 16)[0]) <= 16
+    assert len({-(-(1 + n // 128) // 64) for n in range(32000, 160001, 128)}) == 17
+    g = torch.Generator().manual_seed(14)
+    wavs = [0.1 * torch.randn(1, n, generator=g) for n in lens]
+    y = torch.zeros(4, max(lens))
+    for k, w in enumerate(wavs):
+        y[k, :lens[k]] = w[0]
+    peak = ops.peak_abs(y.to(dev), lens)
+    Y = ops.stft(y.to(dev), peak, spec_factor=0.15, spec_abs_exponent=0.5, pad_to=64, lengths=lens)
+    w = ops.istft(Y, max(lens), peak, spec_factor=0.15, spec_abs_exponent=0.5, lengths=lens).cpu()
+    for k in range(4):
+        Yk, nf, T0 = FR.wav_to_spec(wavs[k])
+        assert abs(float(peak[k]) - nf) <= 1e-7 * nf and rel_l2(Y[k].cpu(), Yk[0, 0]) < 5e-6
+        assert rel_l2(w[k, :lens[k]], FR.spec_to_wav(Yk, nf, T0)) < 5e-6 and float(w[k, lens[k]:].abs().max() if lens[k] < max(lens) else 0) == 0.0
+    m = ScoreModel(backbone="ncsnpp", **dict(COMMON))
+    m.dnn.load_state_dict(NR.seeded_state_dict(NR.NCSNppConfig(nf=8, input_channels=4), seed=5))
+    m.eval(no_ema=True)
+    m = m.to(dev)
+    noise = [SR.complex_randn((4, 1, 256, 64), torch.Generator().manual_seed(20 + i)) for i in range(1 + 2 * 2)]
+    it = iter([n.to(dev) for n in noise])
+    out = m.enhance_batch(y.to(dev), N=2, corrector="langevin", snr=0.5, lengths=lens, noise_fn=lambda: next(it)).cpu()
+    for k in (0, 3):
+        itk = iter([n[k:k + 1].to(dev) for n in noise])
+        alone = m.enhance_batch(wavs[k].to(dev), N=2, corrector="langevin", snr=0.5, noise_fn=lambda: next(itk)).cpu()
+        assert rel_l2(out[k, :lens[k]], alone[0]) < 1e-5
+    with pytest.raises(ValueError):
+        m.enhance_batch(torch.zeros(2, 9000).to(dev), lengths=[9000, 4000])     # 71 vs 32 frames: not one bucket
