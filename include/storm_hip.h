@@ -111,6 +111,20 @@ int storm_conv_tiles(const storm_conv_args* a);
 const char* storm_conv_kernel_name(const storm_conv_args* a);
 
 /* ------------------------------------------------------------------------------------------
+ * Fused single-head attention (flash style: online softmax, the [L][L] scores never leave the chip).  Replaces the two
+ * einsums and F.softmax of AttnBlockpp.forward (layerspp.py:82-86):
+ *   out[b][i][:] = sum_j softmax_j(scale * <q[b][i], k[b][j]>) v[b][j][:] + bias[:]
+ * q, k, out: [B][L][C] (C contiguous, = NHWC activations of the NIN projections, layerspp.py:78-80); vT: [B][C][ldv]
+ * (v transposed, row stride ldv >= L, a multiple of 8, zero past L); bias = the NIN_2 (v) bias, which passes through the
+ * softmax-weighted sum unchanged (rows of the weights sum to one), or NULL.  bf16, C in {32, 64, 128, 256}; other
+ * cases return STORM_ERR_UNSUPPORTED (storm_attention_supported tells beforehand) and run as GEMM + storm_softmax_rows.
+ * ------------------------------------------------------------------------------------------ */
+int storm_attention_supported(int C, int dtype);
+int storm_attention(const void* q, const void* k, const void* vT, const float* bias, void* out, int B, int L, int C, int ldv,
+                    long long q_bstride, long long k_bstride, long long vT_bstride, long long out_bstride, float scale,
+                    int dtype, storm_stream_t s);
+
+/* ------------------------------------------------------------------------------------------
  * GroupNorm(min(C/4,32) groups, eps) [+ SiLU] [+ FIR x2 up / down of BOTH the activated and
  * the raw tensor].  Replaces nn.GroupNorm(eps=1e-6) + nn.SiLU (layerspp.py:219,231,243,264;
  * ncsnpp.py:238,250,392,406; layerspp.py:67,77) and, fused, upsample_2d/downsample_2d on h
@@ -267,7 +281,8 @@ int storm_istft(const float* spec, const float* peak, float* wav, float* frames,
 enum {
     STORM_OP_MEMSET = 0, STORM_OP_PACK_INPUT = 1, STORM_OP_TEMB = 2, STORM_OP_DENSE = 3,
     STORM_OP_CONV = 4, STORM_OP_GN_STATS = 5, STORM_OP_GN_APPLY = 6, STORM_OP_FIR_UP = 7,
-    STORM_OP_FIR_DOWN = 8, STORM_OP_SOFTMAX = 9, STORM_OP_OUTPUT_HEAD = 10, STORM_OP_GN_FINALIZE = 11
+    STORM_OP_FIR_DOWN = 8, STORM_OP_SOFTMAX = 9, STORM_OP_OUTPUT_HEAD = 10, STORM_OP_GN_FINALIZE = 11,
+    STORM_OP_ATTENTION = 12
 };
 #define STORM_OP_NPTR 12
 #define STORM_OP_NINT 24

@@ -69,6 +69,8 @@ _SIGNATURES = {
     "storm_gn_apply": ([_vp, _i, _vp, _i, _i, _i, _i, _i, _vp, _vp, _vp, _f, _i, _i, _vp, _vp, _i, _vp], C.c_int),
     "storm_fir_up2": ([_vp, _vp, _vp, _i, _i, _i, _i, _i, _vp], C.c_int),
     "storm_fir_down2": ([_vp, _vp, _i, _i, _i, _i, _i, _vp], C.c_int),
+    "storm_attention_supported": ([_i, _i], C.c_int),
+    "storm_attention": ([_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _ll, _ll, _ll, _ll, _f, _i, _vp], C.c_int),
     "storm_softmax_rows": ([_vp, _vp, _ll, _i, _i, _i, _vp], C.c_int),
     "storm_pack_input": ([C.POINTER(_vp), _i, _vp, _i, _i, _i, _i, _vp], C.c_int),
     "storm_time_embedding": ([_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _vp], C.c_int),

@@ -17,7 +17,7 @@ from .. import _lib as L
 
 # op codes (include/storm_hip.h)
 OP_MEMSET, OP_PACK_INPUT, OP_TEMB, OP_DENSE, OP_CONV, OP_GN_STATS, OP_GN_APPLY, OP_FIR_UP, OP_FIR_DOWN, \
-    OP_SOFTMAX, OP_OUTPUT_HEAD, OP_GN_FINALIZE = range(12)
+    OP_SOFTMAX, OP_OUTPUT_HEAD, OP_GN_FINALIZE, OP_ATTENTION = range(13)
 
 # buffer slots of storm_program_run
 BUF_WS, BUF_PARAMS, BUF_IN0, BUF_IN1, BUF_IN2, BUF_T, BUF_OUT = range(7)
@@ -274,8 +274,9 @@ class Act:
 
 class Program:
     def __init__(self, cfg: NCSNppConfig, layout: ParamLayout, B: int, F: int, T: int, fuse_stats: bool = True,
-                 fuse_apply: bool = True):
+                 fuse_apply: bool = True, fused_attention: bool = True):
         self.cfg, self.layout, self.B, self.F, self.T = cfg, layout, B, F, T
+        self.fused_attention = fused_attention
         self.fuse_stats = fuse_stats       # GroupNorm statistics from the producing conv's epilogue (no stats pass)
         self.fuse_apply = fuse_apply and fuse_stats   # GroupNorm apply + SiLU inside the consuming conv's operand load
         self.dtype = layout.dtype
@@ -503,18 +504,28 @@ class Program:
         vT = self.conv([dict(a=(BUF_PARAMS, e2.offset, Cc), w=("ws", h.off), CinP=Cc, rows=Lp, taps=1,
                              w_bstride=Lp * Cc)], Lp, 1, Cc, outC=Lp8, src0_bstride=0)
         self.free(h)
-        S = self.conv([dict(a=q, w=("ws", kk.off), CinP=Cc, rows=Lp, taps=1, w_bstride=Lp * Cc)], Lp, 1, Lp, outC=Lp8,
-                      scale=float(int(Cc) ** (-0.5)), out_f32=True)
-        self.free(q); self.free(kk)
-        P = self.new_act(1, Lp, Lp8)
-        op = self._op(OP_SOFTMAX)
-        self._ws(op, 0, S); self._ws(op, 1, P)
-        op.i[0], op.i[1], op.i[2] = self.B * Lp, Lp, Lp8
-        self.free(S)
-        # h = P v (+ b_v: rows of P sum to one, so the NIN_2 bias passes through unchanged)
-        o = self.conv([dict(a=P, w=("ws", vT.off), CinP=Lp8, rows=Cc, taps=1, w_bstride=Cc * Lp8)], Cc, 1, Lp,
-                      bias_key=k + "NIN_2.b")
-        self.free(P); self.free(vT)
+        if self.fused_attention and L.lib().storm_attention_supported(Cc, self.dtype):
+            # flash-style kernel: softmax(q k^T / sqrt C) v + b_v in one launch, the [L][L] scores never reach HBM
+            o = self.new_act(1, Lp, Cc)
+            op = self._op(OP_ATTENTION)
+            self._ws(op, 0, q); self._ws(op, 1, kk); self._ws(op, 2, vT); self._par(op, 3, k + "NIN_2.b"); self._ws(op, 4, o)
+            op.i[0], op.i[1], op.i[2], op.i[3] = self.B, Lp, Cc, Lp8
+            op.f[0] = float(int(Cc) ** (-0.5))
+            self.flops += 4 * self.B * Lp * Lp * Cc
+            self.free(q); self.free(kk); self.free(vT)
+        else:
+            S = self.conv([dict(a=q, w=("ws", kk.off), CinP=Cc, rows=Lp, taps=1, w_bstride=Lp * Cc)], Lp, 1, Lp, outC=Lp8,
+                          scale=float(int(Cc) ** (-0.5)), out_f32=True)
+            self.free(q); self.free(kk)
+            P = self.new_act(1, Lp, Lp8)
+            op = self._op(OP_SOFTMAX)
+            self._ws(op, 0, S); self._ws(op, 1, P)
+            op.i[0], op.i[1], op.i[2] = self.B * Lp, Lp, Lp8
+            self.free(S)
+            # h = P v (+ b_v: rows of P sum to one, so the NIN_2 bias passes through unchanged)
+            o = self.conv([dict(a=P, w=("ws", vT.off), CinP=Lp8, rows=Cc, taps=1, w_bstride=Cc * Lp8)], Cc, 1, Lp,
+                          bias_key=k + "NIN_2.b")
+            self.free(P); self.free(vT)
         xl = Act(x.off, 1, Lp, Cc)
         out = self.conv([self.wseg(o, k + "NIN_3.W", 1)], Cc, 1, Lp, bias_key=k + "NIN_3.b", skip=xl,
                         scale=1.0 / math.sqrt(2.0), want_part=self.fuse_stats)

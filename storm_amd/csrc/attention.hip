@@ -1,0 +1,227 @@
+// Fused single-head attention of AttnBlockpp (layerspp.py:75-91):
+//   w = softmax_j(<q_i, k_j> * C^-1/2),  h_i = sum_j w_ij v_j      (the two einsums + F.softmax of :82-86)
+// as ONE kernel with an online softmax: the [L][L] score matrix (268 MB fp32 at batch 16, L = 2048; 1.7 GB at
+// 10-s utterances) is never written - round 1 materialised it (S GEMM -> row softmax -> P.V GEMM).
+//
+// CDNA4 layout ("swapped" products, so that everything per query is lane-local):
+//   * a workgroup = 4 waves x 32 queries; key tiles of 32 keys, K [32][C] and V^T [C][32] staged in LDS (XOR-swizzled,
+//     double buffered, the next tile's global loads in flight under the MFMAs: one barrier per tile).
+//   * S^T = K Q^T per wave: A = K fragment (LDS), B = Q fragment (registers for the whole kernel), v_mfma_f32_32x32x16:
+//     lane (query j = lane & 31, half h = lane >> 5) ends up with 16 of its query's 32 scores - a row max / sum is
+//     15 VALU ops + one lane-pair exchange.
+//   * O^T += V^T P^T: A = V^T fragment (LDS), B = P^T fragment = the lane's own probabilities packed in register order.
+//     The contraction index of an MFMA k-group is summed over, so its 16 slots may carry the keys in ANY order as long
+//     as both operands agree: slot (h, e) <-> key 16 m + 4 h + (e & 3) + 8 (e >> 2) is exactly the order the S^T
+//     accumulator leaves them in, so P needs no shuffle; the V^T fragment is two 8-byte reads.
+//   * the rescale factor of the online softmax is a per-lane scalar (one query per lane column of O^T).
+// bf16 operands, fp32 accumulation / softmax.  C = 32 * CT channels (CT in {1, 2, 4, 8}); any L (ragged tiles masked).
+#include "conv_params.h"
+
+namespace storm {
+
+namespace attn { constexpr int BQ = 128, BK = 32, THREADS = 256; }
+using attn::BQ; using attn::BK;
+// (the kernel lives in namespace storm itself: the dynamic LDS array of every kernel is storm::smem)
+constexpr int ATTN_THREADS = attn::THREADS;
+
+__device__ __forceinline__ uint4 ldg16(const void* p) { return *reinterpret_cast<const uint4*>(p); }
+
+template <int CT>
+__global__ __launch_bounds__(ATTN_THREADS)
+void attention_kernel(const bf16_t* __restrict__ q, const bf16_t* __restrict__ k, const bf16_t* __restrict__ vT,
+                      const float* __restrict__ bias, bf16_t* __restrict__ out, int L, int ldv, long long q_bs,
+                      long long k_bs, long long v_bs, long long o_bs, float scale_log2e) {
+    constexpr int C = 32 * CT, KG = C / 16;            // channels; 16-channel k-groups of the score product
+    constexpr int KROW = C * 2, KSLOTS = KROW / 16;    // K tile row: bytes, 16-B slots
+    constexpr int KTILE = BK * KROW, VTILE = C * 64;   // bytes per buffer
+    constexpr int KPT = BK * KSLOTS / ATTN_THREADS > 0 ? BK * KSLOTS / ATTN_THREADS : 1;      // 16-B pieces per thread (K)
+    constexpr int VPT = C * 4 / ATTN_THREADS > 0 ? C * 4 / ATTN_THREADS : 1;                  // 16-B pieces per thread (V^T)
+    typedef bf16x8 Frag;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* const kbuf = smem;                            // [2][KTILE]
+    char* const vbuf = smem + 2 * KTILE;                // [2][VTILE]
+
+    const int b = blockIdx.y, q0 = blockIdx.x * BQ;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int j = lane & 31, h = lane >> 5;
+    const bf16_t* qb = q + (long long)b * q_bs;
+    const bf16_t* kb = k + (long long)b * k_bs;
+    const bf16_t* vb = vT + (long long)b * v_bs;
+
+    // Q fragments of this lane's query (clamped: rows past L are computed and dropped)
+    const int qi = min(q0 + wave * 32 + j, L - 1);
+    Frag qf[KG];
+#pragma unroll
+    for (int g = 0; g < KG; ++g) {
+        const uint4 v = ldg16(qb + (long long)qi * C + 16 * g + 8 * h);
+        qf[g] = *reinterpret_cast<const Frag*>(&v);
+    }
+
+    f32x16 o[CT];
+#pragma unroll
+    for (int t = 0; t < CT; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) o[t][r] = 0.f;
+    float m_run = -INFINITY, l_run = 0.f;
+
+    // ---- staging: global -> registers (issued a tile ahead) -> LDS ------------------------------------------------
+    uint4 kreg[KPT], vreg[VPT];
+    auto load_tile = [&](int j0) {
+#pragma unroll
+        for (int i = 0; i < KPT; ++i) {
+            const int u = tid + i * ATTN_THREADS;
+            if (u < BK * KSLOTS) {
+                const int r = u / KSLOTS, s = u % KSLOTS;
+                kreg[i] = ldg16(kb + (long long)min(j0 + r, L - 1) * C + 8 * s);
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < VPT; ++i) {
+            const int u = tid + i * ATTN_THREADS;
+            if (u < C * 4) {
+                const int c = u >> 2, p = u & 3;
+                vreg[i] = (j0 + 8 * p + 8 <= ldv) ? ldg16(vb + (long long)c * ldv + j0 + 8 * p) : make_uint4(0u, 0u, 0u, 0u);
+            }
+        }
+    };
+    auto store_tile = [&](int buf) {
+#pragma unroll
+        for (int i = 0; i < KPT; ++i) {
+            const int u = tid + i * ATTN_THREADS;
+            if (u < BK * KSLOTS) {
+                const int r = u / KSLOTS, s = u % KSLOTS;
+                *reinterpret_cast<uint4*>(kbuf + buf * KTILE + r * KROW + ((s ^ (r & (KSLOTS - 1))) << 4)) = kreg[i];
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < VPT; ++i) {
+            const int u = tid + i * ATTN_THREADS;
+            if (u < C * 4) {
+                const int c = u >> 2, p = u & 3, x = (c >> 2) & 7;
+                char* row = vbuf + buf * VTILE + c * 64;
+                *reinterpret_cast<uint2*>(row + (((2 * p) ^ x) << 3)) = make_uint2(vreg[i].x, vreg[i].y);
+                *reinterpret_cast<uint2*>(row + (((2 * p + 1) ^ x) << 3)) = make_uint2(vreg[i].z, vreg[i].w);
+            }
+        }
+    };
+
+    const int ntiles = (L + BK - 1) / BK;
+    load_tile(0);
+    store_tile(0);
+    __syncthreads();
+    for (int n = 0; n < ntiles; ++n) {
+        const int buf = n & 1, j0 = n * BK;
+        if (n + 1 < ntiles) load_tile(j0 + BK);                      // in flight under this tile's MFMAs
+        // ---- S^T = K Q^T (32 keys x 32 queries per wave) ------------------------------------------------------------
+        f32x16 s;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) s[r] = 0.f;
+        const char* kt = kbuf + buf * KTILE + j * KROW;              // A fragment: key j of the tile (lane & 31)
+#pragma unroll
+        for (int g = 0; g < KG; ++g) {
+            const Frag kf = *reinterpret_cast<const Frag*>(kt + (((2 * g + h) ^ (j & (KSLOTS - 1))) << 4));
+            Mma<bf16_t>::run(kf, qf[g], s);
+        }
+        // ---- online softmax over this lane's 16 keys + its partner's 16 ------------------------------------------------
+        float mx = -INFINITY;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int key = j0 + cidx::acc_row(lane, r);
+            s[r] = key < L ? s[r] * scale_log2e : -INFINITY;
+            mx = fmaxf(mx, s[r]);
+        }
+        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+        const float m_new = fmaxf(m_run, mx);
+        const float alpha = exp2f(m_run - m_new);                    // (first tile: exp2(-inf) = 0 on a zero accumulator)
+        float ps = 0.f;
+        float p[16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { p[r] = exp2f(s[r] - m_new); ps += p[r]; }
+        ps += __shfl_xor(ps, 32, 64);
+        l_run = l_run * alpha + ps;
+        m_run = m_new;
+#pragma unroll
+        for (int t = 0; t < CT; ++t)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) o[t][r] *= alpha;
+        // ---- O^T += V^T P^T: two k-groups of 16 keys, slot (h, e) <-> key 16 m + 4 h + (e & 3) + 8 (e >> 2) ---------------
+#pragma unroll
+        for (int mk = 0; mk < 2; ++mk) {
+            uint32_t pw[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) pw[e] = pack_bf16x2(p[8 * mk + 2 * e], p[8 * mk + 2 * e + 1]);
+            const uint4 pv = make_uint4(pw[0], pw[1], pw[2], pw[3]);
+            const Frag pf = *reinterpret_cast<const Frag*>(&pv);
+#pragma unroll
+            for (int t = 0; t < CT; ++t) {
+                const int c = 32 * t + j, x = (c >> 2) & 7;
+                const char* row = vbuf + buf * VTILE + c * 64;
+                const uint2 lo = *reinterpret_cast<const uint2*>(row + (((4 * mk + h) ^ x) << 3));
+                const uint2 hi = *reinterpret_cast<const uint2*>(row + (((4 * mk + h + 2) ^ x) << 3));
+                const uint4 vv = make_uint4(lo.x, lo.y, hi.x, hi.y);
+                Mma<bf16_t>::run(*reinterpret_cast<const Frag*>(&vv), pf, o[t]);
+            }
+        }
+        if (n + 1 < ntiles) store_tile(buf ^ 1);
+        __syncthreads();
+    }
+
+    // ---- epilogue: h = O / l + b_v (rows of P sum to one, so the NIN_2 bias passes through), bf16, 8-byte stores ------------
+    const int qrow = q0 + wave * 32 + j;
+    if (qrow < L) {
+        const float inv = 1.0f / l_run;
+        bf16_t* orow = out + (long long)b * o_bs + (long long)qrow * C;
+#pragma unroll
+        for (int t = 0; t < CT; ++t)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int c = 32 * t + 8 * g + 4 * h;
+                float v[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = o[t][4 * g + e] * inv + (bias ? bias[c + e] : 0.f);
+                *reinterpret_cast<uint2*>(orow + c) = make_uint2(pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]));
+            }
+    }
+}
+
+template <int CT>
+static int attn_launch(const void* q, const void* k, const void* vT, const float* bias, void* out, int B, int L, int ldv,
+                  long long q_bs, long long k_bs, long long v_bs, long long o_bs, float scale, hipStream_t st) {
+    constexpr int C = 32 * CT;
+    constexpr int lds = 2 * (BK * C * 2) + 2 * (C * 64);
+    auto kern = attention_kernel<CT>;
+    static bool attr_set = false;
+    if (!attr_set) {
+        STORM_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(kern, dim3(cdiv(L, BQ), B), dim3(ATTN_THREADS), lds, st, (const bf16_t*)q, (const bf16_t*)k, (const bf16_t*)vT,
+                       bias, (bf16_t*)out, L, ldv, q_bs, k_bs, v_bs, o_bs, scale * 1.44269504088896341f);
+    STORM_LAUNCH_CHECK();
+    return STORM_OK;
+}
+
+}  // namespace storm
+
+extern "C" int storm_attention_supported(int C, int dtype) {
+    return dtype == STORM_BF16 && (C == 32 || C == 64 || C == 128 || C == 256);
+}
+
+extern "C" int storm_attention(const void* q, const void* k, const void* vT, const float* bias, void* out, int B, int L, int C,
+                               int ldv, long long q_bstride, long long k_bstride, long long vT_bstride, long long out_bstride,
+                               float scale, int dtype, storm_stream_t s) {
+    using namespace storm;
+    STORM_CHECK(q && k && vT && out && B > 0 && L > 0, "storm_attention: bad arguments");
+    STORM_CHECK(ldv >= L && ldv % 8 == 0, "storm_attention: ldv=%d (L=%d)", ldv, L);
+    if (!storm_attention_supported(C, dtype)) {
+        set_error("storm_attention: C=%d dtype=%d is outside the fused kernel (use the GEMM + softmax path)", C, dtype);
+        return STORM_ERR_UNSUPPORTED;
+    }
+    hipStream_t st = (hipStream_t)s;
+    switch (C) {
+        case 32: return attn_launch<1>(q, k, vT, bias, out, B, L, ldv, q_bstride, k_bstride, vT_bstride, out_bstride, scale, st);
+        case 64: return attn_launch<2>(q, k, vT, bias, out, B, L, ldv, q_bstride, k_bstride, vT_bstride, out_bstride, scale, st);
+        case 128: return attn_launch<4>(q, k, vT, bias, out, B, L, ldv, q_bstride, k_bstride, vT_bstride, out_bstride, scale, st);
+        default: return attn_launch<8>(q, k, vT, bias, out, B, L, ldv, q_bstride, k_bstride, vT_bstride, out_bstride, scale, st);
+    }
+}

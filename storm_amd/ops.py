@@ -116,6 +116,15 @@ def gn_finalize(part_a, part_b=None, gamma=None, beta=None, count=None, eps=1e-6
     return stats, ss
 
 
+def attention(q, k, vT, bias, scale):
+    """q, k [B, L, C], vT [B, C, ldv] (bf16) -> softmax(scale q k^T) v + bias, [B, L, C] (storm_attention)."""
+    B, Lq, Cc = q.shape
+    out = torch.empty_like(q)
+    L.check(L.lib().storm_attention(L.ptr(q), L.ptr(k), L.ptr(vT), L.ptr(bias), L.ptr(out), B, Lq, Cc, vT.shape[-1], Lq * Cc, Lq * Cc,
+                                    Cc * vT.shape[-1], Lq * Cc, float(scale), L.dt(q), L.stream()), "storm_attention")
+    return out
+
+
 # ---------------------------------------------------------------- norm / resample ---------
 def gn_groups(C):
     return min(C // 4, 32)

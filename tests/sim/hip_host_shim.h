@@ -26,6 +26,8 @@ struct dim3 { unsigned x, y, z; dim3(unsigned x_ = 1, unsigned y_ = 1, unsigned 
 struct float2 { float x, y; };
 struct alignas(16) float4 { float x, y, z, w; };
 struct alignas(16) uint4 { uint32_t x, y, z, w; };
+struct alignas(8) uint2 { uint32_t x, y; };
+inline uint2 make_uint2(uint32_t x, uint32_t y) { return uint2{x, y}; }
 inline float2 make_float2(float x, float y) { return float2{x, y}; }
 inline float4 make_float4(float x, float y, float z, float w) { return float4{x, y, z, w}; }
 inline uint4 make_uint4(uint32_t x, uint32_t y, uint32_t z, uint32_t w) { return uint4{x, y, z, w}; }

@@ -441,3 +441,54 @@ def test_conv_wait_placement_under_late_dma_landing():
     r = subprocess.run([sys.executable, "-m", "pytest", os.path.join(root, "tests", "test_ops.py"), "-q", "-x", "-m", "not gpu",
                         "-k", "conv and not late_dma", "-p", "no:cacheprovider"], env=env, capture_output=True, text=True, timeout=1500)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-1000:]
+
+
+@pytest.mark.parametrize("C,Lq", [(32, 100), (64, 32), (256, 70)])
+def test_fused_attention(dev, C, Lq):
+    """storm_attention (flash style, online softmax) == softmax(q k^T / sqrt C) v + b_v of AttnBlockpp (layerspp.py:82-86),
+    ragged key / query tiles, zero-padded v^T rows."""
+    from storm_amd import ops
+    g = torch.Generator().manual_seed(40 + C)
+    B = 2
+    q, k, v = (torch.randn(B, Lq, C, generator=g) for _ in range(3))
+    q = q * 1.5                                             # sharper distributions: the running max must move between tiles
+    bias = 0.1 * torch.randn(C, generator=g)
+    ldv = ops.round_up(Lq, 8)
+    vT = torch.zeros(B, C, ldv)
+    vT[:, :, :Lq] = v.transpose(1, 2)
+    bf = lambda t: t.to(torch.bfloat16)
+    out = ops.attention(bf(q).to(dev), bf(k).to(dev), bf(vT).to(dev), bias.to(dev), C ** -0.5).float().cpu()
+    w = torch.softmax(torch.einsum("bic,bjc->bij", bf(q).float(), bf(k).float()) * C ** -0.5, -1)
+    ref = torch.einsum("bij,bjc->bic", w, bf(v).float()) + bias
+    assert rel_l2(out, ref) < 8e-3                           # P and the output are rounded to bf16
+
+
+@pytest.mark.gpu
+def test_attention_block_L2048_vs_reference_golden(golden):
+    """AttnBlockpp at the bench shape (256 channels, 32 x 64 = 2048 positions; layerspp.py:60-91) against the REFERENCE's
+    output (fixture F8), composed from the C-ABI ops exactly as the planner does: GroupNorm -> NIN q, k (1x1 GEMMs), v^T by
+    the swapped GEMM -> storm_attention -> NIN_3 + skip, rescaled.  bf16 operands."""
+    import hashlib
+    from storm_amd import ops
+    from tests.backend import setup_backend
+    from tests.test_net import seeded_input
+    dev = setup_backend("hip")
+    g = golden["f8_bench_shape"]
+    x = seeded_input((1, 256, 32, 64), 810, 1.0, torch.float32)
+    assert hashlib.sha256(x.contiguous().numpy().tobytes()).hexdigest() == str(g["attn_xhash"])
+    C, Lp, dt = 256, 2048, torch.bfloat16
+    P = {k[len("attn_"):]: torch.from_numpy(g[k]).to(dev) for k in g.files if k.startswith("attn_") and k not in ("attn_y", "attn_xhash")}
+    xb = nhwc(x).to(dt).to(dev).repeat(2, 1, 1, 1)           # batch 2: rows must agree
+    st = ops.gn_stats(xb)
+    h = ops.gn_apply(xb, st, P["GroupNorm_0.weight"], P["GroupNorm_0.bias"], silu=False)
+    hl = h.reshape(2, 1, Lp, C)
+    W = [ops.pack_matrix(P[f"NIN_{i}.W"], dt, transpose=True) for i in range(4)]
+    q = ops.conv([ops.Seg(hl, W[0], 1)], C, bias=P["NIN_0.b"])
+    k = ops.conv([ops.Seg(hl, W[1], 1)], C, bias=P["NIN_1.b"])
+    vT = ops.conv([ops.Seg(W[2].reshape(1, 1, C, C), hl.reshape(2, Lp, C), 1, w_batched=True, src_bstride=0)], Lp, outC=Lp, B=2, H=1, W=C)
+    o = ops.attention(q.reshape(2, Lp, C), k.reshape(2, Lp, C), vT.reshape(2, C, Lp), P["NIN_2.b"], C ** -0.5)
+    y = ops.conv([ops.Seg(o.reshape(2, 1, Lp, C), W[3], 1)], C, bias=P["NIN_3.b"], skip=xb.reshape(2, 1, Lp, C), scale=2 ** -0.5)
+    y = nchw(y.reshape(2, 32, 64, C).float().cpu())
+    err = rel_l2(y[:1], g["attn_y"])
+    print(f"AttnBlockpp L=2048 bf16 (fused attention) vs reference: rel-L2 {err:.3e}")
+    assert err < 2e-2 and torch.equal(y[0], y[1])
