@@ -94,33 +94,34 @@ def cpu_baseline(backbone, seconds, reps=3):
 
 
 def profile_ops(net, Y, nfe_count):
-    """Per-op HIP-event timing of `nfe_count` score evaluations (same batch / shapes as the timed steps)."""
+    """Per-op HIP-event timing of `nfe_count` score evaluations (same batch / shapes as the timed steps): the op program
+    the C-ABI network object planned (storm_ncsnpp_program) run through storm_program_run_timed."""
     from storm_amd import _lib as L
     from storm_amd.backbones.plan import BUF_IN0, BUF_OUT, BUF_PARAMS, BUF_T, BUF_WS, N_BUFS
     B, _, F, T = Y.shape
     dev = Y.device
     code = L.dt(net.compute_dtype)
-    _, arena = net._get_arena(code, dev)
-    prog, ws = net._get_program(B, F, T, code, dev)
+    h = net._get_handle(code, dev)
+    ops, n, _ = net.program(B, F, T)
+    ws = net._get_workspace(h, B, F, T, code, dev)
     x = torch.randn_like(Y)
     out = torch.empty_like(Y)
     tvec = torch.full((B,), 0.5, device=dev)
     bufs = (C.c_void_p * N_BUFS)()
-    bufs[BUF_WS], bufs[BUF_PARAMS] = ws.data_ptr(), arena.data_ptr()
-    bufs[BUF_IN0], bufs[BUF_IN0 + 1] = torch.view_as_real(x[:, 0].contiguous()).data_ptr(), torch.view_as_real(Y[:, 0].contiguous()).data_ptr()
+    bufs[BUF_WS], bufs[BUF_PARAMS] = ws.data_ptr(), L.lib().storm_ncsnpp_arena(h)
     xin, yin = x[:, 0].contiguous(), Y[:, 0].contiguous()
     bufs[BUF_IN0], bufs[BUF_IN0 + 1] = torch.view_as_real(xin).data_ptr(), torch.view_as_real(yin).data_ptr()
     bufs[BUF_T], bufs[BUF_OUT] = tvec.data_ptr(), torch.view_as_real(out).data_ptr()
-    n = len(prog.ops)
     acc = [0.0] * n
     ms = (C.c_float * n)()
     st = torch.cuda.current_stream().cuda_stream
     for _ in range(nfe_count):
-        L.check(L.lib().storm_program_run_timed(prog.op_array, n, bufs, N_BUFS, code, st, ms), "storm_program_run_timed")
+        L.check(L.lib().storm_program_run_timed(ops, n, bufs, N_BUFS, code, st, ms), "storm_program_run_timed")
         for k in range(n):
             acc[k] += ms[k] / nfe_count
     rows = []
-    for k, op in enumerate(prog.ops):
+    for k in range(n):
+        op = ops[k]
         row = dict(idx=k, code=int(op.code), ms=acc[k])
         if op.code == 4:
             nseg, Bq, H, W, outC, Cout = [int(op.i[j]) for j in range(6)]
@@ -129,20 +130,10 @@ def profile_ops(net, Y, nfe_count):
                 q = 8 + 7 * gseg
                 flops += 2 * Bq * H * W * Cout * (int(op.i[q]) + int(op.i[q + 1])) * int(op.i[q + 4])
                 taps.append(int(op.i[q + 4]))
-            row.update(flops=flops, H=H, W=W, Cout=Cout, taps=taps, big=outC > 32, cin=[int(op.i[8]) + int(op.i[9])])
+            row.update(flops=flops, H=H, W=W, Cout=Cout, taps=taps, big=outC > 32, cin=[int(op.i[8]) + int(op.i[9])],
+                       kernel=L.lib().storm_program_kernel_name(ops, k, code).decode())
         rows.append(row)
-    return rows, prog
-
-
-def conv_kernel_names(prog, code):
-    """Kernel name per conv op of a planned program, asked of the LAUNCHER (storm_program_kernel_name): the roofline then
-    names the kernel that really ran instead of a copy of the dispatch rule."""
-    from storm_amd import _lib as L
-    names = {}
-    for k, op in enumerate(prog.ops):
-        if op.code == 4:
-            names[k] = L.lib().storm_program_kernel_name(prog.op_array, k, code).decode()
-    return names
+    return rows
 
 
 def selftest_cpu(args, rank, world):
@@ -230,16 +221,12 @@ def main():
     }
 
     if rank == 0 and not args.no_roofline:
-        from storm_amd import _lib as LL
         Y, _, _ = model._prepare(wav)
-        rows, prog = profile_ops(model.dnn, Y, args.profile_nfe)
-        knames = conv_kernel_names(prog, LL.dt(model.dnn.compute_dtype))
+        rows = profile_ops(model.dnn, Y, args.profile_nfe)
         groups = {}                                        # 3x3 convolutions on the matrix cores, by the kernel the launcher picked
         for r in rows:
-            if r["code"] == 4:
-                r["kernel"] = knames[r["idx"]]
-                if r["big"] and 9 in r["taps"]:
-                    groups.setdefault(r["kernel"], []).append(r)
+            if r["code"] == 4 and r["big"] and 9 in r["taps"]:
+                groups.setdefault(r["kernel"], []).append(r)
         kname, big = max(groups.items(), key=lambda kv: sum(r["ms"] for r in kv[1]))
         flops, ms = sum(r["flops"] for r in big), sum(r["ms"] for r in big)
         total_ms = sum(r["ms"] for r in rows)

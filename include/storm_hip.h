@@ -306,6 +306,49 @@ int storm_program_run_timed(const storm_op* ops, int n_ops, void* const* bufs, i
 /* name of the kernel op k of a program launches (STORM_OP_CONV ops; "" otherwise), see storm_conv_kernel_name */
 const char* storm_program_kernel_name(const storm_op* ops, int k, int dtype);
 
+/* ------------------------------------------------------------------------------------------
+ * Whole-network entry points: NCSN++ as ONE object of the C ABI (a host in any language builds it from the reference's
+ * state_dict tensors and evaluates the score with one call; the Python class storm_amd.backbones.NCSNpp is a thin caller).
+ * Replaces NCSNpp.__init__ / load_state_dict (ncsnpp.py:38-273) and NCSNpp.forward (ncsnpp.py:281-450) for the
+ * configuration family of the StoRM hot path (BigGAN blocks, FIR resampling, output_skip / input_skip pyramids, Fourier
+ * time embedding, swish).
+ * ------------------------------------------------------------------------------------------ */
+typedef struct storm_ncsnpp_config {
+    int nf;                     /* base width (128)                                                  */
+    int n_levels;               /* len(ch_mult)                                                      */
+    int ch_mult[8];             /* (1, 2, 2, 2); ncsnpplarge (1, 1, 2, 2, 2, 2, 2)                    */
+    int num_res_blocks;
+    int n_attn;
+    int attn_resolutions[4];    /* frequency heights that get an AttnBlockpp ((0,) = bottleneck only)  */
+    int image_size;             /* 256                                                               */
+    int input_channels;         /* real channels of the score net input: 4 (x, y) or 6 (x, y, y_den)   */
+    int discriminative;         /* predictive denoiser: 2 channels, no time conditioning, no 1/t       */
+} storm_ncsnpp_config;
+typedef struct storm_ncsnpp storm_ncsnpp;
+
+/* the reference state_dict of this configuration: count, then (name, shape) of tensor i in the reference's order */
+int storm_ncsnpp_num_tensors(const storm_ncsnpp_config* cfg);
+int storm_ncsnpp_tensor_info(const storm_ncsnpp_config* cfg, int i, char* name, int name_len, int* ndim, long long* shape4);
+long long storm_ncsnpp_arena_bytes(const storm_ncsnpp_config* cfg, int dtype);
+/* weights[i] = device pointer to fp32 tensor i of the state_dict (contiguous).  Packs them (stream s) into the engine's
+ * layout: arena = caller-owned device buffer of storm_ncsnpp_arena_bytes() or NULL (the handle allocates one). */
+int storm_ncsnpp_create(const storm_ncsnpp_config* cfg, const void* const* weights, int n_weights, int dtype, void* arena,
+                        storm_stream_t s, storm_ncsnpp** out);
+void storm_ncsnpp_destroy(storm_ncsnpp* h);
+/* A/B switches of the planner (all on by default): GroupNorm statistics from conv epilogues, GroupNorm apply in conv operand
+ * loads, fused attention kernel */
+int storm_ncsnpp_set_fusion(storm_ncsnpp* h, int fuse_stats, int fuse_apply, int fused_attention);
+/* bytes of scratch one forward at (B, F, T) needs (liveness-planned; 5.2 GB at B = 16, 256 x 512, bf16); -1 on error */
+long long storm_ncsnpp_workspace_bytes(storm_ncsnpp* h, int B, int F, int T);
+/* out[b] = dnn(cat[parts...], t) (negate != 0: its negative = the score, model.py:131-132).  parts: n device pointers to
+ * complex64 [B][F][T]; t fp32 [B] (NULL when discriminative); out complex64 [B][F][T]; ws: >= workspace_bytes. */
+int storm_ncsnpp_forward(storm_ncsnpp* h, const void* const* parts, int n_parts, const float* t, void* out, void* ws,
+                         long long ws_bytes, int B, int F, int T, int negate, storm_stream_t s);
+/* the planned op list of (B, F, T) (owned by the handle) for storm_program_run_timed / storm_program_kernel_name, the packed
+ * arena, and the algorithmic FLOPs of one forward */
+int storm_ncsnpp_program(storm_ncsnpp* h, int B, int F, int T, const storm_op** ops, int* n_ops, long long* flops);
+const void* storm_ncsnpp_arena(storm_ncsnpp* h);
+
 #ifdef __cplusplus
 }
 #endif

@@ -41,6 +41,11 @@ class ConvArgs(C.Structure):
                 ("out_f32", C.c_int), ("dtype", C.c_int), ("gn_part", C.c_void_p)]
 
 
+class NcsnppConfig(C.Structure):
+    _fields_ = [("nf", C.c_int), ("n_levels", C.c_int), ("ch_mult", C.c_int * 8), ("num_res_blocks", C.c_int), ("n_attn", C.c_int),
+                ("attn_resolutions", C.c_int * 4), ("image_size", C.c_int), ("input_channels", C.c_int), ("discriminative", C.c_int)]
+
+
 class Ouve(C.Structure):
     _fields_ = [("theta", C.c_float), ("sigma_min", C.c_float), ("sigma_max", C.c_float), ("N", C.c_int)]
 
@@ -91,6 +96,16 @@ _SIGNATURES = {
     "storm_stft": ([_vp, _vp, _vp, _vp, _vp, _i, _ll, _ll, _i, _i, _i, _i, _f, _f, _vp, _vp], C.c_int),
     "storm_istft": ([_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _ll, _ll, _i, _i, _f, _f, _vp, _vp], C.c_int),
     "storm_program_run": ([C.POINTER(Op), _i, C.POINTER(_vp), _i, _i, _vp], C.c_int),
+    "storm_ncsnpp_num_tensors": ([C.POINTER(NcsnppConfig)], C.c_int),
+    "storm_ncsnpp_tensor_info": ([C.POINTER(NcsnppConfig), _i, C.c_char_p, _i, C.POINTER(C.c_int), C.POINTER(C.c_longlong)], C.c_int),
+    "storm_ncsnpp_arena_bytes": ([C.POINTER(NcsnppConfig), _i], C.c_longlong),
+    "storm_ncsnpp_create": ([C.POINTER(NcsnppConfig), C.POINTER(_vp), _i, _i, _vp, _vp, C.POINTER(_vp)], C.c_int),
+    "storm_ncsnpp_destroy": ([_vp], None),
+    "storm_ncsnpp_set_fusion": ([_vp, _i, _i, _i], C.c_int),
+    "storm_ncsnpp_workspace_bytes": ([_vp, _i, _i, _i], C.c_longlong),
+    "storm_ncsnpp_forward": ([_vp, C.POINTER(_vp), _i, _vp, _vp, _vp, _ll, _i, _i, _i, _i, _vp], C.c_int),
+    "storm_ncsnpp_program": ([_vp, _i, _i, _i, C.POINTER(C.POINTER(Op)), C.POINTER(C.c_int), C.POINTER(C.c_longlong)], C.c_int),
+    "storm_ncsnpp_arena": ([_vp], _vp),
     "storm_program_kernel_name": ([C.POINTER(Op), _i, _i], C.c_char_p),
     "storm_program_run_timed": ([C.POINTER(Op), _i, C.POINTER(_vp), _i, _i, _vp, C.POINTER(C.c_float)], C.c_int),
 }

@@ -15,8 +15,7 @@ import torch
 import torch.nn as nn
 
 from .. import _lib as L
-from .plan import (BUF_IN0, BUF_OUT, BUF_PARAMS, BUF_T, BUF_WS, N_BUFS, NCSNppConfig, ParamLayout, Program,
-                   module_list)
+from .plan import NCSNppConfig, module_list
 from .shared import BackboneRegistry
 import ctypes as C
 
@@ -155,8 +154,8 @@ class NCSNpp(nn.Module):
         self.all_modules = nn.ModuleList(mods)
         self.compute_dtype = torch.float32
         self.negate_output = False        # ScoreModel folds the "score = -dnn(...)" sign into the output head
-        self._arena = {}                  # dtype code -> (ParamLayout, arena tensor, params version)
-        self._programs = {}               # (B, F, T, dtype, negate) -> (Program, workspace)
+        self._handles = {}                # dtype code -> (engine handle, arena tensor, params version, device)
+        self._workspaces = {}             # (B, F, T, dtype) -> workspace tensor
         self._param_version = 0
         self.register_load_state_dict_post_hook(lambda m, keys: m.invalidate())
 
@@ -173,71 +172,88 @@ class NCSNpp(nn.Module):
         return self
 
     def invalidate(self):
-        """Call after changing parameters in place (e.g. EMA swap): re-packs the weight arena lazily."""
+        """Call after changing parameters in place (e.g. EMA swap): the engine re-packs its weight arena lazily."""
         self._param_version += 1
 
     def _apply(self, fn, *a, **k):
         self.invalidate()
-        self._programs.clear()
+        self._drop_handles()
         return super()._apply(fn, *a, **k)
 
-    def _get_arena(self, dtype_code, device):
-        ent = self._arena.get(dtype_code)
-        if ent is not None and ent[2] == self._param_version and ent[1].device == device:
-            return ent[0], ent[1]
-        layout = ent[0] if ent is not None else ParamLayout(self.cfg, dtype_code)
-        arena = torch.zeros(layout.size, dtype=torch.uint8, device=device)
-        sd = {k: v.detach().to(device=device, dtype=torch.float32).contiguous() for k, v in self.state_dict().items()}
-        base = arena.data_ptr() if not L.is_sim() else arena.data_ptr()
-        lib, st = L.lib(), L.stream()
-        keep = []
-        for e in layout.entries.values():
-            dst = base + e.offset
-            if e.kind == "conv":
-                w = sd[e.sources[0]]
-                Cout, Cin, taps = w.shape[0], w.shape[1], w.shape[2] * w.shape[3]
-                L.check(lib.storm_pack_conv_weight(L.ptr(w), dst, Cout, Cin, taps, e.shape[1], e.shape[2], dtype_code, st),
-                        "storm_pack_conv_weight")
-            elif e.kind == "nin":
-                w = sd[e.sources[0]]                      # [Cin][Cout]
-                L.check(lib.storm_pack_matrix(L.ptr(w), dst, w.shape[1], w.shape[0], 1, e.shape[1], e.shape[2], dtype_code, st),
-                        "storm_pack_matrix")
-            else:
-                if e.kind == "f32":
-                    src = sd[e.sources[0]].reshape(-1)
-                elif e.kind == "f32sum":
-                    src = sd[e.sources[0]] + sd[e.sources[1]]
-                elif e.kind == "dense_w":
-                    src = torch.cat([sd[s] for s in e.sources], 0).reshape(-1)
-                elif e.kind == "dense_b":
-                    src = torch.cat([sd[s] for s in e.sources], 0)
-                else:
-                    raise AssertionError(e.kind)
-                assert src.numel() * 4 == e.nbytes, (e.key, src.shape, e.nbytes)
-                arena[e.offset:e.offset + e.nbytes].copy_(src.contiguous().view(torch.uint8))
-            keep.append(e)
+    def _drop_handles(self):
+        for h, _, _, _ in self._handles.values():
+            L.lib().storm_ncsnpp_destroy(h)
+        self._handles.clear()
+        self._workspaces.clear()
+
+    def __del__(self):
+        try:
+            self._drop_handles()
+        except Exception:
+            pass
+
+    def c_config(self):
+        """the storm_ncsnpp_config of this network (include/storm_hip.h)"""
+        c = L.NcsnppConfig()
+        c.nf, c.n_levels, c.num_res_blocks = self.cfg.nf, len(self.cfg.ch_mult), self.cfg.num_res_blocks
+        for i, v in enumerate(self.cfg.ch_mult):
+            c.ch_mult[i] = v
+        c.n_attn = len(self.cfg.attn_resolutions)
+        for i, v in enumerate(self.cfg.attn_resolutions):
+            c.attn_resolutions[i] = v
+        c.image_size, c.input_channels, c.discriminative = self.cfg.image_size, self.cfg.input_channels, int(self.cfg.discriminative)
+        return c
+
+    def _get_handle(self, dtype_code, device):
+        """The C-ABI network object for (dtype, device): storm_ncsnpp_create over this module's state_dict tensors (the
+        planner, the weight packing and the op program all live behind the ABI, csrc/ncsnpp_graph.hip)."""
+        ent = self._handles.get(dtype_code)
+        if ent is not None and ent[2] == self._param_version and ent[3] == device:
+            return ent[0]
+        if ent is not None:
+            L.lib().storm_ncsnpp_destroy(ent[0])
+            self._workspaces.clear()
+        cfg = self.c_config()
+        lib = L.lib()
+        sd = [v.detach().to(device=device, dtype=torch.float32).contiguous() for v in self.state_dict().values()]
+        n = lib.storm_ncsnpp_num_tensors(C.byref(cfg))
+        if n != len(sd):
+            raise L.StormError(f"state_dict has {len(sd)} tensors, the engine's enumeration {n}")
+        ptrs = (C.c_void_p * n)(*[L.ptr(t) for t in sd])
+        arena = torch.empty(lib.storm_ncsnpp_arena_bytes(C.byref(cfg), dtype_code), dtype=torch.uint8, device=device)
+        h = C.c_void_p()
+        L.check(lib.storm_ncsnpp_create(C.byref(cfg), ptrs, n, dtype_code, L.ptr(arena), L.stream(), C.byref(h)), "storm_ncsnpp_create")
+        L.check(lib.storm_ncsnpp_set_fusion(h, int(os.environ.get("STORM_FUSE_GN_STATS", "1") != "0"),
+                                            int(os.environ.get("STORM_FUSE_GN_APPLY", "1") != "0"),
+                                            int(os.environ.get("STORM_FUSED_ATTENTION", "1") != "0")), "storm_ncsnpp_set_fusion")
         if not L.is_sim():
-            torch.cuda.current_stream().synchronize()    # sd temporaries die with this scope
-        self._arena[dtype_code] = (layout, arena, self._param_version)
-        return layout, arena
+            torch.cuda.current_stream().synchronize()    # the fp32 staging copies die with this scope
+        self._handles[dtype_code] = (h, arena, self._param_version, device)
+        return h
 
-    def _get_program(self, B, F, T, dtype_code, device):
-        key = (B, F, T, dtype_code, bool(self.negate_output))
-        ent = self._programs.get(key)
-        if ent is None:
-            layout, _ = self._get_arena(dtype_code, device)
-            prog = Program(self.cfg, layout, B, F, T, fuse_stats=os.environ.get("STORM_FUSE_GN_STATS", "1") != "0",
-                           fuse_apply=os.environ.get("STORM_FUSE_GN_APPLY", "1") != "0")
-            prog.ops[-1].i[4] = int(self.negate_output)
-            prog.op_array = (L.Op * len(prog.ops))(*prog.ops)
-            ws = torch.empty(prog.ws_bytes, dtype=torch.uint8, device=device)
-            ent = (prog, ws)
-            self._programs[key] = ent
-        return ent
+    def _get_workspace(self, h, B, F, T, dtype_code, device):
+        key = (B, F, T, dtype_code)
+        ws = self._workspaces.get(key)
+        if ws is None or ws.device != device:
+            n = L.lib().storm_ncsnpp_workspace_bytes(h, B, F, T)
+            if n < 0:
+                raise L.StormError(f"storm_ncsnpp_workspace_bytes: {L.lib().storm_last_error().decode()}")
+            ws = torch.empty(n, dtype=torch.uint8, device=device)
+            self._workspaces[key] = ws
+        return ws
 
-    def workspace_bytes(self, B, F, T, dtype=None):
+    def workspace_bytes(self, B, F, T, dtype=None, device=None):
         code = L.dt(dtype or self.compute_dtype)
-        return Program(self.cfg, ParamLayout(self.cfg, code), B, F, T).ws_bytes
+        dev = device or next(self.parameters()).device
+        return int(L.lib().storm_ncsnpp_workspace_bytes(self._get_handle(code, dev), B, F, T))
+
+    def program(self, B, F, T, dtype=None):
+        """(ops pointer, n_ops, flops) of the planned forward - for profilers (storm_program_run_timed)"""
+        code = L.dt(dtype or self.compute_dtype)
+        h = self._get_handle(code, next(self.parameters()).device)
+        ops, n, fl = C.POINTER(L.Op)(), C.c_int(), C.c_longlong()
+        L.check(L.lib().storm_ncsnpp_program(h, B, F, T, C.byref(ops), C.byref(n), C.byref(fl)), "storm_ncsnpp_program")
+        return ops, n.value, fl.value
 
     # ---- forward ---------------------------------------------------------------------------
     def forward(self, x, time_cond=None):
@@ -252,30 +268,28 @@ class NCSNpp(nn.Module):
 
     def forward_parts(self, ins, time_cond=None):
         """Same as forward() but takes the complex channels as separate contiguous [B,F,T] tensors
-        (avoids materialising torch.cat([x, y], 1) every score evaluation)."""
+        (avoids materialising torch.cat([x, y], 1) every score evaluation).  One C-ABI call: storm_ncsnpp_forward."""
         x0 = ins[0]
         B, F, T = x0.shape
         dev = x0.device
         code = L.dt(self.compute_dtype)
-        _, arena = self._get_arena(code, dev)
-        prog, ws = self._get_program(B, F, T, code, dev)
+        h = self._get_handle(code, dev)
+        ws = self._get_workspace(h, B, F, T, code, dev)
         out = torch.empty((B, 1, F, T), dtype=torch.complex64, device=dev)
-        bufs = (C.c_void_p * N_BUFS)()
-        bufs[BUF_WS], bufs[BUF_PARAMS] = L.ptr(ws), L.ptr(arena)
+        parts = (C.c_void_p * len(ins))()
         for j, t_in in enumerate(ins):
             if t_in.dtype != torch.complex64 or t_in.shape != x0.shape:
                 raise TypeError("inputs must be complex64 tensors of identical shape")
-            bufs[BUF_IN0 + j] = L.ptr(torch.view_as_real(t_in))
+            parts[j] = L.ptr(torch.view_as_real(t_in))
+        tc = None
         if self.cfg.conditional:
             if time_cond is None:
                 raise ValueError("time_cond is required for a score network")
             tc = time_cond.to(device=dev, dtype=torch.float32).contiguous()
             if tc.shape != (B,):
                 raise ValueError(f"time_cond must have shape [{B}]")
-            bufs[BUF_T] = L.ptr(tc)
-        bufs[BUF_OUT] = L.ptr(torch.view_as_real(out))
-        L.check(L.lib().storm_program_run(prog.op_array, len(prog.ops), bufs, N_BUFS, code, L.stream()),
-                "storm_program_run")
+        L.check(L.lib().storm_ncsnpp_forward(h, parts, len(ins), L.ptr(tc), L.ptr(torch.view_as_real(out)), L.ptr(ws), ws.numel(),
+                                             B, F, T, int(self.negate_output), L.stream()), "storm_ncsnpp_forward")
         return out
 
 

@@ -140,6 +140,10 @@ inline const char* hipGetErrorString(hipError_t) { return "sim"; }
 inline hipError_t hipGetLastError() { return hipSuccess; }
 inline hipError_t hipFuncSetAttribute(const void*, int, int) { return hipSuccess; }
 inline hipError_t hipMemsetAsync(void* p, int v, size_t n, hipStream_t) { memset(p, v, n); return hipSuccess; }
+enum hipMemcpyKind { hipMemcpyHostToHost = 0, hipMemcpyHostToDevice, hipMemcpyDeviceToHost, hipMemcpyDeviceToDevice, hipMemcpyDefault };
+inline hipError_t hipMemcpyAsync(void* d, const void* s, size_t n, hipMemcpyKind, hipStream_t) { memcpy(d, s, n); return hipSuccess; }
+inline hipError_t hipMalloc(void** p, size_t n) { *p = malloc(n ? n : 1); return *p ? hipSuccess : 1; }
+inline hipError_t hipFree(void* p) { free(p); return hipSuccess; }
 inline hipError_t hipGetDevice(int* d) { *d = 0; return hipSuccess; }
 inline hipError_t hipGetDeviceProperties(hipDeviceProp_t* p, int) {
     strcpy(p->gcnArchName, "host-sim"); p->multiProcessorCount = 0; p->totalGlobalMem = 0; return hipSuccess;

@@ -42,3 +42,57 @@ def test_product_does_not_import_the_oracle():
     base = bench.index("def cpu_baseline")
     nxt = bench.index("\ndef ", base + 1)
     assert uses and all(base < u < nxt for u in uses)
+
+
+def _run_c_host(tmp_path, lib_path, compiler, extra, golden, ldflags=()):
+    """compile tests/c/ncsnpp_host.c, hand it the reference's tiny4 golden input + the seeded state_dict as raw files, run it"""
+    import subprocess
+
+    import numpy as np
+    import torch
+
+    from oracle import ncsnpp_ref as NR
+    g = golden["f2_tiny_nets"]
+    cfg = NR.NCSNppConfig(nf=8, input_channels=4)
+    sd = NR.seeded_state_dict(cfg, seed=7)
+    d = str(tmp_path)
+    for i, v in enumerate(sd.values()):
+        v.detach().contiguous().numpy().astype(np.float32).tofile(os.path.join(d, f"w{i}.bin"))
+    x = g["tiny4_x"]                                        # complex64 [2, 2, 32, 64]
+    for j in range(2):
+        np.ascontiguousarray(x[:, j]).tofile(os.path.join(d, f"x{j}.bin"))
+    g["t"].astype(np.float32).tofile(os.path.join(d, "t.bin"))
+    exe = os.path.join(d, "ncsnpp_host")
+    libdir, libname = os.path.dirname(lib_path), os.path.basename(lib_path)[3:-3]
+    cmd = [compiler] + extra + ["-I", os.path.join(ROOT, "include"), os.path.join(ROOT, "tests", "c", "ncsnpp_host.c"), "-o", exe,
+                                "-L", libdir, "-l" + libname, "-Wl,-rpath," + libdir] + list(ldflags)
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr[-3000:]
+    r = subprocess.run([exe, d, "8", "4", "2", "32", "64", "0"], capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, (r.stdout + r.stderr)[-3000:]
+    out = np.fromfile(os.path.join(d, "out.bin"), dtype=np.complex64).reshape(2, 1, 32, 64)
+    ref = g["tiny4_y"]
+    err = float(np.linalg.norm(out - ref) / np.linalg.norm(ref))
+    assert err < 1e-4, err
+    return r.stdout
+
+
+def test_c_host_runs_a_forward_through_the_whole_network_abi(tmp_path, golden):
+    """A host written in C (no Python planning / packing / dispatch): storm_ncsnpp_tensor_info -> storm_ncsnpp_create ->
+    storm_ncsnpp_workspace_bytes -> storm_ncsnpp_forward, linked against the host simulation of the kernels; its output
+    equals the REFERENCE's forward of the tiny4 network (fixture F2, fp32 <= 1e-4)."""
+    from tests.sim.build_sim import build
+    out = _run_c_host(tmp_path, build(), "gcc", ["-std=c99", "-O1"], golden)
+    assert "271 tensors" in out
+
+
+import pytest  # noqa: E402
+
+
+@pytest.mark.gpu
+def test_c_host_on_the_gpu(tmp_path, golden):
+    """the same C host against libstorm_hip.so on the MI355X: plain g++ (-DUSE_HIP: device memory through the HIP runtime
+    API, hipMalloc / hipMemcpy), no device code in the host program"""
+    from storm_amd.build import build
+    _run_c_host(tmp_path, build(), "g++", ["-x", "c++", "-DUSE_HIP", "-D__HIP_PLATFORM_AMD__", "-O1", "-I", "/opt/rocm/include"], golden,
+                ldflags=["-L", "/opt/rocm/lib", "-lamdhip64", "-Wl,-rpath,/opt/rocm/lib"])
