@@ -44,12 +44,16 @@ def parse():
     p.add_argument("--N", type=int, default=30, help="reverse steps of the PC sampler")
     p.add_argument("--corrector", default="ald", choices=["ald", "langevin", "none"])
     p.add_argument("--corrector-steps", type=int, default=1)
-    p.add_argument("--precision", default="bf16", choices=["bf16", "fp32"])
+    p.add_argument("--precision", default="bf16", choices=["bf16", "fp16", "fp32"])
     p.add_argument("--backbone", default="ncsnpp")
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--no-roofline", action="store_true")
     p.add_argument("--profile-nfe", type=int, default=2, help="score evaluations profiled with per-op HIP events")
     p.add_argument("--ops-json", default=None, help="write the per-op timing table of the profiled pass here")
+    p.add_argument("--sampler", default="pc", choices=["pc", "ode"], help="pc: predictor-corrector (configs[1-3]); ode: probability-flow RK45 (configs[4])")
+    p.add_argument("--stream", type=int, default=0, metavar="N",
+                   help="configs[4]: a step = N synthetic utterances of 2-10 s (seeded lengths), micro-batched by padded frame count "
+                        "(<= --batch per launch, ragged rows) instead of one equal-length batch")
     p.add_argument("--selftest-cpu", action="store_true",
                    help="(tests) run the launch / sharding / timing skeleton with a stand-in step on CPU ranks (gloo)")
     return p.parse_args()
@@ -196,13 +200,32 @@ def main():
     g = torch.Generator().manual_seed(1234 + rank)
     wav = (0.1 * torch.randn(args.batch, L, generator=g)).to(dev)          # inputs resident in HBM
 
+    skw = dict(sampler_type="pc", predictor="reverse_diffusion", corrector=args.corrector, N=args.N, corrector_steps=args.corrector_steps,
+               snr=0.5) if args.sampler == "pc" else dict(sampler_type="ode", N=args.N)
+    units = args.batch
+    if args.stream:                                         # configs[4]: ragged micro-batches (2-10 s), resident in HBM
+        lens = [int(v) for v in torch.randint(32000, 160001, (args.stream,), generator=torch.Generator().manual_seed(77 + rank))]
+        batches = []
+        for ids in D.bucket_by_frames(lens, args.batch):
+            bl = [lens[i] for i in ids]
+            yb = torch.zeros(len(ids), max(bl))
+            for k, n_ in enumerate(bl):
+                yb[k, :n_] = 0.1 * torch.randn(n_, generator=g)
+            batches.append((yb.to(dev), None if len(set(bl)) == 1 else bl))
+        units = args.stream
+
     def step(i):
-        return model.enhance_batch(wav, predictor="reverse_diffusion", corrector=args.corrector, N=args.N,
-                                   corrector_steps=args.corrector_steps, snr=0.5, seed=1000 * rank + i, return_nfe=True)
+        if not args.stream:
+            return model.enhance_batch(wav, seed=1000 * rank + i, return_nfe=True, **skw)
+        nfes, out = [], None
+        for k, (yb, bl) in enumerate(batches):
+            out, n_ = model.enhance_batch(yb, seed=1000 * rank + 100 * i + k, return_nfe=True, lengths=bl, **skw)
+            nfes.append(n_ * yb.shape[0])
+        return out, sum(nfes) / args.stream                 # mean score evaluations per utterance
 
     elapsed, per_rank, (out, nfe) = D.timed_steps(step, args.steps, args.warmup, sync=torch.cuda.synchronize)
     assert torch.isfinite(out).all(), "non-finite output"
-    value = args.batch * world * args.steps / elapsed
+    value = units * world * args.steps / elapsed
 
     cfg_name = {("ncsnpp", 4.0, 30): "configs[1]" if world == 1 else "configs[2]", ("ncsnpplarge", 8.0, 50): "configs[3]"}.get(
         (args.backbone, float(args.seconds), args.N), "custom")
@@ -210,17 +233,20 @@ def main():
         "metric": METRIC, "value": value, "unit": "utterances/s", "n_gpus": world, "steps": args.steps,
         "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True,
         "scaling": "weak", "vs_baseline": None, "dtype": args.precision, "data": "synthetic",
-        "config": {"workload": f"{cfg_name}: {args.backbone} batch={args.batch}x{args.seconds:g} s@16 kHz per GPU, "
-                               f"{args.N}-step PC sampler (reverse_diffusion + {args.corrector} x{args.corrector_steps}), "
+        "config": {"workload": (f"configs[4]-style: {args.backbone} stream of {args.stream} utterances of 2-10 s@16 kHz per GPU in "
+                                f"{len(batches)} ragged micro-batches (<= {args.batch}, bucketed by padded frame count), " if args.stream else
+                                f"{cfg_name}: {args.backbone} batch={args.batch}x{args.seconds:g} s@16 kHz per GPU, ") +
+                               (f"{args.N}-step PC sampler (reverse_diffusion + {args.corrector} x{args.corrector_steps}), " if args.sampler == "pc"
+                                else "probability-flow ODE sampler (RK45, rtol = atol = 1e-5), ") +
                                f"{args.precision} operands, wav->wav incl. STFT/iSTFT, inputs resident in HBM "
                                f"(H2D + D2H of {2 * args.batch * L * 4 / 1e6:.1f} MB per step would add < 0.01 %)",
                    "batch_per_gpu": args.batch, "global_batch": args.batch * world, "seconds": args.seconds,
                    "pc_steps": args.N, "nfe_per_utterance": nfe, "parallelism": f"utterance-sharded x{world}"},
-        "nfe_per_s": value * nfe, "ms_per_nfe_batch": 1e3 * elapsed / args.steps / nfe,
+        "nfe_per_s": value * nfe, "ms_per_nfe_batch": None if args.stream else 1e3 * elapsed / args.steps / nfe,
         "per_rank_s": [round(t, 4) for t in per_rank],
     }
 
-    if rank == 0 and not args.no_roofline:
+    if rank == 0 and not args.no_roofline and not args.stream:
         Y, _, _ = model._prepare(wav)
         rows = profile_ops(model.dnn, Y, args.profile_nfe)
         groups = {}                                        # 3x3 convolutions on the matrix cores, by the kernel the launcher picked
@@ -232,7 +258,7 @@ def main():
         total_ms = sum(r["ms"] for r in rows)
         all_conv = [r for r in rows if r["code"] == 4]
         all3 = [r for g in groups.values() for r in g]
-        peak = BF16_MFMA_PEAK_TFLOPS if args.precision == "bf16" else F32_MFMA_PEAK_TFLOPS
+        peak = F32_MFMA_PEAK_TFLOPS if args.precision == "fp32" else BF16_MFMA_PEAK_TFLOPS     # (fp16 MFMA peak = bf16 peak)
         ach = flops / (ms * 1e-3) / 1e12
         names = {0: "memset", 1: "pack_input", 2: "temb", 3: "dense", 4: "conv", 5: "gn_stats", 6: "gn_apply",
                  7: "fir_up", 8: "fir_down", 9: "softmax", 10: "output_head", 11: "gn_finalize", 12: "attention"}

@@ -45,7 +45,7 @@ def main():
     p.add_argument("--corrector-steps", type=int, default=1)
     p.add_argument("--snr", type=float, default=0.5)
     p.add_argument("--N", type=int, default=50)
-    p.add_argument("--precision", choices=("fp32", "bf16"), default="fp32")
+    p.add_argument("--precision", choices=("fp32", "bf16", "fp16"), default="fp32")
     p.add_argument("--batch", type=int, default=16)
     p.add_argument("--seed", type=int, default=None, help="Philox seed of the sampler noise (default: drawn from torch's RNG, as the reference)")
     args = p.parse_args()

@@ -34,7 +34,7 @@ extern "C" {
 typedef void* storm_stream_t;              /* hipStream_t */
 
 enum { STORM_OK = 0, STORM_ERR_INVALID = -1, STORM_ERR_HIP = -2, STORM_ERR_UNSUPPORTED = -3 };
-enum { STORM_F32 = 0, STORM_BF16 = 1 };    /* activation / operand dtype */
+enum { STORM_F32 = 0, STORM_BF16 = 1, STORM_F16 = 2 };    /* activation / operand dtype (fp32 accumulation always) */
 
 const char* storm_last_error(void);
 int storm_abi_version(void);

@@ -14,9 +14,9 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 # STORM_LIB: tools/ point this at the profiling build (libstorm_hip_prof.so, python -m storm_amd.build --profiling)
 LIB_PATH = os.environ.get("STORM_LIB") or os.path.join(_HERE, "csrc", "libstorm_hip.so")
 
-F32, BF16 = 0, 1
-_TORCH2DT = {torch.float32: F32, torch.bfloat16: BF16}
-_DT2TORCH = {F32: torch.float32, BF16: torch.bfloat16}
+F32, BF16, F16 = 0, 1, 2
+_TORCH2DT = {torch.float32: F32, torch.bfloat16: BF16, torch.float16: F16}
+_DT2TORCH = {F32: torch.float32, BF16: torch.bfloat16, F16: torch.float16}
 
 OP_NPTR, OP_NINT, OP_NFLT = 12, 24, 4
 

@@ -16,6 +16,8 @@ typedef __attribute__((ext_vector_type(4))) float f32x4;
 typedef __attribute__((ext_vector_type(2))) float f32x2;
 
 struct bf16_t { uint16_t v; };   // storage type for bf16 activations / weights
+struct half_t { uint16_t v; };   // storage type for fp16 activations / weights (BASELINE.json configs[4])
+typedef __attribute__((ext_vector_type(8))) _Float16 f16x8;
 
 // ---- error reporting (storm_last_error) ----
 void set_error(const char* fmt, ...);
@@ -47,6 +49,19 @@ __device__ inline uint32_t pack_bf16x2(float lo, float hi) {
     return r;
 #endif
 }
+// fp16 <-> f32 (round-to-nearest-even; the compiler's _Float16 conversions: v_cvt_f16_f32 / v_cvt_f32_f16 on the device)
+__host__ __device__ inline uint16_t f32_to_f16_bits(float f) {
+    const _Float16 h = (_Float16)f;
+    uint16_t u; __builtin_memcpy(&u, &h, 2);
+    return u;
+}
+__host__ __device__ inline float f16_bits_to_f32(uint16_t u) {
+    _Float16 h; __builtin_memcpy(&h, &u, 2);
+    return (float)h;
+}
+__device__ inline uint32_t pack_f16x2(float lo, float hi) {
+    return (uint32_t)f32_to_f16_bits(lo) | ((uint32_t)f32_to_f16_bits(hi) << 16);
+}
 // raw hardware transcendentals (v_exp_f32 / v_rcp_f32, ~1 ulp): used where the result is rounded to bf16 anyway
 __device__ inline float hw_exp2(float x) {
 #ifdef STORM_HOST_SIM
@@ -73,6 +88,10 @@ template <> struct Elem<bf16_t> {
     static constexpr int PER16 = 8;
     static constexpr int DT = STORM_BF16;
 };
+template <> struct Elem<half_t> {
+    static constexpr int PER16 = 8;
+    static constexpr int DT = STORM_F16;
+};
 
 // Load / store 8 consecutive elements as fp32 (addresses 16-B aligned for bf16, 32-B for f32).
 __device__ inline void load8(const float* p, float (&v)[8]) {
@@ -89,6 +108,21 @@ __device__ inline void load8(const bf16_t* p, float (&v)[8]) {
         v[2 * i + 1] = __uint_as_float(w[i] & 0xffff0000u);
     }
 }
+__device__ inline void load8(const half_t* p, float (&v)[8]) {
+    const uint4 r = *reinterpret_cast<const uint4*>(p);
+    const uint32_t w[4] = {r.x, r.y, r.z, r.w};
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        v[2 * i] = f16_bits_to_f32((uint16_t)(w[i] & 0xffffu));
+        v[2 * i + 1] = f16_bits_to_f32((uint16_t)(w[i] >> 16));
+    }
+}
+__device__ inline void store8(half_t* p, const float (&v)[8]) {
+    uint32_t w[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) w[i] = pack_f16x2(v[2 * i], v[2 * i + 1]);
+    *reinterpret_cast<uint4*>(p) = make_uint4(w[0], w[1], w[2], w[3]);
+}
 __device__ inline void store8(float* p, const float (&v)[8]) {
     *reinterpret_cast<float4*>(p) = make_float4(v[0], v[1], v[2], v[3]);
     *reinterpret_cast<float4*>(p + 4) = make_float4(v[4], v[5], v[6], v[7]);
@@ -103,6 +137,8 @@ __device__ inline float to_f32(float x) { return x; }
 __device__ inline float to_f32(bf16_t x) { return bf16_bits_to_f32(x.v); }
 __device__ inline void from_f32(float& d, float x) { d = x; }
 __device__ inline void from_f32(bf16_t& d, float x) { d.v = f32_to_bf16_bits(x); }
+__device__ inline float to_f32(half_t x) { return f16_bits_to_f32(x.v); }
+__device__ inline void from_f32(half_t& d, float x) { d.v = f32_to_f16_bits(x); }
 
 __device__ inline float silu_f(float x) { return x / (1.0f + expf(-x)); }
 

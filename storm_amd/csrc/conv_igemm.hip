@@ -26,6 +26,7 @@
 //     skip / bias reads) are 16-32 B per lane, full 128-B lines per 4-8 lanes.
 //   * bf16 operands: v_mfma_f32_32x32x16_bf16 (fp32 accumulate).  fp32 operands:
 //     v_mfma_f32_32x32x2_f32 (exact fp32, used by the parity path).
+#include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include "common.h"
@@ -669,7 +670,7 @@ static int dispatch_conv(const storm_conv_args& a, hipStream_t st) {
 #endif
     if (any9) {
         if (small) return launch_conv<T, 9, 1, 1, 4, false>(a, st);
-        if (variant == 3 && conv_pipe_supports(a)) return launch_conv_pipe(a, st, 256);
+        if (variant == 3 && conv_pipe_supports(a)) return launch_conv_pipe(a, st);
         if (variant == 2) return launch_conv<T, 9, 2, 4, 2, true>(a, st);
         if (variant == 1) return launch_conv<T, 9, 2, 2, 4, false>(a, st);
         return dma ? launch_conv<T, 9, 2, 2, 2, false, true>(a, st) : launch_conv<T, 9, 2, 2, 2, false, false>(a, st);
@@ -683,19 +684,18 @@ static int dispatch_conv(const storm_conv_args& a, hipStream_t st) {
 static const char* kernel_name_of(const storm_conv_args& a) {
     bool any9 = false;
     for (int s = 0; s < a.nseg; ++s) any9 = any9 || a.seg[s].ntaps == 9;
-    const bool bf = a.dtype == STORM_BF16;
-    if (a.outC <= 32) return any9 ? (bf ? "storm::conv_igemm_kernel<storm::bf16_t, 9, 1, 1, 4, false, false, 0>" : "storm::conv_igemm_kernel<float, 9, 1, 1, 4, false, false, 0>")
-                                  : (bf ? "storm::conv_igemm_kernel<storm::bf16_t, 1, 1, 1, 4, false, false, 0>" : "storm::conv_igemm_kernel<float, 1, 1, 1, 4, false, false, 0>");
-    const int variant = choose_variant(a, any9);
-    if (any9) {
-        if (variant == 3 && conv_pipe_supports(a)) return conv_pipe_kernel_name(256);
-        if (variant == 2) return bf ? "storm::conv_igemm_kernel<storm::bf16_t, 9, 2, 4, 2, true, false, 0>" : "storm::conv_igemm_kernel<float, 9, 2, 4, 2, true, false, 0>";
-        if (variant == 1) return bf ? "storm::conv_igemm_kernel<storm::bf16_t, 9, 2, 2, 4, false, false, 0>" : "storm::conv_igemm_kernel<float, 9, 2, 2, 4, false, false, 0>";
-        return bf ? "storm::conv_igemm_kernel<storm::bf16_t, 9, 2, 2, 2, false, true, 0>" : "storm::conv_igemm_kernel<float, 9, 2, 2, 2, false, true, 0>";
-    }
-    if (variant == 2) return bf ? "storm::conv_igemm_kernel<storm::bf16_t, 1, 2, 4, 2, true, false, 0>" : "storm::conv_igemm_kernel<float, 1, 2, 4, 2, true, false, 0>";
-    if (variant == 1) return bf ? "storm::conv_igemm_kernel<storm::bf16_t, 1, 2, 2, 4, false, false, 0>" : "storm::conv_igemm_kernel<float, 1, 2, 2, 4, false, false, 0>";
-    return bf ? "storm::conv_igemm_kernel<storm::bf16_t, 1, 2, 2, 2, false, false, 0>" : "storm::conv_igemm_kernel<float, 1, 2, 2, 2, false, false, 0>";
+    const char* tn = a.dtype == STORM_BF16 ? "storm::bf16_t" : a.dtype == STORM_F16 ? "storm::half_t" : "float";
+    const int taps = any9 ? 9 : 1;
+    const char* shape;
+    const int variant = a.outC <= 32 ? -1 : choose_variant(a, any9);
+    if (a.outC <= 32) shape = "1, 1, 4, false, false";
+    else if (any9 && variant == 3 && conv_pipe_supports(a)) return conv_pipe_kernel_name(a.dtype);
+    else if (variant == 2) shape = "2, 4, 2, true, false";
+    else if (variant == 1) shape = "2, 2, 4, false, false";
+    else shape = any9 ? "2, 2, 2, false, true" : "2, 2, 2, false, false";
+    static thread_local char buf[160];
+    snprintf(buf, sizeof(buf), "storm::conv_igemm_kernel<%s, %d, %s, 0>", tn, taps, shape);
+    return buf;
 }
 
 }  // namespace storm
@@ -717,7 +717,7 @@ extern "C" int storm_conv(const storm_conv_args* ap, storm_stream_t s) {
     STORM_CHECK(a.B > 0 && a.H > 0 && a.W > 0, "storm_conv: bad shape B=%d H=%d W=%d", a.B, a.H, a.W);
     STORM_CHECK(a.outC > 0 && a.outC % 8 == 0 && a.Cout <= a.outC, "storm_conv: outC=%d Cout=%d", a.outC, a.Cout);
     STORM_CHECK(a.out != nullptr, "storm_conv: null out");
-    const int per16 = a.dtype == STORM_BF16 ? 8 : 4;
+    const int per16 = a.dtype == STORM_F32 ? 4 : 8;
     for (int i = 0; i < a.nseg; ++i) {
         const storm_conv_seg& g = a.seg[i];
         STORM_CHECK(g.src_a && g.w, "storm_conv: seg %d null pointer", i);
@@ -728,6 +728,7 @@ extern "C" int storm_conv(const storm_conv_args* ap, storm_stream_t s) {
     }
     hipStream_t st = reinterpret_cast<hipStream_t>(s);
     if (a.dtype == STORM_BF16) return dispatch_conv<bf16_t>(a, st);
+    if (a.dtype == STORM_F16) return dispatch_conv<half_t>(a, st);
     if (a.dtype == STORM_F32) return dispatch_conv<float>(a, st);
     STORM_CHECK(false, "storm_conv: dtype %d", a.dtype);
 }

@@ -18,6 +18,12 @@ template <> struct Mma<bf16_t> {
         c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
     }
 };
+template <> struct Mma<half_t> {
+    typedef f16x8 Frag;
+    static __device__ __forceinline__ void run(const Frag& a, const Frag& b, f32x16& c) {
+        c = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0);
+    }
+};
 template <> struct Mma<float> {
     typedef f32x4 Frag;
     static __device__ __forceinline__ void run(const Frag& a, const Frag& b, f32x16& c) {
@@ -164,6 +170,18 @@ __device__ __forceinline__ uint4 gn_act_slot(uint4 v, const float (&ss)[16], int
     }
     return make_uint4(w[0], w[1], w[2], w[3]);
 }
+__device__ __forceinline__ uint4 gn_act_slot(uint4 v, const float (&ss)[16], int silu, half_t*) {
+    uint32_t w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        float lo = f16_bits_to_f32((uint16_t)(w[i] & 0xffffu)), hi = f16_bits_to_f32((uint16_t)(w[i] >> 16));
+        lo = fmaf(lo, ss[4 * i], ss[4 * i + 1]);
+        hi = fmaf(hi, ss[4 * i + 2], ss[4 * i + 3]);
+        if (silu) { lo = fast_silu(lo); hi = fast_silu(hi); }
+        w[i] = pack_f16x2(lo, hi);
+    }
+    return make_uint4(w[0], w[1], w[2], w[3]);
+}
 __device__ __forceinline__ uint4 gn_act_slot(uint4 v, const float (&ss)[16], int silu, float*) {
     float x[4] = {__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w)};
 #pragma unroll
@@ -262,9 +280,9 @@ struct PipeParams {
 };
 }  // namespace pipe
 
-// defined in conv_pipe.hip: software-pipelined 3x3 kernels (bf16): 256 or 128 output channels per workgroup
+// defined in conv_pipe.hip: software-pipelined 3x3 kernel (bf16 / fp16 operands), 256 output channels per workgroup
 bool conv_pipe_supports(const storm_conv_args& a);
-int launch_conv_pipe(const storm_conv_args& a, hipStream_t st, int bn);
-const char* conv_pipe_kernel_name(int bn);
+int launch_conv_pipe(const storm_conv_args& a, hipStream_t st);
+const char* conv_pipe_kernel_name(int dtype);
 
 }  // namespace storm

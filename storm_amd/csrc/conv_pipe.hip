@@ -127,7 +127,7 @@ using namespace pipe;
 // ABL: profiling-only instantiations (built with -DSTORM_PROFILING into libstorm_hip_prof.so, never in the product
 // library): 8 no weight DMA after the prologue, 16 no fragment reads, 32 no MFMAs, 128 no patch DMA / transform,
 // 64 wave-timeline stamps (tools/conv_trace.py).
-template <int BN, int TH, int ABL>
+template <typename T, int BN, int TH, int ABL>
 __global__ __launch_bounds__(pipe::THREADS, 2)
 void conv_pipe_kernel(const PipeParams a, const int n_ct, const int tiles_per_xcd,
                       const int ntiles, const int tiles_x, const int tiles_per_img, const int total_vblocks) {
@@ -137,8 +137,7 @@ void conv_pipe_kernel(const PipeParams a, const int n_ct, const int tiles_per_xc
     constexpr int PATCH_BYTES = Cfg::PATCH_BYTES, PPIECES = Cfg::PPIECES, CPIECES = Cfg::CPIECES;
     constexpr int NSLOT = Cfg::NSLOT, NSLOT1 = Cfg::NSLOT1, WPHASE = Cfg::WPHASE, RINGB = Cfg::RINGB;
     constexpr int OFF_RING = Cfg::OFF_RING, OFF_SS = Cfg::OFF_SS;
-    typedef bf16_t T;
-    typedef bf16x8 Frag;
+    typedef typename Mma<T>::Frag Frag;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     // The parameter block is read through the kernarg segment pointer (PipeParams is the first argument, offset 0),
     // re-laundered at every tile and before every epilogue: otherwise every scalar load of the block is hoisted out of
@@ -709,7 +708,7 @@ void conv_pipe_kernel(const PipeParams a, const int n_ct, const int tiles_per_xc
 // The K loop as chunk descriptors.  Returns false when the convolution is outside what the pipelined kernel covers.
 static bool build_pipe_params(const storm_conv_args& a, PipeParams& p) {
     memset(&p, 0, sizeof(p));
-    if (a.dtype != STORM_BF16 || a.nseg < 1 || a.seg[0].ntaps != 9) return false;
+    if ((a.dtype != STORM_BF16 && a.dtype != STORM_F16) || a.nseg < 1 || a.seg[0].ntaps != 9) return false;
     int n = 0, nw = 0;
     for (int s = 0; s < a.nseg; ++s) {
         const storm_conv_seg& g = a.seg[s];
@@ -764,10 +763,10 @@ bool conv_pipe_supports(const storm_conv_args& a) {
     return build_pipe_params(a, p);
 }
 
-template <int BN, int TH, int ABL>
+template <typename T, int BN, int TH, int ABL>
 static int launch_pipe(const storm_conv_args& a, hipStream_t st) {
     typedef PCfg<BN, TH> Cfg;
-    auto kern = conv_pipe_kernel<BN, TH, ABL>;
+    auto kern = conv_pipe_kernel<T, BN, TH, ABL>;
     static bool attr_set = false;                       // per instantiation; benign race (idempotent)
     if (!attr_set) {
         STORM_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, Cfg::LDS_BYTES));
@@ -803,30 +802,29 @@ static int launch_pipe(const storm_conv_args& a, hipStream_t st) {
     return STORM_OK;
 }
 
-int launch_conv_pipe(const storm_conv_args& a, hipStream_t st, int bn) {
-    (void)bn;
+int launch_conv_pipe(const storm_conv_args& a, hipStream_t st) {
+    if (a.dtype == STORM_F16) return launch_pipe<half_t, 256, 8, 0>(a, st);
 #if defined(STORM_PROFILING)
     const char* abl_env = getenv("STORM_CONV_ABLATE");
     switch (abl_env ? atoi(abl_env) : 0) {
-        case 8: return launch_pipe<256, 8, 8>(a, st);
-        case 16: return launch_pipe<256, 8, 16>(a, st);
-        case 32: return launch_pipe<256, 8, 32>(a, st);
-        case 128: return launch_pipe<256, 8, 128>(a, st);
-        case 184: return launch_pipe<256, 8, 184>(a, st);       // barriers + scalar skeleton only
-        case 136: return launch_pipe<256, 8, 136>(a, st);       // no DMA of either kind
-        case 152: return launch_pipe<256, 8, 152>(a, st);       // MFMAs + barriers only
-        case 64: return launch_pipe<256, 8, 64>(a, st);
-        case 256: return launch_pipe<256, 8, 256>(a, st);       // fragment reads in two bursts per MFMA interval
-        case 512: return launch_pipe<256, 8, 512>(a, st);       // barrier arrival before the last four MFMAs
+        case 8: return launch_pipe<bf16_t, 256, 8, 8>(a, st);
+        case 16: return launch_pipe<bf16_t, 256, 8, 16>(a, st);
+        case 32: return launch_pipe<bf16_t, 256, 8, 32>(a, st);
+        case 128: return launch_pipe<bf16_t, 256, 8, 128>(a, st);
+        case 184: return launch_pipe<bf16_t, 256, 8, 184>(a, st);       // barriers + scalar skeleton only
+        case 136: return launch_pipe<bf16_t, 256, 8, 136>(a, st);       // no DMA of either kind
+        case 152: return launch_pipe<bf16_t, 256, 8, 152>(a, st);       // MFMAs + barriers only
+        case 64: return launch_pipe<bf16_t, 256, 8, 64>(a, st);
+        case 256: return launch_pipe<bf16_t, 256, 8, 256>(a, st);       // fragment reads in two bursts per MFMA interval
+        case 512: return launch_pipe<bf16_t, 256, 8, 512>(a, st);       // barrier arrival before the last four MFMAs
         default: break;
     }
 #endif
-    return launch_pipe<256, 8, 0>(a, st);
+    return launch_pipe<bf16_t, 256, 8, 0>(a, st);
 }
 
-const char* conv_pipe_kernel_name(int bn) {
-    (void)bn;
-    return "storm::conv_pipe_kernel<256, 8, 0>";
+const char* conv_pipe_kernel_name(int dtype) {
+    return dtype == STORM_F16 ? "storm::conv_pipe_kernel<storm::half_t, 256, 8, 0>" : "storm::conv_pipe_kernel<storm::bf16_t, 256, 8, 0>";
 }
 
 }  // namespace storm

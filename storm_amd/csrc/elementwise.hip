@@ -126,6 +126,7 @@ extern "C" int storm_pack_input(const float* const* cplx_in, int n_in, void* out
     const int nb = cdiv(npix, 256);
     hipStream_t st = (hipStream_t)s;
     if (dtype == STORM_BF16) hipLaunchKernelGGL((pack_input_kernel<bf16_t>), dim3(nb), dim3(256), 0, st, pp, n_in, (bf16_t*)out, npix);
+    else if (dtype == STORM_F16) hipLaunchKernelGGL((pack_input_kernel<half_t>), dim3(nb), dim3(256), 0, st, pp, n_in, (half_t*)out, npix);
     else if (dtype == STORM_F32) hipLaunchKernelGGL((pack_input_kernel<float>), dim3(nb), dim3(256), 0, st, pp, n_in, (float*)out, npix);
     else STORM_CHECK(false, "storm_pack_input: dtype %d", dtype);
     STORM_LAUNCH_CHECK();
@@ -157,6 +158,7 @@ extern "C" int storm_softmax_rows(const float* scores, void* probs, long long ro
     const int nb = cdiv(rows, 4);
     hipStream_t st = (hipStream_t)s;
     if (dtype == STORM_BF16) hipLaunchKernelGGL((softmax_rows_kernel<bf16_t>), dim3(nb), dim3(256), 0, st, scores, (bf16_t*)probs, rows, L, ld);
+    else if (dtype == STORM_F16) hipLaunchKernelGGL((softmax_rows_kernel<half_t>), dim3(nb), dim3(256), 0, st, scores, (half_t*)probs, rows, L, ld);
     else if (dtype == STORM_F32) hipLaunchKernelGGL((softmax_rows_kernel<float>), dim3(nb), dim3(256), 0, st, scores, (float*)probs, rows, L, ld);
     else STORM_CHECK(false, "storm_softmax_rows: dtype %d", dtype);
     STORM_LAUNCH_CHECK();
@@ -171,6 +173,7 @@ extern "C" int storm_output_head(const void* pyr, const float* t, const float* W
     const float sign = negate ? -1.0f : 1.0f;
     hipStream_t st = (hipStream_t)s;
     if (dtype == STORM_BF16) hipLaunchKernelGGL((output_head_kernel<bf16_t>), dim3(nb), dim3(256), 0, st, (const bf16_t*)pyr, t, W, bias, cin, out_cplx, per_b, npix, sign);
+    else if (dtype == STORM_F16) hipLaunchKernelGGL((output_head_kernel<half_t>), dim3(nb), dim3(256), 0, st, (const half_t*)pyr, t, W, bias, cin, out_cplx, per_b, npix, sign);
     else if (dtype == STORM_F32) hipLaunchKernelGGL((output_head_kernel<float>), dim3(nb), dim3(256), 0, st, (const float*)pyr, t, W, bias, cin, out_cplx, per_b, npix, sign);
     else STORM_CHECK(false, "storm_output_head: dtype %d", dtype);
     STORM_LAUNCH_CHECK();
@@ -204,6 +207,7 @@ static int pack_weight(const float* src, void* dst, int Cout, int Cin, int ntaps
     const int nb = cdiv(total, 256);
     hipStream_t st = (hipStream_t)s;
     if (dtype == STORM_BF16) hipLaunchKernelGGL((pack_weight_kernel<bf16_t>), dim3(nb), dim3(256), 0, st, src, (bf16_t*)dst, Cout, Cin, ntaps, CoutP, CinP, transpose);
+    else if (dtype == STORM_F16) hipLaunchKernelGGL((pack_weight_kernel<half_t>), dim3(nb), dim3(256), 0, st, src, (half_t*)dst, Cout, Cin, ntaps, CoutP, CinP, transpose);
     else if (dtype == STORM_F32) hipLaunchKernelGGL((pack_weight_kernel<float>), dim3(nb), dim3(256), 0, st, src, (float*)dst, Cout, Cin, ntaps, CoutP, CinP, transpose);
     else STORM_CHECK(false, "storm_pack_*: dtype %d", dtype);
     STORM_LAUNCH_CHECK();

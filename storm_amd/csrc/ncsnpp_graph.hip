@@ -543,7 +543,7 @@ extern "C" long long storm_ncsnpp_arena_bytes(const storm_ncsnpp_config* c, int 
 extern "C" int storm_ncsnpp_create(const storm_ncsnpp_config* c, const void* const* weights, int n_weights, int dtype, void* arena,
                                    storm_stream_t s, storm_ncsnpp** out) {
     STORM_CHECK(out != nullptr && weights != nullptr, "storm_ncsnpp_create: null argument");
-    STORM_CHECK(dtype == STORM_F32 || dtype == STORM_BF16, "storm_ncsnpp_create: dtype %d", dtype);
+    STORM_CHECK(dtype == STORM_F32 || dtype == STORM_BF16 || dtype == STORM_F16, "storm_ncsnpp_create: dtype %d", dtype);
     Cfg cfg; if (int rc = to_cfg(c, cfg)) return rc;
     const auto sd = state_dict(cfg);
     STORM_CHECK(n_weights == (int)sd.size(), "storm_ncsnpp_create: %d weight tensors given, the configuration has %zu", n_weights, sd.size());

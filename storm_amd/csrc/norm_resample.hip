@@ -413,6 +413,7 @@ extern "C" int storm_gn_stats(const void* xa, int Ca, const void* xb, int Cb, in
     STORM_CHECK((Cb == 0) == (xb == nullptr), "storm_gn_stats: xb / Cb mismatch");
     hipStream_t st = (hipStream_t)s;
     if (dtype == STORM_BF16) return gn_stats_t<bf16_t>(xa, Ca, xb, Cb, B, HW, groups, stats, st);
+    if (dtype == STORM_F16) return gn_stats_t<half_t>(xa, Ca, xb, Cb, B, HW, groups, stats, st);
     if (dtype == STORM_F32) return gn_stats_t<float>(xa, Ca, xb, Cb, B, HW, groups, stats, st);
     STORM_CHECK(false, "storm_gn_stats: dtype %d", dtype);
 }
@@ -456,6 +457,7 @@ extern "C" int storm_gn_apply(const void* xa, int Ca, const void* xb, int Cb, in
         default: return gn_apply_t<T, 2>(xa, Ca, xb, Cb, B, H, W, groups, stats, gamma, beta, eps, silu, out_act, out_raw, st); \
     }
     if (dtype == STORM_BF16) { STORM_GN_DISPATCH(bf16_t) }
+    if (dtype == STORM_F16) { STORM_GN_DISPATCH(half_t) }
     if (dtype == STORM_F32) { STORM_GN_DISPATCH(float) }
 #undef STORM_GN_DISPATCH
     STORM_CHECK(false, "storm_gn_apply: dtype %d", dtype);
@@ -466,6 +468,7 @@ extern "C" int storm_fir_up2(const void* x, const void* add, void* out, int B, i
     STORM_CHECK(x && out && C > 0 && C % 8 == 0 && C <= GN_MAX_C, "storm_fir_up2: bad arguments (C=%d)", C);
     hipStream_t st = (hipStream_t)s;
     if (dtype == STORM_BF16) return fir_t<bf16_t, 1>(x, add, out, B, H, W, C, st);
+    if (dtype == STORM_F16) return fir_t<half_t, 1>(x, add, out, B, H, W, C, st);
     if (dtype == STORM_F32) return fir_t<float, 1>(x, add, out, B, H, W, C, st);
     STORM_CHECK(false, "storm_fir_up2: dtype %d", dtype);
 }
@@ -475,6 +478,7 @@ extern "C" int storm_fir_down2(const void* x, void* out, int B, int H, int W, in
     STORM_CHECK(H % 2 == 0 && W % 2 == 0, "storm_fir_down2: needs even H, W");
     hipStream_t st = (hipStream_t)s;
     if (dtype == STORM_BF16) return fir_t<bf16_t, 2>(x, nullptr, out, B, H, W, C, st);
+    if (dtype == STORM_F16) return fir_t<half_t, 2>(x, nullptr, out, B, H, W, C, st);
     if (dtype == STORM_F32) return fir_t<float, 2>(x, nullptr, out, B, H, W, C, st);
     STORM_CHECK(false, "storm_fir_down2: dtype %d", dtype);
 }

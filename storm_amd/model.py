@@ -21,7 +21,8 @@ from .data_module import SpecsDataModule
 from .sdes import SDERegistry
 from .util.other import pad_spec
 
-_PRECISIONS = {"fp32": torch.float32, "float32": torch.float32, "bf16": torch.bfloat16, "bfloat16": torch.bfloat16}
+_PRECISIONS = {"fp32": torch.float32, "float32": torch.float32, "bf16": torch.bfloat16, "bfloat16": torch.bfloat16,
+               "fp16": torch.float16, "float16": torch.float16, "half": torch.float16}
 
 
 class _EMA:
@@ -90,7 +91,7 @@ class _Base(nn.Module):
         return [m for m in self.children() if hasattr(m, "set_compute_dtype")]
 
     def set_precision(self, precision):
-        """'fp32': exact-fp32 MFMA path (reference numerics); 'bf16': bf16 MFMA operands / activations
+        """'fp32': exact-fp32 MFMA path (reference numerics); 'bf16' / 'fp16': 16-bit MFMA operands / activations
         with fp32 accumulation, statistics, time embedding and SDE state."""
         dt = _PRECISIONS[precision] if isinstance(precision, str) else precision
         for m in self._backbones():

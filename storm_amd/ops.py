@@ -25,7 +25,7 @@ def pack_conv_weight(w, dtype, cout_pad=32):
     """nn.Conv2d weight [Cout, Cin, kh, kw] fp32 -> packed [taps][CoutP][CinP]."""
     Cout, Cin, kh, kw = w.shape
     ntaps = kh * kw
-    per16 = 8 if dtype == torch.bfloat16 else 4
+    per16 = 4 if dtype == torch.float32 else 8
     CoutP, CinP = round_up(Cout, cout_pad), round_up(Cin, per16 * 2)
     w = w.contiguous().float()
     out = _alloc((ntaps, CoutP, CinP), dtype, w)
@@ -38,7 +38,7 @@ def pack_matrix(w, dtype, transpose=False, cout_pad=32):
     """[Cout][Cin] fp32 (or [Cin][Cout] with transpose=True, e.g. NIN.W) -> packed [CoutP][CinP]."""
     w = w.contiguous().float()
     Cin, Cout = (w.shape[0], w.shape[1]) if transpose else (w.shape[1], w.shape[0])
-    per16 = 8 if dtype == torch.bfloat16 else 4
+    per16 = 4 if dtype == torch.float32 else 8
     CoutP, CinP = round_up(Cout, cout_pad), round_up(Cin, per16 * 2)
     out = _alloc((1, CoutP, CinP), dtype, w)
     L.check(L.lib().storm_pack_matrix(L.ptr(w), L.ptr(out), Cout, Cin, int(transpose), CoutP, CinP, L.dt(dtype), L.stream()),

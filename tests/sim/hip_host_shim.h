@@ -119,6 +119,14 @@ inline sim_f32x16 mfma_bf16(sim_bf16x8 a, sim_bf16x8 b, sim_f32x16 c, int, int, 
     wave_collective(&in, &r, sizeof(r), &mfma32_fn, 0);
     return r;
 }
+typedef __attribute__((ext_vector_type(8))) _Float16 sim_f16x8;
+inline sim_f32x16 mfma_f16(sim_f16x8 a, sim_f16x8 b, sim_f32x16 c, int, int, int) {
+    MfmaIn in; in.nk = 8; in.c = c;
+    for (int e = 0; e < 8; ++e) { in.a[e] = (float)a[e]; in.b[e] = (float)b[e]; }
+    sim_f32x16 r;
+    wave_collective(&in, &r, sizeof(r), &mfma32_fn, 0);
+    return r;
+}
 inline sim_f32x16 mfma_f32(float a, float b, sim_f32x16 c, int, int, int) {
     MfmaIn in; in.nk = 1; in.c = c; in.a[0] = a; in.b[0] = b;
     sim_f32x16 r;
@@ -129,6 +137,7 @@ inline sim_f32x16 mfma_f32(float a, float b, sim_f32x16 c, int, int, int) {
 #define __builtin_amdgcn_sched_barrier(x) ((void)0)
 #define __builtin_amdgcn_mfma_f32_32x32x16_bf16 simrt::mfma_bf16
 #define __builtin_amdgcn_mfma_f32_32x32x2f32 simrt::mfma_f32
+#define __builtin_amdgcn_mfma_f32_32x32x16_f16 simrt::mfma_f16
 
 // ---- runtime API stubs ---------------------------------------------------------------------------
 typedef void* hipStream_t;

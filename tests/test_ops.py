@@ -63,7 +63,8 @@ def test_conv_persistent_tile_loop(dev, dtype, k, monkeypatch):
 
 
 @pytest.mark.parametrize("variant", [3])
-@pytest.mark.parametrize("case", ["plain", "block_tail", "gn_fused", "ragged", "deep_k", "plain@8", "block_tail@8", "gn_fused@8"])
+@pytest.mark.parametrize("case", ["plain", "block_tail", "gn_fused", "ragged", "deep_k", "plain@8", "block_tail@8", "gn_fused@8",
+                                  "plain:f16", "gn_fused:f16"])
 def test_conv_pipelined_kernels(dev, variant, case, monkeypatch):
     """conv_pipe.hip (chunk-unrolled LDS-DMA pipeline, 256-cout tile) on shapes the default dispatch would give
     to conv_igemm.hip: plain 3x3, fused 1x1 shortcut over a concat, fused GroupNorm-apply operand, ragged sizes, many
@@ -75,6 +76,8 @@ def test_conv_pipelined_kernels(dev, variant, case, monkeypatch):
         monkeypatch.setenv("STORM_CONV_CUS", "8")
         case = case[:-2]
     dtype = torch.bfloat16
+    if case.endswith(":f16"):                               # fp16 operands (v_mfma_f32_32x32x16_f16): same kernel template
+        dtype, case = torch.float16, case[:-4]
     g = torch.Generator().manual_seed(31)
     if case == "plain":
         B, Cin, Cout, H, W = 2, 72, 288, 19, 45
