@@ -129,12 +129,15 @@ def profile_ops(net, Y, nfe_count):
         row = dict(idx=k, code=int(op.code), ms=acc[k])
         if op.code == 4:
             nseg, Bq, H, W, outC, Cout = [int(op.i[j]) for j in range(6)]
-            flops, taps = 0, []
+            flops, taps, esz = 0, [], 4 if code == 0 else 2
+            abytes = Bq * H * W * outC * esz                # algorithmic HBM bytes: every operand once, the output once
             for gseg in range(nseg):
                 q = 8 + 7 * gseg
-                flops += 2 * Bq * H * W * Cout * (int(op.i[q]) + int(op.i[q + 1])) * int(op.i[q + 4])
-                taps.append(int(op.i[q + 4]))
-            row.update(flops=flops, H=H, W=W, Cout=Cout, taps=taps, big=outC > 32, cin=[int(op.i[8]) + int(op.i[9])],
+                cin, nt = int(op.i[q]) + int(op.i[q + 1]), int(op.i[q + 4])
+                flops += 2 * Bq * H * W * Cout * cin * nt
+                abytes += (Bq * H * W * cin + Cout * cin * nt) * esz
+                taps.append(nt)
+            row.update(flops=flops, algorithmic_bytes=abytes, H=H, W=W, Cout=Cout, taps=taps, big=outC > 32, cin=[int(op.i[8]) + int(op.i[9])],
                        kernel=L.lib().storm_program_kernel_name(ops, k, code).decode())
         rows.append(row)
     return rows
@@ -279,6 +282,7 @@ def main():
             "bound": "mfma", "kernel": kname,
             "achieved": ach, "peak": peak, "unit": "TFLOP/s", "frac": ach / peak, "traffic": traffic, "traffic_source": tsrc,
             "launches_per_nfe": len(big), "avg_launch_ms": ms / len(big), "avg_launch_gflop": flops / len(big) / 1e9,
+            "avg_launch_algorithmic_bytes": sum(r["algorithmic_bytes"] for r in big) / len(big),
             "nfe_ms_profiled": total_ms, "ms_by_op_kind": {k: round(v, 3) for k, v in by_kind.items()},
             "conv3x3_by_kernel": by_kernel,
             "all_3x3_tflops": sum(r["flops"] for r in all3) / (sum(r["ms"] for r in all3) * 1e-3) / 1e12,

@@ -1,7 +1,6 @@
 #!/bin/bash
 export TMPDIR=/tmp
-mkdir -p gpurun_out
 export STORM_LIB=$PWD/storm_amd/csrc/libstorm_hip_prof.so
-for i in 1 2 3; do for abl in 0 512 256; do
+for i in 1 2 3; do for abl in 0 4096; do
   echo "abl $abl: $(STORM_CONV_ABLATE=$abl STORM_CONV_VARIANT=3 timeout 300 python tools/conv_probe.py --reps 10 2>&1 | grep -E '^c' | tr '\n' ' ')"
 done; done

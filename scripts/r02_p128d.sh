@@ -1,0 +1,8 @@
+#!/bin/bash
+# conv_pipe128 A/B: who transforms (XF) x setprio, on one fused layer (256->128 @256x512x16), cycles via PMC + time via events
+mkdir -p gpurun_out; export TMPDIR=/tmp
+for m in 0 1 2 3 4 5; do
+  echo "== STORM_P128_MODE=$m (XF=$((m/2)) NOPRIO=$((m%2)))"
+  STORM_P128_MODE=$m timeout 120 python tools/probe128.py --only 2 --reps 5 2>&1 | grep -v amdgpu.ids
+  STORM_P128_MODE=$m timeout 120 python tools/probe128.py --only 2 --reps 5 --nogn 2>&1 | grep -v amdgpu.ids
+done

@@ -635,12 +635,19 @@ static int env_int(const char* name, int dflt) {
 //   0: conv_igemm 128 cout x 256 px, 4 waves (64x128 each), 2 workgroups / CU overlap each other's staging; LDS-DMA
 //   1: conv_igemm 128 cout x 256 px, 8 waves (64x64 each), 2 workgroups / CU
 //   2: conv_igemm 256 cout x 256 px, 8 waves, 1 workgroup / CU, patch double-buffered through registers
-//   3: conv_pipe.hip, 256 cout x 256 px, 8 waves in two ping-pong groups, chunk-unrolled LDS-DMA pipeline (bf16 3x3)
+//   3: conv_pipe.hip, 256 cout x 256 px, 8 waves in two ping-pong groups, chunk-unrolled LDS-DMA pipeline (16-bit 3x3)
+//   4: conv_pipe128.hip, 128 cout x 512 px, the same pipeline for layers with <= 128 output channels (16-bit 3x3)
 static int choose_variant(const storm_conv_args& a, bool any9) {
     const int forced = env_int("STORM_CONV_VARIANT", -1);
     if (forced >= 0) return forced;
     const long long px_tiles = (long long)a.B * cdiv((long long)a.H * a.W, TILE_H * TILE_W);
     if (a.outC > 128 && px_tiles >= 512) return any9 && conv_pipe_supports(a) ? 3 : 2;
+    // conv_pipe128: measured against this file's two-workgroup kernel on MI355X (tools/probe128.py, profiles/r02_pipe128_ab.txt) it
+    // wins 13-20 % at 4 of its tiles per CU (128 x 256 x 16) and ties or loses (0 ... -10 %) at 16 tiles per CU (256 x 512 x 16):
+    // with K this short the exposed epilogue and the fused GroupNorm transform weigh the same in both kernels and two resident
+    // workgroups hide them at least as well.  (A stem-like layer with fewer than 32 input channels is HBM-bound either way.)
+    if (a.outC > 32 && a.outC <= 128 && any9 && px_tiles >= 1024 && px_tiles <= 4096 && a.seg[0].Ca + a.seg[0].Cb >= 32 &&
+        env_int("STORM_CONV_PIPE128", 1) != 0 && conv_pipe128_supports(a)) return 4;    // (A/B switch: 0 = conv_igemm for these layers)
     return 0;
 }
 
@@ -654,7 +661,7 @@ static int dispatch_conv(const storm_conv_args& a, hipStream_t st) {
 #if defined(STORM_PROFILING)
     // work-skipping instantiations for tools/ (no MFMA, no fragment reads, ...): profiling build only
     const int abl = env_int("STORM_CONV_ABLATE", 0);
-    if (any9 && !small && abl && variant != 3) {
+    if (any9 && !small && abl && variant != 3 && variant != 4) {
         const bool v2 = variant == 2;
         switch (abl) {
             case 1: return v2 ? launch_conv<T, 9, 2, 4, 2, true, false, 1>(a, st) : launch_conv<T, 9, 2, 2, 2, false, false, 1>(a, st);
@@ -671,6 +678,7 @@ static int dispatch_conv(const storm_conv_args& a, hipStream_t st) {
     if (any9) {
         if (small) return launch_conv<T, 9, 1, 1, 4, false>(a, st);
         if (variant == 3 && conv_pipe_supports(a)) return launch_conv_pipe(a, st);
+        if (variant == 4 && conv_pipe128_supports(a)) return launch_conv_pipe128(a, st);
         if (variant == 2) return launch_conv<T, 9, 2, 4, 2, true>(a, st);
         if (variant == 1) return launch_conv<T, 9, 2, 2, 4, false>(a, st);
         return dma ? launch_conv<T, 9, 2, 2, 2, false, true>(a, st) : launch_conv<T, 9, 2, 2, 2, false, false>(a, st);
@@ -690,6 +698,7 @@ static const char* kernel_name_of(const storm_conv_args& a) {
     const int variant = a.outC <= 32 ? -1 : choose_variant(a, any9);
     if (a.outC <= 32) shape = "1, 1, 4, false, false";
     else if (any9 && variant == 3 && conv_pipe_supports(a)) return conv_pipe_kernel_name(a.dtype);
+    else if (any9 && variant == 4 && conv_pipe128_supports(a)) return conv_pipe128_kernel_name(a.dtype);
     else if (variant == 2) shape = "2, 4, 2, true, false";
     else if (variant == 1) shape = "2, 2, 4, false, false";
     else shape = any9 ? "2, 2, 2, false, true" : "2, 2, 2, false, false";

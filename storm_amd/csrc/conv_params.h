@@ -247,7 +247,7 @@ static inline ConvParams make_params(const storm_conv_args& a) {
 }
 
 // ---- conv_pipe.hip: the K loop as a host-built list of chunk descriptors -----------------------------------
-// One chunk = 64 channels (128 B per pixel) of one run under all its taps.  Everything that does not depend on the
+// One chunk = 64 channels (128 B per pixel; conv_pipe128.hip: 32 channels, 64 B) of one run under all its taps.  Everything that does not depend on the
 // workgroup's batch index is computed on the host, so the kernel's chunk boundary is two scalar loads and a few
 // scalar adds - no per-tap or per-chunk address arithmetic is left in the pipelined loop.
 namespace pipe {
@@ -259,7 +259,7 @@ struct ChunkDesc {                    // 64 bytes
     unsigned int ss_bstride;          // bytes
     unsigned int src_bytes;           // one batch image in bytes (= num_records; 0 in the terminator: every read is zero)
     int C2, cbeg2;                    // pixel stride / this chunk's first channel, in bytes
-    int cvalid, ntaps;                // channels of this chunk (<= 64); 9 or 1
+    int cvalid, ntaps;                // channels of this chunk (<= 64 / 32); 9 or 1
     int silu, wrun;                   // SiLU after the fused affine; index of the weight run
     int w_soff, new_wrun;             // byte offset of the chunk's first weight column inside a weight row; run changes here
 };
@@ -284,5 +284,9 @@ struct PipeParams {
 bool conv_pipe_supports(const storm_conv_args& a);
 int launch_conv_pipe(const storm_conv_args& a, hipStream_t st);
 const char* conv_pipe_kernel_name(int dtype);
+// defined in conv_pipe128.hip: the same pipeline for layers with <= 128 output channels (128 couts x 512 pixels per workgroup)
+bool conv_pipe128_supports(const storm_conv_args& a);
+int launch_conv_pipe128(const storm_conv_args& a, hipStream_t st);
+const char* conv_pipe128_kernel_name(int dtype);
 
 }  // namespace storm

@@ -47,9 +47,7 @@
 // pre-read.
 #include <cstdlib>
 #include <cstring>
-#include <type_traits>
-#include <utility>
-#include "conv_params.h"
+#include "conv_pipe_common.h"
 
 namespace storm {
 using namespace cidx;
@@ -58,9 +56,7 @@ namespace pipe {
 
 constexpr int PW = TILE_W + 2;
 constexpr int PIXB = 128, KC = 64, SLOTS = 8;                 // bytes / channels / 16-B slots per pixel and K-chunk
-constexpr int WROW = 64;                                      // bytes per weight row and phase (two k-groups)
 constexpr int PR = 1;                                         // pixel rows (of 32 px) staged per epilogue pass and wave
-constexpr uint32_t OOB = BUF_OOB;                             // per-lane offset that is out of range of every buffer here
 constexpr int NWAVES = 8, THREADS = 512;
 
 template <int BN_, int TH_> struct PCfg {
@@ -91,36 +87,11 @@ template <int BN_, int TH_> struct PCfg {
     static_assert(NSLOT - 1 + LAZY <= 16, "the whole patch is transformed two phases before a nine-tap chunk ends");
 };
 
-// LDS byte offset of 16-B slot s (0..3) of row `row` of a weight phase tile: the 16 lanes of a ds_read_b128
-// group hit 16 distinct 16-B bank groups.
-STORM_HD int w_off(int row, int s) { return row * WROW + ((s ^ ((row >> 2) & 3)) << 4); }
 // Patch image: pixel row r, 128 B; its eight 16-B slots are XOR-swizzled by the pixel COLUMN ((px >> 1) & 7).
 // 16 lanes of a fragment read are 16 consecutive px -> 16 distinct bank groups; and because the swizzle does not
 // depend on the pixel row, taps / wave rows / buffers are plain additions.
 STORM_HD int p_swz(int px, int slot) { return (slot ^ ((px >> 1) & 7)) << 4; }
 
-template <int N> using IC = std::integral_constant<int, N>;
-template <typename F, int... Is> __device__ __forceinline__ void static_for_impl(F&& f, std::integer_sequence<int, Is...>) {
-    (f(IC<Is>{}), ...);
-}
-template <int N, typename F> __device__ __forceinline__ void static_for(F&& f) {
-    static_for_impl(f, std::make_integer_sequence<int, N>{});
-}
-
-// keep a wave-uniform value in an SGPR (stops re-materialisation from the kernarg segment inside the loop)
-__device__ __forceinline__ int pin(int x) {
-#if defined(__HIP_DEVICE_COMPILE__)
-    asm volatile("" : "+s"(x));
-#endif
-    return x;
-}
-__device__ __forceinline__ int uniform(int x) {
-#if defined(__HIP_DEVICE_COMPILE__)
-    return __builtin_amdgcn_readfirstlane(x);
-#else
-    return x;
-#endif
-}
 }  // namespace pipe
 using namespace pipe;
 
@@ -581,6 +552,18 @@ void conv_pipe_kernel(const PipeParams a, const int n_ct, const int tiles_per_xc
         }
 
             STORM_RELAUNDER();
+#if defined(__HIP_DEVICE_COMPILE__)
+        if (ABL & 1024) {                                   // (profiling: no epilogue; the accumulators stay live)
+#pragma unroll
+            for (int mi = 0; mi < WM; ++mi)
+#pragma unroll
+                for (int ni = 0; ni < WN; ++ni) asm volatile("" ::"v"(acc[mi][ni]));
+            if (!has_next) break;
+            first = false;
+            __syncthreads();
+            continue;
+        }
+#endif
     // ---- epilogue: LDS transpose -> (bias, temb bias, skip, scale) -> wide stores (as conv_igemm.hip).  Staging lives in
         // patch buffer 1 (waves 0-4) and ring slots 2, 3 (waves 5-7): the next tile's first loads are landing in buffer 0 /
         // slots 0, 1 meanwhile.
@@ -648,7 +631,7 @@ void conv_pipe_kernel(const PipeParams a, const int n_ct, const int tiles_per_xc
                 const int gy = e_ty0 + trow, gx = e_tx0 + n;
                 const bool ok = gy < imgH && gx < imgW;
                 const int pix = gy * imgW + gx;
-                if (ok && co_ok) {
+                if (ok && co_ok && !(ABL & 2048)) {
                     if (ap->skip) {
                         float sk[8];
                         load8(skip_b + (uint32_t)(pix * skipC + co), sk);
@@ -664,6 +647,14 @@ void conv_pipe_kernel(const PipeParams a, const int n_ct, const int tiles_per_xc
                     const float v[8] = {v2[0].x, v2[0].y, v2[1].x, v2[1].y, v2[2].x, v2[2].y, v2[3].x, v2[3].y};
                     const uint32_t o = (uint32_t)(pix * ap->outC + co);
                     if (ap->out_f32) store8(reinterpret_cast<float*>(ap->out) + (long long)e_b * ap->out_bstride + o, v);
+                    else if (ABL & 4096) {                       // (profiling A/B: non-temporal output stores)
+                        uint32_t w4[4];
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) w4[i] = sizeof(T) == 2 && Elem<T>::DT == STORM_BF16 ? pack_bf16x2(v[2 * i], v[2 * i + 1]) : pack_f16x2(v[2 * i], v[2 * i + 1]);
+                        typedef uint32_t u32x4_nt __attribute__((ext_vector_type(4)));
+                        u32x4_nt val = {w4[0], w4[1], w4[2], w4[3]};
+                        __builtin_nontemporal_store(val, reinterpret_cast<u32x4_nt*>(reinterpret_cast<T*>(ap->out) + (long long)e_b * ap->out_bstride + o));
+                    }
                     else store8(reinterpret_cast<T*>(ap->out) + (long long)e_b * ap->out_bstride + o, v);
                 }
             }
@@ -705,8 +696,9 @@ void conv_pipe_kernel(const PipeParams a, const int n_ct, const int tiles_per_xc
 #undef STORM_RELAUNDER
 
 // ---- host side ---------------------------------------------------------------------------------------------------
-// The K loop as chunk descriptors.  Returns false when the convolution is outside what the pipelined kernel covers.
-static bool build_pipe_params(const storm_conv_args& a, PipeParams& p) {
+// The K loop as chunk descriptors (declared in conv_pipe_common.h).
+bool pipe::build_pipe_params(const storm_conv_args& a, PipeParams& p, const int kc) {
+    const int pixb = 2 * kc;                                           // bytes per pixel and chunk
     memset(&p, 0, sizeof(p));
     if ((a.dtype != STORM_BF16 && a.dtype != STORM_F16) || a.nseg < 1 || a.seg[0].ntaps != 9) return false;
     int n = 0, nw = 0;
@@ -726,20 +718,20 @@ static bool build_pipe_params(const storm_conv_args& a, PipeParams& p) {
             WRunDesc& R = p.wrun[nw];
             R.w = (unsigned long long)(reinterpret_cast<const char*>(g.w) + 2LL * wc0);
             R.bytes = (unsigned int)w_bytes; R.CinP2 = g.CinP * 2; R.rows = g.w_rows; R.tapbytes = (int)(g.w_tapstride * 2);
-            const int nch = (C + KC - 1) / KC;
+            const int nch = (C + kc - 1) / kc;
             for (int ch = 0; ch < nch; ++ch) {
                 if (n >= MAX_CHUNKS) return false;
                 ChunkDesc& d = p.chunk[n++];
                 d.src = (unsigned long long)(part == 0 ? g.src_a : g.src_b);
                 d.bstride = (unsigned long long)(bstride * 2);
                 d.src_bytes = (unsigned int)img_bytes;
-                d.C2 = C * 2; d.cbeg2 = ch * PIXB; d.cvalid = C - ch * KC < KC ? C - ch * KC : KC;
+                d.C2 = C * 2; d.cbeg2 = ch * pixb; d.cvalid = C - ch * kc < kc ? C - ch * kc : kc;
                 d.ntaps = g.ntaps; d.silu = g.gn_silu;
                 if (g.gn_ss) {
-                    d.ss = (unsigned long long)(g.gn_ss + 2 * (wc0 + ch * KC));
+                    d.ss = (unsigned long long)(g.gn_ss + 2 * (wc0 + ch * kc));
                     d.ss_bstride = (unsigned int)((g.Ca + g.Cb) * 8);
                 }
-                d.wrun = nw; d.w_soff = ch * PIXB; d.new_wrun = ch == 0;
+                d.wrun = nw; d.w_soff = ch * pixb; d.new_wrun = ch == 0;
             }
             ++nw;
         }
@@ -760,7 +752,7 @@ static bool build_pipe_params(const storm_conv_args& a, PipeParams& p) {
 
 bool conv_pipe_supports(const storm_conv_args& a) {
     PipeParams p;
-    return build_pipe_params(a, p);
+    return build_pipe_params(a, p, KC);
 }
 
 template <typename T, int BN, int TH, int ABL>
@@ -773,7 +765,7 @@ static int launch_pipe(const storm_conv_args& a, hipStream_t st) {
         attr_set = true;
     }
     PipeParams prm;
-    STORM_CHECK(build_pipe_params(a, prm), "storm_conv: convolution outside the pipelined kernel's coverage");
+    STORM_CHECK(build_pipe_params(a, prm, KC), "storm_conv: convolution outside the pipelined kernel's coverage");
     const int tiles_x = cdiv(a.W, TILE_W);
     const int tiles_per_img = tiles_x * cdiv(a.H, TH);
     const long long ntiles = (long long)a.B * tiles_per_img;
@@ -817,6 +809,9 @@ int launch_conv_pipe(const storm_conv_args& a, hipStream_t st) {
         case 64: return launch_pipe<bf16_t, 256, 8, 64>(a, st);
         case 256: return launch_pipe<bf16_t, 256, 8, 256>(a, st);       // fragment reads in two bursts per MFMA interval
         case 512: return launch_pipe<bf16_t, 256, 8, 512>(a, st);       // barrier arrival before the last four MFMAs
+        case 4096: return launch_pipe<bf16_t, 256, 8, 4096>(a, st);     // non-temporal output stores
+        case 1024: return launch_pipe<bf16_t, 256, 8, 1024>(a, st);     // no epilogue
+        case 2048: return launch_pipe<bf16_t, 256, 8, 2048>(a, st);     // epilogue without global stores / skip loads
         default: break;
     }
 #endif

@@ -74,29 +74,44 @@ __global__ void gn_stats_kernel(const T* __restrict__ xa, int Ca, const T* __res
 }
 
 // Finalise fused statistics: sum the per-tile fp32 partials of a conv epilogue into [B][G][2] fp64.
-__global__ void gn_finalize_kernel(const float* __restrict__ pa, int Ca, int tiles_a, const float* __restrict__ pb,
-                                   int Cb, int tiles_b, int G, double* __restrict__ stats, long long count,
-                                   const float* __restrict__ gamma, const float* __restrict__ beta, float eps,
-                                   float* __restrict__ ss) {
-    const int g = blockIdx.x, b = blockIdx.y, lane = threadIdx.x;
+__global__ __launch_bounds__(256)
+void gn_finalize_kernel(const float* __restrict__ pa, int Ca, int tiles_a, const float* __restrict__ pb,
+                        int Cb, int tiles_b, int G, double* __restrict__ stats, long long count,
+                        const float* __restrict__ gamma, const float* __restrict__ beta, float eps,
+                        float* __restrict__ ss) {
+    // one workgroup (4 waves) per (group, batch item): the group's gs channels of a tile are contiguous (gs float2), so a
+    // thread walks (tile, channel) pairs with the channel fastest; fp64 partial sums, fixed reduction order (deterministic)
+    __shared__ double red[2][4];
+    const int g = blockIdx.x, b = blockIdx.y, tid = threadIdx.x;
     const int C = Ca + Cb, gs = C / G;
     double s0 = 0.0, s1 = 0.0;
-    for (int k = 0; k < gs; ++k) {
-        const int c = g * gs + k;
-        const float* p; int Cs, cc, nt;
-        if (c < Ca) { p = pa; Cs = Ca; cc = c; nt = tiles_a; } else { p = pb; Cs = Cb; cc = c - Ca; nt = tiles_b; }
-        const float2* q = reinterpret_cast<const float2*>(p) + (long long)b * nt * Cs + cc;
-        for (int t = lane; t < nt; t += 64) { const float2 v = q[(long long)t * Cs]; s0 += (double)v.x; s1 += (double)v.y; }
+    const int c_lo = g * gs, c_hi = c_lo + gs;
+    for (int part = 0; part < 2; ++part) {
+        const float* p = part == 0 ? pa : pb;
+        const int Cs = part == 0 ? Ca : Cb, nt = part == 0 ? tiles_a : tiles_b, off = part == 0 ? 0 : Ca;
+        const int lo = max(c_lo, off) - off, hi = min(c_hi, off + Cs) - off;       // this group's channels inside the part
+        const int w = hi - lo;
+        if (p == nullptr || w <= 0) continue;
+        const float2* q = reinterpret_cast<const float2*>(p) + (long long)b * nt * Cs + lo;
+        for (int i = tid; i < nt * w; i += 256) {
+            const int t = i / w, k = i - t * w;
+            const float2 v = q[(long long)t * Cs + k];
+            s0 += (double)v.x; s1 += (double)v.y;
+        }
     }
     s0 = wave_sum_d(s0); s1 = wave_sum_d(s1);
-    if (lane == 0) { stats[((long long)b * G + g) * 2] = s0; stats[((long long)b * G + g) * 2 + 1] = s1; }
+    if ((tid & 63) == 0) { red[0][tid >> 6] = s0; red[1][tid >> 6] = s1; }
+    __syncthreads();
+    s0 = (red[0][0] + red[0][1]) + (red[0][2] + red[0][3]);
+    s1 = (red[1][0] + red[1][1]) + (red[1][2] + red[1][3]);
+    if (tid == 0) { stats[((long long)b * G + g) * 2] = s0; stats[((long long)b * G + g) * 2 + 1] = s1; }
     if (ss != nullptr) {
         const double n = (double)gs * (double)count;
         const double m = s0 / n;
         double var = s1 / n - m * m;
         if (var < 0.0) var = 0.0;
         const float rstd = (float)(1.0 / sqrt(var + (double)eps));
-        for (int k = lane; k < gs; k += 64) {
+        for (int k = tid; k < gs; k += 256) {
             const int c = g * gs + k;
             const float sc = rstd * gamma[c];
             ss[((long long)b * C + c) * 2] = sc;
@@ -423,7 +438,7 @@ extern "C" int storm_gn_finalize(const float* part_a, int Ca, int tiles_a, const
     if (int e = check_c("storm_gn_finalize", Ca, Cb, groups)) return e;
     STORM_CHECK(part_a && stats && B > 0 && tiles_a > 0, "storm_gn_finalize: bad arguments");
     STORM_CHECK((Cb == 0) == (part_b == nullptr), "storm_gn_finalize: part_b / Cb mismatch");
-    hipLaunchKernelGGL(gn_finalize_kernel, dim3(groups, B), dim3(64), 0, (hipStream_t)s, part_a, Ca, tiles_a, part_b, Cb,
+    hipLaunchKernelGGL(gn_finalize_kernel, dim3(groups, B), dim3(256), 0, (hipStream_t)s, part_a, Ca, tiles_a, part_b, Cb,
                        tiles_b, groups, stats, 0LL, (const float*)nullptr, (const float*)nullptr, 0.f, (float*)nullptr);
     STORM_LAUNCH_CHECK();
     return STORM_OK;
@@ -435,7 +450,7 @@ extern "C" int storm_gn_finalize_ss(const float* part_a, int Ca, int tiles_a, co
     if (int e = check_c("storm_gn_finalize_ss", Ca, Cb, groups)) return e;
     STORM_CHECK(part_a && stats && ss && gamma && beta && B > 0 && tiles_a > 0 && count > 0, "storm_gn_finalize_ss: bad arguments");
     STORM_CHECK((Cb == 0) == (part_b == nullptr), "storm_gn_finalize_ss: part_b / Cb mismatch");
-    hipLaunchKernelGGL(gn_finalize_kernel, dim3(groups, B), dim3(64), 0, (hipStream_t)s, part_a, Ca, tiles_a, part_b, Cb,
+    hipLaunchKernelGGL(gn_finalize_kernel, dim3(groups, B), dim3(256), 0, (hipStream_t)s, part_a, Ca, tiles_a, part_b, Cb,
                        tiles_b, groups, stats, count, gamma, beta, eps, ss);
     STORM_LAUNCH_CHECK();
     return STORM_OK;

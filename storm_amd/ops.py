@@ -57,9 +57,9 @@ class Seg:
         self.gn_ss, self.gn_silu = gn_ss, gn_silu      # fused GroupNorm apply (+SiLU) on load
 
 
-def conv(segs, Cout, out=None, outC=None, bias=None, tbias=None, skip=None, scale=1.0, out_f32=False,
-         B=None, H=None, W=None, gn_partials=False):
-    """out[b,h,w,co] = (sum_seg conv(seg) + bias + tbias[b] + skip) * scale   (storm_conv)."""
+def _conv_args(segs, Cout, out=None, outC=None, bias=None, tbias=None, skip=None, scale=1.0, out_f32=False,
+               B=None, H=None, W=None):
+    """storm_conv_args for a convolution (+ the output tensor it points at)"""
     x = segs[0].src_a
     if B is None:
         B, H, W = x.shape[0], x.shape[1], x.shape[2]
@@ -90,13 +90,25 @@ def conv(segs, Cout, out=None, outC=None, bias=None, tbias=None, skip=None, scal
     if skip is not None:
         a.skip, a.skip_bstride = L.ptr(skip), H * W * outC
     a.scale, a.out_f32, a.dtype = scale, int(out_f32), L.dt(dtype)
+    return a, out
+
+
+def conv(segs, Cout, gn_partials=False, **kw):
+    """out[b,h,w,co] = (sum_seg conv(seg) + bias + tbias[b] + skip) * scale   (storm_conv)."""
+    a, out = _conv_args(segs, Cout, **kw)
     part = None
     if gn_partials:
         tiles = L.lib().storm_conv_tiles(C.byref(a))
-        part = torch.zeros((B, tiles, outC, 2), dtype=torch.float32, device=x.device)
+        part = torch.zeros((a.B, tiles, a.outC, 2), dtype=torch.float32, device=out.device)
         a.gn_part = L.ptr(part)
     L.check(L.lib().storm_conv(C.byref(a), L.stream()), "storm_conv")
     return (out, part) if gn_partials else out
+
+
+def conv_kernel_name(segs, Cout, **kw):
+    """name of the kernel storm_conv launches for these arguments (storm_conv_kernel_name)"""
+    a, _ = _conv_args(segs, Cout, **kw)
+    return L.lib().storm_conv_kernel_name(C.byref(a)).decode()
 
 
 def gn_finalize(part_a, part_b=None, gamma=None, beta=None, count=None, eps=1e-6):

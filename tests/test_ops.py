@@ -147,6 +147,79 @@ def test_conv_pipelined_kernels(dev, variant, case, monkeypatch):
         assert rel_l2(nchw(y)[:, :Cout], F.conv2d(q(x, dtype), q(w, dtype), padding=1)) < 6e-3
 
 
+PIPE128_CASES = {
+    # name: (B, H, W, Cout, (Ca, Cb) of the 3x3 operand, fused GroupNorm on it, (Sa, Sb) of the fused 1x1 shortcut or None, CUs)
+    "plain": (2, 19, 45, 120, (72, 0), False, None, None),            # 3 chunks (the last ragged), ragged tile rows / columns
+    "one_chunk": (1, 16, 32, 128, (32, 0), False, None, None),        # a single nine-tap chunk: the prefetch targets are terminators
+    "one_chunk_tail": (1, 20, 40, 64, (24, 0), False, (40, 0), None), # one nine-tap chunk, then two one-tap chunks
+    "block_tail": (2, 9, 35, 104, (104, 0), False, (72, 16), None),
+    "gn_fused": (2, 10, 36, 40, (72, 56), True, None, None),
+    "deep_k": (1, 18, 33, 120, (136, 88), True, (136, 72), None),     # 5 + 3 nine-tap chunks (fused GN), 5 + 3 one-tap chunks
+    "plain@8": (2, 35, 70, 120, (72, 0), False, None, 8),             # 18 tiles on 8 persistent workgroups
+    "block_tail@8": (2, 35, 70, 104, (40, 0), False, (72, 16), 8),
+    "gn_fused@8": (2, 35, 70, 40, (72, 56), True, None, 8),
+    "gn_fused:f16": (2, 10, 36, 40, (72, 56), True, None, None),
+}
+
+
+@pytest.mark.parametrize("case", list(PIPE128_CASES))
+def test_conv_pipelined_128cout_kernel(dev, case, monkeypatch):
+    """conv_pipe128.hip (128 couts x 16 x 32 pixels per workgroup, 32-channel chunks, triple-buffered patches): plain 3x3, fused
+    1x1 shortcut over a concat, fused GroupNorm-apply operand, ragged sizes, 1 .. 8 nine-tap chunks, persistent tile walk,
+    GroupNorm partials in the 8-row tile layout - on shapes the default dispatch would give to conv_igemm.hip."""
+    from storm_amd import ops
+    B, H, W, Co, (Ca, Cb), gn, one, cus = PIPE128_CASES[case]
+    dtype = torch.float16 if case.endswith(":f16") else torch.bfloat16
+    g = torch.Generator().manual_seed(131)
+    dd = lambda t: t.to(dtype).to(dev)
+    if gn:   # the operand is produced by convs (default dispatch) so that its GroupNorm partials exist
+        x0 = torch.randn(B, 8, H, W, generator=g)
+        wa, wb = torch.randn(Ca, 8, 3, 3, generator=g) * 0.4, torch.randn(max(Cb, 8), 8, 1, 1, generator=g) * 0.7
+        gam, bet = 1 + 0.1 * torch.randn(Ca + Cb, generator=g), 0.1 * torch.randn(Ca + Cb, generator=g)
+        xa, pa = ops.conv([ops.Seg(dd(nhwc(x0)), ops.pack_conv_weight(wa.to(dev), dtype), 9)], Ca, gn_partials=True)
+        xb, pb = ops.conv([ops.Seg(dd(nhwc(x0)), ops.pack_conv_weight(wb.to(dev), dtype), 1)], Cb, gn_partials=True) if Cb else (None, None)
+        _, ss = ops.gn_finalize(pa, pb, gamma=gam.to(dev), beta=bet.to(dev), count=H * W)
+        xcat = torch.cat([nchw(t.float().cpu()) for t in (xa, xb) if t is not None], 1)
+        a_ref = NR.silu(NR.group_norm(xcat, gam, bet))
+    else:
+        xcat = torch.randn(B, Ca + Cb, H, W, generator=g)
+        xa, xb = dd(nhwc(xcat[:, :Ca])), (dd(nhwc(xcat[:, Ca:])) if Cb else None)
+        ss, a_ref = None, xcat
+    w = torch.randn(Co, Ca + Cb, 3, 3, generator=g) * 0.05
+    bias, tb = torch.randn(Co, generator=g), torch.randn(B, Co + 8, generator=g)
+    segs = [ops.Seg(xa, ops.pack_conv_weight(w.to(dev), dtype), 9, src_b=xb, gn_ss=ss, gn_silu=True)]
+    ref = F.conv2d(q(a_ref, dtype), q(w, dtype), padding=1) + bias[None, :, None, None] + tb[:, 8:8 + Co, None, None]
+    skip = None
+    if one is not None:
+        Sa, Sb = one
+        s = torch.randn(B, Sa + Sb, H, W, generator=g)
+        w2 = torch.randn(Co, Sa + Sb, 1, 1, generator=g) * 0.1
+        segs.append(ops.Seg(dd(nhwc(s[:, :Sa])), ops.pack_conv_weight(w2.to(dev), dtype), 1, src_b=dd(nhwc(s[:, Sa:])) if Sb else None))
+        ref = ref + F.conv2d(q(s, dtype), q(w2, dtype))
+    else:
+        skip = torch.randn(B, ops.round_up(Co, 8), H, W, generator=g)
+        ref = ref + q(skip, dtype)[:, :Co]
+        skip = dd(nhwc(skip))
+    ref = ref * 0.5
+    tbd = tb.to(dev)
+    y_generic, part_generic = ops.conv(segs, Co, bias=bias.to(dev), tbias=tbd[:, 8:], skip=skip, scale=0.5, gn_partials=True)
+    monkeypatch.setenv("STORM_CONV_VARIANT", "4")
+    if cus:
+        monkeypatch.setenv("STORM_CONV_CUS", str(cus))
+    assert ops.conv_kernel_name(segs, Co, bias=bias.to(dev), tbias=tbd[:, 8:], skip=skip, scale=0.5).startswith("storm::conv_pipe128_kernel")
+    y, part = ops.conv(segs, Co, bias=bias.to(dev), tbias=tbd[:, 8:], skip=skip, scale=0.5, gn_partials=True)
+    yc = nchw(y.float().cpu())
+    assert rel_l2(yc[:, :Co], ref) < (1e-2 if gn else 6e-3)
+    if yc.shape[1] > Co:
+        assert float(yc[:, Co:].abs().max()) == 0.0
+    # same result as the generic kernel up to the accumulation order; statistics partials in the same 8 x 32 tile layout
+    assert rel_l2(yc, nchw(y_generic.float().cpu())) < 3e-3
+    assert part.shape == part_generic.shape
+    assert torch.allclose(part.cpu(), part_generic.cpu(), rtol=2e-2, atol=2e-2 * float(part_generic.abs().max()))
+    st, sref = ops.gn_finalize(part).cpu(), ops.gn_stats(y).cpu()
+    assert torch.allclose(st, sref, rtol=2e-3, atol=2e-3 * float(sref.abs().max()))
+
+
 @pytest.mark.parametrize("dtype", DTYPES)
 def test_conv_fused_block_tail(dev, dtype):
     """Conv_1 3x3 over h + Conv_2 1x1 over cat[xa, xb] + bias + temb bias, rescaled (layerspp.py:266-274)."""
@@ -495,3 +568,97 @@ def test_attention_block_L2048_vs_reference_golden(golden):
     err = rel_l2(y[:1], g["attn_y"])
     print(f"AttnBlockpp L=2048 bf16 (fused attention) vs reference: rel-L2 {err:.3e}")
     assert err < 2e-2 and torch.equal(y[0], y[1])
+
+
+@pytest.mark.parametrize("tag", ["plain", "up", "down", "widen"])
+def test_resblock_vs_reference_golden(dev, golden, tag):
+    """ResnetBlockBigGANpp (layerspp.py:222-274: plain / up / down / channel-changing) against the REFERENCE's outputs
+    (fixture F1 res_*), composed from the C-ABI ops the way the planner does: GroupNorm(+SiLU)(+FIR of h and x in one
+    pass) -> Conv_0 + bias + Dense_0(act(temb)) with GroupNorm statistics from its epilogue -> GroupNorm+SiLU ->
+    Conv_1 (+ fused 1x1 Conv_2 shortcut | + skip), rescaled.  fp32."""
+    from storm_amd import ops
+    g = golden["f1_ops"]
+    P = {k[len(f"res_{tag}_"):]: torch.from_numpy(g[k]) for k in g.files if k.startswith(f"res_{tag}_")}
+    d = lambda name: P[name].to(dev)
+    dt = torch.float32
+    x = nhwc(P["x"]).to(dev)
+    Cout = P["Conv_0.weight"].shape[0]
+    st0 = ops.gn_stats(x)
+    if tag in ("up", "down"):
+        h, xr = ops.gn_apply(x, st0, d("GroupNorm_0.weight"), d("GroupNorm_0.bias"), resample=1 if tag == "up" else 2)
+    else:
+        h, xr = ops.gn_apply(x, st0, d("GroupNorm_0.weight"), d("GroupNorm_0.bias")), x
+    tb = ops.dense(F.silu(P["temb"]).to(dev), d("Dense_0.weight"), d("Dense_0.bias"))
+    h, part = ops.conv([ops.Seg(h, ops.pack_conv_weight(d("Conv_0.weight"), dt), 9)], Cout, bias=d("Conv_0.bias"), tbias=tb,
+                       gn_partials=True)
+    st1 = ops.gn_finalize(part)
+    ref1 = ops.gn_stats(h)
+    assert torch.allclose(st1.cpu(), ref1.cpu(), rtol=1e-5, atol=1e-5 * float(ref1.abs().max()))
+    h = ops.gn_apply(h, st1, d("GroupNorm_1.weight"), d("GroupNorm_1.bias"))
+    segs = [ops.Seg(h, ops.pack_conv_weight(d("Conv_1.weight"), dt), 9)]
+    if "Conv_2.weight" in P:
+        segs.append(ops.Seg(xr, ops.pack_conv_weight(d("Conv_2.weight"), dt), 1))
+        y = ops.conv(segs, Cout, bias=d("Conv_1.bias") + d("Conv_2.bias"), scale=2 ** -0.5)
+    else:
+        y = ops.conv(segs, Cout, bias=d("Conv_1.bias"), skip=xr, scale=2 ** -0.5)
+    assert rel_l2(nchw(y.cpu()), P["y"]) < 5e-6
+
+
+def test_attnblock_vs_reference_golden(dev, golden):
+    """AttnBlockpp (layerspp.py:60-91) against the REFERENCE's output (fixture F1 attn_*), fp32, op-by-op path of the
+    planner: GroupNorm -> NIN q, k, v (1x1 GEMMs) -> scores by the batched GEMM -> row softmax -> weights x v -> NIN_3 + skip."""
+    from storm_amd import ops
+    g = golden["f1_ops"]
+    P = {k[len("attn_"):]: torch.from_numpy(g[k]) for k in g.files if k.startswith("attn_")}
+    d = lambda name: P[name].to(dev)
+    dt = torch.float32
+    B, C, H, W = P["x"].shape
+    Lp = H * W
+    x = nhwc(P["x"]).to(dev)
+    h = ops.gn_apply(x, ops.gn_stats(x), d("GroupNorm_0.weight"), d("GroupNorm_0.bias"), silu=False).reshape(B, 1, Lp, C)
+    Wm = [ops.pack_matrix(d(f"NIN_{i}.W"), dt, transpose=True) for i in range(4)]
+    q = ops.conv([ops.Seg(h, Wm[0], 1)], C, bias=d("NIN_0.b"))
+    k = ops.conv([ops.Seg(h, Wm[1], 1)], C, bias=d("NIN_1.b"))
+    v = ops.conv([ops.Seg(h, Wm[2], 1)], C, bias=d("NIN_2.b"))
+    # reference semantics through torch on the HIP tensors' VALUES would hide the kernels: use the row softmax kernel and
+    # the batched-weights GEMM (scores[b] = q[b] k[b]^T: k as the per-batch weight matrix, rows padded to 32)
+    LpP = ops.round_up(Lp, 32)
+    kw = torch.zeros(B, LpP, C, device=dev); kw[:, :Lp] = k.reshape(B, Lp, C)
+    s = ops.conv([ops.Seg(q, kw.reshape(B, 1, LpP, C), 1, w_batched=True)], Lp, outC=LpP, scale=C ** -0.5)
+    w = ops.softmax_rows(s.reshape(B, Lp, LpP), dt, valid=Lp)
+    vT = torch.zeros(B, ops.round_up(C, 32), LpP, device=dev); vT[:, :C, :Lp] = v.reshape(B, Lp, C).transpose(1, 2)
+    o = ops.conv([ops.Seg(w.reshape(B, 1, Lp, LpP), vT.reshape(B, 1, -1, LpP), 1, w_batched=True)], C)
+    y = ops.conv([ops.Seg(o, Wm[3], 1)], C, bias=d("NIN_3.b"), skip=x.reshape(B, 1, Lp, C), scale=2 ** -0.5)
+    assert rel_l2(nchw(y.reshape(B, H, W, C).cpu()), P["y"]) < 5e-6
+
+
+@pytest.mark.parametrize("fac", [0.15, 0.33])
+def test_frontend_4s_vs_reference_golden(dev, golden, fac):
+    """4 s utterance (64000 samples -> 500 frames padded to 512): spectrogram slice around the padded-frame boundary and the
+    head / tail of the resynthesised waveform against the reference (fixture F5 L64000_*)."""
+    from storm_amd import ops
+    g = golden["f5_frontend"]
+    key = f"L64000_f{int(fac * 100)}"
+    y = torch.randn(1, 64000, generator=torch.Generator().manual_seed(1234 + 64000)) * 0.1
+    yd = y.to(dev)
+    Y = ops.stft(yd, ops.peak_abs(yd), spec_factor=fac, spec_abs_exponent=0.5, pad_to=64)
+    assert Y.shape == (1, 256, 512)
+    assert rel_l2(Y[..., 245:262].cpu(), torch.from_numpy(g[f"{key}_Yslice"])[0]) < 5e-6
+    w = ops.istft(Y, 64000, None, spec_factor=fac, spec_abs_exponent=0.5).cpu()
+    assert rel_l2(w[..., -512:], g[f"{key}_wavtail"]) < 5e-6
+    assert rel_l2(w[..., :512], g[f"{key}_wavhead"]) < 5e-6
+
+
+@pytest.mark.parametrize("e,fac", [(0.5, 0.15), (1.0, 1.0), (0.667, 0.065)])
+def test_spec_transform_standalone(dev, e, fac):
+    """storm_spec_transform == spec_fwd / spec_back (data_module.py:182-207) and they invert each other"""
+    from storm_amd import ops
+    from oracle import frontend_ref as FR
+    g = torch.Generator().manual_seed(77)
+    s = torch.complex(torch.randn(2, 256, 40, generator=g), torch.randn(2, 256, 40, generator=g))
+    s[0, 0, 0] = 0                                            # |z| = 0: angle 0, stays 0
+    f = ops.spec_transform(s.to(dev), fac, e, inverse=False)
+    assert rel_l2(f.cpu(), FR.spec_fwd(s, fac, e)) < 2e-6
+    b = ops.spec_transform(f, fac, e, inverse=True)
+    assert rel_l2(b.cpu(), FR.spec_back(FR.spec_fwd(s, fac, e), fac, e)) < 2e-6
+    assert rel_l2(b.cpu(), s) < 5e-6

@@ -25,4 +25,7 @@ for (k, grid), c in sorted(acc.items()):
     for n in ("SQ_WAVE_CYCLES", "SQ_WAIT_ANY", "SQ_WAIT_INST_ANY", "SQ_ACTIVE_INST_ANY"):
         if n in med and med.get("SQ_WAVE_CYCLES"):
             line += f"  {n[3:]} {med[n] / med['SQ_WAVE_CYCLES']:5.3f}" if n != "SQ_WAVE_CYCLES" else ""
+    for n in ("SQ_LDS_BANK_CONFLICT", "SQ_LDS_IDX_ACTIVE"):
+        if n in med and gui:
+            line += f"  {n[3:]}/cyc {med[n] / (gui * 256):6.3f}"          # per CU and cycle
     print(line)

@@ -1,0 +1,58 @@
+#!/usr/bin/env python
+"""A/B probe of the <= 128-cout 3x3 layers of the bench shape: conv_pipe128.hip vs conv_igemm.hip (STORM_CONV_PIPE128=0),
+with the fusions the network uses (GroupNorm-apply operand, statistics epilogue, temb bias, fused 1x1 shortcut)."""
+import argparse
+import os
+import sys
+
+import torch
+
+sys.path.insert(0, ".")
+from storm_amd import ops  # noqa: E402
+
+p = argparse.ArgumentParser()
+p.add_argument("--reps", type=int, default=5)
+p.add_argument("--B", type=int, default=16)
+p.add_argument("--nogn", action="store_true", help="plain operand: no fused GroupNorm-apply + SiLU on the load")
+p.add_argument("--only", type=int, default=-1)
+args = p.parse_args()
+dev, dt = torch.device("cuda:0"), torch.bfloat16
+g = torch.Generator().manual_seed(0)
+rnd = lambda *s: torch.randn(*s, generator=g)  # noqa: E731
+
+# (name, H, W, cin of the 3x3 operand, channels of the fused 1x1 shortcut or 0): idx 6/8, 105, 109, 107/111, 11, 13 of the op list
+CASES = [("128->128 @256x512", 256, 512, 128, 0), ("384->128 @256x512", 256, 512, 384, 0), ("256->128 @256x512", 256, 512, 256, 0),
+         ("128->128 +1x1(256) @256x512", 256, 512, 128, 256), ("128->128 @128x256", 128, 256, 128, 0),
+         ("128->128 +1x1(128) @128x256", 128, 256, 128, 128), ("128->128 @256x1024 (8 s)", 256, 1024, 128, 0)]
+ev = lambda: torch.cuda.Event(enable_timing=True)  # noqa: E731
+for ci_, (name, H, W, cin, sc) in enumerate(CASES):
+    if args.only >= 0 and ci_ != args.only:
+        continue
+    B = args.B if W <= 512 else args.B // 2
+    cout = 128
+    x = rnd(B, H, W, cin).to(dt).to(dev)
+    w = ops.pack_conv_weight((rnd(cout, cin, 3, 3) * 0.05).to(dev), dt)
+    ss = torch.stack([1 + 0.1 * rnd(B, cin), 0.1 * rnd(B, cin)], -1).contiguous().to(dev)
+    segs = [ops.Seg(x, w, 9, gn_ss=None if args.nogn else ss, gn_silu=True)]
+    kw = dict(bias=rnd(cout).to(dev), tbias=rnd(B, cout).to(dev), gn_partials=True, scale=0.7)
+    if sc:
+        segs.append(ops.Seg(rnd(B, H, W, sc).to(dt).to(dev), ops.pack_conv_weight((rnd(cout, sc, 1, 1) * 0.05).to(dev), dt), 1))
+    fl = 2 * B * H * W * cout * (cin * 9 + sc)
+    out = {}
+    for sw in ("1", "0"):
+        os.environ["STORM_CONV_PIPE128"] = sw
+        kn = ops.conv_kernel_name(segs, cout, bias=kw["bias"], tbias=kw["tbias"], scale=0.7)
+        for _ in range(2):
+            y, part = ops.conv(segs, cout, **kw)
+        e0, e1 = ev(), ev()
+        e0.record()
+        for _ in range(args.reps):
+            y, part = ops.conv(segs, cout, **kw)
+        e1.record()
+        torch.cuda.synchronize()
+        ms = e0.elapsed_time(e1) / args.reps
+        out[sw] = (ms, y.float(), part, kn)
+    d = (out["1"][1] - out["0"][1]).norm() / out["0"][1].norm()
+    pd = (out["1"][2] - out["0"][2]).abs().max() / out["0"][2].abs().max()
+    print(f"{name:34s} pipe128 {out['1'][0]:.3f} ms {fl / out['1'][0] / 1e9:6.0f} TF | igemm {out['0'][0]:.3f} ms {fl / out['0'][0] / 1e9:6.0f} TF"
+          f" | rel diff {float(d):.2e} partials {float(pd):.2e} | {out['1'][3].split('<')[0]}")
