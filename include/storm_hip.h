@@ -77,8 +77,8 @@ typedef struct storm_conv_seg {
     int ntaps;                  /* 9 (3x3, pad 1) or 1                                    */
     long long w_bstride;        /* elements between per-batch weight matrices, 0 = shared */
     long long w_tapstride;      /* elements between taps of w                             */
-    const float* gn_ss;         /* optional: fused GroupNorm apply on load, fp32 [B][Ca+Cb][2] =
-                                   (scale, shift) per batch item and channel from storm_gn_finalize:
+    const float* gn_ss;         /* optional: fused GroupNorm apply on load: the fp32 (scale, shift) table storm_gn_finalize_ss
+                                   writes, [B][(Ca+Cb)/8][2][8] (per 8 channels: their 8 scales, then their 8 shifts);
                                    the conv consumes act(x*scale+shift) (zero padded) instead of x   */
     int gn_silu;                /* apply SiLU after the affine                            */
 } storm_conv_seg;
@@ -139,7 +139,8 @@ int storm_gn_stats(const void* xa, int Ca, const void* xb, int Cb, int B, int HW
 int storm_gn_finalize(const float* part_a, int Ca, int tiles_a, const float* part_b, int Cb, int tiles_b,
                       int B, int groups, double* stats, storm_stream_t s);
 /* Same, and also the per-channel affine of the normalisation for consumers that fuse the apply:
- * ss[b][c] = (rstd*gamma[c], beta[c] - mean*rstd*gamma[c]); count = elements per channel (H*W). */
+ * scale[c] = rstd*gamma[c], shift[c] = beta[c] - mean*rstd*gamma[c], stored as ss [B][C/8][2][8] (the 8 scales of a channel
+ * octet, then its 8 shifts: the order the kernels' packed fp32 math reads them in); count = elements per channel (H*W). */
 int storm_gn_finalize_ss(const float* part_a, int Ca, int tiles_a, const float* part_b, int Cb, int tiles_b,
                          int B, int groups, long long count, const float* gamma, const float* beta, float eps,
                          double* stats, float* ss, storm_stream_t s);

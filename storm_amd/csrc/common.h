@@ -44,9 +44,11 @@ __device__ inline uint32_t pack_bf16x2(float lo, float hi) {
 #ifdef STORM_HOST_SIM
     return (uint32_t)f32_to_bf16_bits(lo) | ((uint32_t)f32_to_bf16_bits(hi) << 16);
 #else
-    uint32_t r;
-    asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(r) : "v"(lo), "v"(hi));
-    return r;
+    // (the compiler's own conversion, not inline asm: behind an asm statement the hazard recognizer cannot see the consumer, and
+    // a v_cvt_pk_bf16_f32 issued straight after the v_dot2c_f32_bf16 that produced its operand read the STALE register on gfx950)
+    typedef __bf16 v2bf_ __attribute__((ext_vector_type(2)));
+    const f32x2 v = {lo, hi};
+    return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, v2bf_));
 #endif
 }
 // fp16 <-> f32 (round-to-nearest-even; the compiler's _Float16 conversions: v_cvt_f16_f32 / v_cvt_f32_f16 on the device)
@@ -78,6 +80,38 @@ __device__ inline float hw_rcp(float x) {
 #endif
 }
 __device__ inline float fast_silu(float y) { return y * hw_rcp(1.0f + hw_exp2(-1.44269504088896341f * y)); }
+// the same on a channel pair: everything but the two transcendentals per element is a packed fp32 operation
+__device__ __forceinline__ f32x2 silu2(f32x2 y) {
+    const f32x2 a = y * f32x2{-1.44269504088896341f, -1.44269504088896341f};
+    const f32x2 d = f32x2{hw_exp2(a.x), hw_exp2(a.y)} + f32x2{1.0f, 1.0f};
+    return y * f32x2{hw_rcp(d.x), hw_rcp(d.y)};
+}
+
+// acc + x.lo * w.lo + x.hi * w.hi on a dword of two 16-bit values (v_dot2c_f32_bf16 / v_dot2c_f32_f16): a filter tap on packed
+// 16-bit data without unpacking - w = (weight, 0) adds the low channel's tap, (0, weight) the high channel's.  With one half
+// of w zero and a weight of few mantissa bits the product is exact in fp32: the same value as fmaf(weight, x, acc).
+__device__ __forceinline__ float dot2_acc(uint32_t x, uint32_t w, float acc, bf16_t*) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    typedef __bf16 v2bf __attribute__((ext_vector_type(2)));
+    return __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(v2bf, x), __builtin_bit_cast(v2bf, w), acc, false);
+#else
+    return fmaf(bf16_bits_to_f32((uint16_t)(x & 0xffffu)), bf16_bits_to_f32((uint16_t)(w & 0xffffu)),
+                fmaf(bf16_bits_to_f32((uint16_t)(x >> 16)), bf16_bits_to_f32((uint16_t)(w >> 16)), acc));
+#endif
+}
+__device__ __forceinline__ float dot2_acc(uint32_t x, uint32_t w, float acc, half_t*) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    typedef _Float16 v2h __attribute__((ext_vector_type(2)));
+    return __builtin_amdgcn_fdot2(__builtin_bit_cast(v2h, x), __builtin_bit_cast(v2h, w), acc, false);
+#else
+    return fmaf(f16_bits_to_f32((uint16_t)(x & 0xffffu)), f16_bits_to_f32((uint16_t)(w & 0xffffu)),
+                fmaf(f16_bits_to_f32((uint16_t)(x >> 16)), f16_bits_to_f32((uint16_t)(w >> 16)), acc));
+#endif
+}
+__device__ __forceinline__ uint32_t pack2(float lo, float hi, bf16_t*) { return pack_bf16x2(lo, hi); }
+__device__ __forceinline__ uint32_t pack2(float lo, float hi, half_t*) { return pack_f16x2(lo, hi); }
+__device__ __forceinline__ uint32_t tap_weight_bits(float w, bf16_t*) { return f32_to_bf16_bits(w); }   // (exact for the FIR taps)
+__device__ __forceinline__ uint32_t tap_weight_bits(float w, half_t*) { return f32_to_f16_bits(w); }
 
 template <typename T> struct Elem;
 template <> struct Elem<float> {

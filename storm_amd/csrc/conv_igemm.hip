@@ -207,13 +207,9 @@ __device__ __forceinline__ void conv_tile(const ConvParams& a, const int vblock,
     auto patch_commit = [&](const Chunk& c, char* dst, int i0, int i1) {
         float ss[16];
         if (c.gn_ss != nullptr) {
-            const float* q = c.gn_ss + 2 * ((tid & 7) * PER16);
 #pragma unroll
-            for (int i = 0; i < 2 * PER16; i += 4) {
-                float4 t4 = make_float4(1.f, 0.f, 1.f, 0.f);
-                if ((tid & 7) * PER16 < c.cvalid) t4 = *reinterpret_cast<const float4*>(q + i);
-                ss[i] = t4.x; ss[i + 1] = t4.y; ss[i + 2] = t4.z; ss[i + 3] = t4.w;
-            }
+            for (int i = 0; i < 8; ++i) { ss[i] = 1.f; ss[8 + i] = 0.f; }
+            if ((tid & 7) * PER16 < c.cvalid) load_ss<PER16>(c.gn_ss, tid & 7, ss);
         }
 #pragma unroll
         for (int i = 0; i < Cfg::PU; ++i) {
@@ -276,12 +272,7 @@ __device__ __forceinline__ void conv_tile(const ConvParams& a, const int vblock,
                 const int slot = (lane & 7) ^ (((p % PW) >> 1) & 7);
                 uint4* const q = reinterpret_cast<uint4*>(dst + k * 1024 + lane * 16);
                 float ss[16];
-                const float* t = reinterpret_cast<const float*>(smem + Cfg::OFF_SS) + 2 * PER16 * slot;
-#pragma unroll
-                for (int j = 0; j < 2 * PER16; j += 4) {
-                    const float4 t4 = *reinterpret_cast<const float4*>(t + j);
-                    ss[j] = t4.x; ss[j + 1] = t4.y; ss[j + 2] = t4.z; ss[j + 3] = t4.w;
-                }
+                load_ss<PER16>(reinterpret_cast<const float*>(smem + Cfg::OFF_SS), slot, ss);
                 *q = gn_act_slot(*q, ss, c.gn_silu, (T*)nullptr);
             }
         }

@@ -156,17 +156,21 @@ __device__ __forceinline__ void prio(int p) {
 #endif
 }
 
-// y = act(x * scale + shift) on the 16-byte slot held in `v` (GroupNorm-apply + SiLU fused into the
-// operand load: the normalised tensor is never written to HBM).
+// y = act(x * scale + shift) on the 16-byte slot held in `v` (GroupNorm-apply + SiLU fused into the operand load: the
+// normalised tensor is never written to HBM).  ss = the slot's channels' scales in ss[0 .. PER16), shifts in ss[8 .. 8 + PER16)
+// (the table layout of storm_gn_finalize_ss), so channel pairs are adjacent registers and the affine, the exponent scaling,
+// the +1 and the final product are packed fp32 operations; the two transcendentals per element (v_exp_f32, v_rcp_f32:
+// quarter rate) are 70 % of what is left - this transform costs 11-30 % of a fused convolution's time.
+__device__ __forceinline__ f32x2 gn_affine2(f32x2 x, const float (&ss)[16], int i) {
+    return __builtin_elementwise_fma(x, f32x2{ss[2 * i], ss[2 * i + 1]}, f32x2{ss[8 + 2 * i], ss[8 + 2 * i + 1]});
+}
 __device__ __forceinline__ uint4 gn_act_slot(uint4 v, const float (&ss)[16], int silu, bf16_t*) {
     uint32_t w[4] = {v.x, v.y, v.z, v.w};
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-        float lo = __uint_as_float(w[i] << 16), hi = __uint_as_float(w[i] & 0xffff0000u);
-        lo = fmaf(lo, ss[4 * i], ss[4 * i + 1]);
-        hi = fmaf(hi, ss[4 * i + 2], ss[4 * i + 3]);
-        if (silu) { lo = fast_silu(lo); hi = fast_silu(hi); }
-        w[i] = pack_bf16x2(lo, hi);
+        f32x2 y = gn_affine2(f32x2{__uint_as_float(w[i] << 16), __uint_as_float(w[i] & 0xffff0000u)}, ss, i);
+        if (silu) y = silu2(y);
+        w[i] = pack_bf16x2(y.x, y.y);
     }
     return make_uint4(w[0], w[1], w[2], w[3]);
 }
@@ -174,11 +178,9 @@ __device__ __forceinline__ uint4 gn_act_slot(uint4 v, const float (&ss)[16], int
     uint32_t w[4] = {v.x, v.y, v.z, v.w};
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-        float lo = f16_bits_to_f32((uint16_t)(w[i] & 0xffffu)), hi = f16_bits_to_f32((uint16_t)(w[i] >> 16));
-        lo = fmaf(lo, ss[4 * i], ss[4 * i + 1]);
-        hi = fmaf(hi, ss[4 * i + 2], ss[4 * i + 3]);
-        if (silu) { lo = fast_silu(lo); hi = fast_silu(hi); }
-        w[i] = pack_f16x2(lo, hi);
+        f32x2 y = gn_affine2(f32x2{f16_bits_to_f32((uint16_t)(w[i] & 0xffffu)), f16_bits_to_f32((uint16_t)(w[i] >> 16))}, ss, i);
+        if (silu) y = silu2(y);
+        w[i] = pack_f16x2(y.x, y.y);
     }
     return make_uint4(w[0], w[1], w[2], w[3]);
 }
@@ -186,10 +188,22 @@ __device__ __forceinline__ uint4 gn_act_slot(uint4 v, const float (&ss)[16], int
     float x[4] = {__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w)};
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-        x[i] = fmaf(x[i], ss[2 * i], ss[2 * i + 1]);
+        x[i] = fmaf(x[i], ss[i], ss[8 + i]);
         if (silu) x[i] = silu_f(x[i]);
     }
     return make_uint4(__float_as_uint(x[0]), __float_as_uint(x[1]), __float_as_uint(x[2]), __float_as_uint(x[3]));
+}
+// The PER16 scales / shifts of 16-byte slot `slot` of a chunk from its (scale, shift) table (global memory or its LDS image):
+// 16-bit operands: slot = one channel octet = 16 consecutive floats; fp32: half an octet.
+template <int PER16>
+__device__ __forceinline__ void load_ss(const float* table, int slot, float (&ss)[16]) {
+    const float* q = table + (PER16 == 8 ? 16 * slot : 16 * (slot >> 1) + 4 * (slot & 1));
+#pragma unroll
+    for (int j = 0; j < PER16; j += 4) {
+        const float4 a = *reinterpret_cast<const float4*>(q + j), b = *reinterpret_cast<const float4*>(q + 8 + j);
+        ss[j] = a.x; ss[j + 1] = a.y; ss[j + 2] = a.z; ss[j + 3] = a.w;
+        ss[8 + j] = b.x; ss[9 + j] = b.y; ss[10 + j] = b.z; ss[11 + j] = b.w;
+    }
 }
 
 

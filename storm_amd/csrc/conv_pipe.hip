@@ -272,12 +272,7 @@ void conv_pipe_kernel(const PipeParams a, const int n_ct, const int tiles_per_xc
             if ((int)v >= 0 && (int)(v & 7u) * 8 < nx_cvalid) {
                 uint4* const q = reinterpret_cast<uint4*>(smem + into * PATCH_BYTES + k * 1024 + lane * 16);
                 float ss[16];
-                const float* t = reinterpret_cast<const float*>(smem + OFF_SS + into * 1024) + 16 * (v & 7u);
-#pragma unroll
-                for (int j = 0; j < 16; j += 4) {
-                    const float4 t4 = *reinterpret_cast<const float4*>(t + j);
-                    ss[j] = t4.x; ss[j + 1] = t4.y; ss[j + 2] = t4.z; ss[j + 3] = t4.w;
-                }
+                load_ss<8>(reinterpret_cast<const float*>(smem + OFF_SS + into * 1024), (int)(v & 7u), ss);
                 *q = gn_act_slot(*q, ss, nx_silu, (T*)nullptr);
             }
         }

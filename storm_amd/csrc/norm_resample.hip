@@ -7,6 +7,7 @@
 // reduced per thread in fp32 over <=256 pixels, then in fp64 across threads / workgroups
 // (one fp64 atomicAdd per (batch, group) per workgroup).  The resampling variants fuse
 // GN-apply + SiLU + FIR of BOTH the activated and the raw tensor (BigGAN block) in one pass.
+#include <cstdlib>
 #include "common.h"
 
 namespace storm {
@@ -114,8 +115,9 @@ void gn_finalize_kernel(const float* __restrict__ pa, int Ca, int tiles_a, const
         for (int k = tid; k < gs; k += 256) {
             const int c = g * gs + k;
             const float sc = rstd * gamma[c];
-            ss[((long long)b * C + c) * 2] = sc;
-            ss[((long long)b * C + c) * 2 + 1] = beta[c] - (float)m * sc;
+            float* const o = ss + ((long long)b * C + (c & ~7)) * 2 + (c & 7);     // [C/8][2][8]: 8 scales, then 8 shifts
+            o[0] = sc;
+            o[8] = beta[c] - (float)m * sc;
         }
     }
 }
@@ -208,131 +210,209 @@ __global__ void gn_apply_kernel(const T* __restrict__ xa, int Ca, const T* __res
 // a workgroup stages a 10x18-pixel input tile (8x16 core + 1-pixel halo) of one 128-byte channel
 // group, applying the normalisation + SiLU ONCE per input element, then filters from LDS.
 // Output tile: 4x8 pixels (down) / 16x32 pixels (up).
+// Persistent workgroups with a register prefetch: a workgroup walks a contiguous run of tiles (so its GroupNorm table rarely
+// changes and the halo columns it shares with its previous tile are L2 / L1 hits); the NEXT tile's
+// global loads are issued as soon as the current tile's registers have been written to LDS, so they fly under the
+// current tile's filter + stores (with one tile per workgroup the kernel was bound by the load -> transform -> store
+// latency chain at 3 workgroups per CU: 1.7 TB/s down / 3.3 TB/s up).
 constexpr int RS_IH = 10, RS_IW = 18, RS_NPIX = RS_IH * RS_IW;
 template <typename T, int RESAMPLE>
 __global__ __launch_bounds__(256)
 void gn_apply_resample_kernel(const T* __restrict__ xa, int Ca, const T* __restrict__ xb, int Cb,
                               int H, int W, int G, const double* __restrict__ stats,
                               const float* __restrict__ gamma, const float* __restrict__ beta, float eps,
-                              int silu, T* __restrict__ out_act, T* __restrict__ out_raw, int tiles_x, int tiles_y) {
+                              int silu, T* __restrict__ out_act, T* __restrict__ out_raw, int tiles_x, int tiles_y, int ncg,
+                              int total_tiles) {
     constexpr int PER16 = Elem<T>::PER16;           // elements per 16-byte slot
     constexpr int CG = 8 * PER16;                   // channels per workgroup (128 B per pixel)
     __shared__ __attribute__((aligned(16))) char tile[2 * RS_NPIX * 128];
+    __shared__ float gtab[2 * CG];
     char* const t_act = tile;
     char* const t_raw = tile + RS_NPIX * 128;
-    const int C = Ca + Cb, b = blockIdx.y, tid = threadIdx.x;
-    int bid = blockIdx.x;
-    const int tx = bid % tiles_x; bid /= tiles_x;
-    const int ty = bid % tiles_y; const int cg = bid / tiles_y;
+    const int C = Ca + Cb, tid = threadIdx.x;
     const int slot = tid & 7;
-    const int c = cg * CG + slot * PER16;           // first channel of this thread's 16-byte slot
-    const bool cvalid = c < C;
     const int OH = RESAMPLE == 1 ? 2 * H : H / 2, OW = RESAMPLE == 1 ? 2 * W : W / 2;
-    const int iy0 = ty * 8 - 1, ix0 = tx * 16 - 1;  // input tile origin (core starts at ty*8, tx*16)
-    // GN parameters of the workgroup's CG channels: one thread per channel does the fp64 statistics math once
-    // (scale, shift with y = x * scale + shift), everyone else reads the LDS table after the tile loads are in flight
-    __shared__ float gtab[2 * CG];
     const int gs = C / G;
-    if (tid < CG) {
-        const int cc = cg * CG + tid;
-        float sc = 0.f, sh = 0.f;
-        if (cc < C) {
-            const double n = (double)gs * H * W;
-            const int g = cc / gs;
-            const double m = stats[((long long)b * G + g) * 2] / n;
-            double var = stats[((long long)b * G + g) * 2 + 1] / n - m * m;
-            if (var < 0.0) var = 0.0;
-            const float pm = (float)m;
-            sc = (float)(1.0 / sqrt(var + (double)eps)) * gamma[cc];
-            sh = beta[cc] - pm * sc;
-        }
-        gtab[2 * tid] = sc; gtab[2 * tid + 1] = sh;
-    }
-    const long long ibase = (long long)b * H * W;
-    // ---- stage: raw + activated input tile -> LDS (zeros outside the image) ----
-    // all global loads of the thread are issued before the first dependent use (one memory round trip)
     constexpr int NU = (RS_NPIX * 8 + 255) / 256;
-    uint4 rawv[NU];
-    bool okv[NU];
-#pragma unroll
-    for (int k = 0; k < NU; ++k) {
-        const int u = tid + k * 256;
-        const int p = u >> 3;                        // (u & 7) == slot because 256 % 8 == 0
-        const int py = p / RS_IW, px = p - py * RS_IW;
-        const int iy = iy0 + py, ix = ix0 + px;
-        okv[k] = (u < RS_NPIX * 8) && cvalid && iy >= 0 && iy < H && ix >= 0 && ix < W;
-        rawv[k] = make_uint4(0u, 0u, 0u, 0u);
-        if (okv[k]) {
-            const long long pix = ibase + (long long)iy * W + ix;
-            const T* src = (c < Ca) ? (xa + pix * Ca + c) : (xb + pix * Cb + (c - Ca));
-            rawv[k] = *reinterpret_cast<const uint4*>(src);
-        }
-    }
-    __syncthreads();                                   // gtab visible (the tile loads above are already in flight)
-    float pa[PER16], pb[PER16];
-#pragma unroll
-    for (int e = 0; e < PER16; ++e) { pa[e] = gtab[2 * (slot * PER16 + e)]; pb[e] = gtab[2 * (slot * PER16 + e) + 1]; }
-#pragma unroll
-    for (int k = 0; k < NU; ++k) {
-        const int u = tid + k * 256;
-        if (u >= RS_NPIX * 8) continue;
-        const int p = u >> 3;
-        alignas(16) T raw[PER16];
-        alignas(16) T act[PER16];
-        *reinterpret_cast<uint4*>(raw) = rawv[k];
-        if (okv[k]) {
-#pragma unroll
-            for (int e = 0; e < PER16; ++e) {
-                float y = fmaf(to_f32(raw[e]), pa[e], pb[e]);
-                if (silu) y = (sizeof(T) == 2) ? fast_silu(y) : silu_f(y);
-                from_f32(act[e], y);
-            }
-        } else {
-            *reinterpret_cast<uint4*>(act) = make_uint4(0u, 0u, 0u, 0u);
-        }
-        *reinterpret_cast<uint4*>(t_raw + p * 128 + slot * 16) = rawv[k];
-        *reinterpret_cast<uint4*>(t_act + p * 128 + slot * 16) = *reinterpret_cast<const uint4*>(act);
-    }
-    __syncthreads();
-    if (!cvalid) return;
-    // ---- filter from LDS ----
     constexpr int TOH = RESAMPLE == 1 ? 16 : 4, TOW = RESAMPLE == 1 ? 32 : 8;
-    const long long obase = (long long)b * OH * OW;
-    for (int u = tid; u < TOH * TOW * 8; u += 256) {
-        const int q = u >> 3;
-        const int oy_l = q / TOW, ox_l = q - oy_l * TOW;
-        const int oy = ty * TOH + oy_l, ox = tx * TOW + ox_l;
-        if (oy >= OH || ox >= OW) continue;
-        float va[PER16], vr[PER16];
+
+    struct TileId { int b, cg, ty, tx; };
+    auto decode = [&](int t) {                       // tx fastest, then ty, channel group, batch item
+        TileId d;
+        d.tx = t % tiles_x; t /= tiles_x;
+        d.ty = t % tiles_y; t /= tiles_y;
+        d.cg = t % ncg; d.b = t / ncg;
+        return d;
+    };
+    uint4 rawv[NU];
+    unsigned okmask = 0;
+    // all global loads of a tile are issued back to back (one memory round trip), zeros outside the image
+    auto load_tile = [&](const TileId& d) {
+        const int c = d.cg * CG + slot * PER16;
+        const bool cvalid = c < C;
+        const int iy0 = d.ty * 8 - 1, ix0 = d.tx * 16 - 1;
+        const long long ibase = (long long)d.b * H * W;
+        okmask = 0;
 #pragma unroll
-        for (int e = 0; e < PER16; ++e) { va[e] = 0.f; vr[e] = 0.f; }
-        auto tap = [&](int py, int px, float wgt) {
-            alignas(16) T ra[PER16];
-            alignas(16) T rr[PER16];
-            *reinterpret_cast<uint4*>(ra) = *reinterpret_cast<const uint4*>(t_act + (py * RS_IW + px) * 128 + slot * 16);
-            *reinterpret_cast<uint4*>(rr) = *reinterpret_cast<const uint4*>(t_raw + (py * RS_IW + px) * 128 + slot * 16);
-#pragma unroll
-            for (int e = 0; e < PER16; ++e) { va[e] = fmaf(wgt, to_f32(ra[e]), va[e]); vr[e] = fmaf(wgt, to_f32(rr[e]), vr[e]); }
-        };
-        if (RESAMPLE == 1) {
-            // input pixel (oy>>1, ox>>1) sits at tile coords (+1, +1) relative to the core origin
-            const int py = (oy_l >> 1) + 1, px = (ox_l >> 1) + 1;
-            const int ny = (oy_l & 1) ? py + 1 : py - 1, nx = (ox_l & 1) ? px + 1 : px - 1;
-            tap(py, px, 0.5625f); tap(py, nx, 0.1875f); tap(ny, px, 0.1875f); tap(ny, nx, 0.0625f);
-        } else {
-            const float k[4] = {0.125f, 0.375f, 0.375f, 0.125f};
-#pragma unroll
-            for (int i = 0; i < 4; ++i)
-#pragma unroll
-                for (int j = 0; j < 4; ++j) tap(2 * oy_l + i, 2 * ox_l + j, k[i] * k[j]);
+        for (int k = 0; k < NU; ++k) {
+            const int u = tid + k * 256;
+            const int p = u >> 3;                        // (u & 7) == slot because 256 % 8 == 0
+            const int py = p / RS_IW, px = p - py * RS_IW;
+            const int iy = iy0 + py, ix = ix0 + px;
+            const bool ok = (u < RS_NPIX * 8) && cvalid && iy >= 0 && iy < H && ix >= 0 && ix < W;
+            rawv[k] = make_uint4(0u, 0u, 0u, 0u);
+            if (ok) {
+                const long long pix = ibase + (long long)iy * W + ix;
+                const T* src = (c < Ca) ? (xa + pix * Ca + c) : (xb + pix * Cb + (c - Ca));
+                rawv[k] = *reinterpret_cast<const uint4*>(src);
+                okmask |= 1u << k;
+            }
         }
-        alignas(16) T oa[PER16];
-        alignas(16) T orr[PER16];
+    };
+
+    const int per = (total_tiles + (int)gridDim.x - 1) / (int)gridDim.x;
+    int t = blockIdx.x * per;
+    const int t_end = min(total_tiles, t + per);
+    if (t >= t_end) return;
+    TileId cur = decode(t);
+    load_tile(cur);
+    int tab_b = -1, tab_cg = -1;
+    while (true) {
+        // GN parameters of the tile's CG channels (y = x * scale + shift): one thread per channel does the fp64 statistics
+        // math, only when the (batch item, channel group) changes; the previous tile's filter is done reading LDS
+        __syncthreads();
+        if (cur.b != tab_b || cur.cg != tab_cg) {
+            if (tid < CG) {
+                const int cc = cur.cg * CG + tid;
+                float sc = 0.f, sh = 0.f;
+                if (cc < C) {
+                    const double n = (double)gs * H * W;
+                    const int g = cc / gs;
+                    const double m = stats[((long long)cur.b * G + g) * 2] / n;
+                    double var = stats[((long long)cur.b * G + g) * 2 + 1] / n - m * m;
+                    if (var < 0.0) var = 0.0;
+                    const float pm = (float)m;
+                    sc = (float)(1.0 / sqrt(var + (double)eps)) * gamma[cc];
+                    sh = beta[cc] - pm * sc;
+                }
+                gtab[2 * tid] = sc; gtab[2 * tid + 1] = sh;
+            }
+            tab_b = cur.b; tab_cg = cur.cg;
+            __syncthreads();
+        }
+        // ---- stage: raw + activated input tile -> LDS ----
+        float pa[PER16], pb[PER16];
 #pragma unroll
-        for (int e = 0; e < PER16; ++e) { from_f32(oa[e], va[e]); from_f32(orr[e], vr[e]); }
-        const long long o = (obase + (long long)oy * OW + ox) * C + c;
-        *reinterpret_cast<uint4*>(out_act + o) = *reinterpret_cast<const uint4*>(oa);
-        if (out_raw) *reinterpret_cast<uint4*>(out_raw + o) = *reinterpret_cast<const uint4*>(orr);
+        for (int e = 0; e < PER16; ++e) { pa[e] = gtab[2 * (slot * PER16 + e)]; pb[e] = gtab[2 * (slot * PER16 + e) + 1]; }
+#pragma unroll
+        for (int k = 0; k < NU; ++k) {
+            const int u = tid + k * 256;
+            if (u >= RS_NPIX * 8) continue;
+            const int p = u >> 3;
+            alignas(16) T raw[PER16];
+            alignas(16) T act[PER16];
+            *reinterpret_cast<uint4*>(raw) = rawv[k];
+            if (okmask & (1u << k)) {
+                if constexpr (sizeof(T) == 2) {
+                    uint32_t aw[4];
+#pragma unroll
+                    for (int e = 0; e < PER16; e += 2) {
+                        f32x2 y = __builtin_elementwise_fma(f32x2{to_f32(raw[e]), to_f32(raw[e + 1])}, f32x2{pa[e], pa[e + 1]}, f32x2{pb[e], pb[e + 1]});
+                        if (silu) y = silu2(y);
+                        aw[e / 2] = pack2(y.x, y.y, (T*)nullptr);
+                    }
+                    *reinterpret_cast<uint4*>(act) = make_uint4(aw[0], aw[1], aw[2], aw[3]);
+                } else {
+#pragma unroll
+                    for (int e = 0; e < PER16; ++e) {
+                        float y = fmaf(to_f32(raw[e]), pa[e], pb[e]);
+                        if (silu) y = silu_f(y);
+                        from_f32(act[e], y);
+                    }
+                }
+            } else {
+                *reinterpret_cast<uint4*>(act) = make_uint4(0u, 0u, 0u, 0u);
+            }
+            *reinterpret_cast<uint4*>(t_raw + p * 128 + slot * 16) = rawv[k];
+            *reinterpret_cast<uint4*>(t_act + p * 128 + slot * 16) = *reinterpret_cast<const uint4*>(act);
+        }
+        // ---- the next tile's loads fly under this tile's filter + stores ----
+        const TileId me = cur;
+        const int tn = t + 1;
+        const bool has_next = tn < t_end;
+        if (has_next) { cur = decode(tn); load_tile(cur); }
+        __syncthreads();
+        // ---- filter from LDS ----
+        const int c = me.cg * CG + slot * PER16;
+        if (c < C) {
+            const long long obase = (long long)me.b * OH * OW;
+            for (int u = tid; u < TOH * TOW * 8; u += 256) {
+                const int q = u >> 3;
+                const int oy_l = q / TOW, ox_l = q - oy_l * TOW;
+                const int oy = me.ty * TOH + oy_l, ox = me.tx * TOW + ox_l;
+                if (oy >= OH || ox >= OW) continue;
+                float va[PER16], vr[PER16];
+#pragma unroll
+                for (int e = 0; e < PER16; ++e) { va[e] = 0.f; vr[e] = 0.f; }
+                auto tap = [&](int py, int px, float wgt) {
+                    const uint4 qa = *reinterpret_cast<const uint4*>(t_act + (py * RS_IW + px) * 128 + slot * 16);
+                    const uint4 qr = *reinterpret_cast<const uint4*>(t_raw + (py * RS_IW + px) * 128 + slot * 16);
+                    if constexpr (sizeof(T) == 2) {
+                        // 16-bit data: one v_dot2c per channel and tap on the packed dwords (no unpack; exact, see dot2_acc)
+                        uint32_t wl = tap_weight_bits(wgt, (T*)nullptr), wh = wl << 16;
+#if defined(__HIP_DEVICE_COMPILE__)
+                        // the weights must reach v_dot2c in REGISTERS: as a 32-bit literal of a packed-16-bit operand only the
+                        // low half is honoured (measured on gfx950: the (0, w) literal acted as (0, 0))
+                        asm volatile("" : "+v"(wl), "+v"(wh));
+#endif
+                        const uint32_t a[4] = {qa.x, qa.y, qa.z, qa.w}, r[4] = {qr.x, qr.y, qr.z, qr.w};
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) {
+                            va[2 * i] = dot2_acc(a[i], wl, va[2 * i], (T*)nullptr); va[2 * i + 1] = dot2_acc(a[i], wh, va[2 * i + 1], (T*)nullptr);
+                            vr[2 * i] = dot2_acc(r[i], wl, vr[2 * i], (T*)nullptr); vr[2 * i + 1] = dot2_acc(r[i], wh, vr[2 * i + 1], (T*)nullptr);
+                        }
+                    } else {
+                        alignas(16) T ra[PER16];
+                        alignas(16) T rr[PER16];
+                        *reinterpret_cast<uint4*>(ra) = qa;
+                        *reinterpret_cast<uint4*>(rr) = qr;
+#pragma unroll
+                        for (int e = 0; e < PER16; ++e) { va[e] = fmaf(wgt, to_f32(ra[e]), va[e]); vr[e] = fmaf(wgt, to_f32(rr[e]), vr[e]); }
+                    }
+                };
+                if (RESAMPLE == 1) {
+                    // input pixel (oy>>1, ox>>1) sits at tile coords (+1, +1) relative to the core origin
+                    const int py = (oy_l >> 1) + 1, px = (ox_l >> 1) + 1;
+                    const int ny = (oy_l & 1) ? py + 1 : py - 1, nx = (ox_l & 1) ? px + 1 : px - 1;
+                    tap(py, px, 0.5625f); tap(py, nx, 0.1875f); tap(ny, px, 0.1875f); tap(ny, nx, 0.0625f);
+                } else {
+                    // one filter row (4 taps x 2 tensors) in flight at a time: unrolling all 16 taps costs > 200 registers
+                    // and the occupancy this kernel lives on
+#pragma unroll 1
+                    for (int i = 0; i < 4; ++i) {
+                        const int py = 2 * oy_l + i, px = 2 * ox_l;
+                        if (i == 0 || i == 3) { tap(py, px, 0.015625f); tap(py, px + 1, 0.046875f); tap(py, px + 2, 0.046875f); tap(py, px + 3, 0.015625f); }
+                        else { tap(py, px, 0.046875f); tap(py, px + 1, 0.140625f); tap(py, px + 2, 0.140625f); tap(py, px + 3, 0.046875f); }
+                    }
+                }
+                const long long o = (obase + (long long)oy * OW + ox) * C + c;
+                if constexpr (sizeof(T) == 2) {
+                    *reinterpret_cast<uint4*>(out_act + o) = make_uint4(pack2(va[0], va[1], (T*)nullptr), pack2(va[2], va[3], (T*)nullptr),
+                                                                        pack2(va[4], va[5], (T*)nullptr), pack2(va[6], va[7], (T*)nullptr));
+                    if (out_raw) *reinterpret_cast<uint4*>(out_raw + o) = make_uint4(pack2(vr[0], vr[1], (T*)nullptr), pack2(vr[2], vr[3], (T*)nullptr),
+                                                                                     pack2(vr[4], vr[5], (T*)nullptr), pack2(vr[6], vr[7], (T*)nullptr));
+                } else {
+                    alignas(16) T oa[PER16];
+                    alignas(16) T orr[PER16];
+#pragma unroll
+                    for (int e = 0; e < PER16; ++e) { from_f32(oa[e], va[e]); from_f32(orr[e], vr[e]); }
+                    *reinterpret_cast<uint4*>(out_act + o) = *reinterpret_cast<const uint4*>(oa);
+                    if (out_raw) *reinterpret_cast<uint4*>(out_raw + o) = *reinterpret_cast<const uint4*>(orr);
+                }
+            }
+        }
+        if (!has_next) break;
+        t = tn;
     }
 }
 
@@ -381,9 +461,15 @@ static int gn_apply_t(const void* xa, int Ca, const void* xb, int Cb, int B, int
     if (R != 0) {
         constexpr int CG = 8 * Elem<T>::PER16;
         const int tiles_x = cdiv(W, 16), tiles_y = cdiv(H, 8), ncg = cdiv(Ca + Cb, CG);
-        hipLaunchKernelGGL((gn_apply_resample_kernel<T, R == 0 ? 1 : R>), dim3(tiles_x * tiles_y * ncg, B), dim3(256), 0, st,
+        const long long total = (long long)tiles_x * tiles_y * ncg * B;
+        STORM_CHECK(total > 0 && total < (1LL << 31), "storm_gn_apply: %lld tiles out of range", total);
+        // persistent: 3 workgroups fit a CU (46 KiB of LDS each); a few per slot so that the tail stays short
+        const char* wgs_env = getenv("STORM_RESAMPLE_WGS");             // test hook: cap the persistent grid
+        const long long cap = wgs_env ? atoi(wgs_env) : 256LL * 3 * 4;
+        const long long grid = total < cap ? total : cap;
+        hipLaunchKernelGGL((gn_apply_resample_kernel<T, R == 0 ? 1 : R>), dim3((unsigned)grid), dim3(256), 0, st,
                            (const T*)xa, Ca, (const T*)xb, Cb, H, W, G, stats, gamma, beta, eps, silu, (T*)out_act,
-                           (T*)out_raw, tiles_x, tiles_y);
+                           (T*)out_raw, tiles_x, tiles_y, ncg, (int)total);
         STORM_LAUNCH_CHECK();
         return STORM_OK;
     }

@@ -113,7 +113,8 @@ def conv_kernel_name(segs, Cout, **kw):
 
 def gn_finalize(part_a, part_b=None, gamma=None, beta=None, count=None, eps=1e-6):
     """[B][tiles][C][2] conv-epilogue partials (optionally of two concatenated tensors) -> stats [B][G][2] fp64;
-    with gamma/beta/count also the per-channel affine ss [B][C][2] for convs that fuse the apply."""
+    with gamma/beta/count also the per-channel affine for convs that fuse the apply, ss [B][C/8][2][8] (per channel octet:
+    its 8 scales, then its 8 shifts - see pack_gn_ss)."""
     B, ta, Ca, _ = part_a.shape
     tb, Cb = (part_b.shape[1], part_b.shape[2]) if part_b is not None else (0, 0)
     G = gn_groups(Ca + Cb)
@@ -122,10 +123,16 @@ def gn_finalize(part_a, part_b=None, gamma=None, beta=None, count=None, eps=1e-6
         L.check(L.lib().storm_gn_finalize(L.ptr(part_a), Ca, ta, L.ptr(part_b), Cb, tb, B, G, L.ptr(stats), L.stream()),
                 "storm_gn_finalize")
         return stats
-    ss = torch.empty((B, Ca + Cb, 2), dtype=torch.float32, device=part_a.device)
+    ss = torch.empty((B, (Ca + Cb) // 8, 2, 8), dtype=torch.float32, device=part_a.device)
     L.check(L.lib().storm_gn_finalize_ss(L.ptr(part_a), Ca, ta, L.ptr(part_b), Cb, tb, B, G, int(count), L.ptr(gamma),
                                          L.ptr(beta), eps, L.ptr(stats), L.ptr(ss), L.stream()), "storm_gn_finalize_ss")
     return stats, ss
+
+
+def pack_gn_ss(scale, shift):
+    """per-channel (scale, shift) [B, C] -> the table layout the conv kernels read (storm_gn_finalize_ss)"""
+    B, Cc = scale.shape
+    return torch.stack([scale.reshape(B, Cc // 8, 8), shift.reshape(B, Cc // 8, 8)], 2).contiguous().float()
 
 
 def attention(q, k, vT, bias, scale):

@@ -292,11 +292,16 @@ def test_groupnorm_golden(dev, golden):
 
 @pytest.mark.parametrize("dtype", DTYPES)
 @pytest.mark.parametrize("resample", [1, 2])
-def test_groupnorm_fir_fused(dev, dtype, resample):
-    """h = FIR(SiLU(GN(x))) and x = FIR(x) of a BigGAN up/down block in one pass (layerspp.py:243-255)."""
+@pytest.mark.parametrize("shape", [(2, 24, 6, 10, None), (2, 72, 20, 36, 5)])
+def test_groupnorm_fir_fused(dev, dtype, resample, shape, monkeypatch):
+    """h = FIR(SiLU(GN(x))) and x = FIR(x) of a BigGAN up/down block in one pass (layerspp.py:243-255); second shape: 36 tiles
+    (two channel groups, two batch items) on 5 persistent workgroups - every workgroup walks a run of tiles that crosses
+    channel-group / batch boundaries with the next tile's loads in flight."""
     from storm_amd import ops
     g = torch.Generator().manual_seed(5)
-    B, C, H, W = 2, 24, 6, 10
+    B, C, H, W, wgs = shape
+    if wgs:
+        monkeypatch.setenv("STORM_RESAMPLE_WGS", str(wgs))
     x = torch.randn(B, C, H, W, generator=g)
     gam, bet = 1 + 0.1 * torch.randn(C, generator=g), 0.1 * torch.randn(C, generator=g)
     xa = nhwc(x).to(dtype).to(dev)

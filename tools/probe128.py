@@ -23,16 +23,19 @@ rnd = lambda *s: torch.randn(*s, generator=g)  # noqa: E731
 # (name, H, W, cin of the 3x3 operand, channels of the fused 1x1 shortcut or 0): idx 6/8, 105, 109, 107/111, 11, 13 of the op list
 CASES = [("128->128 @256x512", 256, 512, 128, 0), ("384->128 @256x512", 256, 512, 384, 0), ("256->128 @256x512", 256, 512, 256, 0),
          ("128->128 +1x1(256) @256x512", 256, 512, 128, 256), ("128->128 @128x256", 128, 256, 128, 0),
-         ("128->128 +1x1(128) @128x256", 128, 256, 128, 128), ("128->128 @256x1024 (8 s)", 256, 1024, 128, 0)]
+         ("128->128 +1x1(128) @128x256", 128, 256, 128, 128), ("128->128 @256x1024 (8 s)", 256, 1024, 128, 0),
+         # 256-cout layers (conv_pipe.hip on both sides of the A/B): what the fused GroupNorm operand costs there (--nogn)
+         ("256->256 @128x256", 128, 256, 256, 0, 256), ("512->256 @128x256", 128, 256, 512, 0, 256), ("256->256 @256x512", 256, 512, 256, 0, 256)]
 ev = lambda: torch.cuda.Event(enable_timing=True)  # noqa: E731
-for ci_, (name, H, W, cin, sc) in enumerate(CASES):
+for ci_, case in enumerate(CASES):
+    name, H, W, cin, sc = case[:5]
     if args.only >= 0 and ci_ != args.only:
         continue
     B = args.B if W <= 512 else args.B // 2
-    cout = 128
+    cout = case[5] if len(case) > 5 else 128
     x = rnd(B, H, W, cin).to(dt).to(dev)
     w = ops.pack_conv_weight((rnd(cout, cin, 3, 3) * 0.05).to(dev), dt)
-    ss = torch.stack([1 + 0.1 * rnd(B, cin), 0.1 * rnd(B, cin)], -1).contiguous().to(dev)
+    ss = ops.pack_gn_ss(1 + 0.1 * rnd(B, cin), 0.1 * rnd(B, cin)).to(dev)
     segs = [ops.Seg(x, w, 9, gn_ss=None if args.nogn else ss, gn_silu=True)]
     kw = dict(bias=rnd(cout).to(dev), tbias=rnd(B, cout).to(dev), gn_partials=True, scale=0.7)
     if sc:
