@@ -417,7 +417,7 @@ __device__ __forceinline__ void conv_tile(const ConvParams& a, const int vblock,
     constexpr int LPR = WM * 4;                 // lanes per staged row (8 couts each)
     constexpr int RPI = 64 / LPR;               // rows per read iteration
     const int skipC = a.outC;
-    const int c8 = lane % LPR;
+    const int c8 = lane & (LPR - 1);
     const int co = cout0 + wm * WM * 32 + c8 * 8;              // this lane's 8 output channels (same in every iteration)
     float badd[8];                              // bias + per-batch time-embedding bias, loaded once
 #pragma unroll
@@ -451,6 +451,18 @@ __device__ __forceinline__ void conv_tile(const ConvParams& a, const int vblock,
     float gsum[8], gsq[8];                      // GroupNorm partials of this lane's 8 channels (fused statistics)
 #pragma unroll
     for (int e = 0; e < 8; ++e) { gsum[e] = 0.f; gsq[e] = 0.f; }
+    // store-loop constants: parameters read once (scalar), the lane's pixel / channel offset, the two staged-row swizzles
+    const int outC = a.outC, out_f32 = a.out_f32, imgH = a.H, imgW = a.W;
+    const bool has_skip = a.skip != nullptr;
+    char* const out_b = reinterpret_cast<char*>(a.out) + (long long)b * a.out_bstride * (out_f32 ? 4 : (int)sizeof(T));
+    const int l8 = (lane >> 3) & 7;             // LPR == 8: the pixel (of the 8 per iteration) this lane stores
+    const int gx0 = tx0 + l8;
+    const uint32_t o_lane = (uint32_t)(l8 * outC + co);
+    int srow[2][2];
+#pragma unroll
+    for (int odd = 0; odd < 2; ++odd)
+#pragma unroll
+        for (int h = 0; h < 2; ++h) srow[odd][h] = stage_off<WM>(odd * 8 + l8, 2 * c8 + h) - odd * 8 * (WM * 128);
 #pragma unroll
     for (int pass = 0; pass < WN / PR; ++pass) {
         if (pass > 0) wave_sync();              // this wave's reads of the previous pass are done
@@ -466,27 +478,51 @@ __device__ __forceinline__ void conv_tile(const ConvParams& a, const int vblock,
                         make_float4(c[4 * g], c[4 * g + 1], c[4 * g + 2], c[4 * g + 3]);
                 }
         wave_sync();                            // LDS executes a wave's requests in order: no workgroup barrier
-#pragma unroll 4
+        // store loop: an iteration stores RPI pixels x (WM x 32) couts per wave.  With 8 lanes per pixel (WM = 2) everything that
+        // does not depend on the lane is scalar - the pixel row's validity, the element offset of the iteration's first pixel -
+        // and the lane adds its own (pixel l8, cout octet c8) offset; the staged row's swizzle has two variants (it even / odd).
+        // (`lane` is opaque to the compiler here, so the generic row / column arithmetic cost 30 VALU instructions per store:
+        // measured in conv_pipe.hip, 5.9 k of the epilogue's 12.1 k cycles per tile.)
+#pragma unroll
         for (int it = 0; it < SROWS / RPI; ++it) {
-            const int row = it * RPI + lane / LPR;
-            const float4 v0 = *reinterpret_cast<const float4*>(stage + stage_off<WM>(row, 2 * c8));
-            const float4 v1 = *reinterpret_cast<const float4*>(stage + stage_off<WM>(row, 2 * c8 + 1));
-            f32x2 v2[4] = {f32x2{v0.x, v0.y}, f32x2{v0.z, v0.w}, f32x2{v1.x, v1.y}, f32x2{v1.z, v1.w}};
-            const int trow = wn * WN + pass * PR + (row >> 5), n = row & 31;
-            int pix;                               // pixel index inside this batch image (fits 32 bits)
+            float4 v0, v1;
             bool ok;
-            if (TAPS == 9) {
-                const int gy = ty0 + trow, gx = tx0 + n;
-                ok = gy < a.H && gx < a.W;
-                pix = gy * a.W + gx;
+            uint32_t o;
+            if constexpr (LPR == 8) {
+                const int trow = wn * WN + pass * PR + it / 4, nb = (it % 4) * RPI;          // (it is a compile-time constant)
+                const char* const sp = stage + it * RPI * (WM * 128);
+                v0 = *reinterpret_cast<const float4*>(sp + srow[it & 1][0]);
+                v1 = *reinterpret_cast<const float4*>(sp + srow[it & 1][1]);
+                if (TAPS == 9) {
+                    const int gy = ty0 + trow;
+                    ok = gy < imgH && gx0 + nb < imgW;
+                    o = (uint32_t)(gy * imgW + tx0 + nb) * (uint32_t)outC + o_lane;
+                } else {
+                    const int pix_u = (int)lin0 + trow * TILE_W + nb;
+                    ok = pix_u + l8 < (int)npix;
+                    o = (uint32_t)pix_u * (uint32_t)outC + o_lane;
+                }
             } else {
-                pix = (int)lin0 + trow * TILE_W + n;
-                ok = pix < (int)npix;
+                const int row = it * RPI + lane / LPR;
+                v0 = *reinterpret_cast<const float4*>(stage + stage_off<WM>(row, 2 * c8));
+                v1 = *reinterpret_cast<const float4*>(stage + stage_off<WM>(row, 2 * c8 + 1));
+                const int trow = wn * WN + pass * PR + (row >> 5), n = row & 31;
+                int pix;                               // pixel index inside this batch image (fits 32 bits)
+                if (TAPS == 9) {
+                    const int gy = ty0 + trow, gx = tx0 + n;
+                    ok = gy < imgH && gx < imgW;
+                    pix = gy * imgW + gx;
+                } else {
+                    pix = (int)lin0 + trow * TILE_W + n;
+                    ok = pix < (int)npix;
+                }
+                o = (uint32_t)(pix * outC + co);
             }
+            f32x2 v2[4] = {f32x2{v0.x, v0.y}, f32x2{v0.z, v0.w}, f32x2{v1.x, v1.y}, f32x2{v1.z, v1.w}};
             if (ok && co_ok) {
-                if (a.skip) {
+                if (has_skip) {
                     float sk[8];
-                    load8(skip_b + (uint32_t)(pix * skipC + co), sk);
+                    load8(skip_b + o, sk);
 #pragma unroll
                     for (int i = 0; i < 4; ++i) v2[i] += f32x2{sk[2 * i], sk[2 * i + 1]};
                 }
@@ -497,9 +533,8 @@ __device__ __forceinline__ void conv_tile(const ConvParams& a, const int vblock,
                     gsq2[i] = __builtin_elementwise_fma(v2[i], v2[i], gsq2[i]);
                 }
                 const float v[8] = {v2[0].x, v2[0].y, v2[1].x, v2[1].y, v2[2].x, v2[2].y, v2[3].x, v2[3].y};
-                const uint32_t o = (uint32_t)(pix * a.outC + co);
-                if (a.out_f32) store8(reinterpret_cast<float*>(a.out) + (long long)b * a.out_bstride + o, v);
-                else store8(reinterpret_cast<T*>(a.out) + (long long)b * a.out_bstride + o, v);
+                if (out_f32) store8(reinterpret_cast<float*>(out_b) + o, v);
+                else store8(reinterpret_cast<T*>(out_b) + o, v);
             }
         }
     }

@@ -245,9 +245,12 @@ void conv_pipe_kernel(const PipeParams a, const int n_ct, const int tiles_per_xc
         const int k = lw + Cfg::NLAG * i;
         if (k >= PPIECES) { issue_table(into); return; }     // surplus slot: identical table bytes again - harmless whenever
                                                              // they land (a repeated PIECE could land on its transformed image)
-        const uint32_t v = R[i];
+        uint32_t v = R[i];
+#if defined(__HIP_DEVICE_COMPILE__)
+        asm volatile("" : "+v"(v));       // opaque per use: values DERIVED from the table entry must not be hoisted out of the tile loop
+#endif                                    // as eleven more live registers (one of them spilled: scratch reload + vmcnt(0) in the loop)
         const bool ok = (int)v >= 0 && (int)(v & 7u) * 8 < nx_cvalid;
-        dma16(nx_srd, ok ? (v >> 3) * (uint32_t)nx_C2 + (v & 7u) * 16u : OOB, (uint32_t)nx_cbeg2,
+        dma16(nx_srd, ok ? mad24(v >> 3, (uint32_t)nx_C2, (v & 7u) * 16u) : OOB, (uint32_t)nx_cbeg2,
               smem + into * PATCH_BYTES + k * 1024, lane);
     };
     // (lagging) one compact piece (one-tap chunk: TH x 32 pixels, no halo): piece k = pixel row k >> 2, columns 8 (k & 3) ..
@@ -256,7 +259,7 @@ void conv_pipe_kernel(const PipeParams a, const int n_ct, const int tiles_per_xc
         const int slot = (lane & 7) ^ ((n >> 1) & 7);
         const int gy = ty0 + trow, gx = tx0 + n;
         const bool ok = gy < imgH && gx < imgW && slot * 8 < nx_cvalid;
-        dma16(nx_srd, ok ? (uint32_t)(gy * imgW + gx) * (uint32_t)nx_C2 + (uint32_t)slot * 16u : OOB, (uint32_t)nx_cbeg2,
+        dma16(nx_srd, ok ? mad24((uint32_t)(gy * imgW + gx), (uint32_t)nx_C2, (uint32_t)slot * 16u) : OOB, (uint32_t)nx_cbeg2,
               smem + into * PATCH_BYTES + k * 1024, lane);
     };
     auto issue_any = [&](int i, int into) {                 // (lagging) slot i, in the next chunk's layout
@@ -268,7 +271,10 @@ void conv_pipe_kernel(const PipeParams a, const int n_ct, const int tiles_per_xc
     auto commit_slot = [&](int i, int into) {
         const int k = lw + Cfg::NLAG * i;
         if (k < PPIECES) {
-            const uint32_t v = R[i];
+            uint32_t v = R[i];
+#if defined(__HIP_DEVICE_COMPILE__)
+            asm volatile("" : "+v"(v));
+#endif
             if ((int)v >= 0 && (int)(v & 7u) * 8 < nx_cvalid) {
                 uint4* const q = reinterpret_cast<uint4*>(smem + into * PATCH_BYTES + k * 1024 + lane * 16);
                 float ss[16];
@@ -568,8 +574,19 @@ void conv_pipe_kernel(const PipeParams a, const int n_ct, const int tiles_per_xc
         char* const stage = smem + (wave < 5 ? PATCH_BYTES + wave * WSTAGE : OFF_RING + 2 * WPHASE + (wave - 5) * WSTAGE);
         constexpr int LPR = WM * 4;                 // lanes per staged row (8 couts each)
         constexpr int RPI = 64 / LPR;               // rows per read iteration
-        const int skipC = ap->outC;
-        const int c8 = lane % LPR;
+        // epilogue parameters: read ONCE per tile and pinned in SGPRs (through the kernarg pointer the compiler re-loaded the
+        // output pointer / strides inside the store loop: a scalar load + s_waitcnt lgkmcnt(0) and a 64-bit multiply per store)
+        const int outC = pin(ap->outC), skipC = outC, out_f32 = pin(ap->out_f32);
+        const bool has_skip = ap->skip != nullptr;
+#if defined(__HIP_DEVICE_COMPILE__)
+        unsigned long long out_u = reinterpret_cast<unsigned long long>(ap->out) + (unsigned long long)((long long)e_b * ap->out_bstride * (out_f32 ? 4 : (int)sizeof(T)));
+        asm volatile("" : "+s"(out_u));
+        typedef __attribute__((address_space(1))) char GChar;       // (keeps the stores global_store: behind the asm the pointer's origin is opaque)
+        char* const out_b = (char*)(GChar*)out_u;
+#else
+        char* const out_b = reinterpret_cast<char*>(ap->out) + (long long)e_b * ap->out_bstride * (out_f32 ? 4 : (int)sizeof(T));
+#endif
+        const int c8 = lane & (LPR - 1);
         const int co = e_cout0 + wm * WM * 32 + c8 * 8;
         float badd[8];
 #pragma unroll
@@ -589,7 +606,7 @@ void conv_pipe_kernel(const PipeParams a, const int n_ct, const int tiles_per_xc
                     if (ap->tbias) badd[e] += ap->tbias[(long long)e_b * ap->tbias_stride + co + e];
                 }
         }
-        const bool co_ok = co < ap->outC;
+        const bool co_ok = co < outC;
         const T* const skip_b = reinterpret_cast<const T*>(ap->skip) + (long long)e_b * ap->skip_bstride;
         // out = (acc + bias + temb bias + skip) * scale, evaluated as packed fma: (acc [+ skip]) * scale + (bias * scale);
         // channel pairs stay in adjacent registers from the staging read to the bf16 pack (v_pk_fma_f32 / v_pk_add_f32)
@@ -601,6 +618,15 @@ void conv_pipe_kernel(const PipeParams a, const int n_ct, const int tiles_per_xc
             gsum2[i] = f32x2{0.f, 0.f}; gsq2[i] = f32x2{0.f, 0.f};
         }
         float gsum[8], gsq[8];
+        static_assert(PR == 1 && LPR == 8 && RPI == 8 && WM == 2, "store loop index math");
+        const int l8 = (lane >> 3) & 7;                         // the pixel (of the 8 per iteration) this lane stores
+        const int gx0 = e_tx0 + l8;
+        const uint32_t o_lane = (uint32_t)(gx0 * outC + co);
+        int srow[2][2];                                         // staged row it * 8 + l8, slots 2 c8 / 2 c8 + 1: stage_off<WM> without its `it * 8` rows
+#pragma unroll
+        for (int odd = 0; odd < 2; ++odd)
+#pragma unroll
+            for (int h = 0; h < 2; ++h) srow[odd][h] = stage_off<WM>(odd * 8 + l8, 2 * c8 + h) - odd * 8 * (WM * 128);
 #pragma unroll
         for (int pass = 0; pass < WN / PR; ++pass) {
             if (pass > 0) wave_sync();
@@ -616,41 +642,51 @@ void conv_pipe_kernel(const PipeParams a, const int n_ct, const int tiles_per_xc
                             make_float4(c[4 * g], c[4 * g + 1], c[4 * g + 2], c[4 * g + 3]);
                     }
             wave_sync();
-#pragma unroll 4
-            for (int it = 0; it < SROWS / RPI; ++it) {
-                const int row = it * RPI + lane / LPR;
-                const float4 v0 = *reinterpret_cast<const float4*>(stage + stage_off<WM>(row, 2 * c8));
-                const float4 v1 = *reinterpret_cast<const float4*>(stage + stage_off<WM>(row, 2 * c8 + 1));
-                f32x2 v2[4] = {f32x2{v0.x, v0.y}, f32x2{v0.z, v0.w}, f32x2{v1.x, v1.y}, f32x2{v1.z, v1.w}};
-                const int trow = wn * WN + pass * PR + (row >> 5), n = row & 31;
-                const int gy = e_ty0 + trow, gx = e_tx0 + n;
-                const bool ok = gy < imgH && gx < imgW;
-                const int pix = gy * imgW + gx;
-                if (ok && co_ok && !(ABL & 2048)) {
-                    if (ap->skip) {
-                        float sk[8];
-                        load8(skip_b + (uint32_t)(pix * skipC + co), sk);
+            // store loop: a pass is ONE pixel row of the tile (PR = 1), an iteration 8 of its pixels x 64 couts per wave.  Everything
+            // that does not depend on the lane is scalar: the row's validity, the element offset of (row, 8 * it) - the lane adds
+            // its own (pixel l8, cout octet c8) offset, and the staged row's swizzle has two variants (it even / odd).  (Written out by
+            // hand: `lane` is opaque to the compiler in this kernel, so the generic row / column arithmetic stayed 30 VALU
+            // instructions per store - measured: 5.9 k of the epilogue's 12.1 k cycles per tile.)
+            const int gy = e_ty0 + wn * WN + pass;
+            if (gy < imgH) {
+                const uint32_t o_row = (uint32_t)(gy * imgW) * (uint32_t)outC;                    // (uniform)
 #pragma unroll
-                        for (int i = 0; i < 4; ++i) v2[i] += f32x2{sk[2 * i], sk[2 * i + 1]};
-                    }
+                for (int it = 0; it < SROWS / RPI; ++it) {
+                    const char* const sp = stage + it * RPI * (WM * 128);
+                    const float4 v0 = *reinterpret_cast<const float4*>(sp + srow[it & 1][0]);
+                    const float4 v1 = *reinterpret_cast<const float4*>(sp + srow[it & 1][1]);
+                    f32x2 v2[4] = {f32x2{v0.x, v0.y}, f32x2{v0.z, v0.w}, f32x2{v1.x, v1.y}, f32x2{v1.z, v1.w}};
+                    if (gx0 + it * RPI < imgW && co_ok && !(ABL & 2048)) {
+                        const uint32_t o = o_row + (uint32_t)(it * RPI) * (uint32_t)outC + o_lane;
+                        if (has_skip) {
+                            alignas(16) T sk[8];
+                            *reinterpret_cast<uint4*>(sk) = *reinterpret_cast<const uint4*>(skip_b + o);
 #pragma unroll
-                    for (int i = 0; i < 4; ++i) {
-                        v2[i] = __builtin_elementwise_fma(v2[i], scale2, badd2[i]);
-                        gsum2[i] += v2[i];
-                        gsq2[i] = __builtin_elementwise_fma(v2[i], v2[i], gsq2[i]);
-                    }
-                    const float v[8] = {v2[0].x, v2[0].y, v2[1].x, v2[1].y, v2[2].x, v2[2].y, v2[3].x, v2[3].y};
-                    const uint32_t o = (uint32_t)(pix * ap->outC + co);
-                    if (ap->out_f32) store8(reinterpret_cast<float*>(ap->out) + (long long)e_b * ap->out_bstride + o, v);
-                    else if (ABL & 4096) {                       // (profiling A/B: non-temporal output stores)
-                        uint32_t w4[4];
+                            for (int i = 0; i < 4; ++i) v2[i] += f32x2{to_f32(sk[2 * i]), to_f32(sk[2 * i + 1])};
+                        }
 #pragma unroll
-                        for (int i = 0; i < 4; ++i) w4[i] = sizeof(T) == 2 && Elem<T>::DT == STORM_BF16 ? pack_bf16x2(v[2 * i], v[2 * i + 1]) : pack_f16x2(v[2 * i], v[2 * i + 1]);
-                        typedef uint32_t u32x4_nt __attribute__((ext_vector_type(4)));
-                        u32x4_nt val = {w4[0], w4[1], w4[2], w4[3]};
-                        __builtin_nontemporal_store(val, reinterpret_cast<u32x4_nt*>(reinterpret_cast<T*>(ap->out) + (long long)e_b * ap->out_bstride + o));
+                        for (int i = 0; i < 4; ++i) {
+                            v2[i] = __builtin_elementwise_fma(v2[i], scale2, badd2[i]);
+                            gsum2[i] += v2[i];
+                            gsq2[i] = __builtin_elementwise_fma(v2[i], v2[i], gsq2[i]);
+                        }
+                        const float v[8] = {v2[0].x, v2[0].y, v2[1].x, v2[1].y, v2[2].x, v2[2].y, v2[3].x, v2[3].y};
+                        if (out_f32) store8(reinterpret_cast<float*>(out_b) + o, v);
+                        else if (ABL & 4096) {                       // (profiling A/B: non-temporal output stores)
+                            uint32_t w4[4];
+#pragma unroll
+                            for (int i = 0; i < 4; ++i) w4[i] = sizeof(T) == 2 && Elem<T>::DT == STORM_BF16 ? pack_bf16x2(v[2 * i], v[2 * i + 1]) : pack_f16x2(v[2 * i], v[2 * i + 1]);
+                            typedef uint32_t u32x4_nt __attribute__((ext_vector_type(4)));
+                            u32x4_nt val = {w4[0], w4[1], w4[2], w4[3]};
+                            __builtin_nontemporal_store(val, reinterpret_cast<u32x4_nt*>(reinterpret_cast<T*>(out_b) + o));
+                        }
+                        else if (ABL & 8192) {                       // (profiling: all of the epilogue's arithmetic, no global store)
+#if defined(__HIP_DEVICE_COMPILE__)
+                            asm volatile("" ::"v"(v[0]), "v"(v[1]), "v"(v[2]), "v"(v[3]), "v"(v[4]), "v"(v[5]), "v"(v[6]), "v"(v[7]), "v"(o));
+#endif
+                        }
+                        else store8(reinterpret_cast<T*>(out_b) + o, v);
                     }
-                    else store8(reinterpret_cast<T*>(ap->out) + (long long)e_b * ap->out_bstride + o, v);
                 }
             }
         }
@@ -807,6 +843,7 @@ int launch_conv_pipe(const storm_conv_args& a, hipStream_t st) {
         case 4096: return launch_pipe<bf16_t, 256, 8, 4096>(a, st);     // non-temporal output stores
         case 1024: return launch_pipe<bf16_t, 256, 8, 1024>(a, st);     // no epilogue
         case 2048: return launch_pipe<bf16_t, 256, 8, 2048>(a, st);     // epilogue without global stores / skip loads
+        case 8192: return launch_pipe<bf16_t, 256, 8, 8192>(a, st);     // epilogue arithmetic, no global stores
         default: break;
     }
 #endif

@@ -191,7 +191,7 @@ void conv_pipe128_kernel(const PipeParams a, const int n_ct, const int tiles_per
         if (k >= PPIECES) { issue_table(into); return; }     // surplus slot: identical table bytes again (keeps the VMEM count uniform)
         const uint32_t v = patch_entry(i);
         const bool ok = (int)v >= 0 && (int)(v & 7u) * 8 < pd_cvalid;
-        dma16(pd_srd, ok ? (v >> 3) * (uint32_t)pd_C2 + (v & 7u) * 16u : OOB, (uint32_t)pd_cbeg2,
+        dma16(pd_srd, ok ? mad24(v >> 3, (uint32_t)pd_C2, (v & 7u) * 16u) : OOB, (uint32_t)pd_cbeg2,
               smem + into * PATCH_BYTES + k * 1024, lane);
     };
     // one compact piece (one-tap chunk: TH x 32 pixels, no halo): piece k = pixel row k >> 1, columns 16 (k & 1) ..
@@ -200,7 +200,7 @@ void conv_pipe128_kernel(const PipeParams a, const int n_ct, const int tiles_per
         const int slot = (lane & 3) ^ ((n >> 2) & 3);
         const int gy = ty0 + trow, gx = tx0 + n;
         const bool ok = gy < imgH && gx < imgW && slot * 8 < pd_cvalid;
-        dma16(pd_srd, ok ? (uint32_t)(gy * imgW + gx) * (uint32_t)pd_C2 + (uint32_t)slot * 16u : OOB, (uint32_t)pd_cbeg2,
+        dma16(pd_srd, ok ? mad24((uint32_t)(gy * imgW + gx), (uint32_t)pd_C2, (uint32_t)slot * 16u) : OOB, (uint32_t)pd_cbeg2,
               smem + into * PATCH_BYTES + k * 1024, lane);
     };
     auto issue_any = [&](int i, int into) {                 // slot i in the layout of the chunk being issued
@@ -427,8 +427,19 @@ void conv_pipe128_kernel(const PipeParams a, const int n_ct, const int tiles_per
         char* const stage = smem + PATCH_BYTES + wave * WSTAGE;
         constexpr int LPR = WM * 4;                 // lanes per staged row (8 couts each)
         constexpr int RPI = 64 / LPR;               // rows per read iteration
-        const int skipC = ap->outC;
-        const int c8 = lane % LPR;
+        // epilogue parameters: read ONCE per tile and pinned in SGPRs (through the kernarg pointer the compiler re-loaded the
+        // output pointer / strides inside the store loop: a scalar load + s_waitcnt lgkmcnt(0) and a 64-bit multiply per store)
+        const int outC = pin(ap->outC), skipC = outC, out_f32 = pin(ap->out_f32);
+        const bool has_skip = ap->skip != nullptr;
+#if defined(__HIP_DEVICE_COMPILE__)
+        unsigned long long out_u = reinterpret_cast<unsigned long long>(ap->out) + (unsigned long long)((long long)e_b * ap->out_bstride * (out_f32 ? 4 : (int)sizeof(T)));
+        asm volatile("" : "+s"(out_u));
+        typedef __attribute__((address_space(1))) char GChar;       // (keeps the stores global_store: behind the asm the pointer's origin is opaque)
+        char* const out_b = (char*)(GChar*)out_u;
+#else
+        char* const out_b = reinterpret_cast<char*>(ap->out) + (long long)e_b * ap->out_bstride * (out_f32 ? 4 : (int)sizeof(T));
+#endif
+        const int c8 = lane & (LPR - 1);
         const int co = e_cout0 + wm * WM * 32 + c8 * 8;
         float badd[8];
 #pragma unroll
@@ -448,7 +459,7 @@ void conv_pipe128_kernel(const PipeParams a, const int n_ct, const int tiles_per
                     if (ap->tbias) badd[e] += ap->tbias[(long long)e_b * ap->tbias_stride + co + e];
                 }
         }
-        const bool co_ok = co < ap->outC;
+        const bool co_ok = co < outC;
         const T* const skip_b = reinterpret_cast<const T*>(ap->skip) + (long long)e_b * ap->skip_bstride;
         // out = (acc + bias + temb bias + skip) * scale as packed fma: (acc [+ skip]) * scale + (bias * scale)
         f32x2 badd2[4], gsum2[4], gsq2[4];
@@ -459,8 +470,29 @@ void conv_pipe128_kernel(const PipeParams a, const int n_ct, const int tiles_per
             gsum2[i] = f32x2{0.f, 0.f}; gsq2[i] = f32x2{0.f, 0.f};
         }
         float gsum[8], gsq[8];
+        static_assert(PR == 1 && WM == 2, "store loop index math");
+        const int l8 = (lane >> 3) & 7;                         // the pixel (of the 8 per iteration) this lane stores
+        const int gx0 = e_tx0 + l8;
+        const uint32_t o_lane = (uint32_t)(gx0 * outC + co);
+        int srow[2][2];                                         // staged row it * 8 + l8, slots 2 c8 / 2 c8 + 1 (see conv_pipe.hip)
+#pragma unroll
+        for (int odd = 0; odd < 2; ++odd)
+#pragma unroll
+            for (int h = 0; h < 2; ++h) srow[odd][h] = stage_off<WM>(odd * 8 + l8, 2 * c8 + h) - odd * 8 * (WM * 128);
 #pragma unroll
         for (int pass = 0; pass < WN / PR; ++pass) {
+            // a pass is ONE pixel row of the tile: its validity and element offset are scalar, the lane adds its own (pixel, cout octet)
+            // offset (conv_pipe.hip); skip operands are fetched ONE store ahead (the first under the staging writes)
+            const int gy = e_ty0 + wn * WN + pass;
+            const bool row_ok = gy < imgH;
+            const uint32_t o_row = (uint32_t)(gy * imgW) * (uint32_t)outC;
+            auto skip_fetch = [&](int it) {
+                uint4 q = make_uint4(0u, 0u, 0u, 0u);
+                if (row_ok && gx0 + it * RPI < imgW && co_ok) q = *reinterpret_cast<const uint4*>(skip_b + (o_row + (uint32_t)(it * RPI) * (uint32_t)outC + o_lane));
+                return q;
+            };
+            uint4 sk_next = make_uint4(0u, 0u, 0u, 0u);
+            if (has_skip) sk_next = skip_fetch(0);
             if (pass > 0) wave_sync();
 #pragma unroll
             for (int nn = 0; nn < PR; ++nn)
@@ -474,22 +506,20 @@ void conv_pipe128_kernel(const PipeParams a, const int n_ct, const int tiles_per
                             make_float4(c[4 * g], c[4 * g + 1], c[4 * g + 2], c[4 * g + 3]);
                     }
             wave_sync();
-#pragma unroll 4
-            for (int it = 0; it < SROWS / RPI; ++it) {
-                const int row = it * RPI + lane / LPR;
-                const float4 v0 = *reinterpret_cast<const float4*>(stage + stage_off<WM>(row, 2 * c8));
-                const float4 v1 = *reinterpret_cast<const float4*>(stage + stage_off<WM>(row, 2 * c8 + 1));
-                f32x2 v2[4] = {f32x2{v0.x, v0.y}, f32x2{v0.z, v0.w}, f32x2{v1.x, v1.y}, f32x2{v1.z, v1.w}};
-                const int trow = wn * WN + pass * PR + (row >> 5), n = row & 31;
-                const int gy = e_ty0 + trow, gx = e_tx0 + n;
-                const bool ok = gy < imgH && gx < imgW;
-                const int pix = gy * imgW + gx;
-                if (ok && co_ok) {
-                    if (ap->skip) {
-                        float sk[8];
-                        load8(skip_b + (uint32_t)(pix * skipC + co), sk);
 #pragma unroll
-                        for (int i = 0; i < 4; ++i) v2[i] += f32x2{sk[2 * i], sk[2 * i + 1]};
+            for (int it = 0; it < SROWS / RPI; ++it) {
+                const uint4 sk_cur = sk_next;
+                if (has_skip && it + 1 < SROWS / RPI) sk_next = skip_fetch(it + 1);
+                const char* const sp = stage + it * RPI * (WM * 128);
+                const float4 v0 = *reinterpret_cast<const float4*>(sp + srow[it & 1][0]);
+                const float4 v1 = *reinterpret_cast<const float4*>(sp + srow[it & 1][1]);
+                f32x2 v2[4] = {f32x2{v0.x, v0.y}, f32x2{v0.z, v0.w}, f32x2{v1.x, v1.y}, f32x2{v1.z, v1.w}};
+                if (row_ok && gx0 + it * RPI < imgW && co_ok) {
+                    if (has_skip) {
+                        alignas(16) T sk[8];
+                        *reinterpret_cast<uint4*>(sk) = sk_cur;
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) v2[i] += f32x2{to_f32(sk[2 * i]), to_f32(sk[2 * i + 1])};
                     }
 #pragma unroll
                     for (int i = 0; i < 4; ++i) {
@@ -498,9 +528,9 @@ void conv_pipe128_kernel(const PipeParams a, const int n_ct, const int tiles_per
                         gsq2[i] = __builtin_elementwise_fma(v2[i], v2[i], gsq2[i]);
                     }
                     const float v[8] = {v2[0].x, v2[0].y, v2[1].x, v2[1].y, v2[2].x, v2[2].y, v2[3].x, v2[3].y};
-                    const uint32_t o = (uint32_t)(pix * ap->outC + co);
-                    if (ap->out_f32) store8(reinterpret_cast<float*>(ap->out) + (long long)e_b * ap->out_bstride + o, v);
-                    else store8(reinterpret_cast<T*>(ap->out) + (long long)e_b * ap->out_bstride + o, v);
+                    const uint32_t o = o_row + (uint32_t)(it * RPI) * (uint32_t)outC + o_lane;
+                    if (out_f32) store8(reinterpret_cast<float*>(out_b) + o, v);
+                    else store8(reinterpret_cast<T*>(out_b) + o, v);
                 }
             }
         }

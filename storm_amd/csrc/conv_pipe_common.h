@@ -37,6 +37,17 @@ __device__ __forceinline__ int uniform(int x) {
 #endif
 }
 
+// a * b + c for a, b < 2^24 (pixel indices, per-pixel byte strides): ONE 32-bit instruction (v_mad_u32_u24).  A plain 32-bit
+// product goes through v_mad_u64_u32 and a 64-bit register pair - which, spilled, put a scratch reload + s_waitcnt vmcnt(0)
+// into the pipelined loop of conv_pipe.hip (found in round 2: once per chunk, draining every in-flight patch piece).
+__device__ __forceinline__ uint32_t mad24(uint32_t a, uint32_t b, uint32_t c) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __umul24(a, b) + c;
+#else
+    return a * b + c;
+#endif
+}
+
 // The K loop as chunk descriptors of `kc` channels each (conv_pipe.hip; kc = 64 or 32).  Returns false when the convolution
 // is outside what the pipelined kernels cover.
 bool build_pipe_params(const storm_conv_args& a, PipeParams& p, int kc);
