@@ -289,7 +289,9 @@ def main():
             "all_conv_tflops": sum(r["flops"] for r in all_conv) / (sum(r["ms"] for r in all_conv) * 1e-3) / 1e12,
             "method": f"HIP events per op on the launch stream (storm_program_run_timed) over {args.profile_nfe} score "
                       f"evaluations at batch {args.batch}; algorithmic FLOPs = 2*B*H*W*Cout*Cin*taps per launch; kernel names from "
-                      f"the launcher (storm_program_kernel_name)",
+                      f"the launcher (storm_program_kernel_name).  An event bracket around a single launch includes the dispatch / drain gap "
+                      f"of the packets around it (about 20-25 us here): rocprofv3 --kernel-trace of the same command (profiles/) reports "
+                      f"durations about 4 % shorter, so `achieved` is the conservative one of the two",
         }
         if args.ops_json:
             with open(args.ops_json, "w") as f:
