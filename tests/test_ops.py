@@ -667,3 +667,30 @@ def test_spec_transform_standalone(dev, e, fac):
     b = ops.spec_transform(f, fac, e, inverse=True)
     assert rel_l2(b.cpu(), FR.spec_back(FR.spec_fwd(s, fac, e), fac, e)) < 2e-6
     assert rel_l2(b.cpu(), s) < 5e-6
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("shortcut", [0, 128])
+def test_conv_pipe128_bench_layer_vs_generic_kernel(shortcut, monkeypatch):
+    """The two layers of BASELINE.json configs[1] the dispatcher gives to conv_pipe128.hip (128 -> 128 @ 128 x 256, batch 16, fused
+    GroupNorm operand + temb bias + statistics epilogue, with / without the fused 1x1 shortcut) at FULL size: same output as the
+    generic kernel up to the accumulation order (bf16 outputs: a few values differ by one rounding), same statistics partials."""
+    from storm_amd import ops
+    from tests.backend import setup_backend
+    dev = setup_backend("hip")
+    g = torch.Generator().manual_seed(7)
+    B, H, W, cin, cout, dt = 16, 128, 256, 128, 128, torch.bfloat16
+    rnd = lambda *s: torch.randn(*s, generator=g)
+    x = rnd(B, H, W, cin).to(dt).to(dev)
+    ss = ops.pack_gn_ss(1 + 0.1 * rnd(B, cin), 0.1 * rnd(B, cin)).to(dev)
+    segs = [ops.Seg(x, ops.pack_conv_weight((rnd(cout, cin, 3, 3) * 0.05).to(dev), dt), 9, gn_ss=ss, gn_silu=True)]
+    if shortcut:
+        segs.append(ops.Seg(rnd(B, H, W, shortcut).to(dt).to(dev), ops.pack_conv_weight((rnd(cout, shortcut, 1, 1) * 0.05).to(dev), dt), 1))
+    kw = dict(bias=rnd(cout).to(dev), tbias=rnd(B, cout).to(dev), scale=0.7)
+    assert ops.conv_kernel_name(segs, cout, **kw).startswith("storm::conv_pipe128_kernel")          # the production choice
+    y, part = ops.conv(segs, cout, gn_partials=True, **kw)
+    monkeypatch.setenv("STORM_CONV_PIPE128", "0")
+    assert ops.conv_kernel_name(segs, cout, **kw).startswith("storm::conv_igemm_kernel")
+    y0, part0 = ops.conv(segs, cout, gn_partials=True, **kw)
+    assert rel_l2(y.float().cpu(), y0.float().cpu()) < 1e-3
+    assert torch.allclose(part.cpu(), part0.cpu(), rtol=1e-3, atol=1e-3 * float(part0.abs().max()))
