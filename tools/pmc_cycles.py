@@ -12,7 +12,7 @@ acc = collections.defaultdict(lambda: collections.defaultdict(list))
 for f in glob.glob(root + "/**/*counter_collection.csv", recursive=True):
     for r in csv.DictReader(open(f)):
         k = r["Kernel_Name"]
-        if "conv_pipe" not in k:
+        if "conv_" not in k:
             continue
         acc[(k.split("(")[0][-34:], r["Grid_Size"])][r["Counter_Name"]].append(float(r["Counter_Value"]))
 for (k, grid), c in sorted(acc.items()):
