@@ -1,0 +1,580 @@
+// Pipelined 3x3 implicit-GEMM convolution for layers with <= 128 output channels, TWO workgroups per CU (bf16 / fp16
+// operands): conv_igemm.hip's geometry - 128 output channels x (8 x 32) pixels per 4-wave workgroup, two of them resident on a
+// CU, so that one's epilogue (exposed in a one-workgroup-per-CU design: its stores gate every later counted wait) and its
+// staging intervals run under the other's MFMAs - with conv_pipe128.hip's loop: the K dimension as host-built 32-channel
+// chunk descriptors, tap bodies unrolled at compile time, every operand byte copied global -> LDS by `buffer_load ... lds`,
+// counted vmcnt waits, one fragment read per MFMA gap.  (Read conv_pipe.hip's header first.)
+//
+// Why: on these layers conv_igemm's generic loop, not the matrix pipe, is the bound - without its MFMAs a 128 -> 128 launch
+// still takes 76 % of its cycles, matrix pipes 58 % busy (profiles/r02_conv_igemm_ablation_cycles.txt) - while the 8-wave
+// conv_pipe128 keeps the pipes busy in its loop and then loses the gain to its exposed epilogue.
+//
+//   * every wave owns 64 couts x (4 x 32) pixels = 8 accumulator tiles (wave grid 2 x 2); a phase = one tap of a 32-channel
+//     chunk = two k-groups = 16 MFMAs per wave; no roles and no stagger inside the workgroup: the co-resident workgroup is
+//     the other half of the ping-pong.
+//   * LDS (78 KiB, so two workgroups fit): two 22-KiB patch buffers (10 x 34 pixels x 64 B), a 4-slot ring of 8-KiB weight
+//     phases, two (scale, shift) tables.
+//   * every wave issues, per phase: the 2 weight pieces of the phase after the next one, then (phases 0-5 of a nine-tap chunk)
+//     ONE 1-KiB piece of the next chunk's patch (phase 0: also its table).  vmcnt retires in order, so ONE counted wait per
+//     phase - "everything up to the previous phase's weights" = vmcnt(patch DMAs of the previous phase + this phase's issues)
+//     - also guarantees the patch piece issued TWO phases ago: that piece is transformed (fused GroupNorm-apply + SiLU, in
+//     place, by the lane that fetched it) right behind the wait.  Slot q: issued in phase q, landed and transformed in phase
+//     q + 2 (<= 7), so the whole next patch is ready before the pre-read of its first k-group in phase 8.
+//   * a one-tap chunk (fused 1x1 shortcut) is one phase over a compact 8 x 32 image; the next one's image (4 pieces per wave)
+//     is issued in the same phase and waited for in the next: one phase of latency slack (HBM-bound phases by construction).
+//
+// Phase P:  S(P): issue weights of P+2 -> ring slot (P+2)&3 | issue patch slot | vmcnt | transform slot P-2 | barrier
+//           C(P): 2 MFMAs | read k-group 1 | 6 MFMAs | read k-group 0 of P+1 | 8 MFMAs | barrier
+// LDS lifetimes: ring slot (P+2)&3 was last read in C(P-2); the weights of P+1 (issued in S(P-1)) are landed by S(P)'s wait and
+// pre-read in C(P).  The other patch buffer was last read in the previous chunk's C(8) (incl. the pre-read of THIS chunk's
+// first k-group, which reads this chunk's buffer); pieces land in it from S(0) on, transforms run in S(2)..S(7), the first
+// reader is the pre-read in C(8).
+//
+// K order: (32-channel chunk, tap, k-group), as conv_pipe128.hip: results agree with conv_igemm.hip / conv_pipe.hip to
+// rounding (fp32 summation order), not bit for bit.
+#include <cstdlib>
+#include <cstring>
+#include "conv_pipe_common.h"
+
+namespace storm {
+using namespace cidx;
+
+namespace duo {
+using namespace pipe;
+
+constexpr int BN = 128, TH = 8;                               // output channels x pixel rows (of 32 px) per workgroup
+constexpr int KC = 32, PIXB = 64;                             // channels / bytes per pixel and K-chunk
+constexpr int PW = TILE_W + 2;
+constexpr int NWAVES = 4, THREADS = 256;
+constexpr int WAVES_M = 2, WAVES_N = 2, WM = 2, WN = 4;       // wave grid; 32-cout tiles / pixel rows per wave
+constexpr int NPIX = (TH + 2) * PW;
+constexpr int PXP = 1024 / PIXB;                              // pixels per 1-KiB DMA piece
+constexpr int PPIECES = (NPIX + PXP - 1) / PXP;               // 22
+constexpr int PATCH_BYTES = PPIECES * 1024;
+constexpr int CPIECES = TH * TILE_W / PXP;                    // pieces of a compact (one-tap) image: 16
+constexpr int NSLOT = (PPIECES + NWAVES - 1) / NWAVES;        // haloed pieces per wave: 6 (phases 0-5)
+constexpr int NSLOT1 = CPIECES / NWAVES;                      // compact pieces per wave: 4
+constexpr int WPHASE = BN * WROW, RINGB = 4 * WPHASE;
+constexpr int NWD = BN / 16 / NWAVES;                         // weight DMA instructions per wave and phase: 2
+constexpr int OFF_RING = 2 * PATCH_BYTES;
+constexpr int OFF_SS = OFF_RING + RINGB;
+constexpr int LDS_BYTES = OFF_SS + 2 * 1024;
+constexpr int PR = 1;
+constexpr int WSTAGE = 32 * PR * WM * 128;                    // epilogue staging per wave
+static_assert(2 * LDS_BYTES <= 160 * 1024, "two workgroups per CU");
+static_assert(PATCH_BYTES % 256 == 0, "k-group XOR must stay inside the slot field");
+static_assert(NSLOT == 6 && NSLOT + 2 <= 8, "slot q is issued in phase q and transformed in phase q + 2 <= 7");
+static_assert(CPIECES % NWAVES == 0 && NSLOT1 <= NSLOT, "compact pieces fit the same slots");
+static_assert(2 * WSTAGE + WAVES_N * BN * 8 <= PATCH_BYTES && 2 * WSTAGE <= 2 * WPHASE, "epilogue staging beside the next tile's loads");
+
+STORM_HD int p_swz(int px, int slot) { return (slot ^ ((px >> 2) & 3)) << 4; }      // (conv_pipe128.hip)
+
+// patch / table DMA instructions a wave issues in phase tp of a nine-tap chunk (after that phase's weight pieces)
+constexpr int n_patch(int tp) { return tp == 0 ? 2 : (tp < NSLOT ? 1 : 0); }
+
+}  // namespace duo
+using namespace duo;
+
+template <typename T>
+__global__ __launch_bounds__(duo::THREADS, 2)
+void conv_duo_kernel(const PipeParams a, const int n_ct, const int tiles_per_xcd,
+                     const int ntiles, const int tiles_x, const int tiles_per_img, const int total_vblocks) {
+    typedef typename Mma<T>::Frag Frag;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+#if defined(__HIP_DEVICE_COMPILE__)
+    typedef const PipeParams __attribute__((address_space(4)))* KArgPtr;   // parameter block through the kernarg pointer (conv_pipe.hip)
+    KArgPtr ap = (KArgPtr)__builtin_amdgcn_kernarg_segment_ptr();
+    (void)a;
+#define STORM_RELAUNDER() asm volatile("" : "+s"(ap))
+#else
+    const PipeParams* ap = &a;
+#define STORM_RELAUNDER() ((void)0)
+#endif
+
+    // persistent workgroups (two per CU) walking the XCD-aware virtual block ids
+    int vb = blockIdx.x;
+    while (vb < total_vblocks && block_map(vb, n_ct, tiles_per_xcd).tile >= ntiles) vb += gridDim.x;
+    if (vb >= total_vblocks) return;
+    int tile, b, ty0, tx0, cout0;                           // the tile whose loads are being ISSUED
+    auto decode = [&](int v) {
+        const BlockMap bm = block_map(v, n_ct, tiles_per_xcd);
+        tile = bm.tile;
+        b = bm.tile / tiles_per_img;
+        const int trem = bm.tile - b * tiles_per_img;
+        ty0 = (trem / tiles_x) * TH;
+        tx0 = (trem % tiles_x) * TILE_W;
+        cout0 = bm.ct * BN;
+    };
+    decode(vb);
+    const int imgH = pin(ap->H), imgW = pin(ap->W);
+
+    const int tid = threadIdx.x;
+    int lane = tid & 63;                                    // re-laundered at every chunk
+    const int wave = uniform(tid >> 6);
+    const int wm = wave % WAVES_M, wn = wave / WAVES_M;
+
+    f32x16 acc[WM][WN];
+
+    // ---- lane constants ---------------------------------------------------------------------------------------
+    const int aoff = OFF_RING + w_off(wm * WM * 32 + (lane & 31), lane >> 5);
+    const int aoff1 = aoff ^ 32;                            // second k-group of a phase
+    int pbase[3];                                           // this lane's pixel of ni = 0 under tap (0, dx), k-group 0, current buffer
+#pragma unroll
+    for (int d = 0; d < 3; ++d) pbase[d] = ((wn * WN) * PW + (lane & 31)) * PIXB + p_swz((lane & 31) + d, lane >> 5);
+    const int cdelta = wn * WN * (PW - TILE_W) * PIXB;      // haloed row index - compact row index of this wave's pixels
+
+    // patch entry of haloed piece wave + 4 i for this lane: (pixel index << 3) | logical 16-B slot that lands in this lane's
+    // physical slot, or -1 (padding / past the patch: hardware zero fill); recomputed where used (conv_pipe128.hip)
+    const int prow0 = wave * PXP + (lane >> 2);
+    auto patch_entry = [&](int i) -> uint32_t {
+        const int row = prow0 + NWAVES * PXP * i;
+        const int py = row / PW, px = row - py * PW;
+        const int slot = (lane & 3) ^ ((px >> 2) & 3);
+        const int gy = ty0 + py - 1, gx = tx0 + px - 1;
+        const bool ok = row < NPIX && gy >= 0 && gy < imgH && gx >= 0 && gx < imgW;
+        return ok ? (uint32_t)(((gy * imgW + gx) << 3) | slot) : 0xffffffffu;
+    };
+    uint32_t R[NWD];                                        // per-lane source offsets of this wave's weight pieces of the current run
+
+    // ---- descriptor state.  While chunk c is computed: pd_* / w1_* = chunk c+1 (patch being issued / transformed, weight
+    // stream), w2_* = weight stream position of chunk c+2 ----------------------------------------------------------------------
+    u32x4 pd_srd, pd_ss_srd, w_srd;
+    const int nchunks_k = pin(ap->nchunks);                 // index of the terminator descriptor
+    int pd_C2 = 0, pd_cbeg2 = 0, pd_cvalid = 0, pd_ntaps = 9, pd_gn = 0, pd_silu = 0;
+    int w1_neww = 0, w1_wrun = 0, w1_wsoff = 0, w2_neww = 0, w2_wrun = 0, w2_wsoff = 0;
+    int w_soff = 0, w_tapbytes = 0;
+    auto load_patch_desc = [&](int i) {                     // descriptor i -> pd_*, w1_*
+        const ChunkDesc& d = ap->chunk[i < nchunks_k ? i : nchunks_k];
+        pd_srd = make_srd(reinterpret_cast<const char*>(d.src + (unsigned long long)b * d.bstride), d.src_bytes);
+        pd_gn = d.ss != 0ull;
+        pd_ss_srd = make_srd(reinterpret_cast<const char*>(pd_gn ? d.ss + (unsigned long long)b * d.ss_bstride : d.src),
+                             pd_gn ? (uint32_t)d.cvalid * 8u : 0u);
+        pd_C2 = d.C2; pd_cbeg2 = d.cbeg2; pd_cvalid = d.cvalid; pd_ntaps = d.ntaps; pd_silu = d.silu;
+        w1_wrun = d.wrun; w1_wsoff = d.w_soff; w1_neww = d.new_wrun;
+    };
+    auto load_w2_desc = [&](int i) {                        // descriptor i -> w2_*
+        const ChunkDesc& d = ap->chunk[i < nchunks_k ? i : nchunks_k];
+        w2_wrun = d.wrun; w2_wsoff = d.w_soff; w2_neww = d.new_wrun;
+    };
+    auto enter_wrun = [&](int r) {
+        const WRunDesc& W = ap->wrun[r];
+        w_srd = make_srd(reinterpret_cast<const char*>(W.w), W.bytes);
+        w_tapbytes = W.tapbytes;
+#pragma unroll
+        for (int j = 0; j < NWD; ++j) {
+            const int row = (wave * NWD + j) * 16 + (lane >> 2);
+            const int co = cout0 + row;                          // rows past the matrix: zeros (never stored)
+            R[j] = co < W.rows ? (uint32_t)(co * W.CinP2 + ((lane & 3) ^ ((row >> 2) & 3)) * 16) : OOB;
+        }
+    };
+    int ring_rd = 0;                                        // byte offset of the ring slot of the phase being read
+    auto w_issue = [&]() {                                  // the stream's tap -> the slot two phases ahead
+        char* dst = smem + OFF_RING + (ring_rd ^ (2 * WPHASE)) + wave * (NWD * 1024);
+#pragma unroll
+        for (int j = 0; j < NWD; ++j) dma16(w_srd, R[j], (uint32_t)w_soff, dst + j * 1024, lane);
+    };
+    auto ring_next = [&]() { ring_rd = (ring_rd + WPHASE) & (RINGB - 1); };
+
+    int par = 0;                                            // patch buffer of the chunk being read (folded into pbase)
+    auto issue_table = [&](int into) { dma16(pd_ss_srd, (uint32_t)lane * 16u, 0u, smem + OFF_SS + into * 1024, lane); };
+    auto issue_slot = [&](int i, int into) {                // haloed piece wave + 4 i
+        const int k = wave + NWAVES * i;
+        if (k >= PPIECES) { issue_table(into); return; }     // surplus slot: identical table bytes again (keeps the VMEM count uniform)
+        const uint32_t v = patch_entry(i);
+        const bool ok = (int)v >= 0 && (int)(v & 7u) * 8 < pd_cvalid;
+        dma16(pd_srd, ok ? mad24(v >> 3, (uint32_t)pd_C2, (v & 7u) * 16u) : OOB, (uint32_t)pd_cbeg2,
+              smem + into * PATCH_BYTES + k * 1024, lane);
+    };
+    // one compact piece (one-tap chunk: TH x 32 pixels, no halo): piece k = pixel row k >> 1, columns 16 (k & 1) ..
+    auto issue_compact = [&](int k, int into) {
+        const int trow = k >> 1, n = (k & 1) * PXP + (lane >> 2);
+        const int slot = (lane & 3) ^ ((n >> 2) & 3);
+        const int gy = ty0 + trow, gx = tx0 + n;
+        const bool ok = gy < imgH && gx < imgW && slot * 8 < pd_cvalid;
+        dma16(pd_srd, ok ? mad24((uint32_t)(gy * imgW + gx), (uint32_t)pd_C2, (uint32_t)slot * 16u) : OOB, (uint32_t)pd_cbeg2,
+              smem + into * PATCH_BYTES + k * 1024, lane);
+    };
+    auto issue_any = [&](int i, int into) {                 // slot i in the layout of the chunk being issued
+        if (pd_ntaps == 9) issue_slot(i, into);
+        else if (i < NSLOT1) issue_compact(wave + NWAVES * i, into);
+        else issue_table(into);
+    };
+    // fused GroupNorm-apply (+ SiLU) of the chunk being fetched: in place, by the lane that fetched the unit
+    auto commit_slot = [&](int i, int into) {
+        const int k = wave + NWAVES * i;
+        if (k < PPIECES) {
+            const uint32_t v = patch_entry(i);
+            if ((int)v >= 0 && (int)(v & 7u) * 8 < pd_cvalid) {
+                uint4* const q = reinterpret_cast<uint4*>(smem + into * PATCH_BYTES + k * 1024 + lane * 16);
+                float ss[16];
+                load_ss<8>(reinterpret_cast<const float*>(smem + OFF_SS + into * 1024), (int)(v & 7u), ss);
+                *q = gn_act_slot(*q, ss, pd_silu, (T*)nullptr);
+            }
+        }
+    };
+
+    // ---- fragment reads / MFMAs (as conv_pipe128.hip) ---------------------------------------------------------------
+    auto read_frags = [&](Frag (&fa)[WM], Frag (&fb)[WN], int ring, int pb, auto kg_, auto poff_, auto prow_) {
+        constexpr int kg = decltype(kg_)::value, POFF = decltype(poff_)::value, PROW = decltype(prow_)::value;
+        const char* wb = smem + ring + (kg ? aoff1 : aoff);
+#pragma unroll
+        for (int mi = 0; mi < WM; ++mi) fa[mi] = *reinterpret_cast<const Frag*>(wb + mi * 32 * WROW);
+        const char* pp = smem + (pb ^ (kg << 5)) + POFF;
+#pragma unroll
+        for (int ni = 0; ni < WN; ++ni) fb[ni] = *reinterpret_cast<const Frag*>(pp + ni * PROW);
+    };
+    auto read_a = [&](Frag& f, int ring, auto kg_, auto mi_) {
+        constexpr int kg = decltype(kg_)::value, mi = decltype(mi_)::value;
+        f = *reinterpret_cast<const Frag*>(smem + ring + (kg ? aoff1 : aoff) + mi * 32 * WROW);
+    };
+    auto read_b = [&](Frag& f, int pb, auto kg_, auto poff_, auto prow_, auto ni_) {
+        constexpr int kg = decltype(kg_)::value, POFF = decltype(poff_)::value, PROW = decltype(prow_)::value, ni = decltype(ni_)::value;
+        f = *reinterpret_cast<const Frag*>(smem + (pb ^ (kg << 5)) + POFF + ni * PROW);
+    };
+    auto mma_part = [&](const Frag (&fa)[WM], const Frag (&fb)[WN], int lo, int hi) {
+#pragma unroll
+        for (int i = 0; i < WM * WN; ++i)
+            if (i >= lo && i < hi) Mma<T>::run(fa[i / WN], fb[i % WN], acc[i / WN][i % WN]);
+    };
+    Frag fa0[WM], fb0[WN], fa1[WM], fb1[WN];
+    typedef IC<PW * PIXB> Prow9; typedef IC<TILE_W * PIXB> Prow1;
+
+    // ---- one phase: tap TP of a chunk with NT taps ---------------------------------------------------------------
+    auto phase = [&](auto t_, auto nt_) {
+        constexpr int TP = decltype(t_)::value, NT = decltype(nt_)::value;
+        constexpr int DX = NT == 9 ? TP % 3 : 0;
+        constexpr int POFF = NT == 9 ? ((TP / 3) * PW + DX) * PIXB : 0;
+        constexpr int DXN = NT == 9 ? (TP + 1) % 3 : 0;                          // the next tap of the chunk
+        constexpr int POFFN = NT == 9 ? (((TP + 1) / 3) * PW + DXN) * PIXB : 0;
+        typedef IC<POFF> Poff; typedef IC<POFFN> PoffN;
+        typedef std::conditional_t<NT == 9, Prow9, Prow1> Prow;
+        const int pb = NT == 9 ? pbase[DX] : pbase[0] - cdelta;
+        const int into = par ^ 1;
+        // the weight stream moves to the phase after the next one
+        if constexpr (NT == 9 && TP <= 6) w_soff += w_tapbytes;
+        else if constexpr (NT == 9 && TP == 7) { if (w1_neww) enter_wrun(w1_wrun); w_soff = w1_wsoff; }
+        else if (NT == 9 && pd_ntaps == 9) w_soff += w_tapbytes;
+        else { if (w2_neww) enter_wrun(w2_wrun); w_soff = w2_wsoff; }
+        // ================= S =================
+        w_issue();
+        if constexpr (NT == 9) {
+            if constexpr (TP == 0) issue_table(into);
+            if constexpr (TP < NSLOT) issue_any(TP, into);
+            // everything up to the previous phase's weight pieces has landed - and with it the patch piece of two phases ago
+            vm_wait<n_patch(TP == 0 ? 8 : TP - 1) + NWD + n_patch(TP)>();
+            if constexpr (TP >= 2 && TP - 2 < NSLOT) { if (pd_gn) commit_slot(TP - 2, into); }
+        } else {
+#pragma unroll
+            for (int i = 0; i < NSLOT1; ++i) issue_compact(wave + NWAVES * i, into);
+            vm_wait<NWD + NSLOT1>();                         // everything older: this chunk's image and the next phase's weights
+        }
+        raw_barrier();
+        // ================= C =================
+        __builtin_amdgcn_sched_barrier(0);
+        if constexpr (NT == 1) read_frags(fa0, fb0, ring_rd, pb, IC<0>{}, Poff{}, Prow{});   // (a compact image has just landed: no pre-read)
+        prio(1);
+        {
+            const int rn = (ring_rd + WPHASE) & (RINGB - 1);
+            auto next_a = [&](auto mi_) {
+                constexpr int mi = decltype(mi_)::value;
+                if constexpr (NT == 9 && TP < 8) read_a(fa0[mi], rn, IC<0>{}, mi_);
+                else if constexpr (NT == 9) { if (pd_ntaps == 9) read_a(fa0[mi], rn, IC<0>{}, mi_); }
+            };
+            auto next_b = [&](auto ni_) {
+                if constexpr (NT == 9 && TP < 8) read_b(fb0[decltype(ni_)::value], pbase[DXN], IC<0>{}, PoffN{}, Prow{}, ni_);
+                else if constexpr (NT == 9) {
+                    if (pd_ntaps == 9) read_b(fb0[decltype(ni_)::value], pbase[0] + (par ? -PATCH_BYTES : PATCH_BYTES), IC<0>{}, IC<0>{}, Prow9{}, ni_);
+                }
+            };
+            typedef IC<1> K1;
+#define STORM_SB() __builtin_amdgcn_sched_barrier(0)
+            mma_part(fa0, fb0, 0, 1); read_a(fa1[0], ring_rd, K1{}, IC<0>{}); read_b(fb1[0], pb, K1{}, Poff{}, Prow{}, IC<0>{}); STORM_SB();
+            mma_part(fa0, fb0, 1, 2); read_b(fb1[1], pb, K1{}, Poff{}, Prow{}, IC<1>{}); read_b(fb1[2], pb, K1{}, Poff{}, Prow{}, IC<2>{}); STORM_SB();
+            mma_part(fa0, fb0, 2, 3); read_b(fb1[3], pb, K1{}, Poff{}, Prow{}, IC<3>{}); read_a(fa1[1], ring_rd, K1{}, IC<1>{}); STORM_SB();
+            mma_part(fa0, fb0, 3, 4); STORM_SB();
+            mma_part(fa0, fb0, 4, 5); next_a(IC<0>{}); STORM_SB();          // fa0[0]: last used by MFMA 3
+            mma_part(fa0, fb0, 5, 6); next_b(IC<0>{}); STORM_SB();          // fb0[0]: last used by MFMA 4
+            mma_part(fa0, fb0, 6, 7); next_b(IC<1>{}); STORM_SB();
+            mma_part(fa0, fb0, 7, 8); next_b(IC<2>{}); STORM_SB();
+            mma_part(fa1, fb1, 0, 1); next_b(IC<3>{}); next_a(IC<1>{}); STORM_SB();   // fb0[3], fa0[1]: last used by MFMA 7
+            mma_part(fa1, fb1, 1, WM * WN); STORM_SB();
+#undef STORM_SB
+            raw_barrier();
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        prio(0);
+        ring_next();
+    };
+
+    // ---- tile start, part A: chunk 0's patch -> buffer 0 / table 0, the first two taps' weights -> ring slots 0, 1: regions
+    // the previous tile's epilogue staging does not touch
+    auto tile_issue = [&]() {
+        load_patch_desc(0);
+        enter_wrun(w1_wrun);
+        w_soff = w1_wsoff;
+        char* dst = smem + OFF_RING + wave * (NWD * 1024);
+#pragma unroll
+        for (int j = 0; j < NWD; ++j) dma16(w_srd, R[j], (uint32_t)w_soff, dst + j * 1024, lane);
+        w_soff += w_tapbytes;                                    // (the first chunk has nine taps)
+#pragma unroll
+        for (int j = 0; j < NWD; ++j) dma16(w_srd, R[j], (uint32_t)w_soff, dst + WPHASE + j * 1024, lane);
+        issue_table(0);
+#pragma unroll
+        for (int i = 0; i < NSLOT; ++i) issue_slot(i, 0);
+    };
+    const int nchunks = pin(ap->nchunks), n9 = pin(ap->nchunks9);
+    auto chunk_change = [&](int ci) {                       // chunk ci is done: the fetched buffer becomes current; descriptors of ci + 2 / ci + 3
+        par ^= 1;
+        const int dlt = par ? PATCH_BYTES : -PATCH_BYTES;
+#pragma unroll
+        for (int d = 0; d < 3; ++d) pbase[d] += dlt;
+        load_patch_desc(ci + 2);
+        load_w2_desc(ci + 3);
+#if defined(__HIP_DEVICE_COMPILE__)
+        asm volatile("" : "+v"(lane));
+#endif
+    };
+    tile_issue();
+    while (true) {
+        // ---- tile start, part B: everything issued has landed; fused GroupNorm transform of the first patch (all four waves) ----
+        STORM_RELAUNDER();
+        vm_wait<0>();
+        if (pd_gn) {
+#pragma unroll
+            for (int i = 0; i < NSLOT; ++i) commit_slot(i, 0);
+        }
+        load_patch_desc(1);
+        load_w2_desc(2);
+        raw_barrier();
+        read_frags(fa0, fb0, 0, pbase[0], IC<0>{}, IC<0>{}, Prow9{});   // first k-group of phase 0
+#pragma unroll
+        for (int mi = 0; mi < WM; ++mi)
+#pragma unroll
+            for (int ni = 0; ni < WN; ++ni)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[mi][ni][r] = 0.0f;
+
+        // ---- main loops: the nine-tap chunks, then the one-tap chunks of a fused 1x1 shortcut ---------------------------
+        int ci = 0;
+        for (; ci < n9; ++ci) {
+            static_for<9>([&](auto t) { phase(t, IC<9>{}); });
+            chunk_change(ci);
+        }
+        for (; ci < nchunks; ++ci) {
+            phase(IC<0>{}, IC<1>{});
+            chunk_change(ci);
+        }
+
+        // ---- hand-over: this tile's coordinates go to the epilogue; the next tile's first loads are issued -----------------
+        vm_wait<0>();                                       // trailing (zero-fill) patch / ring loads landed ...
+        raw_barrier();                                      // ... and every wave is done reading: all of LDS is free
+        const int e_tile = tile, e_b = b, e_ty0 = ty0, e_tx0 = tx0, e_cout0 = cout0;
+        STORM_RELAUNDER();
+        int nvb = vb + gridDim.x;
+        while (nvb < total_vblocks && block_map(nvb, n_ct, tiles_per_xcd).tile >= ntiles) nvb += gridDim.x;
+        const bool has_next = nvb < total_vblocks;
+        if (par) {                                          // the next tile starts in patch buffer 0 / ring slot 0
+            par = 0;
+#pragma unroll
+            for (int d = 0; d < 3; ++d) pbase[d] -= PATCH_BYTES;
+        }
+        ring_rd = 0;
+        if (has_next) {
+            vb = nvb;
+            decode(vb);
+#if defined(__HIP_DEVICE_COMPILE__)
+            asm volatile("" : "+v"(lane));
+#endif
+            tile_issue();
+        }
+        STORM_RELAUNDER();
+
+        // ---- epilogue: LDS transpose -> (bias, temb bias, skip, scale) -> wide stores (as conv_pipe128.hip).  Staging lives in patch
+        // buffer 1 (waves 0, 1; the statistics scratch behind them) and ring slots 2, 3 (waves 2, 3): the next tile's first loads
+        // are landing in buffer 0 / table 0 / ring slots 0, 1 meanwhile.
+        constexpr int SROWS = 32 * PR;
+        char* const stage = smem + (wave < 2 ? PATCH_BYTES + wave * WSTAGE : OFF_RING + 2 * WPHASE + (wave - 2) * WSTAGE);
+        constexpr int LPR = WM * 4;                 // lanes per staged row (8 couts each)
+        constexpr int RPI = 64 / LPR;               // rows per read iteration
+        // epilogue parameters: read ONCE per tile and pinned in SGPRs
+        const int outC = pin(ap->outC), skipC = outC, out_f32 = pin(ap->out_f32);
+        const bool has_skip = ap->skip != nullptr;
+#if defined(__HIP_DEVICE_COMPILE__)
+        unsigned long long out_u = reinterpret_cast<unsigned long long>(ap->out) + (unsigned long long)((long long)e_b * ap->out_bstride * (out_f32 ? 4 : (int)sizeof(T)));
+        asm volatile("" : "+s"(out_u));
+        typedef __attribute__((address_space(1))) char GChar;       // (keeps the stores global_store: behind the asm the pointer's origin is opaque)
+        char* const out_b = (char*)(GChar*)out_u;
+#else
+        char* const out_b = reinterpret_cast<char*>(ap->out) + (long long)e_b * ap->out_bstride * (out_f32 ? 4 : (int)sizeof(T));
+#endif
+        const int c8 = lane & (LPR - 1);
+        const int co = e_cout0 + wm * WM * 32 + c8 * 8;
+        float badd[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) badd[e] = 0.f;
+        if (co + 8 <= ap->Cout) {
+            if (ap->bias) { float bb[8]; load8(ap->bias + co, bb);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) badd[e] += bb[e]; }
+            if (ap->tbias) { float bb[8]; load8(ap->tbias + (long long)e_b * ap->tbias_stride + co, bb);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) badd[e] += bb[e]; }
+        } else {
+#pragma unroll
+            for (int e = 0; e < 8; ++e)
+                if (co + e < ap->Cout) {
+                    if (ap->bias) badd[e] += ap->bias[co + e];
+                    if (ap->tbias) badd[e] += ap->tbias[(long long)e_b * ap->tbias_stride + co + e];
+                }
+        }
+        const bool co_ok = co < outC;
+        const T* const skip_b = reinterpret_cast<const T*>(ap->skip) + (long long)e_b * ap->skip_bstride;
+        f32x2 badd2[4], gsum2[4], gsq2[4];
+        const f32x2 scale2 = {ap->scale, ap->scale};
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            badd2[i] = f32x2{badd[2 * i] * ap->scale, badd[2 * i + 1] * ap->scale};
+            gsum2[i] = f32x2{0.f, 0.f}; gsq2[i] = f32x2{0.f, 0.f};
+        }
+        float gsum[8], gsq[8];
+        static_assert(PR == 1 && WM == 2, "store loop index math");
+        const int l8 = (lane >> 3) & 7;                         // the pixel (of the 8 per iteration) this lane stores
+        const int gx0 = e_tx0 + l8;
+        const uint32_t o_lane = (uint32_t)(gx0 * outC + co);
+        int srow[2][2];                                         // staged row it * 8 + l8, slots 2 c8 / 2 c8 + 1 (see conv_pipe.hip)
+#pragma unroll
+        for (int odd = 0; odd < 2; ++odd)
+#pragma unroll
+            for (int h = 0; h < 2; ++h) srow[odd][h] = stage_off<WM>(odd * 8 + l8, 2 * c8 + h) - odd * 8 * (WM * 128);
+#pragma unroll
+        for (int pass = 0; pass < WN / PR; ++pass) {
+            const int gy = e_ty0 + wn * WN + pass;
+            const bool row_ok = gy < imgH;
+            const uint32_t o_row = (uint32_t)(gy * imgW) * (uint32_t)outC;
+            auto skip_fetch = [&](int it) {                      // skip operands are fetched ONE store ahead
+                uint4 q = make_uint4(0u, 0u, 0u, 0u);
+                if (row_ok && gx0 + it * RPI < imgW && co_ok) q = *reinterpret_cast<const uint4*>(skip_b + (o_row + (uint32_t)(it * RPI) * (uint32_t)outC + o_lane));
+                return q;
+            };
+            uint4 sk_next = make_uint4(0u, 0u, 0u, 0u);
+            if (has_skip) sk_next = skip_fetch(0);
+            if (pass > 0) wave_sync();
+#pragma unroll
+            for (int mi = 0; mi < WM; ++mi)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const int row = lane & 31;
+                    const f32x16& c = acc[mi][pass];
+                    *reinterpret_cast<float4*>(stage + stage_off<WM>(row, stage_wslot(lane, mi, g))) =
+                        make_float4(c[4 * g], c[4 * g + 1], c[4 * g + 2], c[4 * g + 3]);
+                }
+            wave_sync();
+#pragma unroll
+            for (int it = 0; it < SROWS / RPI; ++it) {
+                const uint4 sk_cur = sk_next;
+                if (has_skip && it + 1 < SROWS / RPI) sk_next = skip_fetch(it + 1);
+                const char* const sp = stage + it * RPI * (WM * 128);
+                const float4 v0 = *reinterpret_cast<const float4*>(sp + srow[it & 1][0]);
+                const float4 v1 = *reinterpret_cast<const float4*>(sp + srow[it & 1][1]);
+                f32x2 v2[4] = {f32x2{v0.x, v0.y}, f32x2{v0.z, v0.w}, f32x2{v1.x, v1.y}, f32x2{v1.z, v1.w}};
+                if (row_ok && gx0 + it * RPI < imgW && co_ok) {
+                    if (has_skip) {
+                        alignas(16) T sk[8];
+                        *reinterpret_cast<uint4*>(sk) = sk_cur;
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) v2[i] += f32x2{to_f32(sk[2 * i]), to_f32(sk[2 * i + 1])};
+                    }
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        v2[i] = __builtin_elementwise_fma(v2[i], scale2, badd2[i]);
+                        gsum2[i] += v2[i];
+                        gsq2[i] = __builtin_elementwise_fma(v2[i], v2[i], gsq2[i]);
+                    }
+                    const float v[8] = {v2[0].x, v2[0].y, v2[1].x, v2[1].y, v2[2].x, v2[2].y, v2[3].x, v2[3].y};
+                    const uint32_t o = o_row + (uint32_t)(it * RPI) * (uint32_t)outC + o_lane;
+                    if (out_f32) store8(reinterpret_cast<float*>(out_b) + o, v);
+                    else store8(reinterpret_cast<T*>(out_b) + o, v);
+                }
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { gsum[2 * i] = gsum2[i].x; gsum[2 * i + 1] = gsum2[i].y; gsq[2 * i] = gsq2[i].x; gsq[2 * i + 1] = gsq2[i].y; }
+        if (ap->gn_part != nullptr) {
+#pragma unroll
+            for (int off = LPR; off < 64; off <<= 1)
+#pragma unroll
+                for (int e = 0; e < 8; ++e) { gsum[e] += __shfl_xor(gsum[e], off, 64); gsq[e] += __shfl_xor(gsq[e], off, 64); }
+            __syncthreads();
+            float* red = reinterpret_cast<float*>(smem + PATCH_BYTES + 2 * WSTAGE);   // [WAVES_N][BN][2]
+            if (lane < LPR) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    const int chl = wm * WM * 32 + lane * 8 + e;
+                    red[(wn * BN + chl) * 2] = gsum[e];
+                    red[(wn * BN + chl) * 2 + 1] = gsq[e];
+                }
+            }
+            __syncthreads();
+            if (tid < BN && e_cout0 + tid < outC) {
+                float s0 = 0.f, s1 = 0.f;
+#pragma unroll
+                for (int w = 0; w < WAVES_N; ++w) { s0 += red[(w * BN + tid) * 2]; s1 += red[(w * BN + tid) * 2 + 1]; }
+                float* dst = ap->gn_part + ((long long)e_tile * outC + e_cout0 + tid) * 2;
+                dst[0] = s0; dst[1] = s1;
+            }
+        }
+        if (!has_next) break;
+        __syncthreads();                                    // the statistics scratch / staging of this tile is free again
+    }
+}
+
+#undef STORM_RELAUNDER
+
+// ---- host side ---------------------------------------------------------------------------------------------------
+bool conv_duo_supports(const storm_conv_args& a) {
+    if (a.outC > duo::BN) return false;
+    PipeParams p;
+    return build_pipe_params(a, p, duo::KC);
+}
+
+template <typename T>
+static int launch_duo(const storm_conv_args& a, hipStream_t st) {
+    auto kern = conv_duo_kernel<T>;
+    static bool attr_set = false;                       // per instantiation; benign race (idempotent)
+    if (!attr_set) {
+        STORM_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, duo::LDS_BYTES));
+        attr_set = true;
+    }
+    PipeParams prm;
+    STORM_CHECK(a.outC <= duo::BN && build_pipe_params(a, prm, duo::KC), "storm_conv: convolution outside the two-workgroup pipelined kernel's coverage");
+    const int tiles_x = cdiv(a.W, TILE_W);
+    const int tiles_per_img = tiles_x * cdiv(a.H, duo::TH);
+    const long long ntiles = (long long)a.B * tiles_per_img;
+    const int n_ct = 1;
+    const int tiles_per_xcd = cdiv(ntiles, 8);
+    const long long vblocks = 8LL * tiles_per_xcd * n_ct;
+    STORM_CHECK(vblocks > 0 && vblocks < (1LL << 31), "storm_conv: grid %lld out of range", vblocks);
+    static int n_cu = 0;
+    if (n_cu == 0) {
+        int dev = 0; hipDeviceProp_t prop;
+        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) n_cu = prop.multiProcessorCount;
+        if (n_cu <= 0) n_cu = 256;
+    }
+    const char* cus_env = getenv("STORM_CONV_CUS");                    // test hook: pretend the device has this many CUs
+    const long long resident = 2LL * (((cus_env ? atoi(cus_env) : n_cu) + 7) / 8 * 8);   // two workgroups per CU; a multiple of 8
+    const long long grid = vblocks < resident ? vblocks : resident;
+    hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(duo::THREADS), duo::LDS_BYTES, st, prm, n_ct, tiles_per_xcd, (int)ntiles,
+                       tiles_x, tiles_per_img, (int)vblocks);
+    STORM_LAUNCH_CHECK();
+    return STORM_OK;
+}
+
+int launch_conv_duo(const storm_conv_args& a, hipStream_t st) {
+    return a.dtype == STORM_F16 ? launch_duo<half_t>(a, st) : launch_duo<bf16_t>(a, st);
+}
+
+const char* conv_duo_kernel_name(int dtype) {
+    return dtype == STORM_F16 ? "storm::conv_duo_kernel<storm::half_t>" : "storm::conv_duo_kernel<storm::bf16_t>";
+}
+
+}  // namespace storm

@@ -663,6 +663,7 @@ static int env_int(const char* name, int dflt) {
 //   2: conv_igemm 256 cout x 256 px, 8 waves, 1 workgroup / CU, patch double-buffered through registers
 //   3: conv_pipe.hip, 256 cout x 256 px, 8 waves in two ping-pong groups, chunk-unrolled LDS-DMA pipeline (16-bit 3x3)
 //   4: conv_pipe128.hip, 128 cout x 512 px, the same pipeline for layers with <= 128 output channels (16-bit 3x3)
+//   5: conv_duo.hip, 128 cout x 256 px, 4 waves, two workgroups / CU, the pipelined loop (16-bit 3x3, <= 128 output channels)
 static int choose_variant(const storm_conv_args& a, bool any9) {
     const int forced = env_int("STORM_CONV_VARIANT", -1);
     if (forced >= 0) return forced;
@@ -674,6 +675,8 @@ static int choose_variant(const storm_conv_args& a, bool any9) {
     // workgroups hide them at least as well.  (A stem-like layer with fewer than 32 input channels is HBM-bound either way.)
     if (a.outC > 32 && a.outC <= 128 && any9 && px_tiles >= 1024 && px_tiles <= 4096 && a.seg[0].Ca + a.seg[0].Cb >= 32 &&
         env_int("STORM_CONV_PIPE128", 1) != 0 && conv_pipe128_supports(a)) return 4;    // (A/B switch: 0 = conv_igemm for these layers)
+    if (a.outC > 32 && a.outC <= 128 && any9 && px_tiles >= 512 && a.seg[0].Ca + a.seg[0].Cb >= 32 &&
+        env_int("STORM_CONV_DUO", 0) != 0 && conv_duo_supports(a)) return 5;
     return 0;
 }
 
@@ -687,7 +690,7 @@ static int dispatch_conv(const storm_conv_args& a, hipStream_t st) {
 #if defined(STORM_PROFILING)
     // work-skipping instantiations for tools/ (no MFMA, no fragment reads, ...): profiling build only
     const int abl = env_int("STORM_CONV_ABLATE", 0);
-    if (any9 && !small && abl && variant != 3 && variant != 4) {
+    if (any9 && !small && abl && variant < 3) {
         const bool v2 = variant == 2;
         switch (abl) {
             case 1: return v2 ? launch_conv<T, 9, 2, 4, 2, true, false, 1>(a, st) : launch_conv<T, 9, 2, 2, 2, false, false, 1>(a, st);
@@ -705,6 +708,7 @@ static int dispatch_conv(const storm_conv_args& a, hipStream_t st) {
         if (small) return launch_conv<T, 9, 1, 1, 4, false>(a, st);
         if (variant == 3 && conv_pipe_supports(a)) return launch_conv_pipe(a, st);
         if (variant == 4 && conv_pipe128_supports(a)) return launch_conv_pipe128(a, st);
+        if (variant == 5 && conv_duo_supports(a)) return launch_conv_duo(a, st);
         if (variant == 2) return launch_conv<T, 9, 2, 4, 2, true>(a, st);
         if (variant == 1) return launch_conv<T, 9, 2, 2, 4, false>(a, st);
         return dma ? launch_conv<T, 9, 2, 2, 2, false, true>(a, st) : launch_conv<T, 9, 2, 2, 2, false, false>(a, st);
@@ -725,6 +729,7 @@ static const char* kernel_name_of(const storm_conv_args& a) {
     if (a.outC <= 32) shape = "1, 1, 4, false, false";
     else if (any9 && variant == 3 && conv_pipe_supports(a)) return conv_pipe_kernel_name(a.dtype);
     else if (any9 && variant == 4 && conv_pipe128_supports(a)) return conv_pipe128_kernel_name(a.dtype);
+    else if (any9 && variant == 5 && conv_duo_supports(a)) return conv_duo_kernel_name(a.dtype);
     else if (variant == 2) shape = "2, 4, 2, true, false";
     else if (variant == 1) shape = "2, 2, 4, false, false";
     else shape = any9 ? "2, 2, 2, false, true" : "2, 2, 2, false, false";

@@ -162,11 +162,14 @@ PIPE128_CASES = {
 }
 
 
+@pytest.mark.parametrize("variant", [4, 5])
 @pytest.mark.parametrize("case", list(PIPE128_CASES))
-def test_conv_pipelined_128cout_kernel(dev, case, monkeypatch):
-    """conv_pipe128.hip (128 couts x 16 x 32 pixels per workgroup, 32-channel chunks, triple-buffered patches): plain 3x3, fused
-    1x1 shortcut over a concat, fused GroupNorm-apply operand, ragged sizes, 1 .. 8 nine-tap chunks, persistent tile walk,
-    GroupNorm partials in the 8-row tile layout - on shapes the default dispatch would give to conv_igemm.hip."""
+def test_conv_pipelined_128cout_kernel(dev, case, variant, monkeypatch):
+    """The pipelined kernels for <= 128 output channels - conv_pipe128.hip (variant 4: 128 couts x 16 x 32 pixels, 8 waves, triple-
+    buffered patches) and conv_duo.hip (variant 5: 128 couts x 8 x 32 pixels, 4 waves, two workgroups per CU, double-buffered
+    patches), both with 32-channel chunks: plain 3x3, fused 1x1 shortcut over a concat, fused GroupNorm-apply operand, ragged
+    sizes, 1 .. 8 nine-tap chunks, persistent tile walk, GroupNorm partials in the 8-row tile layout - on shapes the default
+    dispatch would give to conv_igemm.hip."""
     from storm_amd import ops
     B, H, W, Co, (Ca, Cb), gn, one, cus = PIPE128_CASES[case]
     dtype = torch.float16 if case.endswith(":f16") else torch.bfloat16
@@ -203,10 +206,11 @@ def test_conv_pipelined_128cout_kernel(dev, case, monkeypatch):
     ref = ref * 0.5
     tbd = tb.to(dev)
     y_generic, part_generic = ops.conv(segs, Co, bias=bias.to(dev), tbias=tbd[:, 8:], skip=skip, scale=0.5, gn_partials=True)
-    monkeypatch.setenv("STORM_CONV_VARIANT", "4")
+    monkeypatch.setenv("STORM_CONV_VARIANT", str(variant))
     if cus:
         monkeypatch.setenv("STORM_CONV_CUS", str(cus))
-    assert ops.conv_kernel_name(segs, Co, bias=bias.to(dev), tbias=tbd[:, 8:], skip=skip, scale=0.5).startswith("storm::conv_pipe128_kernel")
+    assert ops.conv_kernel_name(segs, Co, bias=bias.to(dev), tbias=tbd[:, 8:], skip=skip, scale=0.5).startswith(
+        "storm::conv_pipe128_kernel" if variant == 4 else "storm::conv_duo_kernel")
     y, part = ops.conv(segs, Co, bias=bias.to(dev), tbias=tbd[:, 8:], skip=skip, scale=0.5, gn_partials=True)
     yc = nchw(y.float().cpu())
     assert rel_l2(yc[:, :Co], ref) < (1e-2 if gn else 6e-3)

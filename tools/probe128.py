@@ -42,8 +42,11 @@ for ci_, case in enumerate(CASES):
         segs.append(ops.Seg(rnd(B, H, W, sc).to(dt).to(dev), ops.pack_conv_weight((rnd(cout, sc, 1, 1) * 0.05).to(dev), dt), 1))
     fl = 2 * B * H * W * cout * (cin * 9 + sc)
     out = {}
-    for sw in ("1", "0"):
-        os.environ["STORM_CONV_PIPE128"] = sw
+    MODES = {"1": dict(STORM_CONV_PIPE128="1"), "0": dict(STORM_CONV_PIPE128="0"), "duo": dict(STORM_CONV_VARIANT="5")}
+    for sw, env in MODES.items():
+        for k_ in ("STORM_CONV_PIPE128", "STORM_CONV_VARIANT"):
+            os.environ.pop(k_, None)
+        os.environ.update(env)
         kn = ops.conv_kernel_name(segs, cout, bias=kw["bias"], tbias=kw["tbias"], scale=0.7)
         for _ in range(2):
             y, part = ops.conv(segs, cout, **kw)
@@ -55,7 +58,9 @@ for ci_, case in enumerate(CASES):
         torch.cuda.synchronize()
         ms = e0.elapsed_time(e1) / args.reps
         out[sw] = (ms, y.float(), part, kn)
+    os.environ.pop("STORM_CONV_VARIANT", None)
     d = (out["1"][1] - out["0"][1]).norm() / out["0"][1].norm()
     pd = (out["1"][2] - out["0"][2]).abs().max() / out["0"][2].abs().max()
     print(f"{name:34s} pipe128 {out['1'][0]:.3f} ms {fl / out['1'][0] / 1e9:6.0f} TF | igemm {out['0'][0]:.3f} ms {fl / out['0'][0] / 1e9:6.0f} TF"
-          f" | rel diff {float(d):.2e} partials {float(pd):.2e} | {out['1'][3].split('<')[0]}")
+          f" | duo {out['duo'][0]:.3f} ms {fl / out['duo'][0] / 1e9:6.0f} TF ({out['duo'][3].split('<')[0][7:]})"
+          f" | rel diff {float(d):.2e} partials {float(pd):.2e} | duo vs igemm {float((out['duo'][1] - out['0'][1]).norm() / out['0'][1].norm()):.2e}")
