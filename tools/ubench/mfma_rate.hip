@@ -8,10 +8,16 @@ typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
 typedef __attribute__((ext_vector_type(16))) float f32x16;
 
 template <int MODE>
-__global__ __launch_bounds__(512, 2) void k(float* out, unsigned long long* cyc, int iters, int waves_active) {
+__global__ __launch_bounds__(512, 2) void k(float* out, unsigned long long* cyc, int iters, int waves_active, int rnd) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    for (int i = tid; i < 65536 / 4; i += blockDim.x) reinterpret_cast<float*>(smem)[i] = (float)(i & 7) * 0.001f;
+    for (int i = tid; i < 65536 / 4; i += blockDim.x) {
+        if (rnd) {                                           // two pseudo-random bf16 in (-2, 2) per dword: realistic switching activity
+            unsigned h = (unsigned)i * 2654435761u + (unsigned)blockIdx.x * 40503u; h ^= h >> 15; h *= 2246822519u; h ^= h >> 13;
+            const unsigned lo = 0x3f00u | (h & 0x80ffu), hi = 0x3f00u | ((h >> 16) & 0x80ffu);
+            reinterpret_cast<unsigned*>(smem)[i] = lo | (hi << 16);
+        } else reinterpret_cast<float*>(smem)[i] = (float)(i & 7) * 0.001f;
+    }
     __syncthreads();
     if (wave >= waves_active) return;
     f32x16 acc[8];
@@ -62,15 +68,16 @@ int main() {
     const int blocks = 256, iters = 2000;
     hipMalloc(&out, blocks * 512 * 4); hipMalloc(&cyc, blocks * 8 * 8);
     std::vector<unsigned long long> h(blocks * 8);
+    for (int rnd = 0; rnd < 2; ++rnd)
     for (int mode = 0; mode < 3; ++mode)
         for (int wa : {4, 8}) {
             hipMemset(cyc, 0, blocks * 8 * 8);
             auto kern = mode == 0 ? k<0> : (mode == 1 ? k<1> : k<2>);
             hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 65536);
             hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
-            hipLaunchKernelGGL(kern, dim3(blocks), dim3(512), 65536, 0, out, cyc, iters, wa);
+            hipLaunchKernelGGL(kern, dim3(blocks), dim3(512), 65536, 0, out, cyc, iters, wa, rnd);
             hipEventRecord(e0);
-            hipLaunchKernelGGL(kern, dim3(blocks), dim3(512), 65536, 0, out, cyc, iters, wa);
+            hipLaunchKernelGGL(kern, dim3(blocks), dim3(512), 65536, 0, out, cyc, iters, wa, rnd);
             hipEventRecord(e1); hipDeviceSynchronize();
             float ms; hipEventElapsedTime(&ms, e0, e1);
             hipMemcpy(h.data(), cyc, blocks * 8 * 8, hipMemcpyDeviceToHost);
@@ -78,7 +85,7 @@ int main() {
             for (auto v : h) if (v) { sum += (double)v; ++n; }
             const double cyc_per_mfma = sum / n / (iters * 8.0);
             const double tf = 2.0 * 32 * 32 * 16 * 8.0 * iters * wa * blocks / (ms * 1e-3) / 1e12;
-            printf("mode %d (%s) waves/CU %d: %.1f ticks per MFMA per wave, %.3f ms, %.0f TF/s, clock ~%.2f GHz\n", mode,
+            printf("%s operands, mode %d (%s) waves/CU %d: %.1f ticks per MFMA per wave, %.3f ms, %.0f TF/s, clock ~%.2f GHz\n", rnd ? "random" : "regular small", mode,
                    mode == 0 ? "registers only" : (mode == 1 ? "LDS re-read each group" : "LDS re-read, pipelined"), wa, cyc_per_mfma, ms, tf, sum / n / (ms * 1e6));
         }
     return 0;
