@@ -226,6 +226,10 @@ int storm_si_sdr(const float* s, const float* s_hat, float* out, int B, long lon
 /* drift of the probability-flow ODE, out = theta (y - x) - 1/2 g(t)^2 score  (sdes.py:92-121 with probability_flow, :203-207) */
 int storm_ouve_pf_drift(float* out, const float* x, const float* y, const float* score, const float* t, int B,
                         long long n, storm_ouve p, storm_stream_t s);
+/* the same with g(t_b) given per row (device fp32 [B]; the ODE sampler computes it with the reference's own fp32 formula,
+ * sdes.py:203-207, so the right-hand side matches the reference's to the last bit) */
+int storm_ouve_pf_drift_g(float* out, const float* x, const float* y, const float* score, const float* g_rows, int B,
+                          long long n, float theta, storm_stream_t s);
 /* ---- probability-flow ODE sampler (sampling/__init__.py:71-141 hands the state to scipy's RK45 on the host) ----
  * out = x + h * sum_{j<n_terms} coef[j] K[j]   (one Runge-Kutta stage; K = host array of device pointers, <= 7) */
 int storm_rk_combine(float* out, const float* x, const float* const* K, const float* coef, int n_terms, float h,
@@ -236,6 +240,23 @@ int storm_rk_combine(float* out, const float* x, const float* const* K, const fl
 int storm_rk_scaled_sumsq(double* out, double* scratch, int scratch_len, const float* xa, const float* xb,
                           const float* const* K, const float* coef, int n_terms, float h, float atol, float rtol,
                           long long n_complex, storm_stream_t s);
+/* Per-row forms for a batch of B independent utterances that advance with their OWN step sizes (the reference calls solve_ivp
+ * once per utterance: model.py:224-244, minibatch = 1).  scipy keeps its state in complex128 and only the right-hand side
+ * runs in fp32 (sampling/__init__.py:119-123): x / out64 / xa / xb are complex128 [B][n_complex_row], the stages K complex64,
+ * coefficients and step sizes fp64, so step decisions follow scipy's to 1e-16.  h_rows: HOST array of B step sizes
+ * (B <= STORM_RK_MAX_ROWS, passed in the kernel arguments).
+ *   combine_rows:      out[b] = x[b] + h_rows[b] * sum_j coef[j] K[j][b]  -> out64 (complex128) and / or out32 (complex64)
+ *   scaled_sumsq_rows: out[b] = row b's sum of |v|^2 / (atol + max(|xa|, |xb|) rtol)^2; v as in storm_rk_scaled_sumsq
+ *                      (n_terms = -3: v = xa itself); h_rows NULL = 1.  The partial-sum geometry depends on the row length
+ *                      only, so a row's value does not depend on the batch around it; scratch: >= STORM_RK_ROW_BLOCKS * B doubles
+ *   copy_rows:         dst[b] = src[b] for the rows with row_mask[b] != 0 (HOST mask): the accepted rows of a step */
+enum { STORM_RK_MAX_ROWS = 128, STORM_RK_ROW_BLOCKS = 256 };
+int storm_rk_combine_rows(double* out64, float* out32, const double* x, const float* const* K, const double* coef, int n_terms,
+                          const double* h_rows, int B, long long n_complex_row, storm_stream_t s);
+int storm_rk_scaled_sumsq_rows(double* out, double* scratch, long long scratch_len, const double* xa, const double* xb,
+                               const float* const* K, const double* coef, int n_terms, const double* h_rows, double atol,
+                               double rtol, int B, long long n_complex_row, storm_stream_t s);
+int storm_copy_rows(void* dst, const void* src, const int* row_mask, int B, long long row_bytes, storm_stream_t s);
 /* fills z[B*n] complex with standard complex normal noise (Philox) */
 int storm_complex_randn(float* z, long long n_complex, uint64_t seed, uint64_t offset,
                         storm_stream_t s);
@@ -342,7 +363,11 @@ int storm_ncsnpp_set_fusion(storm_ncsnpp* h, int fuse_stats, int fuse_apply, int
 /* bytes of scratch one forward at (B, F, T) needs (liveness-planned; 5.2 GB at B = 16, 256 x 512, bf16); -1 on error */
 long long storm_ncsnpp_workspace_bytes(storm_ncsnpp* h, int B, int F, int T);
 /* out[b] = dnn(cat[parts...], t) (negate != 0: its negative = the score, model.py:131-132).  parts: n device pointers to
- * complex64 [B][F][T]; t fp32 [B] (NULL when discriminative); out complex64 [B][F][T]; ws: >= workspace_bytes. */
+ * complex64 [B][F][T]; t fp32 [B] (NULL when discriminative); out complex64 [B][F][T]; ws: >= workspace_bytes, pure scratch
+ * (nothing is carried from one call to the next: one buffer sized for the largest shape serves every shape).
+ * Threading: a handle may be shared by host threads that call with DIFFERENT streams and workspaces - the per-shape plan
+ * cache is locked and bounded (64 shapes, least recently used out), `negate` is a per-call argument, the weights are read
+ * only; storm_ncsnpp_set_fusion / _destroy must not race with calls. */
 int storm_ncsnpp_forward(storm_ncsnpp* h, const void* const* parts, int n_parts, const float* t, void* out, void* ws,
                          long long ws_bytes, int B, int F, int T, int negate, storm_stream_t s);
 /* the planned op list of (B, F, T) (owned by the handle) for storm_program_run_timed / storm_program_kernel_name, the packed

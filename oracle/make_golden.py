@@ -11,6 +11,7 @@ import hashlib
 import math
 import os
 import sys
+import types
 
 import numpy as np
 import torch
@@ -178,6 +179,148 @@ def gen_f9(ref):
     np.savez_compressed(os.path.join(OUT, "f9_surfaces.npz"), **f9)
 
 
+
+def gen_f10(ref):
+    """F10: the evaluation harness.  (a) si_sdr / si_sdr_torch (util/other.py:82-94) on seeded (clean, estimate) pairs of
+    several lengths and qualities; (b) evaluate_model (util/inference.py:20-72) on a tiny ScoreModel over three validation
+    pairs of DIFFERENT lengths with `pesq` / `stoi` (absent third-party packages) stubbed to the constants 2.5 / 0.75: the
+    reference's returned tuple (incl. its spec / audio lists) and the noise it drew per file."""
+    print("F10 si_sdr / si_sdr_torch / evaluate_model")
+    f10 = {}
+    O, INF = ref["other"], ref["inference"]
+    g = torch.Generator().manual_seed(1010)
+    pairs = []
+    for k, (n, noise) in enumerate(((16000, 0.05), (8000, 0.5), (12345, 2.0), (64000, 0.2), (1000, 1e-4))):
+        s = torch.randn(n, generator=g) * 0.1
+        s_hat = (0.7 + 0.1 * k) * s + noise * 0.1 * torch.randn(n, generator=g)
+        sd_np = float(O.si_sdr(s.numpy(), s_hat.numpy()))
+        sd_t = float(O.si_sdr_torch(s, s_hat))
+        f10.update({f"pair{k}_s": s.numpy(), f"pair{k}_shat": s_hat.numpy(), f"pair{k}_si_sdr": np.array(sd_np),
+                    f"pair{k}_si_sdr_torch": np.array(sd_t)})
+        pairs.append((sd_np, sd_t))
+    # unequal lengths: si_sdr_torch truncates to the shorter one (util/other.py:89-90)
+    s, s_hat = torch.randn(5000, generator=g), torch.randn(4000, generator=g)
+    s_hat = s_hat + s[:4000]
+    f10.update(trunc_s=s.numpy(), trunc_shat=s_hat.numpy(), trunc_si_sdr_torch=np.array(float(O.si_sdr_torch(s, s_hat))))
+    print("  si_sdr (numpy, torch):", [(round(a, 3), round(b, 3)) for a, b in pairs])
+
+    M, DM = ref["model"], ref["data_module"].SpecsDataModule
+    common = dict(sde="ouve", data_module_cls=DM, theta=1.5, sigma_min=0.05, sigma_max=0.5,
+                  spec_factor=0.15, spec_abs_exponent=0.5, nf=8)
+    m = M.ScoreModel(backbone="ncsnpp", **common)
+    cfg = NR.NCSNppConfig(nf=8, input_channels=4)
+    sd = NR.seeded_state_dict(cfg, seed=51)
+    m.dnn.load_state_dict(sd)
+    lengths = (8000, 7000, 4000)                       # 63 / 55 frames -> one 64-frame bucket; 32 frames -> its own
+    clean = [torch.randn(1, n, generator=g) * 0.1 for n in lengths]
+    noisy = [c + 0.05 * torch.randn(c.shape, generator=g) for c in clean]
+
+    class ValidSet:
+        def __getitem__(self, i, raw=False):
+            assert raw
+            return clean[i].clone(), noisy[i].clone()
+    m.data_module.valid_set = ValidSet()
+    INF.pesq = lambda fs, x, x_hat, mode: 2.5
+    INF.stoi = lambda x, x_hat, fs, extended=True: 0.75
+    # the reference's loop calls model.enhance(y) with its defaults (pc, reverse_diffusion + ald, N = 50): keep the defaults but
+    # a short chain, through the one knob the signature offers (the model's own enhance is called positionally with y only)
+    N = 3
+    orig_enh = m.enhance
+    m.enhance = lambda y: orig_enh(y, N=N)
+    noises = []
+    orig = torch.randn_like
+
+    def draw(x, *a, **k):
+        z = SR.complex_randn(x.shape, g)
+        noises.append(z)
+        return z.to(x.dtype)
+    torch.randn_like = draw
+    try:
+        with torch.no_grad():
+            pq, sdr, est, specs, audios = INF.evaluate_model(m, len(lengths), spec=True, audio=True)
+    finally:
+        torch.randn_like = orig
+    per_file = 1 + N * 2                                # prior + N x (ald corrector, predictor)
+    assert len(noises) == per_file * len(lengths)
+    print(f"  evaluate_model: pesq {pq} si_sdr {sdr:.4f} estoi {est}")
+    f10.update(eval_pesq=np.array(pq), eval_si_sdr=np.array(sdr), eval_estoi=np.array(est), eval_N=np.array(N),
+               eval_sdhash=np.array(sd_hash(sd)))
+    for i in range(len(lengths)):
+        f10.update({f"eval_clean{i}": clean[i].numpy(), f"eval_noisy{i}": noisy[i].numpy(),
+                    f"eval_estimate{i}": audios[1][i].numpy(),
+                    f"eval_noise{i}": np.stack([c2np(z) for z in noises[i * per_file:(i + 1) * per_file]]),
+                    f"eval_spec_est{i}": c2np(specs[1][i])})
+    np.savez_compressed(os.path.join(OUT, "f10_eval.npz"), **f10)
+
+
+def gen_f11(ref):
+    """F11: BASELINE.json configs[3]'s network at its own shape - `ncsnpplarge` (65.6 M, ncsnpp.py:460-470) forward of ONE 8-s
+    utterance, [1,2,256,1024]: three attention blocks at 16 x 64 = 1024 positions outside the bottleneck (ncsnpp.py:338,385)."""
+    print("F11 ncsnpplarge forward @ 256x1024 (a few minutes)")
+    torch.set_num_threads(8)
+    cfg = NR.NCSNppConfig(**NR.NAMED_CONFIGS["ncsnpplarge"], input_channels=4)
+    sd = NR.seeded_state_dict(cfg, seed=11)
+    net = ref_backbone(ref, cfg, sd)
+    xin = seeded_input((1, 2, 256, 1024), 1111, 0.5)
+    tt = torch.tensor([0.37])
+    with torch.no_grad():
+        y_ref = net(xin, tt)
+        y_or = NR.ncsnpp_forward(sd, cfg, xin, tt)
+    check("ncsnpplarge forward @ 256x1024", y_or, y_ref, 5e-5)
+    np.savez_compressed(os.path.join(OUT, "f11_large_shape.npz"), large4_y=c2np(y_ref), large4_xhash=np.array(tensor_hash(xin)),
+                        large4_sdhash=np.array(sd_hash(sd)), t=np.array([0.37], dtype=np.float32))
+
+
+def gen_f12(ref):
+    """F12: BASELINE.json configs[4] semantics - the ODE sampler as the reference MODEL runs it, one utterance per solve_ivp
+    call (model.py:224-244, minibatch = 1; sampling/__init__.py:71-141).  (a) analytic score, three utterances of one toy
+    shape solved one by one: end points + nfev each; (b) ScoreModel.enhance(y, sampler_type="ode") wav -> wav with a tiny
+    NCSN++ on three utterances of different lengths that share the 64-frame bucket, one by one."""
+    print("F12 per-utterance ODE runs")
+    f12 = {}
+    g = torch.Generator().manual_seed(1212)
+    sde = ref["sdes"].OUVESDE(theta=1.5, sigma_min=0.05, sigma_max=0.5, N=30)
+
+    def score(x, t, yy):                               # stiffness grows with the utterance's level: different step sequences
+        return -(x - yy) * (1 + 4 * yy.abs().mean(dim=(1, 2, 3), keepdim=True)) / (sde._std(t)[:, None, None, None] ** 2 + 0.1)
+    y = torch.randn(3, 1, 8, 16, dtype=torch.complex64, generator=g) * torch.tensor([0.1, 0.4, 1.5])[:, None, None, None]
+    z = SR.complex_randn(y.shape, g)
+    outs, nfes = [], []
+    orig = torch.randn_like
+    for b in range(3):
+        torch.randn_like = lambda x, *a, **k: z[b:b + 1].to(x.dtype)
+        try:
+            xb, nb = ref["sampling"].get_ode_sampler(sde, score, y=y[b:b + 1], eps=0.03, device="cpu")()
+        finally:
+            torch.randn_like = orig
+        outs.append(xb); nfes.append(nb)
+    print("  analytic: nfev per utterance", nfes)
+    f12.update(toy_y=c2np(y), toy_z=c2np(z), toy_out=c2np(torch.cat(outs, 0)), toy_nfe=np.array(nfes))
+
+    M, DM = ref["model"], ref["data_module"].SpecsDataModule
+    common = dict(sde="ouve", data_module_cls=DM, theta=1.5, sigma_min=0.05, sigma_max=0.5,
+                  spec_factor=0.15, spec_abs_exponent=0.5, nf=8)
+    m = M.ScoreModel(backbone="ncsnpp", **common)
+    cfg = NR.NCSNppConfig(nf=8, input_channels=4)
+    sd = NR.seeded_state_dict(cfg, seed=61)
+    m.dnn.load_state_dict(sd)
+    m.eval(no_ema=True)
+    lengths = (8000, 7300, 6600)                       # 63 / 58 / 52 frames: all pad to 64
+    for i, n in enumerate(lengths):
+        wav = torch.randn(1, n, generator=g) * 0.1
+        zi = SR.complex_randn((1, 1, 256, 64), g)
+        torch.randn_like = lambda x, *a, **k: zi.to(x.dtype)
+        try:
+            with torch.no_grad():
+                xh, nfe, _ = m.enhance(wav.clone(), sampler_type="ode", timeit=True, device="cpu")
+        finally:
+            torch.randn_like = orig
+        print(f"  enhance(ode) {n} samples: nfev {nfe}")
+        f12.update({f"ode_wav{i}": wav.numpy(), f"ode_z{i}": c2np(zi), f"ode_out{i}": xh.numpy(), f"ode_nfe{i}": np.array(int(nfe[0]) if isinstance(nfe, (list, tuple)) else int(nfe))})
+    f12["ode_sdhash"] = np.array(sd_hash(sd))
+    np.savez_compressed(os.path.join(OUT, "f12_ode_rows.npz"), **f12)
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
     if "--only-f9" in sys.argv:
@@ -189,6 +332,10 @@ def main():
     if "--only-f8" in sys.argv:
         gen_f8(import_reference())
         return
+    for flag, fn in (("--only-f10", gen_f10), ("--only-f11", gen_f11), ("--only-f12", gen_f12)):
+        if flag in sys.argv:
+            fn(import_reference())
+            return
     torch.set_num_threads(8)
     torch.manual_seed(0)
     ref = import_reference()
@@ -431,6 +578,9 @@ def main():
     gen_f7(ref)
     gen_f8(ref)
     gen_f9(ref)
+    gen_f10(ref)
+    gen_f11(ref)
+    gen_f12(ref)
     for fn in sorted(os.listdir(OUT)):
         print(f"  {fn}: {os.path.getsize(os.path.join(OUT, fn))/1024:.0f} KiB")
     print("golden fixtures written to", OUT)

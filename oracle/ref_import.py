@@ -95,6 +95,7 @@ def import_reference():
     import sgmse.backbones.ncsnpp_utils.layerspp as layerspp
     import sgmse.backbones.ncsnpp_utils.up_or_down_sampling as updown
     import sgmse.util.other as other
+    import sgmse.util.inference as inference   # (pesq / pystoi are stubs: callers set inference.pesq / .stoi to constants)
     torch.autograd.set_detect_anomaly(False)   # model.py:22 turns it on at import
     return dict(model=model, sdes=sdes, sampling=sampling, data_module=data_module,
-                ncsnpp=ncsnpp, layerspp=layerspp, updown=updown, other=other)
+                ncsnpp=ncsnpp, layerspp=layerspp, updown=updown, other=other, inference=inference)

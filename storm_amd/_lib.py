@@ -88,8 +88,12 @@ _SIGNATURES = {
     "storm_langevin_step": ([_vp, _vp, _vp, _vp, _vp, _vp, _i, _ll, _f, _i, _vp], C.c_int),
     "storm_si_sdr": ([_vp, _vp, _vp, _i, _ll, _ll, _ll, _f, _vp], C.c_int),
     "storm_ouve_pf_drift": ([_vp, _vp, _vp, _vp, _vp, _i, _ll, Ouve, _vp], C.c_int),
+    "storm_ouve_pf_drift_g": ([_vp, _vp, _vp, _vp, _vp, _i, _ll, _f, _vp], C.c_int),
     "storm_rk_combine": ([_vp, _vp, C.POINTER(_vp), C.POINTER(C.c_float), _i, _f, _ll, _vp], C.c_int),
     "storm_rk_scaled_sumsq": ([_vp, _vp, _i, _vp, _vp, C.POINTER(_vp), C.POINTER(C.c_float), _i, _f, _f, _f, _ll, _vp], C.c_int),
+    "storm_rk_combine_rows": ([_vp, _vp, _vp, C.POINTER(_vp), C.POINTER(C.c_double), _i, C.POINTER(C.c_double), _i, _ll, _vp], C.c_int),
+    "storm_rk_scaled_sumsq_rows": ([_vp, _vp, _ll, _vp, _vp, C.POINTER(_vp), C.POINTER(C.c_double), _i, C.POINTER(C.c_double), C.c_double, C.c_double, _i, _ll, _vp], C.c_int),
+    "storm_copy_rows": ([_vp, _vp, C.POINTER(C.c_int), _i, _ll, _vp], C.c_int),
     "storm_complex_randn": ([_vp, _ll, _u64, _u64, _vp], C.c_int),
     "storm_spec_transform": ([_vp, _vp, _ll, _f, _f, _i, _vp], C.c_int),
     "storm_peak_abs": ([_vp, _vp, _i, _ll, _ll, _vp, _vp], C.c_int),

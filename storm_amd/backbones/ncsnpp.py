@@ -155,7 +155,7 @@ class NCSNpp(nn.Module):
         self.compute_dtype = torch.float32
         self.negate_output = False        # ScoreModel folds the "score = -dnn(...)" sign into the output head
         self._handles = {}                # dtype code -> (engine handle, arena tensor, params version, device)
-        self._workspaces = {}             # (B, F, T, dtype) -> workspace tensor
+        self._workspaces = {}             # (device, dtype) -> ONE grow-only scratch tensor (the workspace holds no state between calls)
         self._param_version = 0
         self.register_load_state_dict_post_hook(lambda m, keys: m.invalidate())
 
@@ -232,12 +232,17 @@ class NCSNpp(nn.Module):
         return h
 
     def _get_workspace(self, h, B, F, T, dtype_code, device):
-        key = (B, F, T, dtype_code)
+        """Scratch for one forward at (B, F, T).  The workspace carries nothing from one call to the next, so there is ONE
+        buffer per (device, dtype), grown to the largest size seen: a ragged stream (17 frame buckets x tail batch sizes)
+        holds the memory of its biggest micro-batch, not the sum over shapes."""
+        n = L.lib().storm_ncsnpp_workspace_bytes(h, B, F, T)
+        if n < 0:
+            raise L.StormError(f"storm_ncsnpp_workspace_bytes: {L.lib().storm_last_error().decode()}")
+        key = (str(device), dtype_code)
         ws = self._workspaces.get(key)
-        if ws is None or ws.device != device:
-            n = L.lib().storm_ncsnpp_workspace_bytes(h, B, F, T)
-            if n < 0:
-                raise L.StormError(f"storm_ncsnpp_workspace_bytes: {L.lib().storm_last_error().decode()}")
+        if ws is None or ws.numel() < n:
+            self._workspaces.pop(key, None)
+            ws = None                                  # (release the old buffer before asking the allocator for the larger one)
             ws = torch.empty(n, dtype=torch.uint8, device=device)
             self._workspaces[key] = ws
         return ws

@@ -12,6 +12,8 @@
 // Python (tests compare the two op lists bit for bit).
 #include <algorithm>
 #include <map>
+#include <memory>
+#include <mutex>
 #include <string>
 #include <tuple>
 #include <utility>
@@ -503,8 +505,13 @@ using namespace storm::graph;
 struct storm_ncsnpp {
     Cfg cfg; int dtype; Layout layout; void* arena = nullptr; bool owns_arena = false;
     bool fuse_stats = true, fuse_apply = true, fused_attention = true;
-    std::map<std::tuple<int, int, int>, Program*> programs;
-    ~storm_ncsnpp() { for (auto& kv : programs) delete kv.second; }
+    // planned programs by (B, F, T): a ragged stream produces one per bucket and tail batch size, so the cache is bounded
+    // (least recently used out) and guarded - a handle may be shared by host threads driving different streams
+    std::map<std::tuple<int, int, int>, std::shared_ptr<Program>> programs;
+    std::map<std::tuple<int, int, int>, unsigned long long> last_use;
+    unsigned long long tick = 0;
+    std::mutex mu;
+    static constexpr size_t MAX_PROGRAMS = 64;
 };
 
 static int to_cfg(const storm_ncsnpp_config* c, Cfg& out) {
@@ -554,7 +561,8 @@ extern "C" int storm_ncsnpp_create(const storm_ncsnpp_config* c, const void* con
     hipStream_t st = (hipStream_t)s;
     if (arena) h->arena = arena;
     else {
-        if (hipMalloc(&h->arena, (size_t)h->layout.size) != hipSuccess) { delete h; set_error("storm_ncsnpp_create: hipMalloc(%lld) failed", h->layout.size); return STORM_ERR_HIP; }
+        const long long need = h->layout.size;
+        if (hipMalloc(&h->arena, (size_t)need) != hipSuccess) { delete h; set_error("storm_ncsnpp_create: hipMalloc(%lld) failed", need); return STORM_ERR_HIP; }
         h->owns_arena = true;
     }
     char* base = static_cast<char*>(h->arena);
@@ -600,35 +608,45 @@ extern "C" void storm_ncsnpp_destroy(storm_ncsnpp* h) {
 extern "C" int storm_ncsnpp_set_fusion(storm_ncsnpp* h, int fuse_stats, int fuse_apply, int fused_attention) {
     STORM_CHECK(h != nullptr, "storm_ncsnpp_set_fusion: null handle");
     h->fuse_stats = fuse_stats != 0; h->fuse_apply = fuse_apply != 0 && fuse_stats != 0; h->fused_attention = fused_attention != 0;
-    for (auto& kv : h->programs) delete kv.second;
-    h->programs.clear();
+    std::lock_guard<std::mutex> lk(h->mu);
+    h->programs.clear(); h->last_use.clear();
     return STORM_OK;
 }
 
-static int get_program(storm_ncsnpp* h, int B, int F, int T, Program** out) {
+// The returned program stays alive for as long as the caller holds the shared_ptr (an eviction by another thread only drops
+// the cache's reference).
+static int get_program(storm_ncsnpp* h, int B, int F, int T, std::shared_ptr<Program>* out) {
     STORM_CHECK(h != nullptr && B > 0 && F > 0 && T > 0, "storm_ncsnpp: bad shape B=%d F=%d T=%d", B, F, T);
+    std::lock_guard<std::mutex> lk(h->mu);
     auto key = std::make_tuple(B, F, T);
     auto it = h->programs.find(key);
     if (it == h->programs.end()) {
-        Program* p = new Program(h->cfg, h->layout, B, F, T);
+        std::shared_ptr<Program> p(new Program(h->cfg, h->layout, B, F, T));
         p->fuse_stats = h->fuse_stats; p->fuse_apply = h->fuse_apply && h->fuse_stats; p->fused_attention = h->fused_attention;
         const int rc = p->build();
-        if (rc != STORM_OK) { delete p; return rc; }
+        if (rc != STORM_OK) return rc;
+        if (h->programs.size() >= storm_ncsnpp::MAX_PROGRAMS) {
+            auto old = h->last_use.begin();
+            for (auto u = h->last_use.begin(); u != h->last_use.end(); ++u) if (u->second < old->second) old = u;
+            h->programs.erase(old->first); h->last_use.erase(old);
+        }
         it = h->programs.emplace(key, p).first;
     }
+    h->last_use[key] = ++h->tick;
     *out = it->second;
     return STORM_OK;
 }
 
 extern "C" long long storm_ncsnpp_workspace_bytes(storm_ncsnpp* h, int B, int F, int T) {
-    Program* p = nullptr;
+    std::shared_ptr<Program> p;
     if (get_program(h, B, F, T, &p) != STORM_OK) return -1;
     return p->ws_bytes;
 }
 
-// the planned op list (for profilers: storm_program_run_timed / storm_program_kernel_name); owned by the handle
+// the planned op list (for profilers: storm_program_run_timed / storm_program_kernel_name); owned by the handle: valid until the
+// handle is destroyed, its fusion switches change, or MAX_PROGRAMS other shapes have been planned since
 extern "C" int storm_ncsnpp_program(storm_ncsnpp* h, int B, int F, int T, const storm_op** ops, int* n_ops, long long* flops) {
-    Program* p = nullptr;
+    std::shared_ptr<Program> p;
     if (int rc = get_program(h, B, F, T, &p)) return rc;
     if (ops) *ops = p->ops.data();
     if (n_ops) *n_ops = (int)p->ops.size();
@@ -643,7 +661,7 @@ extern "C" const void* storm_ncsnpp_arena(storm_ncsnpp* h) { return h ? h->arena
 // (model.py:131-132) folded into the output head.
 extern "C" int storm_ncsnpp_forward(storm_ncsnpp* h, const void* const* parts, int n_parts, const float* t, void* out, void* ws,
                                     long long ws_bytes, int B, int F, int T, int negate, storm_stream_t s) {
-    Program* p = nullptr;
+    std::shared_ptr<Program> p;
     if (int rc = get_program(h, B, F, T, &p)) return rc;
     STORM_CHECK(parts && out && ws, "storm_ncsnpp_forward: null pointer");
     STORM_CHECK(n_parts == h->cfg.total() / 2, "storm_ncsnpp_forward: %d complex input channels given, the network takes %d", n_parts, h->cfg.total() / 2);
@@ -653,6 +671,11 @@ extern "C" int storm_ncsnpp_forward(storm_ncsnpp* h, const void* const* parts, i
     bufs[BUF_WS] = ws; bufs[BUF_PARAMS] = h->arena;
     for (int j = 0; j < n_parts; ++j) { STORM_CHECK(parts[j] != nullptr, "storm_ncsnpp_forward: input %d is NULL", j); bufs[BUF_IN0 + j] = const_cast<void*>(parts[j]); }
     bufs[BUF_T] = const_cast<float*>(t); bufs[BUF_OUT] = out;
-    p->ops.back().i[4] = negate ? 1 : 0;
-    return storm_program_run(p->ops.data(), (int)p->ops.size(), bufs, N_BUFS, h->dtype, s);
+    // `negate` is a run-time argument of THIS call: the cached op list is shared by every caller of the handle, so the output
+    // head runs from a local copy instead of being patched in place
+    const int n = (int)p->ops.size();
+    if (int rc = storm_program_run(p->ops.data(), n - 1, bufs, N_BUFS, h->dtype, s)) return rc;
+    storm_op head = p->ops[n - 1];
+    head.i[4] = negate ? 1 : 0;
+    return storm_program_run(&head, 1, bufs, N_BUFS, h->dtype, s);
 }

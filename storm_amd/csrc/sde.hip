@@ -182,6 +182,25 @@ __global__ void ouve_pf_drift_kernel(float* __restrict__ out, const float* __res
     }
 }
 
+// the same with the diffusion coefficient g(t_b) handed in per row (fp32 [B]): the ODE sampler evaluates sigma_min (sigma_max /
+// sigma_min)^t sqrt(2 logsig) with the reference's own fp32 torch ops on the host (sdes.py:203-207), so the right-hand side
+// is the reference's to the last bit - at rtol = atol = 1e-5 the first steps' error estimates sit at the fp32 noise floor and
+// an ulp in g changes which steps RK45 accepts
+__global__ void ouve_pf_drift_g_kernel(float* __restrict__ out, const float* __restrict__ x, const float* __restrict__ y,
+                                       const float* __restrict__ score, const float* __restrict__ g_rows, long long n, float theta) {
+    const int b = blockIdx.y;
+    const float g = g_rows[b];
+    const float g2 = g * g;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+        const long long k = (long long)b * n + i;
+        const float2 xx = reinterpret_cast<const float2*>(x)[k];
+        const float2 yy = reinterpret_cast<const float2*>(y)[k];
+        const float2 s = reinterpret_cast<const float2*>(score)[k];
+        // sde_drift + (-(g^2) * score * 0.5)  in the reference's operation order (sdes.py:129-134)
+        reinterpret_cast<float2*>(out)[k] = make_float2(theta * (yy.x - xx.x) + (-g2 * s.x) * 0.5f, theta * (yy.y - xx.y) + (-g2 * s.y) * 0.5f);
+    }
+}
+
 // ---- probability-flow ODE (Dormand-Prince RK45, sampling/__init__.py:71-141 runs scipy's on the host) ----------------
 // out = x + h * sum_j coef[j] * K[j]  over n floats (one fused pass per stage instead of one pass per term)
 struct RkTerms { const float* k[7]; float c[7]; int n; };
@@ -228,6 +247,74 @@ __global__ void rk_scaled_sumsq_kernel(double* __restrict__ part, const float* _
 }
 __global__ void sum_partials_kernel(const double* __restrict__ part, int n, double* __restrict__ out) {   // fixed order: deterministic
     if (threadIdx.x == 0 && blockIdx.x == 0) { double s = 0.0; for (int i = 0; i < n; ++i) s += part[i]; out[0] = s; }
+}
+
+// ---- per-row forms: B independent utterances advance with their OWN step sizes (the reference integrates one utterance per
+// solve_ivp call, model.py:224-244 minibatch = 1, so every utterance has its own accepted / rejected step sequence).  scipy
+// keeps the solver state in complex128 (it up-casts the complex64 state it is handed and only the right-hand side runs in
+// fp32, sampling/__init__.py:119-123): the state x is fp64 here too, the stages K are the fp32 network outputs, and the
+// algebra is fp64 - the accept / reject decisions then follow scipy's to rounding noise of 1e-16, not 1e-7.
+struct RkTermsD { const float* k[7]; double c[7]; int n; };
+struct alignas(16) Cplx128 { double x, y; };
+struct RkRows { double h[STORM_RK_MAX_ROWS]; };
+// out64 = x + h_b * sum_j c_j K_j (complex128, may be NULL); out32 = the same rounded to complex64 (the next network input)
+__global__ void rk_combine_rows_kernel(double* __restrict__ out64, float* __restrict__ out32, const double* __restrict__ x, RkTermsD t,
+                                       RkRows hr, long long n2) {
+    const int b = blockIdx.y;
+    const double h = hr.h[b];
+    const long long base = (long long)b * n2;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n2; i += (long long)gridDim.x * blockDim.x) {
+        double ax = 0.0, ay = 0.0;
+#pragma unroll
+        for (int j = 0; j < 7; ++j)
+            if (j < t.n) {
+                const float2 k = reinterpret_cast<const float2*>(t.k[j])[base + i];
+                ax = fma(t.c[j], (double)k.x, ax); ay = fma(t.c[j], (double)k.y, ay);
+            }
+        const Cplx128 xx = reinterpret_cast<const Cplx128*>(x)[base + i];
+        const double ox = fma(h, ax, xx.x), oy = fma(h, ay, xx.y);
+        if (out64) reinterpret_cast<Cplx128*>(out64)[base + i] = Cplx128{ox, oy};
+        if (out32) reinterpret_cast<float2*>(out32)[base + i] = make_float2((float)ox, (float)oy);
+    }
+}
+// part[b][block] = that block's share of row b's scaled sum of squares: sum_c |v_c|^2 / (atol + max(|xa_c|, |xb_c|) rtol)^2 with
+// v = h_b * sum_j c_j K_j (t.n > 0), K[0] - K[1] (t.n == -2), K[0] (t.n == -1) or xa itself (t.n == -3).  The block count per row
+// depends on the row length only, so a row's sum is the same number whatever batch it sits in.
+__global__ void rk_scaled_sumsq_rows_kernel(double* __restrict__ part, const double* __restrict__ xa, const double* __restrict__ xb,
+                                            RkTermsD t, RkRows hr, double atol, double rtol, long long nc) {
+    __shared__ double red[4];
+    const int b = blockIdx.y;
+    const double h = hr.h[b];
+    const long long base = (long long)b * nc;
+    double acc = 0.0;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < nc; i += (long long)gridDim.x * blockDim.x) {
+        const Cplx128 a = reinterpret_cast<const Cplx128*>(xa)[base + i];
+        double vx = 0.0, vy = 0.0;
+        if (t.n > 0) {
+#pragma unroll
+            for (int j = 0; j < 7; ++j)
+                if (j < t.n) { const float2 k = reinterpret_cast<const float2*>(t.k[j])[base + i]; vx = fma(t.c[j], (double)k.x, vx); vy = fma(t.c[j], (double)k.y, vy); }
+            vx *= h; vy *= h;
+        } else if (t.n == -3) {
+            vx = a.x; vy = a.y;
+        } else {
+            const float2 k = reinterpret_cast<const float2*>(t.k[0])[base + i];
+            vx = k.x; vy = k.y;
+            if (t.n == -2) { const float2 w = reinterpret_cast<const float2*>(t.k[1])[base + i]; vx -= (double)w.x; vy -= (double)w.y; }
+        }
+        double m = sqrt(a.x * a.x + a.y * a.y);
+        if (xb) { const Cplx128 q = reinterpret_cast<const Cplx128*>(xb)[base + i]; m = fmax(m, sqrt(q.x * q.x + q.y * q.y)); }
+        const double sc = atol + m * rtol;
+        acc += (vx * vx + vy * vy) / (sc * sc);
+    }
+    acc = wave_sum_d(acc);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) part[(long long)b * gridDim.x + blockIdx.x] = red[0] + red[1] + red[2] + red[3];
+}
+__global__ void sum_rows_kernel(const double* __restrict__ part, int n, int B, double* __restrict__ out) {   // one thread per row, fixed order
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b < B) { double s = 0.0; for (int i = 0; i < n; ++i) s += part[(long long)b * n + i]; out[b] = s; }
 }
 
 // SI-SDR of B (reference, estimate) waveform pairs (util/other.py:82-94): alpha = <s_hat, s> / ||s||^2,
@@ -352,10 +439,74 @@ extern "C" int storm_rk_scaled_sumsq(double* out, double* scratch, int scratch_l
     return STORM_OK;
 }
 
+static int fill_rows(RkRows& r, const double* h_rows, int B) {
+    STORM_CHECK(B > 0 && B <= STORM_RK_MAX_ROWS, "storm_rk rows: B=%d outside 1..%d", B, STORM_RK_MAX_ROWS);
+    for (int b = 0; b < STORM_RK_MAX_ROWS; ++b) r.h[b] = (b < B && h_rows) ? h_rows[b] : (h_rows ? 0.0 : 1.0);
+    return STORM_OK;
+}
+static int fill_terms_d(RkTermsD& t, const float* const* K, const double* coef, int n_terms) {
+    STORM_CHECK(n_terms >= -3 && n_terms <= 7 && n_terms != 0, "storm_rk rows: n_terms=%d", n_terms);
+    const int np = n_terms > 0 ? n_terms : (n_terms == -3 ? 0 : -n_terms);
+    STORM_CHECK(np == 0 || K, "storm_rk rows: null stage list");
+    STORM_CHECK(n_terms < 0 || coef, "storm_rk rows: null coefficients");
+    for (int j = 0; j < 7; ++j) { t.k[j] = j < np ? K[j] : nullptr; t.c[j] = (n_terms > 0 && j < np) ? coef[j] : 0.0; }
+    for (int j = 0; j < np; ++j) STORM_CHECK(K[j] != nullptr, "storm_rk rows: null stage %d", j);
+    t.n = n_terms;
+    return STORM_OK;
+}
+
+extern "C" int storm_rk_combine_rows(double* out64, float* out32, const double* x, const float* const* K, const double* coef,
+                                     int n_terms, const double* h_rows, int B, long long n_complex_row, storm_stream_t s) {
+    STORM_CHECK((out64 || out32) && x && n_complex_row > 0 && n_terms > 0 && h_rows, "storm_rk_combine_rows: bad arguments");
+    RkTermsD t; RkRows r;
+    if (int rc = fill_terms_d(t, K, coef, n_terms)) return rc;
+    if (int rc = fill_rows(r, h_rows, B)) return rc;
+    hipLaunchKernelGGL(rk_combine_rows_kernel, dim3(ew_blocks(n_complex_row), B), dim3(256), 0, (hipStream_t)s, out64, out32, x, t, r, n_complex_row);
+    STORM_LAUNCH_CHECK();
+    return STORM_OK;
+}
+
+extern "C" int storm_rk_scaled_sumsq_rows(double* out, double* scratch, long long scratch_len, const double* xa, const double* xb,
+                                          const float* const* K, const double* coef, int n_terms, const double* h_rows, double atol,
+                                          double rtol, int B, long long n_complex_row, storm_stream_t s) {
+    STORM_CHECK(out && scratch && xa && n_complex_row > 0, "storm_rk_scaled_sumsq_rows: bad arguments");
+    RkTermsD t; RkRows r;
+    if (int rc = fill_terms_d(t, K, coef, n_terms)) return rc;
+    if (int rc = fill_rows(r, h_rows, B)) return rc;
+    int nb = ew_blocks(n_complex_row);
+    if (nb > STORM_RK_ROW_BLOCKS) nb = STORM_RK_ROW_BLOCKS;           // a function of the row length ONLY (see the kernel)
+    STORM_CHECK(scratch_len >= (long long)nb * B, "storm_rk_scaled_sumsq_rows: scratch of %lld doubles < %lld", scratch_len, (long long)nb * B);
+    hipLaunchKernelGGL(rk_scaled_sumsq_rows_kernel, dim3(nb, B), dim3(256), 0, (hipStream_t)s, scratch, xa, xb, t, r, atol, rtol, n_complex_row);
+    hipLaunchKernelGGL(sum_rows_kernel, dim3((B + 63) / 64), dim3(64), 0, (hipStream_t)s, scratch, nb, B, out);
+    STORM_LAUNCH_CHECK();
+    return STORM_OK;
+}
+
+extern "C" int storm_copy_rows(void* dst, const void* src, const int* row_mask, int B, long long row_bytes, storm_stream_t s) {
+    STORM_CHECK(dst && src && row_mask && B > 0 && row_bytes > 0, "storm_copy_rows: bad arguments");
+    for (int b = 0; b < B; ) {                                        // one device-to-device copy per run of selected rows
+        if (!row_mask[b]) { ++b; continue; }
+        int e = b;
+        while (e < B && row_mask[e]) ++e;
+        STORM_HIP(hipMemcpyAsync(static_cast<char*>(dst) + (long long)b * row_bytes, static_cast<const char*>(src) + (long long)b * row_bytes,
+                                 (size_t)((long long)(e - b) * row_bytes), hipMemcpyDeviceToDevice, (hipStream_t)s));
+        b = e;
+    }
+    return STORM_OK;
+}
+
 extern "C" int storm_ouve_pf_drift(float* out, const float* x, const float* y, const float* score, const float* t, int B,
                                    long long n, storm_ouve p, storm_stream_t s) {
     STORM_CHECK(out && x && y && score && t && B > 0 && n > 0, "storm_ouve_pf_drift: bad arguments");
     hipLaunchKernelGGL(ouve_pf_drift_kernel, dim3(ew_blocks(n), B), dim3(256), 0, (hipStream_t)s, out, x, y, score, t, n, p);
+    STORM_LAUNCH_CHECK();
+    return STORM_OK;
+}
+
+extern "C" int storm_ouve_pf_drift_g(float* out, const float* x, const float* y, const float* score, const float* g_rows, int B,
+                                     long long n, float theta, storm_stream_t s) {
+    STORM_CHECK(out && x && y && score && g_rows && B > 0 && n > 0, "storm_ouve_pf_drift_g: bad arguments");
+    hipLaunchKernelGGL(ouve_pf_drift_g_kernel, dim3(ew_blocks(n), B), dim3(256), 0, (hipStream_t)s, out, x, y, score, g_rows, n, theta);
     STORM_LAUNCH_CHECK();
     return STORM_OK;
 }

@@ -44,6 +44,9 @@ __global__ void stft_kernel(const float* __restrict__ wav, const float* __restri
         long long idx = (long long)frame * hop + k - pad;
         if (idx < 0) idx = -idx;                   // reflect (no edge repeat)
         if (idx >= L) idx = 2 * (L - 1) - idx;
+        // a ragged row of <= n_fft / 2 samples is rejected by the host wrappers (torch.stft raises for it); a device-side
+        // length the host never saw must still not read outside the row
+        idx = idx < 0 ? 0 : (idx >= L ? L - 1 : idx);
         const float v = peak ? x[idx] / peak[b] : x[idx];    // y / norm_factor (model.py:284)
         xs[k] = v * window[k];
         tws[k] = reinterpret_cast<const float2*>(tw)[k];

@@ -230,10 +230,12 @@ class ScoreModel(_Base):
 
     def enhance_batch(self, y, sampler_type="pc", predictor="reverse_diffusion", corrector="ald", N=50,
                       corrector_steps=1, snr=0.5, return_nfe=False, lengths=None, **kwargs):
-        """B equal-length utterances y [B, L] in one sampler run.  Every op on the path is per utterance and the Langevin
-        corrector runs with per-row step sizes, so with INJECTED noise (noise_fn) row b equals enhance(y[b:b+1]) for every
-        predictor / corrector; with the in-kernel Philox stream (seed=) rows are independent draws but not the draws a
-        batch-1 call with the same seed would make (the counter is the position in the batch).
+        """B equal-length utterances y [B, L] in one sampler run.  Every op on the path is per utterance, the Langevin
+        corrector runs with per-row step sizes and the ODE sampler with one Runge-Kutta step controller per row (the
+        reference solves one utterance per solve_ivp call), so with INJECTED noise (noise_fn) row b equals enhance(y[b:b+1])
+        for every sampler / predictor / corrector; with the in-kernel Philox stream (seed=) rows are independent draws but
+        not the draws a batch-1 call with the same seed would make (the counter is the position in the batch).
+        For sampler_type="ode" the returned nfe is the number of score evaluations executed (= the slowest row's count).
         lengths: ragged micro-batch - rows of different sample counts that share one padded frame count
         (storm_amd.distributed.bucket_by_frames); y is zero filled to the longest row and so is the result."""
         Y, peak, T_orig = self._prepare(y, lengths)
@@ -242,10 +244,12 @@ class ScoreModel(_Base):
             sampler = self.get_pc_sampler(predictor, corrector, Y, N=N, corrector_steps=corrector_steps, snr=snr,
                                           intermediate=False, **kwargs)
         elif sampler_type == "ode":
+            kwargs.setdefault("per_row", True)       # one RK45 step controller per utterance (model.py:224: minibatch = 1)
             sampler = self.get_ode_sampler(Y, N=N, minibatch=None, **kwargs)
         else:
             raise ValueError("{} is not a valid sampler type!".format(sampler_type))
         sample, nfe = sampler()
+        self.last_nfev_rows = getattr(sampler, "nfev_rows", None)     # ODE: the evaluations every row needed on its own
         x_hat = self.data_module.spec_to_wav(sample, T_orig, peak, lengths=lengths)
         return (x_hat, nfe) if return_nfe else x_hat
 

@@ -284,6 +284,21 @@ def batch_l2norm(v):
     return out
 
 
+def _all_reduce_sum(t, group):
+    """in-place SUM of `t` over a torch.distributed ProcessGroup (RCCL on HIP devices, gloo on CPU tensors).  A ProcessGroup
+    has no `all_reduce` method (its `allreduce` returns a Work handle): the functional form is the supported call."""
+    import torch.distributed as dist
+    dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
+
+
+def langevin_group_norms(sn, zn, group):
+    """(mean ||score||, mean ||z||) over the rows of ALL ranks' batches: the two floats (+ the row count) a sharded `langevin`
+    corrector needs to reproduce the unsharded step size (correctors.py:53-55)"""
+    tot = torch.stack([sn.sum(), zn.sum(), torch.tensor(float(sn.shape[0]), device=sn.device, dtype=sn.dtype)])
+    _all_reduce_sum(tot, group)
+    return (tot[0:1] / tot[2]).contiguous(), (tot[1:2] / tot[2]).contiguous()
+
+
 def langevin_step(x, score, z, snr, per_row=False, group=None):
     """Langevin corrector update, IN PLACE on x (returns (x, x_mean)).  Step size from the batch-mean norms (reference
     semantics, correctors.py:53-55), from every row's own norms (per_row: B independent batch-1 calls), or - with a
@@ -292,9 +307,7 @@ def langevin_step(x, score, z, snr, per_row=False, group=None):
     sn, zn = batch_l2norm(score), batch_l2norm(z)
     mode = 1 if per_row else 0
     if group is not None and not per_row:
-        tot = torch.stack([sn.sum(), zn.sum(), torch.tensor(float(x.shape[0]), device=x.device)])
-        group.all_reduce(tot)
-        sn, zn, mode = (tot[0:1] / tot[2]).contiguous(), (tot[1:2] / tot[2]).contiguous(), 2
+        (sn, zn), mode = langevin_group_norms(sn, zn, group), 2
     L.check(L.lib().storm_langevin_step(L.ptr(_r(x)), L.ptr(_r(xm)), L.ptr(_r(score)), L.ptr(_r(z)), L.ptr(sn), L.ptr(zn),
                                         x.shape[0], _n_per_batch(x), float(snr), mode, L.stream()), "storm_langevin_step")
     return x, xm
@@ -316,6 +329,15 @@ def ouve_pf_drift(sde, x, y, score, t):
     t = _t32(t)                                             # (kept alive in a local: a temporary would be freed before the launch)
     L.check(L.lib().storm_ouve_pf_drift(L.ptr(_r(out)), L.ptr(_r(x)), L.ptr(_r(y)), L.ptr(_r(score)), L.ptr(t), x.shape[0],
                                         _n_per_batch(x), _ouve(sde), L.stream()), "storm_ouve_pf_drift")
+    return out
+
+
+def ouve_pf_drift_g(sde, x, y, score, g_rows):
+    """theta (y - x) - 1/2 g_b^2 score with the diffusion coefficient given per row (device fp32 [B])"""
+    out = torch.empty_like(x)
+    g_rows = g_rows.to(device=x.device, dtype=torch.float32).contiguous()
+    L.check(L.lib().storm_ouve_pf_drift_g(L.ptr(_r(out)), L.ptr(_r(x)), L.ptr(_r(y)), L.ptr(_r(score)), L.ptr(g_rows), x.shape[0],
+                                          _n_per_batch(x), float(sde.theta), L.stream()), "storm_ouve_pf_drift_g")
     return out
 
 
@@ -349,6 +371,57 @@ def rk_scaled_sumsq(xa, xb, K, coef, h, atol, rtol, mode=None):
                                           _kptrs(K), cf, n_terms, float(h), float(atol), float(rtol), xa.numel(), L.stream()),
             "storm_rk_scaled_sumsq")
     return out
+
+
+RK_MAX_ROWS, RK_ROW_BLOCKS = 128, 256          # include/storm_hip.h: STORM_RK_MAX_ROWS, STORM_RK_ROW_BLOCKS
+
+
+def _hrows(h, B):
+    if h is None:
+        return None
+    if len(h) != B or B > RK_MAX_ROWS:
+        raise ValueError(f"per-row step sizes: {len(h)} values for {B} rows (at most {RK_MAX_ROWS})")
+    return (C.c_double * B)(*[float(v) for v in h])
+
+
+def rk_combine_rows(x64, K, coef, h_rows, want64=False):
+    """x64[b] + h_rows[b] * sum_j coef[j] K[j][b]: one Runge-Kutta stage of B utterances with their own step sizes.  x64 is
+    the complex128 solver state, K complex64 stages; returns the complex64 rounding (the next network input), with
+    want64=True (out64, out32)."""
+    B = x64.shape[0]
+    out32 = torch.empty(x64.shape, dtype=torch.complex64, device=x64.device)
+    out64 = torch.empty_like(x64) if want64 else None
+    cf = (C.c_double * len(K))(*[float(c) for c in coef])
+    L.check(L.lib().storm_rk_combine_rows(L.ptr(_r(out64)) if want64 else None, L.ptr(_r(out32)), L.ptr(_r(x64)), _kptrs(K), cf, len(K),
+                                          _hrows(h_rows, B), B, _n_per_batch(x64), L.stream()), "storm_rk_combine_rows")
+    return (out64, out32) if want64 else out32
+
+
+def rk_scaled_sumsq_rows(xa, xb, K, coef, h_rows, atol, rtol, mode=None):
+    """Device float64 [B]: row b's sum over its complex elements of |v|^2 / (atol + max(|xa|, |xb|) rtol)^2 with
+    v = h_b sum coef[j] K[j] (mode None), K[0] (-1), K[0] - K[1] (-2) or xa itself (-3); xa / xb complex128, K complex64.
+    A row's value does not depend on the other rows of the batch."""
+    B = xa.shape[0]
+    key = (str(xa.device), "rows")
+    need = RK_ROW_BLOCKS * B
+    if key not in _rk_scratch or _rk_scratch[key].numel() < need:
+        _rk_scratch[key] = torch.empty(need, dtype=torch.float64, device=xa.device)
+    out = torch.empty(B, dtype=torch.float64, device=xa.device)
+    n_terms = len(K) if mode is None else mode
+    cf = (C.c_double * max(1, len(K)))(*[float(c) for c in (coef if coef is not None else [0.0] * max(1, len(K)))])
+    L.check(L.lib().storm_rk_scaled_sumsq_rows(L.ptr(out), L.ptr(_rk_scratch[key]), _rk_scratch[key].numel(), L.ptr(_r(xa)),
+                                               L.ptr(_r(xb)) if xb is not None else None, _kptrs(K) if K else None, cf, n_terms,
+                                               _hrows(h_rows, B), float(atol), float(rtol), B, _n_per_batch(xa), L.stream()),
+            "storm_rk_scaled_sumsq_rows")
+    return out
+
+
+def copy_rows(dst, src, mask):
+    """dst[b] = src[b] for the rows with mask[b] (host booleans): the rows whose Runge-Kutta step was accepted"""
+    B = dst.shape[0]
+    m = (C.c_int * B)(*[int(bool(v)) for v in mask])
+    L.check(L.lib().storm_copy_rows(L.ptr(dst), L.ptr(src), m, B, dst[0].numel() * dst.element_size(), L.stream()), "storm_copy_rows")
+    return dst
 
 
 def complex_randn(shape, device, seed, offset):
@@ -407,6 +480,13 @@ def stft(wav, peak=None, n_fft=510, hop=128, spec_factor=1.0, spec_abs_exponent=
     """wav [B, L] fp32 -> complex64 [B, n_fft/2+1, Tpad] = spec_fwd(stft(wav / peak)), zero padded
     in T to a multiple of `pad_to`.  lengths: per-row sample counts of a ragged batch (rows zero filled past them)."""
     B, Lw = wav.shape
+    # reflect padding by n_fft // 2 samples needs more samples than that in EVERY row (torch.stft raises otherwise,
+    # data_module.py:217-219): a shorter row of a ragged batch would index before its own start
+    shortest = Lw if lengths is None else int(min(int(v) for v in lengths))
+    if shortest <= n_fft // 2:
+        raise ValueError(f"stft: a row of {shortest} samples is too short for reflect padding by n_fft // 2 = {n_fft // 2}")
+    if lengths is not None and int(max(int(v) for v in lengths)) > Lw:
+        raise ValueError(f"stft: a row length exceeds the batch width {Lw}")
     n_frames = 1 + Lw // hop
     Tpad = round_up(n_frames, pad_to)
     win, tw = dft_tables(n_fft, wav.device, window)

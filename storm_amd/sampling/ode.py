@@ -7,7 +7,14 @@ an explicit Dormand-Prince 5(4) integrator with scipy's step-size controller (sa
 safety factor 0.9, growth limits [0.2, 10], same initial-step heuristic), so the accepted steps and
 the number of function evaluations follow scipy's.  The solver algebra runs in fused HIP kernels (one pass per
 Runge-Kutta stage, one for the scaled error norm); every right-hand side is one NCSN++ evaluation on the HIP engine
-plus one fused drift pass; the host reads one scalar per attempted step.
+plus one fused drift pass; the host reads the per-row error sums once per attempted step.
+
+Batches.  solve_ivp sees ONE flattened state, so `get_ode_sampler(sde, score_fn, y)` over a batch couples its rows through
+the error norm exactly like the reference function does (per_row=False, the default: reference semantics for whatever
+batch it is handed).  The reference MODEL never hands it more than one utterance (model.py:224-244, minibatch = 1): every
+utterance has its own accepted / rejected step sequence.  per_row=True keeps that inside a batch: every row has its own
+t, h, error norm and accept / reject decision (rows that reached eps idle with h = 0 until the slowest row is done), so
+row b of a batched run equals the batch-1 run of utterance b - this is what ScoreModel.enhance_batch uses.
 """
 import math
 
@@ -29,12 +36,14 @@ _ERR_EXP = -1.0 / 5.0
 
 
 def get_ode_sampler(sde, score_fn, y, inverse_scaler=None, denoise=True, rtol=1e-5, atol=1e-5, method="RK45",
-                    eps=3e-2, device=None, noise_fn=None, seed=None, conditioning=None, **kwargs):
+                    eps=3e-2, device=None, noise_fn=None, seed=None, conditioning=None, per_row=False, **kwargs):
     """Probability-flow ODE sampler: Dormand-Prince RK45 with scipy's step controller (solve_ivp's `RK45`, which
     sampling/__init__.py:71-141 runs on the host over the flattened COMPLEX state: its norms are
     ||v|| / sqrt(n) over the n complex elements).  Everything per element runs in HIP kernels: one fused pass per
-    stage (storm_rk_combine) and one for the scaled error norm (storm_rk_scaled_sumsq); the host reads ONE scalar per
-    attempted step (the error norm that decides acceptance) - no per-stage synchronisation."""
+    stage (storm_rk_combine_rows) and one for the scaled error sums (storm_rk_scaled_sumsq_rows); the host reads the B row
+    sums once per attempted step (they decide acceptance) - no per-stage synchronisation.
+    per_row: one step controller per row instead of one for the whole batch (module docstring).
+    Returns fn() -> (x, nfe); nfe = score evaluations executed; fn.nfev_rows = evaluations each row needed on its own."""
     if method != "RK45":
         raise NotImplementedError("only RK45 (Dormand-Prince) is implemented on the device")
     from .. import ops
@@ -47,67 +56,100 @@ def get_ode_sampler(sde, score_fn, y, inverse_scaler=None, denoise=True, rtol=1e
         with torch.no_grad():
             yy = y.contiguous()
             B = yy.shape[0]
-            n = yy.numel()
-            nfev = 0
+            n_row = yy.numel() // B
+            groups = [[b] for b in range(B)] if per_row else [list(range(B))]
+            G = len(groups)
+            rows = lambda vals: [vals[g] for g, ids in enumerate(groups) for _ in ids]      # per group -> per row
+            executed = 0
 
-            def f(t, x):
-                nonlocal nfev
-                nfev += 1
-                vec_t = torch.full((B,), float(t), device=yy.device, dtype=torch.float32)
-                if isinstance(sde, OUVESDE):               # fused: theta (y - x) - 1/2 g^2 score in one pass
-                    score = rsde._score(x, vec_t, (yy,), dict(conditioning=conditioning))
-                    return ops.ouve_pf_drift(sde, x, yy, score.contiguous(), vec_t)
+            def f(t_g, x):
+                nonlocal executed
+                executed += 1
+                t_host = torch.tensor(rows(t_g), dtype=torch.float32)
+                vec_t = t_host.to(yy.device)
+                if isinstance(sde, OUVESDE):               # fused: theta (y - x) - 1/2 g^2 score in one pass; g(t) for the B
+                    score = rsde._score(x, vec_t, (yy,), dict(conditioning=conditioning))      # rows in the reference's own ops
+                    return ops.ouve_pf_drift_g(sde, x, yy, score.contiguous(), sde.diffusion(t_host))
                 return rsde.sde(x, vec_t, yy, conditioning=conditioning)[0].contiguous()
 
-            def norm(sumsq):                                   # scipy: ||v|| / sqrt(size); ONE host read
-                return math.sqrt(float(sumsq) / n)
+            def norms(sumsq_rows):                            # scipy: ||v|| / sqrt(size) per solver state; ONE host read
+                s = sumsq_rows.cpu().tolist()
+                return [math.sqrt(sum(s[b] for b in ids) / (n_row * len(ids))) for ids in groups]
 
             zz, sd, off = noise.next(yy)
-            x = (sde.prior_sampling(yy.shape, yy, z=zz, seed=sd, offset=off) if z is None else z).contiguous()
-            t, t_end = float(sde.T), float(eps)
-            direction = -1.0
-            f0 = f(t, x)
-            # scipy's select_initial_step (three scalars, once)
-            d0 = norm(ops.rk_scaled_sumsq(x, None, [x], None, 1.0, atol, rtol, mode=-1))
-            d1 = norm(ops.rk_scaled_sumsq(x, None, [f0], None, 1.0, atol, rtol, mode=-1))
-            h0 = 1e-6 if (d0 < 1e-5 or d1 < 1e-5) else 0.01 * d0 / d1
-            x1 = ops.rk_combine(x, [f0], [1.0], h0 * direction)
-            f1 = f(t + h0 * direction, x1)
-            d2 = norm(ops.rk_scaled_sumsq(x, None, [f1, f0], None, 1.0, atol, rtol, mode=-2)) / h0
-            h1 = max(1e-6, h0 * 1e-3) if (d1 <= 1e-15 and d2 <= 1e-15) else (0.01 / max(d1, d2)) ** (1 / 5)
-            h_abs = min(100 * h0, h1)
+            x32 = (sde.prior_sampling(yy.shape, yy, z=zz, seed=sd, offset=off) if z is None else z).contiguous()
+            x = x32.to(torch.complex128)                      # the solver state is complex128, as in scipy (module docstring)
+            t_end, direction = float(eps), -1.0
+            t = [float(sde.T)] * G
+            f0 = f(t, x32)
+            # scipy's select_initial_step, per solver state (three scalars each, once)
+            d0 = norms(ops.rk_scaled_sumsq_rows(x, None, [], None, None, atol, rtol, mode=-3))
+            d1 = norms(ops.rk_scaled_sumsq_rows(x, None, [f0], None, None, atol, rtol, mode=-1))
+            h0 = [1e-6 if (d0[g] < 1e-5 or d1[g] < 1e-5) else 0.01 * d0[g] / d1[g] for g in range(G)]
+            x1 = ops.rk_combine_rows(x, [f0], [1.0], rows([h * direction for h in h0]))
+            f1 = f([t[g] + h0[g] * direction for g in range(G)], x1)
+            d2 = norms(ops.rk_scaled_sumsq_rows(x, None, [f1, f0], None, None, atol, rtol, mode=-2))
+            h_abs = []
+            for g in range(G):
+                dd2 = d2[g] / h0[g]
+                h1 = max(1e-6, h0[g] * 1e-3) if (d1[g] <= 1e-15 and dd2 <= 1e-15) else (0.01 / max(d1[g], dd2)) ** (1 / 5)
+                h_abs.append(min(100 * h0[g], h1))
+            nfev = [2] * G
             fk = f0
-            while (t - t_end) * direction < 0:
-                min_step = 10 * abs(np.nextafter(t, direction * np.inf) - t)
-                h_abs = max(h_abs, min_step)
-                accepted, rejected = False, False
-                while not accepted:
-                    if h_abs < min_step:
+            new_step, rejected = [True] * G, [False] * G
+            min_step = [0.0] * G
+            active = [(t[g] - t_end) * direction < 0 for g in range(G)]
+            while any(active):
+                h, t_new = [0.0] * G, list(t)
+                for g in range(G):
+                    if not active[g]:
+                        continue
+                    if new_step[g]:                           # RK45._step_impl's preamble
+                        min_step[g] = 10 * abs(np.nextafter(t[g], direction * np.inf) - t[g])
+                        h_abs[g] = max(h_abs[g], min_step[g])
+                        new_step[g], rejected[g] = False, False
+                    if h_abs[g] < min_step[g]:
                         raise RuntimeError("ODE step size underflow")
-                    h = h_abs * direction
-                    t_new = t + h
-                    if direction * (t_new - t_end) > 0:
-                        t_new = t_end
-                    h = t_new - t
-                    h_abs = abs(h)
-                    K = [fk]
-                    for s in range(1, 6):
-                        K.append(f(t + _C[s] * h, ops.rk_combine(x, K, _A[s][:s], h)))
-                    x_new = ops.rk_combine(x, K, _B, h)
-                    f_new = f(t_new, x_new)
-                    K.append(f_new)
-                    err_norm = norm(ops.rk_scaled_sumsq(x, x_new, K, _E, h, atol, rtol))
-                    if err_norm < 1:
-                        factor = _MAX_FACTOR if err_norm == 0 else min(_MAX_FACTOR, _SAFETY * err_norm ** _ERR_EXP)
-                        if rejected:
+                    tn = t[g] + h_abs[g] * direction
+                    if direction * (tn - t_end) > 0:
+                        tn = t_end
+                    t_new[g], h[g] = tn, tn - t[g]
+                    h_abs[g] = abs(h[g])
+                    nfev[g] += 6
+                hr = rows(h)                                  # (idle rows: h = 0, the stages leave them where they are)
+                K = [fk]
+                for s in range(1, 6):
+                    K.append(f([t[g] + _C[s] * h[g] for g in range(G)], ops.rk_combine_rows(x, K, _A[s][:s], hr)))
+                x_new, x_new32 = ops.rk_combine_rows(x, K, _B, hr, want64=True)
+                f_new = f(t_new, x_new32)
+                K.append(f_new)
+                err = norms(ops.rk_scaled_sumsq_rows(x, x_new, K, _E, hr, atol, rtol))
+                accept = [False] * G
+                for g in range(G):
+                    if not active[g]:
+                        continue
+                    e = err[g]
+                    if e < 1:
+                        factor = _MAX_FACTOR if e == 0 else min(_MAX_FACTOR, _SAFETY * e ** _ERR_EXP)
+                        if rejected[g]:
                             factor = min(1.0, factor)
-                        h_abs *= factor
-                        accepted = True
+                        h_abs[g] *= factor
+                        accept[g], new_step[g] = True, True
+                        t[g] = t_new[g]
+                        active[g] = (t[g] - t_end) * direction < 0
                     else:
-                        h_abs *= max(_MIN_FACTOR, _SAFETY * err_norm ** _ERR_EXP)
-                        rejected = True
-                t, x, fk = t_new, x_new, f_new
-            nfe = nfev
+                        h_abs[g] *= max(_MIN_FACTOR, _SAFETY * e ** _ERR_EXP)
+                        rejected[g] = True
+                if all(accept):
+                    x, x32, fk = x_new, x_new32, f_new
+                elif any(accept):                             # the accepted rows move on; the others retry from where they are
+                    acc_rows = rows(accept)
+                    ops.copy_rows(x, x_new, acc_rows)
+                    ops.copy_rows(x32, x_new32, acc_rows)
+                    fk = ops.copy_rows(fk.clone() if fk is f0 else fk, f_new, acc_rows)
+            x = x32
+            ode_sampler.nfev_rows = rows(nfev)
+            nfe = executed
             if denoise:
                 vec_eps = torch.ones(B, device=yy.device) * eps
                 _, x = predictor.denoise_fn(x, vec_eps, yy, conditioning=conditioning)
@@ -115,4 +157,5 @@ def get_ode_sampler(sde, score_fn, y, inverse_scaler=None, denoise=True, rtol=1e
                 x = inverse_scaler(x)
             return x, nfe
 
+    ode_sampler.nfev_rows = None
     return ode_sampler

@@ -116,10 +116,13 @@ class OUVESDE(SDE):
     def T(self):
         return 1
 
-    def sde(self, x, t, y):
-        drift = self.theta * (y - x)
+    def diffusion(self, t):
+        """g(t) = sigma_min (sigma_max / sigma_min)^t sqrt(2 logsig) in the reference's torch operations (sdes.py:203-207)"""
         sigma = self.sigma_min * (self.sigma_max / self.sigma_min) ** t
-        return drift, sigma * np.sqrt(2 * self.logsig)
+        return sigma * np.sqrt(2 * self.logsig)
+
+    def sde(self, x, t, y):
+        return self.theta * (y - x), self.diffusion(t)
 
     def _mean(self, x0, t, y):
         e = torch.exp(-self.theta * t)[:, None, None, None]

@@ -1,5 +1,5 @@
 """Small utilities of sgmse/util/other.py that the hot path and the evaluation loop use:
-pad_spec (:102-109), si_sdr / si_sdr_torch (:82-94), snr_dB (:96-100)."""
+pad_spec (:102-109), si_sdr / si_sdr_torch (:82-94)."""
 import numpy as np
 import torch
 
@@ -32,9 +32,3 @@ def si_sdr_batch(s, s_hat, eps=0.0):
     """[B, L] device tensors -> [B] dB (one launch for the whole evaluation batch)"""
     from .. import ops
     return ops.si_sdr(s.float(), s_hat.float(), eps=eps)
-
-
-def snr_dB(s, n):
-    s_power = 1 / len(s) * np.sum(s ** 2)
-    n_power = 1 / len(n) * np.sum(n ** 2)
-    return 10 * np.log10(s_power / n_power)

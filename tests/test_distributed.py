@@ -98,3 +98,34 @@ def test_bench_gpus_flag_must_match_the_launcher():
     out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--selftest-cpu"], capture_output=True,
                          text=True, timeout=120, env=env, cwd=ROOT)
     assert out.returncode != 0 and "--gpus 2" in out.stderr
+
+
+LANGEVIN_WORKER = r'''
+import os, sys, json, torch
+sys.path.insert(0, {root!r})
+import torch.distributed as dist
+from storm_amd import distributed as D
+from storm_amd import ops
+rank, world, local = D.init(backend="gloo")
+g = torch.Generator().manual_seed(11)
+sn_all, zn_all = torch.rand(5, generator=g) + 0.5, torch.rand(5, generator=g) + 0.5   # per-row norms of the unsharded batch
+rows = [0, 1, 2] if rank == 0 else [3, 4]                                              # uneven shards
+sn, zn = ops.langevin_group_norms(sn_all[rows], zn_all[rows], dist.group.WORLD)        # a REAL ProcessGroup
+if rank == 0:
+    print("RESULT " + json.dumps([float(sn), float(zn), float(sn_all.mean()), float(zn_all.mean())]))
+D.barrier()
+'''
+
+
+def test_langevin_group_norms_two_ranks(tmp_path):
+    """The sharded `langevin` corrector (langevin_group=): the 3-float all-reduce through torch.distributed over a real
+    ProcessGroup (gloo here, RCCL on the GPUs) reproduces the unsharded batch means (correctors.py:53-55) on every rank."""
+    import json
+    script = tmp_path / "worker.py"
+    script.write_text(LANGEVIN_WORKER.format(root=ROOT))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
+           "--master-port", str(free_port()), str(script)]
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=300, env={**os.environ, "OMP_NUM_THREADS": "1"})
+    assert out.returncode == 0, out.stderr[-2000:]
+    sn, zn, sn_ref, zn_ref = json.loads([l for l in out.stdout.splitlines() if l.startswith("RESULT ")][0][7:])
+    assert abs(sn - sn_ref) < 1e-6 and abs(zn - zn_ref) < 1e-6

@@ -89,6 +89,38 @@ def test_ode_sampler_vs_reference(dev, golden):
     assert rel_l2(x.cpu(), g["out"]) < 1e-3
 
 
+def test_ode_per_row_control_equals_the_reference_per_utterance_runs(dev, golden):
+    """The reference MODEL integrates one utterance per solve_ivp call (model.py:224-244, minibatch = 1), so every utterance
+    has its own step sequence.  per_row=True keeps that inside a batch: fixture F12 holds three utterances of different
+    stiffness solved ONE BY ONE by the reference (nfev 32 / 38 / 62): the batched run reproduces every row's nfev and end
+    point, row b is BIT-equal to our own batch-1 run of utterance b, and the coupled form (the reference function handed a
+    whole batch) is a different computation."""
+    from storm_amd.sampling import get_ode_sampler
+    from storm_amd.sdes import OUVESDE
+    g = golden["f12_ode_rows"]
+    sde = OUVESDE(1.5, 0.05, 0.5, N=30)
+
+    def score(x, t, y):
+        return -(x - y) * (1 + 4 * y.abs().mean(dim=(1, 2, 3), keepdim=True)) / (sde._std(t)[:, None, None, None] ** 2 + 0.1)
+    y, z = T(g["toy_y"]).to(dev), T(g["toy_z"]).to(dev)
+    sampler = get_ode_sampler(sde, score, y=y, eps=0.03, noise_fn=lambda: z, per_row=True)
+    x, nfe = sampler()
+    want_nfe = [int(v) for v in g["toy_nfe"]]
+    assert want_nfe == [32, 38, 62]
+    if dev.type == "cpu":      # same torch CPU ops in the score as the reference's run: the same steps, exactly
+        assert sampler.nfev_rows == want_nfe and nfe == max(want_nfe)
+    else:                      # (the first steps' error estimates sit at the fp32 noise floor: an ulp in the device's pow / div
+        assert all(abs(a - b) <= 6 for a, b in zip(sampler.nfev_rows, want_nfe))          # may move one step)
+    for b in range(3):
+        assert rel_l2(x[b].cpu(), g["toy_out"][b]) < 1e-3
+        alone = get_ode_sampler(sde, score, y=y[b:b + 1], eps=0.03, noise_fn=lambda: z[b:b + 1], per_row=True)
+        xb, nb = alone()
+        assert nb == sampler.nfev_rows[b] and torch.equal(xb.cpu(), x[b:b + 1].cpu())
+    coupled = get_ode_sampler(sde, score, y=y, eps=0.03, noise_fn=lambda: z)     # solve_ivp over the flattened batch
+    xc, nc = coupled()
+    assert coupled.nfev_rows == [nc] * 3 and not torch.equal(xc.cpu(), x.cpu())
+
+
 @pytest.mark.gpu
 def test_bf16_sampler_drift_over_a_full_run():
     """BASELINE.json configs[1] numerics: the FULL 30-step PC run (reverse_diffusion + 1 ald step = 60 score evaluations of
@@ -118,7 +150,7 @@ def test_bf16_sampler_drift_over_a_full_run():
     assert err < 5e-2
 
 
-def test_langevin_step_size_modes(dev):
+def test_langevin_step_size_modes(dev, monkeypatch):
     """The Langevin corrector's batch-coupled step size (correctors.py:45-61): default = means over the sampler's batch
     (the oracle's restatement); per_row = B independent batch-1 calls (what the reference CLI computes per file, used by
     enhance_batch); group = means over the batches of all ranks of a sharded run == the unsharded batch."""
@@ -143,17 +175,18 @@ def test_langevin_step_size_modes(dev):
     for b in range(4):
         assert rel_l2(rows[b:b + 1], oracle(x[b:b + 1], s[b:b + 1], z[b:b + 1])[0]) < 1e-6
 
-    class TwoShards:                                       # stands in for dist.all_reduce over two ranks holding rows 0-1 / 2-3
-        def __init__(self, other):
-            self.other = other
-
-        def all_reduce(self, t):
-            t += self.other.to(t.device)
+    # the all-reduce itself (torch.distributed.all_reduce over a real ProcessGroup) is covered by the 2-rank gloo test
+    # tests/test_distributed.py::test_langevin_group_norms_two_ranks; here the other rank's contribution is injected
     n = lambda v: torch.linalg.norm(v.reshape(v.shape[0], -1), dim=-1).sum()
     halves = [slice(0, 2), slice(2, 4)]
     for me, oth in ((0, 1), (1, 0)):
         other = torch.stack([n(s[halves[oth]]), n(z[halves[oth]]), torch.tensor(2.0)])
-        part, _ = run(x[halves[me]], s[halves[me]], z[halves[me]], group=TwoShards(other))
+
+        def fake_all_reduce(t, group, other=other):
+            assert group == "two-shards"
+            t += other.to(t.device)
+        monkeypatch.setattr(ops, "_all_reduce_sum", fake_all_reduce)
+        part, _ = run(x[halves[me]], s[halves[me]], z[halves[me]], group="two-shards")
         assert rel_l2(part, want[halves[me]]) < 1e-6        # sharded == unsharded batch
 
 
