@@ -62,6 +62,8 @@ class Op(C.Structure):
 _vp, _i, _ll, _f, _u64 = C.c_void_p, C.c_int, C.c_longlong, C.c_float, C.c_uint64
 _SIGNATURES = {
     "storm_abi_version": ([], C.c_int),
+    "storm_set_switch": ([C.c_char_p, _ll], C.c_int),
+    "storm_get_switch": ([C.c_char_p], C.c_longlong),
     "storm_device_info": ([C.c_char_p, _i, C.POINTER(C.c_int), C.POINTER(C.c_size_t)], C.c_int),
     "storm_pack_conv_weight": ([_vp, _vp, _i, _i, _i, _i, _i, _i, _vp], C.c_int),
     "storm_pack_matrix": ([_vp, _vp, _i, _i, _i, _i, _i, _i, _vp], C.c_int),

@@ -1,6 +1,7 @@
 // Error channel, version and device info of libstorm_hip.
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include "common.h"
 
@@ -12,7 +13,55 @@ void set_error(const char* fmt, ...) {
     vsnprintf(g_err, sizeof(g_err), fmt, ap);
     va_end(ap);
 }
+
+namespace {
+struct SwitchName { const char* name; int Switches::*field; };
+const SwitchName kSwitches[] = {
+    {"STORM_CONV_VARIANT", &Switches::conv_variant}, {"STORM_CONV_PIPE128", &Switches::conv_pipe128}, {"STORM_CONV_PC", &Switches::conv_pc},
+    {"STORM_CONV_CUS", &Switches::conv_cus}, {"STORM_RESAMPLE_WGS", &Switches::resample_wgs}, {"STORM_CONV_PERSIST", &Switches::conv_persist},
+    {"STORM_CONV_DMA", &Switches::conv_dma}, {"STORM_CONV_ABLATE", &Switches::conv_ablate},
+};
+}  // namespace
+
+Switches& switches() {
+    static Switches sw = [] {
+        Switches v;
+        for (const SwitchName& n : kSwitches)
+            if (const char* e = getenv(n.name)) v.*(n.field) = atoi(e);
+        if (const char* e = getenv("STORM_CONV_TRACE_PTR")) v.conv_trace_ptr = strtoull(e, nullptr, 0);
+        return v;
+    }();
+    return sw;
+}
+
+int device_cus() {
+    const int forced = switches().conv_cus;
+    if (forced > 0) return forced;
+    static int n_cu = 0;
+    if (n_cu == 0) {
+        int dev = 0; hipDeviceProp_t prop;
+        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) n_cu = prop.multiProcessorCount;
+        if (n_cu <= 0) n_cu = 256;
+    }
+    return n_cu;
+}
 }  // namespace storm
+
+// Test / tool hook (not part of the drop-in surface): set one of the switches above by its environment-variable name.
+extern "C" int storm_set_switch(const char* name, long long value) {
+    STORM_CHECK(name != nullptr, "storm_set_switch: null name");
+    if (strcmp(name, "STORM_CONV_TRACE_PTR") == 0) { storm::switches().conv_trace_ptr = (unsigned long long)value; return STORM_OK; }
+    for (const storm::SwitchName& n : storm::kSwitches)
+        if (strcmp(name, n.name) == 0) { storm::switches().*(n.field) = (int)value; return STORM_OK; }
+    STORM_CHECK(false, "storm_set_switch: unknown switch %s", name);
+}
+extern "C" long long storm_get_switch(const char* name) {
+    if (name == nullptr) return 0;
+    if (strcmp(name, "STORM_CONV_TRACE_PTR") == 0) return (long long)storm::switches().conv_trace_ptr;
+    for (const storm::SwitchName& n : storm::kSwitches)
+        if (strcmp(name, n.name) == 0) return storm::switches().*(n.field);
+    return 0;
+}
 
 extern "C" const char* storm_last_error(void) { return storm::g_err; }
 extern "C" int storm_abi_version(void) { return 1; }

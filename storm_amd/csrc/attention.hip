@@ -14,7 +14,8 @@
 //     as both operands agree: slot (h, e) <-> key 16 m + 4 h + (e & 3) + 8 (e >> 2) is exactly the order the S^T
 //     accumulator leaves them in, so P needs no shuffle; the V^T fragment is two 8-byte reads.
 //   * the rescale factor of the online softmax is a per-lane scalar (one query per lane column of O^T).
-// bf16 operands, fp32 accumulation / softmax.  C = 32 * CT channels (CT in {1, 2, 4, 8}); any L (ragged tiles masked).
+// bf16 or fp16 operands (T), fp32 accumulation / softmax.  C = 32 * CT channels (CT in {1, 2, 4, 8}); any L (ragged tiles masked).
+// fp32 (the parity path): attention_f32_kernel below, the same structure on the exact-fp32 MFMA (v_mfma_f32_32x32x2_f32).
 #include "conv_params.h"
 
 namespace storm {
@@ -26,17 +27,17 @@ constexpr int ATTN_THREADS = attn::THREADS;
 
 __device__ __forceinline__ uint4 ldg16(const void* p) { return *reinterpret_cast<const uint4*>(p); }
 
-template <int CT>
+template <typename T, int CT>
 __global__ __launch_bounds__(ATTN_THREADS)
-void attention_kernel(const bf16_t* __restrict__ q, const bf16_t* __restrict__ k, const bf16_t* __restrict__ vT,
-                      const float* __restrict__ bias, bf16_t* __restrict__ out, int L, int ldv, long long q_bs,
+void attention_kernel(const T* __restrict__ q, const T* __restrict__ k, const T* __restrict__ vT,
+                      const float* __restrict__ bias, T* __restrict__ out, int L, int ldv, long long q_bs,
                       long long k_bs, long long v_bs, long long o_bs, float scale_log2e) {
     constexpr int C = 32 * CT, KG = C / 16;            // channels; 16-channel k-groups of the score product
     constexpr int KROW = C * 2, KSLOTS = KROW / 16;    // K tile row: bytes, 16-B slots
     constexpr int KTILE = BK * KROW, VTILE = C * 64;   // bytes per buffer
     constexpr int KPT = BK * KSLOTS / ATTN_THREADS > 0 ? BK * KSLOTS / ATTN_THREADS : 1;      // 16-B pieces per thread (K)
     constexpr int VPT = C * 4 / ATTN_THREADS > 0 ? C * 4 / ATTN_THREADS : 1;                  // 16-B pieces per thread (V^T)
-    typedef bf16x8 Frag;
+    typedef typename Mma<T>::Frag Frag;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char* const kbuf = smem;                            // [2][KTILE]
     char* const vbuf = smem + 2 * KTILE;                // [2][VTILE]
@@ -44,9 +45,9 @@ void attention_kernel(const bf16_t* __restrict__ q, const bf16_t* __restrict__ k
     const int b = blockIdx.y, q0 = blockIdx.x * BQ;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int j = lane & 31, h = lane >> 5;
-    const bf16_t* qb = q + (long long)b * q_bs;
-    const bf16_t* kb = k + (long long)b * k_bs;
-    const bf16_t* vb = vT + (long long)b * v_bs;
+    const T* qb = q + (long long)b * q_bs;
+    const T* kb = k + (long long)b * k_bs;
+    const T* vb = vT + (long long)b * v_bs;
 
     // Q fragments of this lane's query (clamped: rows past L are computed and dropped)
     const int qi = min(q0 + wave * 32 + j, L - 1);
@@ -120,7 +121,7 @@ void attention_kernel(const bf16_t* __restrict__ q, const bf16_t* __restrict__ k
 #pragma unroll
         for (int g = 0; g < KG; ++g) {
             const Frag kf = *reinterpret_cast<const Frag*>(kt + (((2 * g + h) ^ (j & (KSLOTS - 1))) << 4));
-            Mma<bf16_t>::run(kf, qf[g], s);
+            Mma<T>::run(kf, qf[g], s);
         }
         // ---- online softmax over this lane's 16 keys + its partner's 16 ------------------------------------------------
         float mx = -INFINITY;
@@ -149,7 +150,7 @@ void attention_kernel(const bf16_t* __restrict__ q, const bf16_t* __restrict__ k
         for (int mk = 0; mk < 2; ++mk) {
             uint32_t pw[4];
 #pragma unroll
-            for (int e = 0; e < 4; ++e) pw[e] = pack_bf16x2(p[8 * mk + 2 * e], p[8 * mk + 2 * e + 1]);
+            for (int e = 0; e < 4; ++e) pw[e] = pack2(p[8 * mk + 2 * e], p[8 * mk + 2 * e + 1], (T*)nullptr);
             const uint4 pv = make_uint4(pw[0], pw[1], pw[2], pw[3]);
             const Frag pf = *reinterpret_cast<const Frag*>(&pv);
 #pragma unroll
@@ -159,18 +160,18 @@ void attention_kernel(const bf16_t* __restrict__ q, const bf16_t* __restrict__ k
                 const uint2 lo = *reinterpret_cast<const uint2*>(row + (((4 * mk + h) ^ x) << 3));
                 const uint2 hi = *reinterpret_cast<const uint2*>(row + (((4 * mk + h + 2) ^ x) << 3));
                 const uint4 vv = make_uint4(lo.x, lo.y, hi.x, hi.y);
-                Mma<bf16_t>::run(*reinterpret_cast<const Frag*>(&vv), pf, o[t]);
+                Mma<T>::run(*reinterpret_cast<const Frag*>(&vv), pf, o[t]);
             }
         }
         if (n + 1 < ntiles) store_tile(buf ^ 1);
         __syncthreads();
     }
 
-    // ---- epilogue: h = O / l + b_v (rows of P sum to one, so the NIN_2 bias passes through), bf16, 8-byte stores ------------
+    // ---- epilogue: h = O / l + b_v (rows of P sum to one, so the NIN_2 bias passes through), 16-bit, 8-byte stores ----------
     const int qrow = q0 + wave * 32 + j;
     if (qrow < L) {
         const float inv = 1.0f / l_run;
-        bf16_t* orow = out + (long long)b * o_bs + (long long)qrow * C;
+        T* orow = out + (long long)b * o_bs + (long long)qrow * C;
 #pragma unroll
         for (int t = 0; t < CT; ++t)
 #pragma unroll
@@ -179,32 +180,159 @@ void attention_kernel(const bf16_t* __restrict__ q, const bf16_t* __restrict__ k
                 float v[4];
 #pragma unroll
                 for (int e = 0; e < 4; ++e) v[e] = o[t][4 * g + e] * inv + (bias ? bias[c + e] : 0.f);
-                *reinterpret_cast<uint2*>(orow + c) = make_uint2(pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]));
+                *reinterpret_cast<uint2*>(orow + c) = make_uint2(pack2(v[0], v[1], (T*)nullptr), pack2(v[2], v[3], (T*)nullptr));
             }
     }
 }
 
+// ---- fp32 (parity path): the same online-softmax structure on v_mfma_f32_32x32x2_f32 (exact fp32 products, fp32 sums).
+// Key tiles of 32 keys, K [32][C] and V^T [C][32] fp32 in LDS (2 x 32 KB at C = 256, double buffered = 128 KB), Q fragments of the
+// lane's query in registers (C / 2 floats: one 512-register wave per SIMD).  An MFMA contracts over two k-slots (the lane
+// halves): for S^T slot h <-> channel 2 g + h; for O^T slot h of MFMA r <-> key acc_row(h, r), i.e. the B operand of MFMA r is
+// the lane's own p[r] and the A operand one V^T element.
 template <int CT>
+__global__ __launch_bounds__(ATTN_THREADS, 1)
+void attention_f32_kernel(const float* __restrict__ q, const float* __restrict__ k, const float* __restrict__ vT,
+                          const float* __restrict__ bias, float* __restrict__ out, int L, int ldv, long long q_bs,
+                          long long k_bs, long long v_bs, long long o_bs, float scale_log2e) {
+    constexpr int C = 32 * CT;
+    constexpr int KROW = C * 4 + 16;                    // padded rows: the 32 lanes of a fragment read hit 32 banks
+    constexpr int KTILE = BK * KROW, VROW = BK * 4 + 16, VTILE = C * VROW;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* const kbuf = smem;
+    char* const vbuf = smem + 2 * KTILE;
+    const int b = blockIdx.y, q0 = blockIdx.x * BQ;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int j = lane & 31, h = lane >> 5;
+    const float* qb = q + (long long)b * q_bs;
+    const float* kb = k + (long long)b * k_bs;
+    const float* vb = vT + (long long)b * v_bs;
+    const int qi = min(q0 + wave * 32 + j, L - 1);
+    float qf[C / 2];                                    // channel 2 g + h of this lane's query
+#pragma unroll
+    for (int g = 0; g < C / 2; ++g) qf[g] = qb[(long long)qi * C + 2 * g + h];
+    f32x16 o[CT];
+#pragma unroll
+    for (int t = 0; t < CT; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) o[t][r] = 0.f;
+    float m_run = -INFINITY, l_run = 0.f;
+    auto stage = [&](int j0, int buf) {                 // synchronous staging (this path is for parity, not speed)
+        for (int u = tid; u < BK * (C / 4); u += ATTN_THREADS) {
+            const int r = u / (C / 4), s4 = u % (C / 4);
+            *reinterpret_cast<float4*>(kbuf + buf * KTILE + r * KROW + s4 * 16) =
+                *reinterpret_cast<const float4*>(kb + (long long)min(j0 + r, L - 1) * C + 4 * s4);
+        }
+        for (int u = tid; u < C * (BK / 4); u += ATTN_THREADS) {
+            const int c = u / (BK / 4), p4 = u % (BK / 4);
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (j0 + 4 * p4 + 4 <= ldv) v = *reinterpret_cast<const float4*>(vb + (long long)c * ldv + j0 + 4 * p4);
+            *reinterpret_cast<float4*>(vbuf + buf * VTILE + c * VROW + p4 * 16) = v;
+        }
+    };
+    const int ntiles = (L + BK - 1) / BK;
+    stage(0, 0);
+    __syncthreads();
+    for (int n = 0; n < ntiles; ++n) {
+        const int buf = n & 1, j0 = n * BK;
+        if (n + 1 < ntiles) stage(j0 + BK, buf ^ 1);
+        f32x16 s;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) s[r] = 0.f;
+        const float* kt = reinterpret_cast<const float*>(kbuf + buf * KTILE + j * KROW);
+#pragma unroll
+        for (int g = 0; g < C / 2; ++g) s = __builtin_amdgcn_mfma_f32_32x32x2f32(kt[2 * g + h], qf[g], s, 0, 0, 0);
+        float mx = -INFINITY;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int key = j0 + cidx::acc_row(lane, r);
+            s[r] = key < L ? s[r] * scale_log2e : -INFINITY;
+            mx = fmaxf(mx, s[r]);
+        }
+        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+        const float m_new = fmaxf(m_run, mx);
+        const float alpha = exp2f(m_run - m_new);
+        float ps = 0.f, p[16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { p[r] = exp2f(s[r] - m_new); ps += p[r]; }
+        ps += __shfl_xor(ps, 32, 64);
+        l_run = l_run * alpha + ps;
+        m_run = m_new;
+#pragma unroll
+        for (int t = 0; t < CT; ++t)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) o[t][r] *= alpha;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {                  // MFMA r contracts over the two keys acc_row(h = 0, r), acc_row(h = 1, r)
+            const int key = cidx::acc_row(lane, r);
+#pragma unroll
+            for (int t = 0; t < CT; ++t) {
+                const float v = *reinterpret_cast<const float*>(vbuf + buf * VTILE + (32 * t + j) * VROW + key * 4);
+                o[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(v, p[r], o[t], 0, 0, 0);
+            }
+        }
+        __syncthreads();
+    }
+    const int qrow = q0 + wave * 32 + j;
+    if (qrow < L) {
+        const float inv = 1.0f / l_run;
+        float* orow = out + (long long)b * o_bs + (long long)qrow * C;
+#pragma unroll
+        for (int t = 0; t < CT; ++t)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int c = 32 * t + 8 * g + 4 * h;
+                float4 v;
+                v.x = o[t][4 * g] * inv + (bias ? bias[c] : 0.f); v.y = o[t][4 * g + 1] * inv + (bias ? bias[c + 1] : 0.f);
+                v.z = o[t][4 * g + 2] * inv + (bias ? bias[c + 2] : 0.f); v.w = o[t][4 * g + 3] * inv + (bias ? bias[c + 3] : 0.f);
+                *reinterpret_cast<float4*>(orow + c) = v;
+            }
+    }
+}
+
+template <typename T, int CT>
 static int attn_launch(const void* q, const void* k, const void* vT, const float* bias, void* out, int B, int L, int ldv,
                   long long q_bs, long long k_bs, long long v_bs, long long o_bs, float scale, hipStream_t st) {
     constexpr int C = 32 * CT;
-    constexpr int lds = 2 * (BK * C * 2) + 2 * (C * 64);
-    auto kern = attention_kernel<CT>;
+    constexpr bool F32 = sizeof(T) == 4;
+    constexpr int lds = F32 ? 2 * (BK * (C * 4 + 16)) + 2 * (C * (BK * 4 + 16)) : 2 * (BK * C * 2) + 2 * (C * 64);
     static bool attr_set = false;
-    if (!attr_set) {
-        STORM_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
-        attr_set = true;
+    if constexpr (F32) {
+        auto kern = attention_f32_kernel<CT>;
+        if (!attr_set) {
+            STORM_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+            attr_set = true;
+        }
+        hipLaunchKernelGGL(kern, dim3(cdiv(L, BQ), B), dim3(ATTN_THREADS), lds, st, (const float*)q, (const float*)k, (const float*)vT,
+                           bias, (float*)out, L, ldv, q_bs, k_bs, v_bs, o_bs, scale * 1.44269504088896341f);
+    } else {
+        auto kern = attention_kernel<T, CT>;
+        if (!attr_set) {
+            STORM_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+            attr_set = true;
+        }
+        hipLaunchKernelGGL(kern, dim3(cdiv(L, BQ), B), dim3(ATTN_THREADS), lds, st, (const T*)q, (const T*)k, (const T*)vT,
+                           bias, (T*)out, L, ldv, q_bs, k_bs, v_bs, o_bs, scale * 1.44269504088896341f);
     }
-    hipLaunchKernelGGL(kern, dim3(cdiv(L, BQ), B), dim3(ATTN_THREADS), lds, st, (const bf16_t*)q, (const bf16_t*)k, (const bf16_t*)vT,
-                       bias, (bf16_t*)out, L, ldv, q_bs, k_bs, v_bs, o_bs, scale * 1.44269504088896341f);
     STORM_LAUNCH_CHECK();
     return STORM_OK;
+}
+
+template <typename T>
+static int attn_dispatch(int C, const void* q, const void* k, const void* vT, const float* bias, void* out, int B, int L, int ldv,
+                         long long q_bs, long long k_bs, long long v_bs, long long o_bs, float scale, hipStream_t st) {
+    switch (C) {
+        case 32: return attn_launch<T, 1>(q, k, vT, bias, out, B, L, ldv, q_bs, k_bs, v_bs, o_bs, scale, st);
+        case 64: return attn_launch<T, 2>(q, k, vT, bias, out, B, L, ldv, q_bs, k_bs, v_bs, o_bs, scale, st);
+        case 128: return attn_launch<T, 4>(q, k, vT, bias, out, B, L, ldv, q_bs, k_bs, v_bs, o_bs, scale, st);
+        default: return attn_launch<T, 8>(q, k, vT, bias, out, B, L, ldv, q_bs, k_bs, v_bs, o_bs, scale, st);
+    }
 }
 
 }  // namespace storm
 
 extern "C" int storm_attention_supported(int C, int dtype) {
-    return dtype == STORM_BF16 && (C == 32 || C == 64 || C == 128 || C == 256);
+    return (dtype == STORM_BF16 || dtype == STORM_F16 || dtype == STORM_F32) && (C == 32 || C == 64 || C == 128 || C == 256);
 }
 
 extern "C" int storm_attention(const void* q, const void* k, const void* vT, const float* bias, void* out, int B, int L, int C,
@@ -218,10 +346,7 @@ extern "C" int storm_attention(const void* q, const void* k, const void* vT, con
         return STORM_ERR_UNSUPPORTED;
     }
     hipStream_t st = (hipStream_t)s;
-    switch (C) {
-        case 32: return attn_launch<1>(q, k, vT, bias, out, B, L, ldv, q_bstride, k_bstride, vT_bstride, out_bstride, scale, st);
-        case 64: return attn_launch<2>(q, k, vT, bias, out, B, L, ldv, q_bstride, k_bstride, vT_bstride, out_bstride, scale, st);
-        case 128: return attn_launch<4>(q, k, vT, bias, out, B, L, ldv, q_bstride, k_bstride, vT_bstride, out_bstride, scale, st);
-        default: return attn_launch<8>(q, k, vT, bias, out, B, L, ldv, q_bstride, k_bstride, vT_bstride, out_bstride, scale, st);
-    }
+    if (dtype == STORM_F32) return attn_dispatch<float>(C, q, k, vT, bias, out, B, L, ldv, q_bstride, k_bstride, vT_bstride, out_bstride, scale, st);
+    if (dtype == STORM_F16) return attn_dispatch<half_t>(C, q, k, vT, bias, out, B, L, ldv, q_bstride, k_bstride, vT_bstride, out_bstride, scale, st);
+    return attn_dispatch<bf16_t>(C, q, k, vT, bias, out, B, L, ldv, q_bstride, k_bstride, vT_bstride, out_bstride, scale, st);
 }

@@ -21,6 +21,23 @@ typedef __attribute__((ext_vector_type(8))) _Float16 f16x8;
 
 // ---- error reporting (storm_last_error) ----
 void set_error(const char* fmt, ...);
+
+// A/B and test switches of the launchers.  Production never sets them: the table is filled ONCE, when the library is first
+// used, from the environment variables of the same names (so `STORM_CONV_VARIANT=0 python tools/...` still works), and after
+// that only storm_set_switch() - the test / tool hook exported next to the ABI - changes it.  A launch reads plain ints.
+struct Switches {
+    int conv_variant = -1;      // STORM_CONV_VARIANT: force a conv kernel family (see choose_variant), -1 = the dispatcher's choice
+    int conv_pipe128 = 1;       // STORM_CONV_PIPE128: 0 = keep the <= 128-cout 3x3 layers on conv_igemm
+    int conv_pc = 1;            // STORM_CONV_PC: 0 = keep the layers conv_pc.hip takes on the older kernels
+    int conv_cus = 0;           // STORM_CONV_CUS: pretend the device has this many CUs (persistent tile walks in tests), 0 = ask the device
+    int resample_wgs = 0;       // STORM_RESAMPLE_WGS: cap of the resample kernels' persistent grid, 0 = default
+    int conv_persist = 0;       // STORM_CONV_PERSIST (profiling build)
+    int conv_dma = 1;           // STORM_CONV_DMA (profiling build): 0 = register staging in conv_igemm's 128-cout kernel
+    int conv_ablate = 0;        // STORM_CONV_ABLATE (profiling build): work-skipping instantiations
+    unsigned long long conv_trace_ptr = 0;   // STORM_CONV_TRACE_PTR (profiling build): device buffer of tools/conv_trace.py
+};
+Switches& switches();
+int device_cus();               // CU count of the current device (cached), or switches().conv_cus
 #define STORM_CHECK(cond, ...) do { if (!(cond)) { storm::set_error(__VA_ARGS__); return STORM_ERR_INVALID; } } while (0)
 #define STORM_HIP(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) { \
     storm::set_error("%s failed: %s", #expr, hipGetErrorString(e_)); return STORM_ERR_HIP; } } while (0)

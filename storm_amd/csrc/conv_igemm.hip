@@ -622,25 +622,17 @@ static int launch_conv(const storm_conv_args& a, hipStream_t st) {
     const int tiles_per_xcd = cdiv(ntiles, 8);
     const long long vblocks = 8LL * tiles_per_xcd * n_ct;
     STORM_CHECK(vblocks > 0 && vblocks < (1LL << 31), "storm_conv: grid %lld out of range", vblocks);
-    static const int persist = getenv("STORM_CONV_PERSIST") ? atoi(getenv("STORM_CONV_PERSIST")) : 0;
-    static int n_cu = 0;
-    if (n_cu == 0) {
-        int dev = 0; hipDeviceProp_t prop;
-        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) n_cu = prop.multiProcessorCount;
-        if (n_cu <= 0) n_cu = 256;
-    }
     long long grid = vblocks;
-    if (persist) {
-        const char* cus_env = getenv("STORM_CONV_CUS");            // test hook: pretend the device has this many CUs
-        const int cus = cus_env ? ((atoi(cus_env) + 7) / 8) * 8 : ((n_cu + 7) / 8) * 8;
-        const long long resident = (long long)cus * Cfg::BLOCKS_PER_CU * persist;      // multiple of 8
+#if defined(STORM_PROFILING)
+    if (const int persist = switches().conv_persist) {               // (A/B: persistent tile walk in this kernel family)
+        const long long resident = (long long)((device_cus() + 7) / 8 * 8) * Cfg::BLOCKS_PER_CU * persist;      // multiple of 8
         if (grid > resident) grid = resident;
     }
+#endif
     ConvParams prm = make_params(a);
 #if defined(STORM_PROFILING)
     if (ABL & 64) {                                              // device buffer address handed over by tools/conv_trace.py
-        const char* tp = getenv("STORM_CONV_TRACE_PTR");
-        prm.trace = tp ? reinterpret_cast<unsigned long long*>(strtoull(tp, nullptr, 0)) : nullptr;
+        prm.trace = reinterpret_cast<unsigned long long*>(switches().conv_trace_ptr);
     }
 #endif
     hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(Cfg::THREADS), Cfg::LDS_BYTES, st, prm, n_ct,
@@ -649,23 +641,15 @@ static int launch_conv(const storm_conv_args& a, hipStream_t st) {
     return STORM_OK;
 }
 
-// Environment switches (A/B runs and forced-variant tests only; never set in production).  STORM_CONV_VARIANT is read
-// per launch because the tests switch it at run time; it costs one getenv per conv launch.
-static int env_int(const char* name, int dflt) {
-    const char* v = getenv(name);
-    return v ? atoi(v) : dflt;
-}
-
 // Which kernel a convolution runs on (exported as storm_conv_kernel_name, so that bench.py's roofline names the
 // kernel the launcher really picked instead of re-deriving the rule).
 //   0: conv_igemm 128 cout x 256 px, 4 waves (64x128 each), 2 workgroups / CU overlap each other's staging; LDS-DMA
-//   1: conv_igemm 128 cout x 256 px, 8 waves (64x64 each), 2 workgroups / CU
+//   1: conv_igemm 128 cout x 256 px, 8 waves (64x64 each), 2 workgroups / CU      (profiling build only)
 //   2: conv_igemm 256 cout x 256 px, 8 waves, 1 workgroup / CU, patch double-buffered through registers
 //   3: conv_pipe.hip, 256 cout x 256 px, 8 waves in two ping-pong groups, chunk-unrolled LDS-DMA pipeline (16-bit 3x3)
 //   4: conv_pipe128.hip, 128 cout x 512 px, the same pipeline for layers with <= 128 output channels (16-bit 3x3)
-//   5: conv_duo.hip, 128 cout x 256 px, 4 waves, two workgroups / CU, the pipelined loop (16-bit 3x3, <= 128 output channels)
 static int choose_variant(const storm_conv_args& a, bool any9) {
-    const int forced = env_int("STORM_CONV_VARIANT", -1);
+    const int forced = switches().conv_variant;                      // (test / A-B hook, storm_set_switch)
     if (forced >= 0) return forced;
     const long long px_tiles = (long long)a.B * cdiv((long long)a.H * a.W, TILE_H * TILE_W);
     if (a.outC > 128 && px_tiles >= 512) return any9 && conv_pipe_supports(a) ? 3 : 2;
@@ -674,9 +658,7 @@ static int choose_variant(const storm_conv_args& a, bool any9) {
     // with K this short the exposed epilogue and the fused GroupNorm transform weigh the same in both kernels and two resident
     // workgroups hide them at least as well.  (A stem-like layer with fewer than 32 input channels is HBM-bound either way.)
     if (a.outC > 32 && a.outC <= 128 && any9 && px_tiles >= 1024 && px_tiles <= 4096 && a.seg[0].Ca + a.seg[0].Cb >= 32 &&
-        env_int("STORM_CONV_PIPE128", 1) != 0 && conv_pipe128_supports(a)) return 4;    // (A/B switch: 0 = conv_igemm for these layers)
-    if (a.outC > 32 && a.outC <= 128 && any9 && px_tiles >= 512 && a.seg[0].Ca + a.seg[0].Cb >= 32 &&
-        env_int("STORM_CONV_DUO", 0) != 0 && conv_duo_supports(a)) return 5;
+        switches().conv_pipe128 != 0 && conv_pipe128_supports(a)) return 4;    // (A/B switch: 0 = conv_igemm for these layers)
     return 0;
 }
 
@@ -685,11 +667,10 @@ static int dispatch_conv(const storm_conv_args& a, hipStream_t st) {
     bool any9 = false;
     for (int s = 0; s < a.nseg; ++s) any9 = any9 || a.seg[s].ntaps == 9;
     const bool small = a.outC <= 32;
-    const bool dma = env_int("STORM_CONV_DMA", 1) != 0;               // A/B switch: 0 = register staging in the 128-cout kernel
     const int variant = choose_variant(a, any9);
 #if defined(STORM_PROFILING)
     // work-skipping instantiations for tools/ (no MFMA, no fragment reads, ...): profiling build only
-    const int abl = env_int("STORM_CONV_ABLATE", 0);
+    const int abl = switches().conv_ablate;
     if (any9 && !small && abl && variant < 3) {
         const bool v2 = variant == 2;
         switch (abl) {
@@ -708,14 +689,19 @@ static int dispatch_conv(const storm_conv_args& a, hipStream_t st) {
         if (small) return launch_conv<T, 9, 1, 1, 4, false>(a, st);
         if (variant == 3 && conv_pipe_supports(a)) return launch_conv_pipe(a, st);
         if (variant == 4 && conv_pipe128_supports(a)) return launch_conv_pipe128(a, st);
-        if (variant == 5 && conv_duo_supports(a)) return launch_conv_duo(a, st);
         if (variant == 2) return launch_conv<T, 9, 2, 4, 2, true>(a, st);
+#if defined(STORM_PROFILING)                                          // A/B instantiations: 8-wave geometry, register staging
         if (variant == 1) return launch_conv<T, 9, 2, 2, 4, false>(a, st);
-        return dma ? launch_conv<T, 9, 2, 2, 2, false, true>(a, st) : launch_conv<T, 9, 2, 2, 2, false, false>(a, st);
+        if (switches().conv_dma == 0) return launch_conv<T, 9, 2, 2, 2, false, false>(a, st);
+#endif
+        return launch_conv<T, 9, 2, 2, 2, false, true>(a, st);
     }
     if (small) return launch_conv<T, 1, 1, 1, 4, false>(a, st);
     if (variant == 2) return launch_conv<T, 1, 2, 4, 2, true>(a, st);
-    return variant == 1 ? launch_conv<T, 1, 2, 2, 4, false>(a, st) : launch_conv<T, 1, 2, 2, 2, false>(a, st);
+#if defined(STORM_PROFILING)
+    if (variant == 1) return launch_conv<T, 1, 2, 2, 4, false>(a, st);
+#endif
+    return launch_conv<T, 1, 2, 2, 2, false>(a, st);
 }
 
 // Name of the kernel storm_conv launches for these arguments (as rocprofv3 prints it).
@@ -729,9 +715,11 @@ static const char* kernel_name_of(const storm_conv_args& a) {
     if (a.outC <= 32) shape = "1, 1, 4, false, false";
     else if (any9 && variant == 3 && conv_pipe_supports(a)) return conv_pipe_kernel_name(a.dtype);
     else if (any9 && variant == 4 && conv_pipe128_supports(a)) return conv_pipe128_kernel_name(a.dtype);
-    else if (any9 && variant == 5 && conv_duo_supports(a)) return conv_duo_kernel_name(a.dtype);
     else if (variant == 2) shape = "2, 4, 2, true, false";
+#if defined(STORM_PROFILING)
     else if (variant == 1) shape = "2, 2, 4, false, false";
+    else if (any9 && switches().conv_dma == 0) shape = "2, 2, 2, false, false";
+#endif
     else shape = any9 ? "2, 2, 2, false, true" : "2, 2, 2, false, false";
     static thread_local char buf[160];
     snprintf(buf, sizeof(buf), "storm::conv_igemm_kernel<%s, %d, %s, 0>", tn, taps, shape);

@@ -302,9 +302,5 @@ const char* conv_pipe_kernel_name(int dtype);
 bool conv_pipe128_supports(const storm_conv_args& a);
 int launch_conv_pipe128(const storm_conv_args& a, hipStream_t st);
 const char* conv_pipe128_kernel_name(int dtype);
-// defined in conv_duo.hip: the same loop in conv_igemm's geometry (128 couts x 256 pixels, 4 waves, two workgroups per CU)
-bool conv_duo_supports(const storm_conv_args& a);
-int launch_conv_duo(const storm_conv_args& a, hipStream_t st);
-const char* conv_duo_kernel_name(int dtype);
 
 }  // namespace storm

@@ -804,19 +804,11 @@ static int launch_pipe(const storm_conv_args& a, hipStream_t st) {
     const int tiles_per_xcd = cdiv(ntiles, 8);
     const long long vblocks = 8LL * tiles_per_xcd * n_ct;
     STORM_CHECK(vblocks > 0 && vblocks < (1LL << 31), "storm_conv: grid %lld out of range", vblocks);
-    static int n_cu = 0;
-    if (n_cu == 0) {
-        int dev = 0; hipDeviceProp_t prop;
-        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) n_cu = prop.multiProcessorCount;
-        if (n_cu <= 0) n_cu = 256;
-    }
-    const char* cus_env = getenv("STORM_CONV_CUS");                    // test hook: pretend the device has this many CUs
-    const long long resident = ((cus_env ? atoi(cus_env) : n_cu) + 7) / 8 * 8;   // one workgroup per CU; a multiple of 8
+    const long long resident = (device_cus() + 7) / 8 * 8;             // one workgroup per CU; a multiple of 8
     const long long grid = vblocks < resident ? vblocks : resident;
 #if defined(STORM_PROFILING)
     if (ABL & 64) {   // device buffer address handed over by tools/conv_trace.py
-        const char* tp = getenv("STORM_CONV_TRACE_PTR");
-        prm.trace = tp ? reinterpret_cast<unsigned long long*>(strtoull(tp, nullptr, 0)) : nullptr;
+        prm.trace = reinterpret_cast<unsigned long long*>(switches().conv_trace_ptr);
     }
 #endif
     hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(THREADS), Cfg::LDS_BYTES, st, prm, n_ct, tiles_per_xcd, (int)ntiles,
@@ -828,8 +820,7 @@ static int launch_pipe(const storm_conv_args& a, hipStream_t st) {
 int launch_conv_pipe(const storm_conv_args& a, hipStream_t st) {
     if (a.dtype == STORM_F16) return launch_pipe<half_t, 256, 8, 0>(a, st);
 #if defined(STORM_PROFILING)
-    const char* abl_env = getenv("STORM_CONV_ABLATE");
-    switch (abl_env ? atoi(abl_env) : 0) {
+    switch (switches().conv_ablate) {
         case 8: return launch_pipe<bf16_t, 256, 8, 8>(a, st);
         case 16: return launch_pipe<bf16_t, 256, 8, 16>(a, st);
         case 32: return launch_pipe<bf16_t, 256, 8, 32>(a, st);

@@ -597,14 +597,7 @@ static int launch_pipe128(const storm_conv_args& a, hipStream_t st) {
     const int tiles_per_xcd = cdiv(ntiles, 8);
     const long long vblocks = 8LL * tiles_per_xcd * n_ct;
     STORM_CHECK(vblocks > 0 && vblocks < (1LL << 31), "storm_conv: grid %lld out of range", vblocks);
-    static int n_cu = 0;
-    if (n_cu == 0) {
-        int dev = 0; hipDeviceProp_t prop;
-        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) n_cu = prop.multiProcessorCount;
-        if (n_cu <= 0) n_cu = 256;
-    }
-    const char* cus_env = getenv("STORM_CONV_CUS");                    // test hook: pretend the device has this many CUs
-    const long long resident = ((cus_env ? atoi(cus_env) : n_cu) + 7) / 8 * 8;   // one workgroup per CU; a multiple of 8
+    const long long resident = (device_cus() + 7) / 8 * 8;             // one workgroup per CU; a multiple of 8
     const long long grid = vblocks < resident ? vblocks : resident;
     hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(pipe128::THREADS), pipe128::LDS_BYTES, st, prm, n_ct, tiles_per_xcd, (int)ntiles,
                        tiles_x, tiles_per_img, (int)vblocks);

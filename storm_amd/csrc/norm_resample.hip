@@ -464,8 +464,7 @@ static int gn_apply_t(const void* xa, int Ca, const void* xb, int Cb, int B, int
         const long long total = (long long)tiles_x * tiles_y * ncg * B;
         STORM_CHECK(total > 0 && total < (1LL << 31), "storm_gn_apply: %lld tiles out of range", total);
         // persistent: 3 workgroups fit a CU (46 KiB of LDS each); a few per slot so that the tail stays short
-        const char* wgs_env = getenv("STORM_RESAMPLE_WGS");             // test hook: cap the persistent grid
-        const long long cap = wgs_env ? atoi(wgs_env) : 256LL * 3 * 4;
+        const long long cap = switches().resample_wgs > 0 ? switches().resample_wgs : 256LL * 3 * 4;   // (test hook: cap the persistent grid)
         const long long grid = total < cap ? total : cap;
         hipLaunchKernelGGL((gn_apply_resample_kernel<T, R == 0 ? 1 : R>), dim3((unsigned)grid), dim3(256), 0, st,
                            (const T*)xa, Ca, (const T*)xb, Cb, H, W, G, stats, gamma, beta, eps, silu, (T*)out_act,

@@ -80,8 +80,8 @@ def evaluate_model(model, num_eval_files, spec=False, audio=False, discriminativ
     specs = audios = None
     if spec:
         k = min(n, MAX_VIS_SAMPLES)
-        specs = [[model._stft(pairs[i][1][0]) for i in range(k)], [model._stft(est[i]) for i in range(k)],
-                 [model._stft(pairs[i][0][0]) for i in range(k)]]
+        sp = lambda w: model._stft(w.to(dev)).cpu()
+        specs = [[sp(pairs[i][1][0]) for i in range(k)], [sp(est[i]) for i in range(k)], [sp(pairs[i][0][0]) for i in range(k)]]
     if audio:
         k = min(n, MAX_VIS_SAMPLES)
         audios = [[pairs[i][1][0] for i in range(k)], [est[i] for i in range(k)], [pairs[i][0][0] for i in range(k)]]

@@ -23,6 +23,22 @@ def dev(request):
     return setup_backend(request.param)
 
 
+@pytest.fixture
+def switch():
+    """switch(name, value): set one of the library's A/B switches through its test hook (storm_set_switch; the names are the
+    environment variables the table is initialised from) for the duration of the test."""
+    from storm_amd import _lib
+    saved = []
+
+    def set_(name, value):
+        lib = _lib.lib()
+        saved.append((lib, name, lib.storm_get_switch(name.encode())))
+        _lib.check(lib.storm_set_switch(name.encode(), int(value)), "storm_set_switch")
+    yield set_
+    for lib, name, v in reversed(saved):
+        lib.storm_set_switch(name.encode(), v)
+
+
 def nhwc(x):
     return x.permute(0, 2, 3, 1).contiguous()
 

@@ -10,7 +10,7 @@ import torch.nn.functional as F
 from oracle import frontend_ref as FR
 from oracle import ncsnpp_ref as NR
 from oracle import sde_ref as SR
-from tests.backend import dev, nchw, nhwc, tol  # noqa: F401
+from tests.backend import dev, switch, nchw, nhwc, tol  # noqa: F401
 from tests.util import rel_l2
 
 DTYPES = [torch.float32, torch.bfloat16]
@@ -44,10 +44,10 @@ def test_conv(dev, dtype, shape):
 
 @pytest.mark.parametrize("dtype", DTYPES)
 @pytest.mark.parametrize("k", [3, 1])
-def test_conv_persistent_tile_loop(dev, dtype, k, monkeypatch):
+def test_conv_persistent_tile_loop(dev, dtype, k, switch):
     """More tiles than resident workgroups: every workgroup walks several tiles (output + statistics partials)."""
     from storm_amd import ops
-    monkeypatch.setenv("STORM_CONV_CUS", "8")
+    switch("STORM_CONV_CUS", 8)
     g = torch.Generator().manual_seed(21)
     B, Cin, Cout, H, W = 3, 16, 40, 35, 70
     x = torch.randn(B, Cin, H, W, generator=g)
@@ -65,15 +65,15 @@ def test_conv_persistent_tile_loop(dev, dtype, k, monkeypatch):
 @pytest.mark.parametrize("variant", [3])
 @pytest.mark.parametrize("case", ["plain", "block_tail", "gn_fused", "ragged", "deep_k", "plain@8", "block_tail@8", "gn_fused@8",
                                   "plain:f16", "gn_fused:f16"])
-def test_conv_pipelined_kernels(dev, variant, case, monkeypatch):
+def test_conv_pipelined_kernels(dev, variant, case, switch):
     """conv_pipe.hip (chunk-unrolled LDS-DMA pipeline, 256-cout tile) on shapes the default dispatch would give
     to conv_igemm.hip: plain 3x3, fused 1x1 shortcut over a concat, fused GroupNorm-apply operand, ragged sizes, many
     K-chunks; "@8": as if the device had 8 CUs, so every persistent workgroup walks several tiles (next-tile prefetch
     before the epilogue, staging beside the landing loads)."""
     from storm_amd import ops
-    monkeypatch.setenv("STORM_CONV_VARIANT", str(variant))
+    switch("STORM_CONV_VARIANT", variant)
     if case.endswith("@8"):
-        monkeypatch.setenv("STORM_CONV_CUS", "8")
+        switch("STORM_CONV_CUS", 8)
         case = case[:-2]
     dtype = torch.bfloat16
     if case.endswith(":f16"):                               # fp16 operands (v_mfma_f32_32x32x16_f16): same kernel template
@@ -162,12 +162,11 @@ PIPE128_CASES = {
 }
 
 
-@pytest.mark.parametrize("variant", [4, 5])
+@pytest.mark.parametrize("variant", [4])
 @pytest.mark.parametrize("case", list(PIPE128_CASES))
-def test_conv_pipelined_128cout_kernel(dev, case, variant, monkeypatch):
-    """The pipelined kernels for <= 128 output channels - conv_pipe128.hip (variant 4: 128 couts x 16 x 32 pixels, 8 waves, triple-
-    buffered patches) and conv_duo.hip (variant 5: 128 couts x 8 x 32 pixels, 4 waves, two workgroups per CU, double-buffered
-    patches), both with 32-channel chunks: plain 3x3, fused 1x1 shortcut over a concat, fused GroupNorm-apply operand, ragged
+def test_conv_pipelined_128cout_kernel(dev, case, variant, switch):
+    """The pipelined kernel for <= 128 output channels - conv_pipe128.hip (variant 4: 128 couts x 16 x 32 pixels, 8 waves, triple-
+    buffered patches, 32-channel chunks): plain 3x3, fused 1x1 shortcut over a concat, fused GroupNorm-apply operand, ragged
     sizes, 1 .. 8 nine-tap chunks, persistent tile walk, GroupNorm partials in the 8-row tile layout - on shapes the default
     dispatch would give to conv_igemm.hip."""
     from storm_amd import ops
@@ -206,11 +205,10 @@ def test_conv_pipelined_128cout_kernel(dev, case, variant, monkeypatch):
     ref = ref * 0.5
     tbd = tb.to(dev)
     y_generic, part_generic = ops.conv(segs, Co, bias=bias.to(dev), tbias=tbd[:, 8:], skip=skip, scale=0.5, gn_partials=True)
-    monkeypatch.setenv("STORM_CONV_VARIANT", str(variant))
+    switch("STORM_CONV_VARIANT", variant)
     if cus:
-        monkeypatch.setenv("STORM_CONV_CUS", str(cus))
-    assert ops.conv_kernel_name(segs, Co, bias=bias.to(dev), tbias=tbd[:, 8:], skip=skip, scale=0.5).startswith(
-        "storm::conv_pipe128_kernel" if variant == 4 else "storm::conv_duo_kernel")
+        switch("STORM_CONV_CUS", cus)
+    assert ops.conv_kernel_name(segs, Co, bias=bias.to(dev), tbias=tbd[:, 8:], skip=skip, scale=0.5).startswith("storm::conv_pipe128_kernel")
     y, part = ops.conv(segs, Co, bias=bias.to(dev), tbias=tbd[:, 8:], skip=skip, scale=0.5, gn_partials=True)
     yc = nchw(y.float().cpu())
     assert rel_l2(yc[:, :Co], ref) < (1e-2 if gn else 6e-3)
@@ -297,7 +295,7 @@ def test_groupnorm_golden(dev, golden):
 @pytest.mark.parametrize("dtype", DTYPES)
 @pytest.mark.parametrize("resample", [1, 2])
 @pytest.mark.parametrize("shape", [(2, 24, 6, 10, None), (2, 72, 20, 36, 5)])
-def test_groupnorm_fir_fused(dev, dtype, resample, shape, monkeypatch):
+def test_groupnorm_fir_fused(dev, dtype, resample, shape, switch):
     """h = FIR(SiLU(GN(x))) and x = FIR(x) of a BigGAN up/down block in one pass (layerspp.py:243-255); second shape: 36 tiles
     (two channel groups, two batch items) on 5 persistent workgroups - every workgroup walks a run of tiles that crosses
     channel-group / batch boundaries with the next tile's loads in flight."""
@@ -305,7 +303,7 @@ def test_groupnorm_fir_fused(dev, dtype, resample, shape, monkeypatch):
     g = torch.Generator().manual_seed(5)
     B, C, H, W, wgs = shape
     if wgs:
-        monkeypatch.setenv("STORM_RESAMPLE_WGS", str(wgs))
+        switch("STORM_RESAMPLE_WGS", wgs)
     x = torch.randn(B, C, H, W, generator=g)
     gam, bet = 1 + 0.1 * torch.randn(C, generator=g), 0.1 * torch.randn(C, generator=g)
     xa = nhwc(x).to(dtype).to(dev)
@@ -528,10 +526,12 @@ def test_conv_wait_placement_under_late_dma_landing():
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-1000:]
 
 
+@pytest.mark.parametrize("dt,tol", [(torch.bfloat16, 8e-3), (torch.float16, 1.5e-3), (torch.float32, 2e-6)])
 @pytest.mark.parametrize("C,Lq", [(32, 100), (64, 32), (256, 70)])
-def test_fused_attention(dev, C, Lq):
+def test_fused_attention(dev, C, Lq, dt, tol):
     """storm_attention (flash style, online softmax) == softmax(q k^T / sqrt C) v + b_v of AttnBlockpp (layerspp.py:82-86),
-    ragged key / query tiles, zero-padded v^T rows."""
+    ragged key / query tiles, zero-padded v^T rows; bf16 / fp16 operands (P and the output are rounded to the 16-bit type)
+    and the fp32 parity path (exact-fp32 MFMA)."""
     from storm_amd import ops
     g = torch.Generator().manual_seed(40 + C)
     B = 2
@@ -541,11 +541,11 @@ def test_fused_attention(dev, C, Lq):
     ldv = ops.round_up(Lq, 8)
     vT = torch.zeros(B, C, ldv)
     vT[:, :, :Lq] = v.transpose(1, 2)
-    bf = lambda t: t.to(torch.bfloat16)
-    out = ops.attention(bf(q).to(dev), bf(k).to(dev), bf(vT).to(dev), bias.to(dev), C ** -0.5).float().cpu()
-    w = torch.softmax(torch.einsum("bic,bjc->bij", bf(q).float(), bf(k).float()) * C ** -0.5, -1)
-    ref = torch.einsum("bij,bjc->bic", w, bf(v).float()) + bias
-    assert rel_l2(out, ref) < 8e-3                           # P and the output are rounded to bf16
+    rd = lambda t: t.to(dt)
+    out = ops.attention(rd(q).to(dev), rd(k).to(dev), rd(vT).to(dev), bias.to(dev), C ** -0.5).float().cpu()
+    w = torch.softmax(torch.einsum("bic,bjc->bij", rd(q).double(), rd(k).double()) * C ** -0.5, -1)
+    ref = (torch.einsum("bij,bjc->bic", w, rd(v).double()) + bias).float()
+    assert rel_l2(out, ref) < tol
 
 
 @pytest.mark.gpu
@@ -675,7 +675,7 @@ def test_spec_transform_standalone(dev, e, fac):
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("shortcut", [0, 128])
-def test_conv_pipe128_bench_layer_vs_generic_kernel(shortcut, monkeypatch):
+def test_conv_pipe128_bench_layer_vs_generic_kernel(shortcut, switch):
     """The two layers of BASELINE.json configs[1] the dispatcher gives to conv_pipe128.hip (128 -> 128 @ 128 x 256, batch 16, fused
     GroupNorm operand + temb bias + statistics epilogue, with / without the fused 1x1 shortcut) at FULL size: same output as the
     generic kernel up to the accumulation order (bf16 outputs: a few values differ by one rounding), same statistics partials."""
@@ -693,7 +693,7 @@ def test_conv_pipe128_bench_layer_vs_generic_kernel(shortcut, monkeypatch):
     kw = dict(bias=rnd(cout).to(dev), tbias=rnd(B, cout).to(dev), scale=0.7)
     assert ops.conv_kernel_name(segs, cout, **kw).startswith("storm::conv_pipe128_kernel")          # the production choice
     y, part = ops.conv(segs, cout, gn_partials=True, **kw)
-    monkeypatch.setenv("STORM_CONV_PIPE128", "0")
+    switch("STORM_CONV_PIPE128", 0)
     assert ops.conv_kernel_name(segs, cout, **kw).startswith("storm::conv_igemm_kernel")
     y0, part0 = ops.conv(segs, cout, gn_partials=True, **kw)
     assert rel_l2(y.float().cpu(), y0.float().cpu()) < 1e-3
