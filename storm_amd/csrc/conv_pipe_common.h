@@ -48,6 +48,22 @@ __device__ __forceinline__ uint32_t mad24(uint32_t a, uint32_t b, uint32_t c) {
 #endif
 }
 
+// The parameter block of the chunk-descriptor kernels, read through the kernarg segment (it is the kernel's first argument, at
+// offset 0; the constant address space keeps every field access a scalar load and nothing of the 2.6-KiB block is copied).
+#if defined(__HIP_DEVICE_COMPILE__)
+typedef const PipeParams __attribute__((address_space(4)))* PipeArgPtr;
+__device__ __forceinline__ PipeArgPtr pipe_args(const PipeParams&) { return (PipeArgPtr)__builtin_amdgcn_kernarg_segment_ptr(); }
+__device__ __forceinline__ void relaunder(PipeArgPtr& p) { asm volatile("" : "+s"(p)); }     // (stops hoisting of its scalar loads)
+template <typename V> __device__ __forceinline__ void launder(V& v) { asm volatile("" : "+v"(v)); }   // opaque per use: derived values are not kept live
+__device__ __forceinline__ char* as_global(unsigned long long u) { asm volatile("" : "+s"(u)); typedef __attribute__((address_space(1))) char G; return (char*)(G*)u; }
+#else
+typedef const PipeParams* PipeArgPtr;                       // (host simulation / the host pass of the device build)
+__device__ __forceinline__ PipeArgPtr pipe_args(const PipeParams& a) { return &a; }
+__device__ __forceinline__ void relaunder(PipeArgPtr&) {}
+template <typename V> __device__ __forceinline__ void launder(V&) {}
+__device__ __forceinline__ char* as_global(unsigned long long u) { return reinterpret_cast<char*>(u); }
+#endif
+
 // The K loop as chunk descriptors of `kc` channels each (conv_pipe.hip; kc = 64 or 32).  Returns false when the convolution
 // is outside what the pipelined kernels cover.
 bool build_pipe_params(const storm_conv_args& a, PipeParams& p, int kc);

@@ -1,6 +1,7 @@
 #!/usr/bin/env python
-"""A/B probe of the <= 128-cout 3x3 layers of the bench shape: conv_pipe128.hip vs conv_igemm.hip (STORM_CONV_PIPE128=0),
-with the fusions the network uses (GroupNorm-apply operand, statistics epilogue, temb bias, fused 1x1 shortcut)."""
+"""A/B probe of the <= 128-cout 3x3 layers of the bench shape: conv_pc.hip vs conv_pipe128.hip vs conv_igemm.hip (forced through the
+library's STORM_CONV_VARIANT switch), with the fusions the network uses (GroupNorm-apply operand, statistics epilogue, temb bias,
+fused 1x1 shortcut); d = rel-L2 of the output vs the generic kernel's, p = max difference of the statistics partials."""
 import argparse
 import os
 import sys
@@ -9,6 +10,7 @@ import torch
 
 sys.path.insert(0, ".")
 from storm_amd import ops  # noqa: E402
+from storm_amd import _lib as L  # noqa: E402
 
 p = argparse.ArgumentParser()
 p.add_argument("--reps", type=int, default=5)
@@ -42,11 +44,10 @@ for ci_, case in enumerate(CASES):
         segs.append(ops.Seg(rnd(B, H, W, sc).to(dt).to(dev), ops.pack_conv_weight((rnd(cout, sc, 1, 1) * 0.05).to(dev), dt), 1))
     fl = 2 * B * H * W * cout * (cin * 9 + sc)
     out = {}
-    MODES = {"1": dict(STORM_CONV_PIPE128="1"), "0": dict(STORM_CONV_PIPE128="0"), "duo": dict(STORM_CONV_VARIANT="5")}
-    for sw, env in MODES.items():
-        for k_ in ("STORM_CONV_PIPE128", "STORM_CONV_VARIANT"):
-            os.environ.pop(k_, None)
-        os.environ.update(env)
+    lib = L.lib()
+    MODES = {"pc": 5, "p128": 4, "igemm": 0} if cout <= 128 else {"pipe": -1, "igemm": 2}
+    for sw, variant in MODES.items():
+        L.check(lib.storm_set_switch(b"STORM_CONV_VARIANT", variant), "storm_set_switch")
         kn = ops.conv_kernel_name(segs, cout, bias=kw["bias"], tbias=kw["tbias"], scale=0.7)
         for _ in range(2):
             y, part = ops.conv(segs, cout, **kw)
@@ -58,9 +59,12 @@ for ci_, case in enumerate(CASES):
         torch.cuda.synchronize()
         ms = e0.elapsed_time(e1) / args.reps
         out[sw] = (ms, y.float(), part, kn)
-    os.environ.pop("STORM_CONV_VARIANT", None)
-    d = (out["1"][1] - out["0"][1]).norm() / out["0"][1].norm()
-    pd = (out["1"][2] - out["0"][2]).abs().max() / out["0"][2].abs().max()
-    print(f"{name:34s} pipe128 {out['1'][0]:.3f} ms {fl / out['1'][0] / 1e9:6.0f} TF | igemm {out['0'][0]:.3f} ms {fl / out['0'][0] / 1e9:6.0f} TF"
-          f" | duo {out['duo'][0]:.3f} ms {fl / out['duo'][0] / 1e9:6.0f} TF ({out['duo'][3].split('<')[0][7:]})"
-          f" | rel diff {float(d):.2e} partials {float(pd):.2e} | duo vs igemm {float((out['duo'][1] - out['0'][1]).norm() / out['0'][1].norm()):.2e}")
+    lib.storm_set_switch(b"STORM_CONV_VARIANT", -1)
+    ref = out["igemm"]
+    line = f"{name:30s}"
+    for sw in MODES:
+        ms, y, part, kn = out[sw]
+        d = float((y - ref[1]).norm() / ref[1].norm())
+        pd = float((part - ref[2]).abs().max() / ref[2].abs().max())
+        line += f" | {sw} {ms:.3f} ms {fl / ms / 1e9:5.0f} TF d={d:.1e} p={pd:.1e}"
+    print(line + " | " + out[list(MODES)[0]][3].split("<")[0][7:], flush=True)
