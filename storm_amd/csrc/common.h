@@ -28,7 +28,6 @@ void set_error(const char* fmt, ...);
 struct Switches {
     int conv_variant = -1;      // STORM_CONV_VARIANT: force a conv kernel family (see choose_variant), -1 = the dispatcher's choice
     int conv_pipe128 = 1;       // STORM_CONV_PIPE128: 0 = keep the <= 128-cout 3x3 layers on conv_igemm
-    int conv_pc = 1;            // STORM_CONV_PC: 0 = keep the layers conv_pc.hip takes on the older kernels
     int conv_cus = 0;           // STORM_CONV_CUS: pretend the device has this many CUs (persistent tile walks in tests), 0 = ask the device
     int resample_wgs = 0;       // STORM_RESAMPLE_WGS: cap of the resample kernels' persistent grid, 0 = default
     int conv_persist = 0;       // STORM_CONV_PERSIST (profiling build)

@@ -648,7 +648,6 @@ static int launch_conv(const storm_conv_args& a, hipStream_t st) {
 //   2: conv_igemm 256 cout x 256 px, 8 waves, 1 workgroup / CU, patch double-buffered through registers
 //   3: conv_pipe.hip, 256 cout x 256 px, 8 waves in two ping-pong groups, chunk-unrolled LDS-DMA pipeline (16-bit 3x3)
 //   4: conv_pipe128.hip, 128 cout x 512 px, the same pipeline for layers with <= 128 output channels (16-bit 3x3)
-//   5: conv_pc.hip, 128 cout x 256 px, four MFMA waves + four fetch / transform / epilogue waves (16-bit 3x3, <= 128 output channels)
 static int choose_variant(const storm_conv_args& a, bool any9) {
     const int forced = switches().conv_variant;                      // (test / A-B hook, storm_set_switch)
     if (forced >= 0) return forced;
@@ -658,8 +657,6 @@ static int choose_variant(const storm_conv_args& a, bool any9) {
     // wins 13-20 % at 4 of its tiles per CU (128 x 256 x 16) and ties or loses (0 ... -10 %) at 16 tiles per CU (256 x 512 x 16):
     // with K this short the exposed epilogue and the fused GroupNorm transform weigh the same in both kernels and two resident
     // workgroups hide them at least as well.  (A stem-like layer with fewer than 32 input channels is HBM-bound either way.)
-    if (a.outC > 32 && a.outC <= 128 && any9 && px_tiles >= 512 && a.seg[0].Ca + a.seg[0].Cb >= 32 && switches().conv_pc != 0 &&
-        conv_pc_supports(a)) return 5;                                   // (A/B switch STORM_CONV_PC: 0 = the older kernels below)
     if (a.outC > 32 && a.outC <= 128 && any9 && px_tiles >= 1024 && px_tiles <= 4096 && a.seg[0].Ca + a.seg[0].Cb >= 32 &&
         switches().conv_pipe128 != 0 && conv_pipe128_supports(a)) return 4;    // (A/B switch: 0 = conv_igemm for these layers)
     return 0;
@@ -692,7 +689,6 @@ static int dispatch_conv(const storm_conv_args& a, hipStream_t st) {
         if (small) return launch_conv<T, 9, 1, 1, 4, false>(a, st);
         if (variant == 3 && conv_pipe_supports(a)) return launch_conv_pipe(a, st);
         if (variant == 4 && conv_pipe128_supports(a)) return launch_conv_pipe128(a, st);
-        if (variant == 5 && conv_pc_supports(a)) return launch_conv_pc(a, st);
         if (variant == 2) return launch_conv<T, 9, 2, 4, 2, true>(a, st);
 #if defined(STORM_PROFILING)                                          // A/B instantiations: 8-wave geometry, register staging
         if (variant == 1) return launch_conv<T, 9, 2, 2, 4, false>(a, st);
@@ -719,7 +715,6 @@ static const char* kernel_name_of(const storm_conv_args& a) {
     if (a.outC <= 32) shape = "1, 1, 4, false, false";
     else if (any9 && variant == 3 && conv_pipe_supports(a)) return conv_pipe_kernel_name(a.dtype);
     else if (any9 && variant == 4 && conv_pipe128_supports(a)) return conv_pipe128_kernel_name(a.dtype);
-    else if (any9 && variant == 5 && conv_pc_supports(a)) return conv_pc_kernel_name(a.dtype);
     else if (variant == 2) shape = "2, 4, 2, true, false";
 #if defined(STORM_PROFILING)
     else if (variant == 1) shape = "2, 2, 4, false, false";

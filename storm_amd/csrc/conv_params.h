@@ -303,10 +303,4 @@ bool conv_pipe128_supports(const storm_conv_args& a);
 int launch_conv_pipe128(const storm_conv_args& a, hipStream_t st);
 const char* conv_pipe128_kernel_name(int dtype);
 
-// defined in conv_pc.hip: producer / consumer kernel for layers with <= 128 output channels (128 couts x 256 pixels per workgroup:
-// four MFMA waves fed by four fetch / transform / epilogue waves, weights straight from L2 into the operand registers)
-bool conv_pc_supports(const storm_conv_args& a);
-int launch_conv_pc(const storm_conv_args& a, hipStream_t st);
-const char* conv_pc_kernel_name(int dtype);
-
 }  // namespace storm

@@ -162,13 +162,11 @@ PIPE128_CASES = {
 }
 
 
-@pytest.mark.parametrize("variant", [4, 5])
+@pytest.mark.parametrize("variant", [4])
 @pytest.mark.parametrize("case", list(PIPE128_CASES))
 def test_conv_pipelined_128cout_kernel(dev, case, variant, switch):
-    """The kernels for <= 128 output channels - conv_pipe128.hip (variant 4: 128 couts x 16 x 32 pixels, 8 waves, triple-buffered
-    patches, 32-channel chunks) and conv_pc.hip (variant 5: 128 couts x 8 x 32 pixels, four MFMA waves fed by four fetch /
-    transform / epilogue waves, 64-channel chunks in conv_igemm's K order: its stored activations must be BIT-identical to the
-    generic kernel's): plain 3x3, fused 1x1 shortcut over a concat, fused GroupNorm-apply operand, ragged
+    """The pipelined kernel for <= 128 output channels - conv_pipe128.hip (variant 4: 128 couts x 16 x 32 pixels, 8 waves, triple-
+    buffered patches, 32-channel chunks): plain 3x3, fused 1x1 shortcut over a concat, fused GroupNorm-apply operand, ragged
     sizes, 1 .. 8 nine-tap chunks, persistent tile walk, GroupNorm partials in the 8-row tile layout - on shapes the default
     dispatch would give to conv_igemm.hip."""
     from storm_amd import ops
@@ -210,8 +208,7 @@ def test_conv_pipelined_128cout_kernel(dev, case, variant, switch):
     switch("STORM_CONV_VARIANT", variant)
     if cus:
         switch("STORM_CONV_CUS", cus)
-    assert ops.conv_kernel_name(segs, Co, bias=bias.to(dev), tbias=tbd[:, 8:], skip=skip, scale=0.5).startswith(
-        "storm::conv_pipe128_kernel" if variant == 4 else "storm::conv_pc_kernel")
+    assert ops.conv_kernel_name(segs, Co, bias=bias.to(dev), tbias=tbd[:, 8:], skip=skip, scale=0.5).startswith("storm::conv_pipe128_kernel")
     y, part = ops.conv(segs, Co, bias=bias.to(dev), tbias=tbd[:, 8:], skip=skip, scale=0.5, gn_partials=True)
     yc = nchw(y.float().cpu())
     assert rel_l2(yc[:, :Co], ref) < (1e-2 if gn else 6e-3)
@@ -219,8 +216,6 @@ def test_conv_pipelined_128cout_kernel(dev, case, variant, switch):
         assert float(yc[:, Co:].abs().max()) == 0.0
     # same result as the generic kernel up to the accumulation order; statistics partials in the same 8 x 32 tile layout
     assert rel_l2(yc, nchw(y_generic.float().cpu())) < 3e-3
-    if variant == 5:
-        assert torch.equal(y.cpu(), y_generic.cpu())
     assert part.shape == part_generic.shape
     assert torch.allclose(part.cpu(), part_generic.cpu(), rtol=2e-2, atol=2e-2 * float(part_generic.abs().max()))
     st, sref = ops.gn_finalize(part).cpu(), ops.gn_stats(y).cpu()

@@ -61,7 +61,10 @@ struct Tile { int tile, b, ty0, tx0, cout0; };
 }  // namespace pc
 using namespace pc;
 
-template <typename T>
+// ABL (profiling build only, work-skipping instantiations for the cycle budget): 1 = the weight-fragment loads read 1 KiB of
+// CONTIGUOUS bytes per instruction (wrong values: what a fragment-major weight layout would cost the vector memory path),
+// 2 = no pixel-fragment reads, 4 = no weight-fragment loads, 8 = no patch DMA / transform, 16 = no epilogue, 32 = no MFMAs
+template <typename T, int ABL = 0>
 __global__ __launch_bounds__(pc::THREADS, 2)
 void conv_pc_kernel(const PipeParams a, const int n_ct, const int tiles_per_xcd, const int ntiles, const int tiles_x,
                     const int tiles_per_img, const int total_vblocks) {
@@ -120,12 +123,14 @@ void conv_pc_kernel(const PipeParams a, const int n_ct, const int tiles_per_xcd,
             for (int mi = 0; mi < WM; ++mi) {
                 const int row = t.cout0 + wm * (WM * 32) + mi * 32 + (lane & 31);     // rows past the matrix: zeros (never stored)
                 c.voff[mi] = row < W.rows ? (uint32_t)(row * W.CinP2 + (lane >> 5) * 16) : BUF_OOB;
+                if (ABL & 1) c.voff[mi] = (uint32_t)((t.cout0 + wm * (WM * 32) + mi * 32) * W.CinP2 + lane * 16);
             }
             c.soff0 = d.w_soff; c.tapbytes = W.tapbytes;
             return c;
         };
         auto a_load = [&](const ACtx& c, auto tap_, auto kg_, auto slot_) {
             constexpr int tap = decltype(tap_)::value, kg = decltype(kg_)::value, slot = decltype(slot_)::value;
+            if (ABL & 4) return;
 #pragma unroll
             for (int mi = 0; mi < WM; ++mi) {
                 const uint4 v = buf_load16(c.buf, c.voff[mi] + 32u * kg, (uint32_t)(c.soff0 + tap * c.tapbytes));
@@ -134,6 +139,7 @@ void conv_pc_kernel(const PipeParams a, const int n_ct, const int tiles_per_xcd,
         };
         auto read_b = [&](Frag& f, int pb, auto kg_, auto poff_, auto prow_, auto ni_) {
             constexpr int kg = decltype(kg_)::value, POFF = decltype(poff_)::value, PROW = decltype(prow_)::value, ni = decltype(ni_)::value;
+            if (ABL & 2) return;
             f = *reinterpret_cast<const Frag*>(smem + (pb ^ (kg << 5)) + POFF + ni * PROW);
         };
         typedef IC<PW * PIXB> Prow9; typedef IC<TILE_W * PIXB> Prow1;
@@ -155,13 +161,14 @@ void conv_pc_kernel(const PipeParams a, const int n_ct, const int tiles_per_xcd,
             Frag (&fa)[WM] = ar[S % RING];
             Frag (&fc)[WN] = fb[S & 1];
             Frag (&fn)[WN] = fb[S1 & 1];
-            auto mma = [&](auto i_) { constexpr int i = decltype(i_)::value; Mma<T>::run(fa[i / WN], fc[i % WN], acc[i / WN][i % WN]); };
+            auto mma = [&](auto i_) { constexpr int i = decltype(i_)::value; if (!(ABL & 32)) Mma<T>::run(fa[i / WN], fc[i % WN], acc[i / WN][i % WN]); };
             auto rd = [&](auto ni_) { if constexpr (S1 < NS) read_b(fn[decltype(ni_)::value], pb1, IC<KG1>{}, IC<POFF1>{}, Prow{}, ni_); };
-            mma(IC<0>{}); mma(IC<1>{}); __builtin_amdgcn_sched_barrier(0);
-            rd(IC<0>{}); mma(IC<2>{}); __builtin_amdgcn_sched_barrier(0);
-            rd(IC<1>{}); mma(IC<3>{}); __builtin_amdgcn_sched_barrier(0);
-            rd(IC<2>{}); mma(IC<4>{}); __builtin_amdgcn_sched_barrier(0);
-            rd(IC<3>{}); mma(IC<5>{}); __builtin_amdgcn_sched_barrier(0);
+            if constexpr ((ABL & 64) != 0 && S > 0 && S % 2 == 0) raw_barrier();      // (profiling: what a barrier per phase would cost)
+            mma(IC<0>{}); rd(IC<0>{}); __builtin_amdgcn_sched_barrier(0);
+            mma(IC<1>{}); rd(IC<1>{}); __builtin_amdgcn_sched_barrier(0);
+            mma(IC<2>{}); rd(IC<2>{}); __builtin_amdgcn_sched_barrier(0);
+            mma(IC<3>{}); rd(IC<3>{}); __builtin_amdgcn_sched_barrier(0);
+            mma(IC<4>{}); mma(IC<5>{}); __builtin_amdgcn_sched_barrier(0);
             mma(IC<6>{}); mma(IC<7>{}); __builtin_amdgcn_sched_barrier(0);
         };
         auto first_b = [&](auto nt_) {                          // pixel fragments of step 0 (after the chunk barrier)
@@ -174,6 +181,7 @@ void conv_pc_kernel(const PipeParams a, const int n_ct, const int tiles_per_xcd,
         // accumulators of pixel row `pass` -> this wave's staging block of pass parity `pass & 1` (layout: conv_igemm.hip's stage_off)
         auto stage_pass = [&](auto pass_) {
             constexpr int pass = decltype(pass_)::value;
+            if (ABL & 16) return;
             char* const stage = smem + OFF_STAGE + (pass & 1) * PASS_BYTES + w4 * WSTAGE;
 #pragma unroll
             for (int mi = 0; mi < WM; ++mi)
@@ -272,6 +280,7 @@ void conv_pc_kernel(const PipeParams a, const int n_ct, const int tiles_per_xcd,
     // the whole patch of chunk ci of tile `it` -> buffer `into`: every piece of this wave in flight at once, then - in issue
     // order - wait, and apply the fused GroupNorm (+ SiLU) in place by the lane that fetched the 16 bytes
     auto fetch_chunk = [&](int ci, int into) {
+        if (ABL & 8) return;
         load_desc(ci);
         vm_wait<0>();                                           // (stores of an epilogue pass issued before: counted waits start clean)
         char* const pbuf = smem + into * PATCH_BYTES;
@@ -327,6 +336,7 @@ void conv_pc_kernel(const PipeParams a, const int n_ct, const int tiles_per_xcd,
     // passes P0, P0 + 1 (pixel rows P0, P0 + 1 of each half): out = (acc + bias + temb bias + skip) * scale, evaluated as
     // (acc [+ skip]) * scale + (bias * scale) in packed fma exactly as conv_pipe.hip / conv_igemm.hip do
     auto drain = [&](int P0) {
+        if (ABL & 16) return;
         relaunder(ap);
         const int outC = pin(ap->outC), out_f32 = pin(ap->out_f32);
         const bool has_skip = ap->skip != nullptr;
@@ -432,6 +442,7 @@ void conv_pc_kernel(const PipeParams a, const int n_ct, const int tiles_per_xcd,
             if (ci + 1 < nchunks) fetch_chunk(ci + 1, par ^ 1);
             else if (has_next) { it = decode(nvb); patch_table(); fetch_chunk(0, par ^ 1); }
             par ^= 1;
+            if (ABL & 64) { const int nb = ci < n9 ? 17 : 1; for (int k = 0; k < nb; ++k) raw_barrier(); }
         }
         raw_barrier();                                          // E0
         raw_barrier();                                          // E1: passes 0, 1 staged
@@ -454,9 +465,9 @@ bool conv_pc_supports(const storm_conv_args& a) {
     return pipe::build_pipe_params(a, p, pc::KC);
 }
 
-template <typename T>
+template <typename T, int ABL = 0>
 static int launch_pc(const storm_conv_args& a, hipStream_t st) {
-    auto kern = conv_pc_kernel<T>;
+    auto kern = conv_pc_kernel<T, ABL>;
     static bool attr_set = false;                       // per instantiation; benign race (idempotent)
     if (!attr_set) {
         STORM_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, pc::LDS_BYTES));
@@ -480,6 +491,23 @@ static int launch_pc(const storm_conv_args& a, hipStream_t st) {
 }
 
 int launch_conv_pc(const storm_conv_args& a, hipStream_t st) {
+#if defined(STORM_PROFILING)
+    if (a.dtype == STORM_BF16)
+        switch (switches().conv_ablate) {
+            case 1: return launch_pc<bf16_t, 1>(a, st);
+            case 2: return launch_pc<bf16_t, 2>(a, st);
+            case 4: return launch_pc<bf16_t, 4>(a, st);
+            case 6: return launch_pc<bf16_t, 6>(a, st);       // MFMAs + patch pipeline + epilogue
+            case 8: return launch_pc<bf16_t, 8>(a, st);
+            case 14: return launch_pc<bf16_t, 14>(a, st);     // MFMAs + barriers + epilogue
+            case 16: return launch_pc<bf16_t, 16>(a, st);
+            case 30: return launch_pc<bf16_t, 30>(a, st);     // MFMAs + barriers only
+            case 32: return launch_pc<bf16_t, 32>(a, st);
+            case 68: return launch_pc<bf16_t, 68>(a, st);     // no weight loads, a barrier per phase
+            case 78: return launch_pc<bf16_t, 78>(a, st);     // MFMAs + epilogue, a barrier per phase
+            default: break;
+        }
+#endif
     return a.dtype == STORM_F16 ? launch_pc<half_t>(a, st) : launch_pc<bf16_t>(a, st);
 }
 

@@ -1,5 +1,5 @@
 #!/usr/bin/env python
-"""A/B probe of the <= 128-cout 3x3 layers of the bench shape: conv_pc.hip vs conv_pipe128.hip vs conv_igemm.hip (forced through the
+"""A/B probe of the <= 128-cout 3x3 layers of the bench shape: conv_pipe128.hip vs conv_igemm.hip (forced through the
 library's STORM_CONV_VARIANT switch), with the fusions the network uses (GroupNorm-apply operand, statistics epilogue, temb bias,
 fused 1x1 shortcut); d = rel-L2 of the output vs the generic kernel's, p = max difference of the statistics partials."""
 import argparse
@@ -17,6 +17,7 @@ p.add_argument("--reps", type=int, default=5)
 p.add_argument("--B", type=int, default=16)
 p.add_argument("--nogn", action="store_true", help="plain operand: no fused GroupNorm-apply + SiLU on the load")
 p.add_argument("--only", type=int, default=-1)
+p.add_argument("--modes", default="", help="comma list of kernels to time (default: all)")
 args = p.parse_args()
 dev, dt = torch.device("cuda:0"), torch.bfloat16
 g = torch.Generator().manual_seed(0)
@@ -45,7 +46,11 @@ for ci_, case in enumerate(CASES):
     fl = 2 * B * H * W * cout * (cin * 9 + sc)
     out = {}
     lib = L.lib()
-    MODES = {"pc": 5, "p128": 4, "igemm": 0} if cout <= 128 else {"pipe": -1, "igemm": 2}
+    MODES = {"p128": 4, "igemm": 0} if cout <= 128 else {"pipe": -1, "igemm": 2}
+    if args.modes:
+        MODES = {k: v for k, v in MODES.items() if k in args.modes.split(",")}
+        if not MODES:
+            continue
     for sw, variant in MODES.items():
         L.check(lib.storm_set_switch(b"STORM_CONV_VARIANT", variant), "storm_set_switch")
         kn = ops.conv_kernel_name(segs, cout, bias=kw["bias"], tbias=kw["tbias"], scale=0.7)
@@ -60,7 +65,7 @@ for ci_, case in enumerate(CASES):
         ms = e0.elapsed_time(e1) / args.reps
         out[sw] = (ms, y.float(), part, kn)
     lib.storm_set_switch(b"STORM_CONV_VARIANT", -1)
-    ref = out["igemm"]
+    ref = out["igemm"] if "igemm" in out else out[list(MODES)[0]]
     line = f"{name:30s}"
     for sw in MODES:
         ms, y, part, kn = out[sw]
