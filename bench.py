@@ -30,6 +30,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 METRIC = "enhanced utterances/sec @ 30 PC steps, NCSN++ 27.8M, 4 s@16 kHz"
+HBM_PEAK_GBS = 8000.0            # HBM3E specification (MI355X_MICROARCH.md); measured float4 copy: 6290
 BF16_MFMA_PEAK_TFLOPS = 2500.0      # MI355X_MICROARCH.md: dense bf16 MFMA peak
 F32_MFMA_PEAK_TFLOPS = 157.3
 
@@ -139,6 +140,20 @@ def profile_ops(net, Y, nfe_count):
                 taps.append(nt)
             row.update(flops=flops, algorithmic_bytes=abytes, H=H, W=W, Cout=Cout, taps=taps, big=outC > 32, cin=[int(op.i[8]) + int(op.i[9])],
                        kernel=L.lib().storm_program_kernel_name(ops, k, code).decode())
+        elif op.code == 6:                                  # GroupNorm-apply (+ SiLU) (+ FIR x2 of the activated AND the raw tensor)
+            Ca, Cb, Bq, H, W = [int(op.i[j]) for j in range(5)]
+            rs = int(op.i[7])
+            esz, Cc = (4 if code == 0 else 2), Ca + Cb
+            n_in = Bq * H * W * Cc
+            n_out = n_in if rs == 0 else (2 * 4 * n_in if rs == 1 else 2 * n_in // 4)     # up / down: two output tensors
+            row.update(algorithmic_bytes=(n_in + n_out) * esz, H=H, W=W, C=Cc, resample=rs,
+                       kernel="storm::gn_apply_kernel" if rs == 0 else f"storm::gn_apply_resample_kernel<{'up' if rs == 1 else 'down'}>")
+        elif op.code in (7, 8):                             # FIR x2 of the 8-channel pyramids
+            Bq, H, W, Cc = [int(op.i[j]) for j in range(4)]
+            esz = 4 if code == 0 else 2
+            n_in = Bq * H * W * Cc
+            row.update(algorithmic_bytes=(n_in + (4 * n_in if op.code == 7 else n_in // 4) + (4 * n_in if op.code == 7 else 0)) * esz,
+                       kernel="storm::fir_kernel<up>" if op.code == 7 else "storm::fir_kernel<down>")
         rows.append(row)
     return rows
 
@@ -293,6 +308,38 @@ def main():
                       f"of the packets around it (about 20-25 us here): rocprofv3 --kernel-trace of the same command (profiles/) reports "
                       f"durations about 4 % shorter, so `achieved` is the conservative one of the two",
         }
+        # the HBM-bound family (north_star: "fraction of the HBM/MFMA roofline"): GroupNorm-apply / resample kernels and the
+        # narrow convolutions (<= 8 output or input channels: padded MFMA tiles whose time is operand traffic)
+        hbm_rows = {}
+        for r in rows:
+            if "algorithmic_bytes" not in r:
+                continue
+            if r["code"] == 4 and r["big"] and min(r["cin"]) > 8:
+                continue                                      # matrix-core bound convolutions: reported above
+            key = r["kernel"] if r["code"] != 4 else ("narrow conv: " + ("3x3" if 9 in r["taps"] else "1x1") + f" {min(r['cin'])}->{r['Cout']}")
+            hbm_rows.setdefault(key, []).append(r)
+        if hbm_rows:
+            tbl = {k: {"launches_per_nfe": len(v), "ms_per_nfe": round(sum(r["ms"] for r in v), 3),
+                       "algorithmic_mb": round(sum(r["algorithmic_bytes"] for r in v) / 1e6, 1),
+                       "tb_per_s": round(sum(r["algorithmic_bytes"] for r in v) / (sum(r["ms"] for r in v) * 1e-3) / 1e12, 2)}
+                   for k, v in hbm_rows.items()}
+            hk, hv = max(hbm_rows.items(), key=lambda kv: sum(r["ms"] for r in kv[1]))
+            hb, hms = sum(r["algorithmic_bytes"] for r in hv), sum(r["ms"] for r in hv)
+            htraffic = None
+            if os.path.exists(tpath):
+                tkey = {"storm::gn_apply_resample_kernel<down>": "voidstorm::gn_apply_resample_kernel<storm::bf16_t,2>",
+                        "storm::gn_apply_resample_kernel<up>": "voidstorm::gn_apply_resample_kernel<storm::bf16_t,1>"}.get(hk)
+                htraffic = next((v.get("hbm_bytes_per_launch") for k, v in tj.items() if k.replace(" ", "") == tkey), None)
+            result["roofline_hbm"] = {
+                "bound": "hbm", "kernel": hk, "achieved": hb / (hms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": hb / (hms * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": htraffic, "launches_per_nfe": len(hv),
+                "avg_launch_ms": hms / len(hv), "avg_launch_algorithmic_bytes": hb / len(hv),
+                "by_kernel": tbl,
+                "family_ms_per_nfe": round(sum(r["ms"] for v in hbm_rows.values() for r in v), 3),
+                "method": "the dominant HBM-bound kernel of the evaluation by time; algorithmic bytes = every input element read once + "
+                          "every output element written once (op level, as BASELINE.md section 3 counts them) / HIP-event time of its "
+                          "launches; peak = the 8 TB/s HBM3E specification (6.29 TB/s is the measured copy ceiling)",
+            }
         if args.ops_json:
             with open(args.ops_json, "w") as f:
                 json.dump(rows, f, indent=0)

@@ -55,18 +55,6 @@ __host__ __device__ inline float bf16_bits_to_f32(uint16_t h) {
     return c.f;
 }
 
-// two fp32 -> packed bf16x2 (lo in bits 0-15), round-to-nearest-even: one v_cvt_pk_bf16_f32 on gfx950
-__device__ inline uint32_t pack_bf16x2(float lo, float hi) {
-#ifdef STORM_HOST_SIM
-    return (uint32_t)f32_to_bf16_bits(lo) | ((uint32_t)f32_to_bf16_bits(hi) << 16);
-#else
-    // (the compiler's own conversion, not inline asm: behind an asm statement the hazard recognizer cannot see the consumer, and
-    // a v_cvt_pk_bf16_f32 issued straight after the v_dot2c_f32_bf16 that produced its operand read the STALE register on gfx950)
-    typedef __bf16 v2bf_ __attribute__((ext_vector_type(2)));
-    const f32x2 v = {lo, hi};
-    return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, v2bf_));
-#endif
-}
 // fp16 <-> f32 (round-to-nearest-even; the compiler's _Float16 conversions: v_cvt_f16_f32 / v_cvt_f32_f16 on the device)
 __host__ __device__ inline uint16_t f32_to_f16_bits(float f) {
     const _Float16 h = (_Float16)f;
@@ -80,21 +68,10 @@ __host__ __device__ inline float f16_bits_to_f32(uint16_t u) {
 __device__ inline uint32_t pack_f16x2(float lo, float hi) {
     return (uint32_t)f32_to_f16_bits(lo) | ((uint32_t)f32_to_f16_bits(hi) << 16);
 }
-// raw hardware transcendentals (v_exp_f32 / v_rcp_f32, ~1 ulp): used where the result is rounded to bf16 anyway
-__device__ inline float hw_exp2(float x) {
-#ifdef STORM_HOST_SIM
-    return exp2f(x);
-#else
-    return __builtin_amdgcn_exp2f(x);
-#endif
-}
-__device__ inline float hw_rcp(float x) {
-#ifdef STORM_HOST_SIM
-    return 1.0f / x;
-#else
-    return __builtin_amdgcn_rcpf(x);
-#endif
-}
+}  // namespace storm
+#include "hw.h"          // every platform-dependent primitive (gfx950 / host pass / test simulator) lives there
+namespace storm {
+
 __device__ inline float fast_silu(float y) { return y * hw_rcp(1.0f + hw_exp2(-1.44269504088896341f * y)); }
 // the same on a channel pair: everything but the two transcendentals per element is a packed fp32 operation
 __device__ __forceinline__ f32x2 silu2(f32x2 y) {
@@ -103,27 +80,6 @@ __device__ __forceinline__ f32x2 silu2(f32x2 y) {
     return y * f32x2{hw_rcp(d.x), hw_rcp(d.y)};
 }
 
-// acc + x.lo * w.lo + x.hi * w.hi on a dword of two 16-bit values (v_dot2c_f32_bf16 / v_dot2c_f32_f16): a filter tap on packed
-// 16-bit data without unpacking - w = (weight, 0) adds the low channel's tap, (0, weight) the high channel's.  With one half
-// of w zero and a weight of few mantissa bits the product is exact in fp32: the same value as fmaf(weight, x, acc).
-__device__ __forceinline__ float dot2_acc(uint32_t x, uint32_t w, float acc, bf16_t*) {
-#if defined(__HIP_DEVICE_COMPILE__)
-    typedef __bf16 v2bf __attribute__((ext_vector_type(2)));
-    return __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(v2bf, x), __builtin_bit_cast(v2bf, w), acc, false);
-#else
-    return fmaf(bf16_bits_to_f32((uint16_t)(x & 0xffffu)), bf16_bits_to_f32((uint16_t)(w & 0xffffu)),
-                fmaf(bf16_bits_to_f32((uint16_t)(x >> 16)), bf16_bits_to_f32((uint16_t)(w >> 16)), acc));
-#endif
-}
-__device__ __forceinline__ float dot2_acc(uint32_t x, uint32_t w, float acc, half_t*) {
-#if defined(__HIP_DEVICE_COMPILE__)
-    typedef _Float16 v2h __attribute__((ext_vector_type(2)));
-    return __builtin_amdgcn_fdot2(__builtin_bit_cast(v2h, x), __builtin_bit_cast(v2h, w), acc, false);
-#else
-    return fmaf(f16_bits_to_f32((uint16_t)(x & 0xffffu)), f16_bits_to_f32((uint16_t)(w & 0xffffu)),
-                fmaf(f16_bits_to_f32((uint16_t)(x >> 16)), f16_bits_to_f32((uint16_t)(w >> 16)), acc));
-#endif
-}
 __device__ __forceinline__ uint32_t pack2(float lo, float hi, bf16_t*) { return pack_bf16x2(lo, hi); }
 __device__ __forceinline__ uint32_t pack2(float lo, float hi, half_t*) { return pack_f16x2(lo, hi); }
 __device__ __forceinline__ uint32_t tap_weight_bits(float w, bf16_t*) { return f32_to_bf16_bits(w); }   // (exact for the FIR taps)
@@ -209,17 +165,6 @@ __device__ inline double wave_sum_d(double v) {
     return v;
 }
 
-// Wave-level ordering point: the LDS executes one wave's requests in issue order, so data a wave wrote is
-// visible to its own later reads without a workgroup barrier; this only stops compiler reordering.
-__device__ inline void wave_sync() {
-#ifdef STORM_HOST_SIM
-    simrt::wave_rendezvous();
-#else
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-#endif
-}
 
 inline int cdiv(long long a, long long b) { return (int)((a + b - 1) / b); }
 

@@ -94,28 +94,17 @@ __device__ __forceinline__ void conv_tile(const ConvParams& a, const int vblock,
     const int cout0 = bm.ct * BN;
 
     int tid_ = threadIdx.x;
-#if defined(__HIP_DEVICE_COMPILE__)
-    asm volatile("" : "+v"(tid_));       // per-tile opaque: keeps lane-derived address math out of the persistent loop's preheader
-#endif
-#if defined(__HIP_DEVICE_COMPILE__)
-    const int tid = tid_, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-#else
-    const int tid = tid_, lane = tid & 63, wave = tid >> 6;
-#endif
+    launder(tid_);                       // per-tile opaque: keeps lane-derived address math out of the persistent loop's preheader
+    const int tid = tid_, lane = tid & 63, wave = uniform(tid >> 6);
     const int wm = wave % WAVES_M, wn = wave / WAVES_M;
-#if defined(__HIP_DEVICE_COMPILE__)
     unsigned long long* const trace_rec = (ABL & 64) && a.trace ? a.trace + ((long long)vblock * (WAVES_M * WAVES_N) + wave) * TRACE_SLOTS : nullptr;
-    auto stamp = [&](int idx) {
+    auto stamp = [&](int idx) {                         // profiling build only (tools/conv_trace.py)
         if ((ABL & 64) && trace_rec && idx < TRACE_SLOTS) {
-            const unsigned long long t = __builtin_amdgcn_s_memtime();
+            const unsigned long long t = hw_memtime();
             if (lane == 0) trace_rec[idx] = t;
         }
     };
-    if ((ABL & 64) && trace_rec && lane == 0)
-        trace_rec[0] = (unsigned long long)__builtin_amdgcn_s_getreg((31 << 11) | 4) | ((unsigned long long)__builtin_amdgcn_s_getreg((31 << 11) | 20) << 32);
-#else
-    auto stamp = [&](int) {};
-#endif
+    if ((ABL & 64) && trace_rec && lane == 0) trace_rec[0] = hw_ids();
     stamp(1);
 
     f32x16 acc[WM][WN];
@@ -308,14 +297,12 @@ __device__ __forceinline__ void conv_tile(const ConvParams& a, const int vblock,
             for (int j = 0; j < nk; ++j) {
                 if (!(ABL & 2)) load_frags(j, fa, fb);
                 if (!(ABL & 1)) mma(fa, fb);
-#if defined(__HIP_DEVICE_COMPILE__)
                 else {
 #pragma unroll
-                    for (int mi = 0; mi < WM; ++mi) asm volatile("" ::"v"(fa[mi]));
+                    for (int mi = 0; mi < WM; ++mi) keep(fa[mi]);
 #pragma unroll
-                    for (int ni = 0; ni < WN; ++ni) asm volatile("" ::"v"(fb[ni]));
+                    for (int ni = 0; ni < WN; ++ni) keep(fb[ni]);
                 }
-#endif
             }
         } else {
 #pragma unroll 1
@@ -402,15 +389,13 @@ __device__ __forceinline__ void conv_tile(const ConvParams& a, const int vblock,
     stamp(500);
     __syncthreads();
     stamp(501);
-#if defined(__HIP_DEVICE_COMPILE__)
     if (ABL & 8) {                                      // profiling ablation: keep the accumulators alive, store nothing
 #pragma unroll
         for (int mi = 0; mi < WM; ++mi)
 #pragma unroll
-            for (int ni = 0; ni < WN; ++ni) asm volatile("" ::"v"(acc[mi][ni]));
+            for (int ni = 0; ni < WN; ++ni) keep(acc[mi][ni]);
         return;
     }
-#endif
     constexpr int PR = Cfg::PR;                 // pixel rows (of 32 px) staged per pass and wave
     constexpr int SROWS = 32 * PR;
     char* const stage = smem + wave * (SROWS * WM * 128);      // private to this wave: only wave-level ordering needed
@@ -539,9 +524,7 @@ __device__ __forceinline__ void conv_tile(const ConvParams& a, const int vblock,
         }
     }
     stamp(502);
-#if defined(__HIP_DEVICE_COMPILE__)
-    if (ABL & 64) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); stamp(503); }
-#endif
+    if (ABL & 64) { vm_wait<0>(); stamp(503); }
 #pragma unroll
     for (int i = 0; i < 4; ++i) { gsum[2 * i] = gsum2[i].x; gsum[2 * i + 1] = gsum2[i].y; gsq[2 * i] = gsq2[i].x; gsq[2 * i + 1] = gsq2[i].y; }
     if (a.gn_part != nullptr) {
@@ -580,22 +563,13 @@ template <typename T, int TAPS, int WM, int WAVES_M, int WAVES_N, bool PF, bool 
 __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, (ConvCfg<TAPS, WM, WAVES_M, WAVES_N, PF, FP, ABL>::MIN_WAVES_PER_SIMD))
 void conv_igemm_kernel(const ConvParams a, const int n_ct, const int tiles_per_xcd,
                        const int ntiles, const int tiles_x, const int tiles_per_img, const int total_vblocks) {
-#if defined(__HIP_DEVICE_COMPILE__)
-    // The parameter block is read through the kernarg segment pointer (ConvParams is the first argument, offset
-    // 0), re-laundered every tile: otherwise LICM hoists every s_load of the block out of the tile loop and the
-    // ~150 live SGPRs spill into VGPRs and on into scratch.
-    typedef const ConvParams __attribute__((address_space(4)))* KArgPtr;
-    KArgPtr kp = (KArgPtr)__builtin_amdgcn_kernarg_segment_ptr();
-    (void)a;
-#endif
+    // The parameter block is read through the kernarg segment pointer (hw.h: kernarg_of), re-laundered every tile: otherwise
+    // LICM hoists every s_load of the block out of the tile loop and the ~150 live SGPRs spill into VGPRs and on into scratch.
+    auto kp = kernarg_of(a);
     for (int vb = blockIdx.x; vb < total_vblocks; vb += gridDim.x) {
         if (vb != (int)blockIdx.x) __syncthreads();      // LDS of the previous tile (staging / statistics) is free
-#if defined(__HIP_DEVICE_COMPILE__)
-        asm volatile("" : "+s"(kp));
+        relaunder(kp);
         conv_tile<T, TAPS, WM, WAVES_M, WAVES_N, PF, FP, ABL>(*(const ConvParams*)kp, vb, n_ct, tiles_per_xcd, ntiles, tiles_x, tiles_per_img);
-#else
-        conv_tile<T, TAPS, WM, WAVES_M, WAVES_N, PF, FP, ABL>(a, vb, n_ct, tiles_per_xcd, ntiles, tiles_x, tiles_per_img);
-#endif
     }
 }
 

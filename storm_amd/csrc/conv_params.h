@@ -2,10 +2,6 @@
 // MFMA wrappers and the fused GroupNorm-apply slot transform.
 #pragma once
 #include <cstring>
-#if defined(STORM_HOST_SIM)
-#include <cstdlib>
-#include <vector>
-#endif
 #include "common.h"
 #include "conv_index.h"
 
@@ -39,122 +35,7 @@ __device__ __forceinline__ uint4 ld16(const void* base, uint32_t byte_off) {
     return *reinterpret_cast<const uint4*>(static_cast<const char*>(base) + byte_off);
 }
 
-// Raw buffer resource (stride 0): a 16-byte load whose offset lies past `bytes` returns zeros.  Padding pixels,
-// ragged channel counts and rows past a matrix become an out-of-range OFFSET instead of a branch around the load.
-constexpr uint32_t BUF_OOB = 0x80000000u;
-struct BufRsrc {
-#if defined(STORM_HOST_SIM)
-    const char* base; uint32_t bytes;
-#else
-    __amdgpu_buffer_rsrc_t r;
-#endif
-};
-__device__ __forceinline__ BufRsrc make_buf(const void* base, uint32_t bytes) {
-    BufRsrc b;
-#if defined(STORM_HOST_SIM)
-    b.base = static_cast<const char*>(base); b.bytes = bytes;
-#else
-    b.r = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, (int)bytes, 0x00020000);
-#endif
-    return b;
-}
-__device__ __forceinline__ uint4 buf_load16(const BufRsrc& b, uint32_t voff, uint32_t soff) {
-#if defined(STORM_HOST_SIM)
-    uint4 v = make_uint4(0u, 0u, 0u, 0u);
-    if ((uint64_t)voff + soff + 16 <= b.bytes) memcpy(&v, b.base + voff + soff, 16);
-    return v;
-#else
-    typedef uint32_t u32x4_ __attribute__((ext_vector_type(4)));
-    const u32x4_ v = __builtin_amdgcn_raw_buffer_load_b128(b.r, (int)voff, (int)soff, 0);
-    return make_uint4(v[0], v[1], v[2], v[3]);
-#endif
-}
 
-#if defined(STORM_HOST_SIM)
-// Host simulation of the asynchronous LDS-DMA queue (test infrastructure).  Two extremes bracket the hardware:
-//   STORM_SIM_DMA unset : a copy lands the moment it is issued  -> exposes write-after-read hazards (a DMA issued
-//                         while another wave may still read the destination);
-//   STORM_SIM_DMA=late  : a copy lands only when the issuing lane's counted vm_wait<N> retires it (in issue order,
-//                         leaving the N newest in flight)        -> exposes read-after-write hazards (a fragment read
-//                         before the wait + barrier that publishes the data).
-namespace simdma {
-struct Entry { char* dst; char data[16]; };
-inline bool late() { static const bool v = [] { const char* e = getenv("STORM_SIM_DMA"); return e && e[0] == 'l'; }(); return v; }
-inline std::vector<Entry>& queue() {                     // per simulated thread (fibers of a workgroup share an OS thread)
-    static thread_local std::vector<std::vector<Entry>> q(1024);
-    return q[threadIdx.x];
-}
-inline void retire(int keep) {
-    std::vector<Entry>& q = queue();
-    const size_t n = q.size() > (size_t)keep ? q.size() - (size_t)keep : 0;
-    for (size_t i = 0; i < n; ++i) memcpy(q[i].dst, q[i].data, 16);
-    q.erase(q.begin(), q.begin() + (long)n);
-}
-}  // namespace simdma
-#endif
-
-// ---- LDS-DMA primitives shared by the convolution kernels ------------------------------------------------
-typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
-// Raw buffer resource (stride 0): reads past num_records return zeros (and write zeros to LDS).
-__device__ __forceinline__ u32x4 make_srd(const void* base, uint32_t bytes) {
-    const uint64_t p = reinterpret_cast<uint64_t>(base);
-    u32x4 r;
-#if defined(__HIP_DEVICE_COMPILE__)
-    r[0] = __builtin_amdgcn_readfirstlane((uint32_t)p);
-    r[1] = __builtin_amdgcn_readfirstlane((uint32_t)(p >> 32) & 0xffffu);
-    r[2] = __builtin_amdgcn_readfirstlane(bytes);
-    r[3] = 0x00020000u;
-#else
-    r[0] = (uint32_t)p; r[1] = (uint32_t)(p >> 32); r[2] = bytes; r[3] = 0;
-#endif
-    return r;
-}
-// ---- asynchronous copy (inline asm on the device; synchronous on the host simulator) --------------------
-// 16 B per lane: buffer (srd) at voff + soff  ->  LDS at (uniform lds_wave + 16 * lane).
-__device__ __forceinline__ void dma16(u32x4 srd, uint32_t voff, uint32_t soff, char* lds_wave, int lane) {
-#if defined(__HIP_DEVICE_COMPILE__)
-    (void)lane;
-    const uint32_t la = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)lds_wave);
-    // M0 is written and consumed inside this one statement (the compiler keeps nothing live in M0 in this kernel)
-    asm volatile("s_mov_b32 m0, %3\n\ts_nop 0\n\tbuffer_load_dwordx4 %0, %1, %2 offen lds"
-                 :: "v"(voff), "s"(srd), "s"(soff), "s"(la) : "memory");
-#elif defined(STORM_HOST_SIM)
-    const uint64_t off = (uint64_t)voff + soff;
-    const char* base = reinterpret_cast<const char*>(((uint64_t)srd[1] << 32) | srd[0]);
-    simdma::Entry e;
-    e.dst = lds_wave + 16 * lane;
-    if (off + 16 <= srd[2]) memcpy(e.data, base + off, 16); else memset(e.data, 0, 16);
-    if (simdma::late()) simdma::queue().push_back(e);        // lands at the latest legal moment (see simdma)
-    else memcpy(e.dst, e.data, 16);                          // lands at once
-#else
-    (void)srd; (void)voff; (void)soff; (void)lds_wave; (void)lane;     // (host pass of the device build: never called)
-#endif
-}
-template <int N> __device__ __forceinline__ void vm_wait() {
-#if defined(__HIP_DEVICE_COMPILE__)
-    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
-#elif defined(STORM_HOST_SIM)
-    simdma::retire(N);
-    simrt::wave_rendezvous();          // simulator lanes are not in lockstep: every lane's copy is done past this point
-#endif
-}
-// workgroup barrier WITHOUT a vmcnt drain: LDS traffic of this wave retired (lgkmcnt), loads keep flying
-__device__ __forceinline__ void raw_barrier() {
-#if defined(__HIP_DEVICE_COMPILE__)
-    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-#else
-    __syncthreads();
-#endif
-}
-
-// issue priority of this wave (raised around MFMA clusters: the partner wave on the SIMD is staging then)
-__device__ __forceinline__ void prio(int p) {
-#if defined(__HIP_DEVICE_COMPILE__)
-    if (p) __builtin_amdgcn_s_setprio(1); else __builtin_amdgcn_s_setprio(0);
-#else
-    (void)p;
-#endif
-}
 
 // y = act(x * scale + shift) on the 16-byte slot held in `v` (GroupNorm-apply + SiLU fused into the operand load: the
 // normalised tensor is never written to HBM).  ss = the slot's channels' scales in ss[0 .. PER16), shifts in ss[8 .. 8 + PER16)

@@ -110,18 +110,10 @@ void conv_pipe_kernel(const PipeParams a, const int n_ct, const int tiles_per_xc
     constexpr int OFF_RING = Cfg::OFF_RING, OFF_SS = Cfg::OFF_SS;
     typedef typename Mma<T>::Frag Frag;
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    // The parameter block is read through the kernarg segment pointer (PipeParams is the first argument, offset 0),
-    // re-laundered at every tile and before every epilogue: otherwise every scalar load of the block is hoisted out of
-    // the tile loop and the live SGPRs spill.
-#if defined(__HIP_DEVICE_COMPILE__)
-    typedef const PipeParams __attribute__((address_space(4)))* KArgPtr;   // (the constant address space keeps the loads scalar)
-    KArgPtr ap = (KArgPtr)__builtin_amdgcn_kernarg_segment_ptr();
-    (void)a;
-#define STORM_RELAUNDER() asm volatile("" : "+s"(ap))
-#else
-    const PipeParams* ap = &a;
-#define STORM_RELAUNDER() ((void)0)
-#endif
+    // The parameter block is read through the kernarg segment pointer, re-laundered at every tile and before every epilogue:
+    // otherwise every scalar load of the block is hoisted out of the tile loop and the live SGPRs spill.
+    PipeArgPtr ap = pipe_args(a);
+#define STORM_RELAUNDER() relaunder(ap)
 
     // Persistent workgroups: at most one per CU, each walking the virtual block ids blockIdx.x, + gridDim.x, ... (gridDim.x
     // is a multiple of 8, so a workgroup stays on its XCD's tile range).  The first patch and weights of the NEXT tile are
@@ -148,19 +140,14 @@ void conv_pipe_kernel(const PipeParams a, const int n_ct, const int tiles_per_xc
     const int wm = wave % WAVES_M, wn = wave / WAVES_M;
     const int grp = wave >> 2;                              // 0: leading, 1: lagging (one barrier interval behind)
 
-#if defined(__HIP_DEVICE_COMPILE__)
     unsigned long long* const trace_rec = TRACE && ap->trace ? ap->trace + ((long long)blockIdx.x * NWAVES + wave) * TRACE_SLOTS : nullptr;
     auto stamp = [&](int idx) {                             // profiling build only (tools/conv_trace.py)
         if (TRACE && trace_rec && idx < TRACE_SLOTS) {
-            const unsigned long long t = __builtin_amdgcn_s_memtime();
+            const unsigned long long t = hw_memtime();
             if (lane == 0) trace_rec[idx] = t;
         }
     };
-    if (TRACE && trace_rec && lane == 0)
-        trace_rec[0] = (unsigned long long)__builtin_amdgcn_s_getreg((31 << 11) | 4) | ((unsigned long long)__builtin_amdgcn_s_getreg((31 << 11) | 20) << 32);
-#else
-    auto stamp = [&](int) {};
-#endif
+    if (TRACE && trace_rec && lane == 0) trace_rec[0] = hw_ids();
     stamp(1);
 
     f32x16 acc[WM][WN];
@@ -246,9 +233,8 @@ void conv_pipe_kernel(const PipeParams a, const int n_ct, const int tiles_per_xc
         if (k >= PPIECES) { issue_table(into); return; }     // surplus slot: identical table bytes again - harmless whenever
                                                              // they land (a repeated PIECE could land on its transformed image)
         uint32_t v = R[i];
-#if defined(__HIP_DEVICE_COMPILE__)
-        asm volatile("" : "+v"(v));       // opaque per use: values DERIVED from the table entry must not be hoisted out of the tile loop
-#endif                                    // as eleven more live registers (one of them spilled: scratch reload + vmcnt(0) in the loop)
+        launder(v);                       // opaque per use: values DERIVED from the table entry must not be hoisted out of the tile loop
+                                          // as eleven more live registers (one of them spilled: scratch reload + vmcnt(0) in the loop)
         const bool ok = (int)v >= 0 && (int)(v & 7u) * 8 < nx_cvalid;
         dma16(nx_srd, ok ? mad24(v >> 3, (uint32_t)nx_C2, (v & 7u) * 16u) : OOB, (uint32_t)nx_cbeg2,
               smem + into * PATCH_BYTES + k * 1024, lane);
@@ -272,9 +258,7 @@ void conv_pipe_kernel(const PipeParams a, const int n_ct, const int tiles_per_xc
         const int k = lw + Cfg::NLAG * i;
         if (k < PPIECES) {
             uint32_t v = R[i];
-#if defined(__HIP_DEVICE_COMPILE__)
-            asm volatile("" : "+v"(v));
-#endif
+            launder(v);
             if ((int)v >= 0 && (int)(v & 7u) * 8 < nx_cvalid) {
                 uint4* const q = reinterpret_cast<uint4*>(smem + into * PATCH_BYTES + k * 1024 + lane * 16);
                 float ss[16];
@@ -289,15 +273,13 @@ void conv_pipe_kernel(const PipeParams a, const int n_ct, const int tiles_per_xc
     // the tap inside the patch image; PROW = bytes between consecutive pixel rows of the image (haloed: PW, compact: 32 px)
     auto read_frags = [&](Frag (&fa)[WM], Frag (&fb)[WN], int ring, int pb, auto kg_, auto poff_, auto prow_) {
         constexpr int kg = decltype(kg_)::value, POFF = decltype(poff_)::value, PROW = decltype(prow_)::value;
-#if defined(__HIP_DEVICE_COMPILE__)
         if (ABL & 16) {                                      // operands stay whatever the prologue left in the registers
 #pragma unroll
-            for (int mi = 0; mi < WM; ++mi) asm volatile("" : "+v"(fa[mi]));
+            for (int mi = 0; mi < WM; ++mi) keep_rw(fa[mi]);
 #pragma unroll
-            for (int ni = 0; ni < WN; ++ni) asm volatile("" : "+v"(fb[ni]));
+            for (int ni = 0; ni < WN; ++ni) keep_rw(fb[ni]);
             return;
         }
-#endif
         const char* wb = smem + ring + ((kg & 1) ? aoff1 : aoff);
 #pragma unroll
         for (int mi = 0; mi < WM; ++mi) fa[mi] = *reinterpret_cast<const Frag*>(wb + mi * 32 * WROW);
@@ -307,28 +289,22 @@ void conv_pipe_kernel(const PipeParams a, const int n_ct, const int tiles_per_xc
     };
     auto read_a = [&](Frag& f, int ring, auto kg_, auto mi_) {           // one weight fragment
         constexpr int kg = decltype(kg_)::value, mi = decltype(mi_)::value;
-#if defined(__HIP_DEVICE_COMPILE__)
-        if (ABL & 16) { asm volatile("" : "+v"(f)); return; }
-#endif
+        if (ABL & 16) { keep_rw(f); return; }
         f = *reinterpret_cast<const Frag*>(smem + ring + ((kg & 1) ? aoff1 : aoff) + mi * 32 * WROW);
     };
     auto read_b = [&](Frag& f, int pb, auto kg_, auto poff_, auto prow_, auto ni_) {   // one pixel fragment
         constexpr int kg = decltype(kg_)::value, POFF = decltype(poff_)::value, PROW = decltype(prow_)::value, ni = decltype(ni_)::value;
-#if defined(__HIP_DEVICE_COMPILE__)
-        if (ABL & 16) { asm volatile("" : "+v"(f)); return; }
-#endif
+        if (ABL & 16) { keep_rw(f); return; }
         f = *reinterpret_cast<const Frag*>(smem + (pb ^ (kg << 5)) + POFF + ni * PROW);
     };
     auto mma_part = [&](const Frag (&fa)[WM], const Frag (&fb)[WN], int lo, int hi) {   // MFMAs lo..hi-1 of the k-group's WM x WN
-#if defined(__HIP_DEVICE_COMPILE__)
         if (ABL & 32) {
 #pragma unroll
-            for (int mi = 0; mi < WM; ++mi) asm volatile("" ::"v"(fa[mi]));
+            for (int mi = 0; mi < WM; ++mi) keep(fa[mi]);
 #pragma unroll
-            for (int ni = 0; ni < WN; ++ni) asm volatile("" ::"v"(fb[ni]));
+            for (int ni = 0; ni < WN; ++ni) keep(fb[ni]);
             return;
         }
-#endif
 #pragma unroll
         for (int i = 0; i < WM * WN; ++i)
             if (i >= lo && i < hi) Mma<T>::run(fa[i / WN], fb[i % WN], acc[i / WN][i % WN]);
@@ -488,9 +464,7 @@ void conv_pipe_kernel(const PipeParams a, const int n_ct, const int tiles_per_xc
 #pragma unroll
         for (int d = 0; d < 3; ++d) pbase[d] += dlt;
         load_next(ci + 1);
-#if defined(__HIP_DEVICE_COMPILE__)
-        asm volatile("" : "+v"(lane));
-#endif
+        launder(lane);
     };
     tile_issue();
     bool first = true;
@@ -546,25 +520,21 @@ void conv_pipe_kernel(const PipeParams a, const int n_ct, const int tiles_per_xc
                 for (int d = 0; d < 3; ++d) pbase[d] -= PATCH_BYTES;
             }
             ring_rd = 0;
-#if defined(__HIP_DEVICE_COMPILE__)
-            asm volatile("" : "+v"(lane));
-#endif
+            launder(lane);
             tile_issue();
         }
 
             STORM_RELAUNDER();
-#if defined(__HIP_DEVICE_COMPILE__)
         if (ABL & 1024) {                                   // (profiling: no epilogue; the accumulators stay live)
 #pragma unroll
             for (int mi = 0; mi < WM; ++mi)
 #pragma unroll
-                for (int ni = 0; ni < WN; ++ni) asm volatile("" ::"v"(acc[mi][ni]));
+                for (int ni = 0; ni < WN; ++ni) keep(acc[mi][ni]);
             if (!has_next) break;
             first = false;
             __syncthreads();
             continue;
         }
-#endif
     // ---- epilogue: LDS transpose -> (bias, temb bias, skip, scale) -> wide stores (as conv_igemm.hip).  Staging lives in
         // patch buffer 1 (waves 0-4) and ring slots 2, 3 (waves 5-7): the next tile's first loads are landing in buffer 0 /
         // slots 0, 1 meanwhile.
@@ -578,14 +548,8 @@ void conv_pipe_kernel(const PipeParams a, const int n_ct, const int tiles_per_xc
         // output pointer / strides inside the store loop: a scalar load + s_waitcnt lgkmcnt(0) and a 64-bit multiply per store)
         const int outC = pin(ap->outC), skipC = outC, out_f32 = pin(ap->out_f32);
         const bool has_skip = ap->skip != nullptr;
-#if defined(__HIP_DEVICE_COMPILE__)
-        unsigned long long out_u = reinterpret_cast<unsigned long long>(ap->out) + (unsigned long long)((long long)e_b * ap->out_bstride * (out_f32 ? 4 : (int)sizeof(T)));
-        asm volatile("" : "+s"(out_u));
-        typedef __attribute__((address_space(1))) char GChar;       // (keeps the stores global_store: behind the asm the pointer's origin is opaque)
-        char* const out_b = (char*)(GChar*)out_u;
-#else
-        char* const out_b = reinterpret_cast<char*>(ap->out) + (long long)e_b * ap->out_bstride * (out_f32 ? 4 : (int)sizeof(T));
-#endif
+        char* const out_b = as_global(reinterpret_cast<unsigned long long>(ap->out) +
+                                      (unsigned long long)((long long)e_b * ap->out_bstride * (out_f32 ? 4 : (int)sizeof(T))));
         const int c8 = lane & (LPR - 1);
         const int co = e_cout0 + wm * WM * 32 + c8 * 8;
         float badd[8];
@@ -681,9 +645,9 @@ void conv_pipe_kernel(const PipeParams a, const int n_ct, const int tiles_per_xc
                             __builtin_nontemporal_store(val, reinterpret_cast<u32x4_nt*>(reinterpret_cast<T*>(out_b) + o));
                         }
                         else if (ABL & 8192) {                       // (profiling: all of the epilogue's arithmetic, no global store)
-#if defined(__HIP_DEVICE_COMPILE__)
-                            asm volatile("" ::"v"(v[0]), "v"(v[1]), "v"(v[2]), "v"(v[3]), "v"(v[4]), "v"(v[5]), "v"(v[6]), "v"(v[7]), "v"(o));
-#endif
+#pragma unroll
+                            for (int e = 0; e < 8; ++e) keep(v[e]);
+                            keep(o);
                         }
                         else store8(reinterpret_cast<T*>(out_b) + o, v);
                     }

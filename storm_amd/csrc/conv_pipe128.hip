@@ -82,15 +82,8 @@ void conv_pipe128_kernel(const PipeParams a, const int n_ct, const int tiles_per
     typedef typename Mma<T>::Frag Frag;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     // parameter block through the kernarg segment pointer, re-laundered per tile (see conv_pipe.hip)
-#if defined(__HIP_DEVICE_COMPILE__)
-    typedef const PipeParams __attribute__((address_space(4)))* KArgPtr;
-    KArgPtr ap = (KArgPtr)__builtin_amdgcn_kernarg_segment_ptr();
-    (void)a;
-#define STORM_RELAUNDER() asm volatile("" : "+s"(ap))
-#else
-    const PipeParams* ap = &a;
-#define STORM_RELAUNDER() ((void)0)
-#endif
+    PipeArgPtr ap = pipe_args(a);
+#define STORM_RELAUNDER() relaunder(ap)
 
     // persistent workgroups (at most one per CU) walking the XCD-aware virtual block ids
     int vb = blockIdx.x;
@@ -350,9 +343,7 @@ void conv_pipe128_kernel(const PipeParams a, const int n_ct, const int tiles_per
 #pragma unroll
         for (int d = 0; d < 3; ++d) pbase[d] += dlt;
         load_next(ci + 3);
-#if defined(__HIP_DEVICE_COMPILE__)
-        asm volatile("" : "+v"(lane));
-#endif
+        launder(lane);
     };
     tile_issue();
     while (true) {
@@ -413,9 +404,7 @@ void conv_pipe128_kernel(const PipeParams a, const int n_ct, const int tiles_per
         if (has_next) {
             vb = nvb;
             decode(vb);
-#if defined(__HIP_DEVICE_COMPILE__)
-            asm volatile("" : "+v"(lane));
-#endif
+            launder(lane);
             tile_issue();
         }
         STORM_RELAUNDER();
@@ -431,14 +420,8 @@ void conv_pipe128_kernel(const PipeParams a, const int n_ct, const int tiles_per
         // output pointer / strides inside the store loop: a scalar load + s_waitcnt lgkmcnt(0) and a 64-bit multiply per store)
         const int outC = pin(ap->outC), skipC = outC, out_f32 = pin(ap->out_f32);
         const bool has_skip = ap->skip != nullptr;
-#if defined(__HIP_DEVICE_COMPILE__)
-        unsigned long long out_u = reinterpret_cast<unsigned long long>(ap->out) + (unsigned long long)((long long)e_b * ap->out_bstride * (out_f32 ? 4 : (int)sizeof(T)));
-        asm volatile("" : "+s"(out_u));
-        typedef __attribute__((address_space(1))) char GChar;       // (keeps the stores global_store: behind the asm the pointer's origin is opaque)
-        char* const out_b = (char*)(GChar*)out_u;
-#else
-        char* const out_b = reinterpret_cast<char*>(ap->out) + (long long)e_b * ap->out_bstride * (out_f32 ? 4 : (int)sizeof(T));
-#endif
+        char* const out_b = as_global(reinterpret_cast<unsigned long long>(ap->out) +
+                                      (unsigned long long)((long long)e_b * ap->out_bstride * (out_f32 ? 4 : (int)sizeof(T))));
         const int c8 = lane & (LPR - 1);
         const int co = e_cout0 + wm * WM * 32 + c8 * 8;
         float badd[8];

@@ -216,6 +216,11 @@ __global__ void gn_apply_kernel(const T* __restrict__ xa, int Ca, const T* __res
 // current tile's filter + stores (with one tile per workgroup the kernel was bound by the load -> transform -> store
 // latency chain at 3 workgroups per CU: 1.7 TB/s down / 3.3 TB/s up).
 constexpr int RS_IH = 10, RS_IW = 18, RS_NPIX = RS_IH * RS_IW;
+// LDS position of staged pixel p (128 B each).  Down-sampling: the lanes of one ds_read_b128 group read the pixels p, p + 2,
+// p + 4, p + 6 (four output columns, stride two), 64 B each - in a linear image those are 256 B apart, the same banks (every
+// filter read 2-way conflicted); swapping the last two pixels of every group of four puts p + 2 on the other 128-byte half.
+template <int RESAMPLE> __host__ __device__ inline int rs_pos(int p) { return RESAMPLE == 2 ? (p ^ ((p >> 1) & 1)) : p; }
+static_assert(RS_NPIX % 4 == 0, "rs_pos permutes inside groups of four pixels");
 template <typename T, int RESAMPLE>
 __global__ __launch_bounds__(256)
 void gn_apply_resample_kernel(const T* __restrict__ xa, int Ca, const T* __restrict__ xb, int Cb,
@@ -333,8 +338,8 @@ void gn_apply_resample_kernel(const T* __restrict__ xa, int Ca, const T* __restr
             } else {
                 *reinterpret_cast<uint4*>(act) = make_uint4(0u, 0u, 0u, 0u);
             }
-            *reinterpret_cast<uint4*>(t_raw + p * 128 + slot * 16) = rawv[k];
-            *reinterpret_cast<uint4*>(t_act + p * 128 + slot * 16) = *reinterpret_cast<const uint4*>(act);
+            *reinterpret_cast<uint4*>(t_raw + rs_pos<RESAMPLE>(p) * 128 + slot * 16) = rawv[k];
+            *reinterpret_cast<uint4*>(t_act + rs_pos<RESAMPLE>(p) * 128 + slot * 16) = *reinterpret_cast<const uint4*>(act);
         }
         // ---- the next tile's loads fly under this tile's filter + stores ----
         const TileId me = cur;
@@ -355,16 +360,14 @@ void gn_apply_resample_kernel(const T* __restrict__ xa, int Ca, const T* __restr
 #pragma unroll
                 for (int e = 0; e < PER16; ++e) { va[e] = 0.f; vr[e] = 0.f; }
                 auto tap = [&](int py, int px, float wgt) {
-                    const uint4 qa = *reinterpret_cast<const uint4*>(t_act + (py * RS_IW + px) * 128 + slot * 16);
-                    const uint4 qr = *reinterpret_cast<const uint4*>(t_raw + (py * RS_IW + px) * 128 + slot * 16);
+                    const uint4 qa = *reinterpret_cast<const uint4*>(t_act + rs_pos<RESAMPLE>(py * RS_IW + px) * 128 + slot * 16);
+                    const uint4 qr = *reinterpret_cast<const uint4*>(t_raw + rs_pos<RESAMPLE>(py * RS_IW + px) * 128 + slot * 16);
                     if constexpr (sizeof(T) == 2) {
                         // 16-bit data: one v_dot2c per channel and tap on the packed dwords (no unpack; exact, see dot2_acc)
                         uint32_t wl = tap_weight_bits(wgt, (T*)nullptr), wh = wl << 16;
-#if defined(__HIP_DEVICE_COMPILE__)
                         // the weights must reach v_dot2c in REGISTERS: as a 32-bit literal of a packed-16-bit operand only the
                         // low half is honoured (measured on gfx950: the (0, w) literal acted as (0, 0))
-                        asm volatile("" : "+v"(wl), "+v"(wh));
-#endif
+                        keep_rw(wl); keep_rw(wh);
                         const uint32_t a[4] = {qa.x, qa.y, qa.z, qa.w}, r[4] = {qr.x, qr.y, qr.z, qr.w};
 #pragma unroll
                         for (int i = 0; i < 4; ++i) {

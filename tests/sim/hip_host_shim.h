@@ -14,6 +14,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <functional>
+#include <vector>
 
 #define __host__
 #define __device__
@@ -165,3 +166,25 @@ inline hipError_t hipEventSynchronize(hipEvent_t) { return hipSuccess; }
 inline hipError_t hipEventElapsedTime(float* ms, hipEvent_t, hipEvent_t) { *ms = 0.f; return hipSuccess; }
 #define hipLaunchKernelGGL(kern, grid, block, lds, stream, ...) \
     simrt::launch((grid), (block), (size_t)(lds), [=]() { (kern)(__VA_ARGS__); })
+
+// ---- LDS-DMA queue model (used by storm_amd/csrc/hw.h's simulator versions of dma16 / vm_wait) ------------------------
+// Host simulation of the asynchronous LDS-DMA queue (test infrastructure).  Two extremes bracket the hardware:
+//   STORM_SIM_DMA unset : a copy lands the moment it is issued  -> exposes write-after-read hazards (a DMA issued
+//                         while another wave may still read the destination);
+//   STORM_SIM_DMA=late  : a copy lands only when the issuing lane's counted vm_wait<N> retires it (in issue order,
+//                         leaving the N newest in flight)        -> exposes read-after-write hazards (a fragment read
+//                         before the wait + barrier that publishes the data).
+namespace simdma {
+struct Entry { char* dst; char data[16]; };
+inline bool late() { static const bool v = [] { const char* e = getenv("STORM_SIM_DMA"); return e && e[0] == 'l'; }(); return v; }
+inline std::vector<Entry>& queue() {                     // per simulated thread (fibers of a workgroup share an OS thread)
+    static thread_local std::vector<std::vector<Entry>> q(1024);
+    return q[threadIdx.x];
+}
+inline void retire(int keep) {
+    std::vector<Entry>& q = queue();
+    const size_t n = q.size() > (size_t)keep ? q.size() - (size_t)keep : 0;
+    for (size_t i = 0; i < n; ++i) memcpy(q[i].dst, q[i].data, 16);
+    q.erase(q.begin(), q.begin() + (long)n);
+}
+}  // namespace simdma

@@ -8,13 +8,14 @@ import glob
 import sys
 
 root, tag = sys.argv[1], sys.argv[2]
+pats = sys.argv[3].split(",") if len(sys.argv) > 3 else ["conv_"]          # kernel-name substrings to report
 acc = collections.defaultdict(lambda: collections.defaultdict(list))
 for f in glob.glob(root + "/**/*counter_collection.csv", recursive=True):
     for r in csv.DictReader(open(f)):
         k = r["Kernel_Name"]
-        if "conv_" not in k:
+        if not any(p_ in k for p_ in pats):
             continue
-        acc[(k.split("(")[0][-34:], r["Grid_Size"])][r["Counter_Name"]].append(float(r["Counter_Value"]))
+        acc[(k.split("(")[0][-44:], r["Grid_Size"])][r["Counter_Name"]].append(float(r["Counter_Value"]))
 for (k, grid), c in sorted(acc.items()):
     med = {n: sorted(v)[len(v) // 2] for n, v in c.items()}
     gui = med.get("GRBM_GUI_ACTIVE", 0) / 8.0                    # summed over the 8 XCDs
