@@ -123,8 +123,9 @@ const char* storm_conv_kernel_name(const storm_conv_args* a);
  *   out[b][i][:] = sum_j softmax_j(scale * <q[b][i], k[b][j]>) v[b][j][:] + bias[:]
  * q, k, out: [B][L][C] (C contiguous, = NHWC activations of the NIN projections, layerspp.py:78-80); vT: [B][C][ldv]
  * (v transposed, row stride ldv >= L, a multiple of 8, zero past L); bias = the NIN_2 (v) bias, which passes through the
- * softmax-weighted sum unchanged (rows of the weights sum to one), or NULL.  bf16, C in {32, 64, 128, 256}; other
- * cases return STORM_ERR_UNSUPPORTED (storm_attention_supported tells beforehand) and run as GEMM + storm_softmax_rows.
+ * softmax-weighted sum unchanged (rows of the weights sum to one), or NULL.  bf16 / fp16 (P and the output rounded to the
+ * operand type) and fp32 (exact-fp32 MFMA: the parity path), C in {32, 64, 128, 256}, any L; other cases return
+ * STORM_ERR_UNSUPPORTED (storm_attention_supported tells beforehand) and run as GEMM + storm_softmax_rows.
  * ------------------------------------------------------------------------------------------ */
 int storm_attention_supported(int C, int dtype);
 int storm_attention(const void* q, const void* k, const void* vT, const float* bias, void* out, int B, int L, int C, int ldv,

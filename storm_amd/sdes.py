@@ -16,6 +16,8 @@ from . import ops
 from .util.registry import Registry
 
 SDERegistry = Registry("SDE")
+SDERegistry.declare_out_of_scope("ouvp", "OUVPSDE (sdes.py:255-326) is outside the sampling hot path this engine covers (BASELINE.json names the OUVE "
+                                 "SDE only; upstream's own `ald` corrector rejects it, correctors.py:69)")
 
 
 def _bc(v, x):

@@ -8,6 +8,10 @@ class Registry:
     def __init__(self, managed_thing: str):
         self.managed_thing = managed_thing
         self._registry = {}
+        self._not_built = {}           # upstream names deliberately outside this engine's scope -> why
+
+    def declare_out_of_scope(self, name: str, why: str):
+        self._not_built[name] = why
 
     def register(self, name: str) -> Callable:
         def deco(cls):
@@ -20,6 +24,8 @@ class Registry:
     def get_by_name(self, name: str):
         if name in self._registry:
             return self._registry[name]
+        if name in self._not_built:
+            raise ValueError(f"{self.managed_thing} with name '{name}' is registered upstream but not built here: {self._not_built[name]}")
         raise ValueError(f"{self.managed_thing} with name '{name}' unknown.")
 
     def get_all_names(self):

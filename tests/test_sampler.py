@@ -59,6 +59,8 @@ def test_registries_and_errors():
     assert "ouve" in SDERegistry.get_all_names()
     with pytest.raises(ValueError):
         SDERegistry.get_by_name("ouvesde")          # the reference's default string is not a registered name either
+    with pytest.raises(ValueError, match="registered upstream but not built here"):
+        SDERegistry.get_by_name("ouvp")             # upstream's second SDE: deliberately out of scope, and the error says so
 
 
 def test_philox_sampler_is_seeded(dev):
