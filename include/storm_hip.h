@@ -41,7 +41,7 @@ int storm_abi_version(void);
 /* Test / tool hook, not part of the drop-in surface: the launchers' A/B switches (forced kernel family, pretend-small device for
  * persistent tile walks, ...) are a table filled once from the environment variables of the same names when the library is
  * first used; these two calls read / change an entry afterwards (names: STORM_CONV_VARIANT, STORM_CONV_PIPE128,
- * STORM_CONV_CUS, STORM_RESAMPLE_WGS; profiling build also STORM_CONV_PERSIST / _DMA / _ABLATE / _TRACE_PTR).  Production code
+ * STORM_CONV_CUS; profiling build also STORM_CONV_PERSIST / _DMA / _ABLATE / _TRACE_PTR).  Production code
  * never calls them and a launch never reads the environment. */
 int storm_set_switch(const char* name, long long value);
 long long storm_get_switch(const char* name);

@@ -29,7 +29,6 @@ struct Switches {
     int conv_variant = -1;      // STORM_CONV_VARIANT: force a conv kernel family (see choose_variant), -1 = the dispatcher's choice
     int conv_pipe128 = 1;       // STORM_CONV_PIPE128: 0 = keep the <= 128-cout 3x3 layers on conv_igemm
     int conv_cus = 0;           // STORM_CONV_CUS: pretend the device has this many CUs (persistent tile walks in tests), 0 = ask the device
-    int resample_wgs = 0;       // STORM_RESAMPLE_WGS: cap of the resample kernels' persistent grid, 0 = default
     int conv_persist = 0;       // STORM_CONV_PERSIST (profiling build)
     int conv_dma = 1;           // STORM_CONV_DMA (profiling build): 0 = register staging in conv_igemm's 128-cout kernel
     int conv_ablate = 0;        // STORM_CONV_ABLATE (profiling build): work-skipping instantiations

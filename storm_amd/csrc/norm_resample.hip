@@ -206,216 +206,290 @@ __global__ void gn_apply_kernel(const T* __restrict__ xa, int Ca, const T* __res
     }
 }
 
-// Fused GN-apply + SiLU + FIR x2 (up or down) of BOTH the activated and the raw tensor, LDS tiled:
-// a workgroup stages a 10x18-pixel input tile (8x16 core + 1-pixel halo) of one 128-byte channel
-// group, applying the normalisation + SiLU ONCE per input element, then filters from LDS.
-// Output tile: 4x8 pixels (down) / 16x32 pixels (up).
-// Persistent workgroups with a register prefetch: a workgroup walks a contiguous run of tiles (so its GroupNorm table rarely
-// changes and the halo columns it shares with its previous tile are L2 / L1 hits); the NEXT tile's
-// global loads are issued as soon as the current tile's registers have been written to LDS, so they fly under the
-// current tile's filter + stores (with one tile per workgroup the kernel was bound by the load -> transform -> store
-// latency chain at 3 workgroups per CU: 1.7 TB/s down / 3.3 TB/s up).
-constexpr int RS_IH = 10, RS_IW = 18, RS_NPIX = RS_IH * RS_IW;
-// LDS position of staged pixel p (128 B each).  Down-sampling: the lanes of one ds_read_b128 group read the pixels p, p + 2,
-// p + 4, p + 6 (four output columns, stride two), 64 B each - in a linear image those are 256 B apart, the same banks (every
-// filter read 2-way conflicted); swapping the last two pixels of every group of four puts p + 2 on the other 128-byte half.
-template <int RESAMPLE> __host__ __device__ inline int rs_pos(int p) { return RESAMPLE == 2 ? (p ^ ((p >> 1) & 1)) : p; }
-static_assert(RS_NPIX % 4 == 0, "rs_pos permutes inside groups of four pixels");
-template <typename T, int RESAMPLE>
+// Fused GN-apply + SiLU + FIR x2 DOWN of both the activated and the raw tensor, register sliding window (no LDS tile, no
+// barriers in the loop).  The separable filter k = [1,3,3,1] / 8 per axis, out[oy][ox] = sum_i k_i (sum_j k_j x[2 oy - 1 + i][2 ox - 1 + j]):
+// a thread owns one 16-byte channel slot of one output column and walks DOWN a strip of output rows; per output row it loads
+// the four taps of two new input rows (16 B each: the loaded slot feeds both tensors), normalises + activates them once,
+// filters each row horizontally with v_dot2c on the packed 16-bit data, and combines with the carry of the two rows it shares
+// with the previous output row (out[oy] = carry + k2 h[2 oy + 1] + k3 h[2 oy + 2]; carry' = k0 h[2 oy + 1] + k1 h[2 oy + 2]).
+// Workgroup = 8 slots (128 B per pixel: coalesced loads and stores) x 32 output columns; ~80 registers, so 5-6 waves per SIMD
+// keep 8 KiB of loads in flight each - the LDS-tiled predecessor (10 x 18-pixel tiles staged once, 3 workgroups per CU, two
+// barriers per 32 output pixels; git show 9dfa6dc:storm_amd/csrc/norm_resample.hip) ran at 1.7 TB/s with its waves parked half
+// of the time (profiles/r03a_pmc_summary.txt); this one measures 2.8 TB/s.
+constexpr int DN_COLS = 32, DN_ROWS = 16;           // output columns per workgroup / output rows per strip
+template <typename T>
 __global__ __launch_bounds__(256)
-void gn_apply_resample_kernel(const T* __restrict__ xa, int Ca, const T* __restrict__ xb, int Cb,
-                              int H, int W, int G, const double* __restrict__ stats,
-                              const float* __restrict__ gamma, const float* __restrict__ beta, float eps,
-                              int silu, T* __restrict__ out_act, T* __restrict__ out_raw, int tiles_x, int tiles_y, int ncg,
-                              int total_tiles) {
-    constexpr int PER16 = Elem<T>::PER16;           // elements per 16-byte slot
-    constexpr int CG = 8 * PER16;                   // channels per workgroup (128 B per pixel)
-    __shared__ __attribute__((aligned(16))) char tile[2 * RS_NPIX * 128];
+void gn_apply_down_kernel(const T* __restrict__ xa, int Ca, const T* __restrict__ xb, int Cb,
+                          int H, int W, int G, const double* __restrict__ stats,
+                          const float* __restrict__ gamma, const float* __restrict__ beta, float eps,
+                          int silu, T* __restrict__ out_act, T* __restrict__ out_raw, int ncg, int nstrips) {
+    constexpr int PER16 = Elem<T>::PER16;
+    constexpr int CG = 8 * PER16;                   // channels per workgroup
     __shared__ float gtab[2 * CG];
-    char* const t_act = tile;
-    char* const t_raw = tile + RS_NPIX * 128;
     const int C = Ca + Cb, tid = threadIdx.x;
-    const int slot = tid & 7;
-    const int OH = RESAMPLE == 1 ? 2 * H : H / 2, OW = RESAMPLE == 1 ? 2 * W : W / 2;
+    const int slot = tid & 7, col = tid >> 3;
+    const int OH = H / 2, OW = W / 2;
+    int t = blockIdx.y;                             // (channel group, strip, batch item)
+    const int cg = t % ncg; t /= ncg;
+    const int strip = t % nstrips, b = t / nstrips;
     const int gs = C / G;
-    constexpr int NU = (RS_NPIX * 8 + 255) / 256;
-    constexpr int TOH = RESAMPLE == 1 ? 16 : 4, TOW = RESAMPLE == 1 ? 32 : 8;
-
-    struct TileId { int b, cg, ty, tx; };
-    auto decode = [&](int t) {                       // tx fastest, then ty, channel group, batch item
-        TileId d;
-        d.tx = t % tiles_x; t /= tiles_x;
-        d.ty = t % tiles_y; t /= tiles_y;
-        d.cg = t % ncg; d.b = t / ncg;
-        return d;
-    };
-    uint4 rawv[NU];
-    unsigned okmask = 0;
-    // all global loads of a tile are issued back to back (one memory round trip), zeros outside the image
-    auto load_tile = [&](const TileId& d) {
-        const int c = d.cg * CG + slot * PER16;
-        const bool cvalid = c < C;
-        const int iy0 = d.ty * 8 - 1, ix0 = d.tx * 16 - 1;
-        const long long ibase = (long long)d.b * H * W;
-        okmask = 0;
-#pragma unroll
-        for (int k = 0; k < NU; ++k) {
-            const int u = tid + k * 256;
-            const int p = u >> 3;                        // (u & 7) == slot because 256 % 8 == 0
-            const int py = p / RS_IW, px = p - py * RS_IW;
-            const int iy = iy0 + py, ix = ix0 + px;
-            const bool ok = (u < RS_NPIX * 8) && cvalid && iy >= 0 && iy < H && ix >= 0 && ix < W;
-            rawv[k] = make_uint4(0u, 0u, 0u, 0u);
-            if (ok) {
-                const long long pix = ibase + (long long)iy * W + ix;
-                const T* src = (c < Ca) ? (xa + pix * Ca + c) : (xb + pix * Cb + (c - Ca));
-                rawv[k] = *reinterpret_cast<const uint4*>(src);
-                okmask |= 1u << k;
-            }
+    if (tid < CG) {                                 // (scale, shift) of this workgroup's channels: y = x * sc + sh
+        const int cc = cg * CG + tid;
+        float sc = 0.f, sh = 0.f;
+        if (cc < C) {
+            const double n = (double)gs * H * W;
+            const int g = cc / gs;
+            const double m = stats[((long long)b * G + g) * 2] / n;
+            double var = stats[((long long)b * G + g) * 2 + 1] / n - m * m;
+            if (var < 0.0) var = 0.0;
+            const float pm = (float)m;
+            sc = (float)(1.0 / sqrt(var + (double)eps)) * gamma[cc];
+            sh = beta[cc] - pm * sc;
         }
-    };
+        gtab[2 * tid] = sc; gtab[2 * tid + 1] = sh;
+    }
+    __syncthreads();
+    const int c = cg * CG + slot * PER16;
+    const int ox = blockIdx.x * DN_COLS + col;
+    if (c >= C || ox >= OW) return;
+    float pa[PER16], pb[PER16];
+#pragma unroll
+    for (int e = 0; e < PER16; ++e) { pa[e] = gtab[2 * (slot * PER16 + e)]; pb[e] = gtab[2 * (slot * PER16 + e) + 1]; }
+    const T* const src = (c < Ca) ? xa + c : xb + (c - Ca);
+    const int cs = (c < Ca) ? Ca : Cb;              // channel stride of the source this slot lives in
+    const long long ibase = (long long)b * H * W;
+    const long long obase = (long long)b * OH * OW;
+    const int ix0 = 2 * ox - 1;
+    const bool x_in[4] = {ix0 >= 0, true, ix0 + 2 < W, ix0 + 3 < W};     // (ix0 + 1 = 2 ox < W always)
 
-    const int per = (total_tiles + (int)gridDim.x - 1) / (int)gridDim.x;
-    int t = blockIdx.x * per;
-    const int t_end = min(total_tiles, t + per);
-    if (t >= t_end) return;
-    TileId cur = decode(t);
-    load_tile(cur);
-    int tab_b = -1, tab_cg = -1;
-    while (true) {
-        // GN parameters of the tile's CG channels (y = x * scale + shift): one thread per channel does the fp64 statistics
-        // math, only when the (batch item, channel group) changes; the previous tile's filter is done reading LDS
-        __syncthreads();
-        if (cur.b != tab_b || cur.cg != tab_cg) {
-            if (tid < CG) {
-                const int cc = cur.cg * CG + tid;
-                float sc = 0.f, sh = 0.f;
-                if (cc < C) {
-                    const double n = (double)gs * H * W;
-                    const int g = cc / gs;
-                    const double m = stats[((long long)cur.b * G + g) * 2] / n;
-                    double var = stats[((long long)cur.b * G + g) * 2 + 1] / n - m * m;
-                    if (var < 0.0) var = 0.0;
-                    const float pm = (float)m;
-                    sc = (float)(1.0 / sqrt(var + (double)eps)) * gamma[cc];
-                    sh = beta[cc] - pm * sc;
-                }
-                gtab[2 * tid] = sc; gtab[2 * tid + 1] = sh;
-            }
-            tab_b = cur.b; tab_cg = cur.cg;
-            __syncthreads();
-        }
-        // ---- stage: raw + activated input tile -> LDS ----
-        float pa[PER16], pb[PER16];
+    // the horizontally filtered input row iy, activated (hA) and raw (hR): zero rows / taps outside the image
+    auto hrow = [&](int iy, float (&hA)[PER16], float (&hR)[PER16]) {
 #pragma unroll
-        for (int e = 0; e < PER16; ++e) { pa[e] = gtab[2 * (slot * PER16 + e)]; pb[e] = gtab[2 * (slot * PER16 + e) + 1]; }
+        for (int e = 0; e < PER16; ++e) { hA[e] = 0.f; hR[e] = 0.f; }
+        if (iy < 0 || iy >= H) return;
+        const T* const row = src + (ibase + (long long)iy * W) * cs;
+        uint4 q[4];
 #pragma unroll
-        for (int k = 0; k < NU; ++k) {
-            const int u = tid + k * 256;
-            if (u >= RS_NPIX * 8) continue;
-            const int p = u >> 3;
+        for (int j = 0; j < 4; ++j)
+            q[j] = x_in[j] ? *reinterpret_cast<const uint4*>(row + (long long)(ix0 + j) * cs) : make_uint4(0u, 0u, 0u, 0u);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const float wgt = (j == 0 || j == 3) ? 0.125f : 0.375f;
             alignas(16) T raw[PER16];
-            alignas(16) T act[PER16];
-            *reinterpret_cast<uint4*>(raw) = rawv[k];
-            if (okmask & (1u << k)) {
-                if constexpr (sizeof(T) == 2) {
-                    uint32_t aw[4];
+            *reinterpret_cast<uint4*>(raw) = q[j];
+            if constexpr (sizeof(T) == 2) {
+                uint32_t aw[4] = {0u, 0u, 0u, 0u};
+                if (x_in[j]) {
 #pragma unroll
                     for (int e = 0; e < PER16; e += 2) {
                         f32x2 y = __builtin_elementwise_fma(f32x2{to_f32(raw[e]), to_f32(raw[e + 1])}, f32x2{pa[e], pa[e + 1]}, f32x2{pb[e], pb[e + 1]});
                         if (silu) y = silu2(y);
                         aw[e / 2] = pack2(y.x, y.y, (T*)nullptr);
                     }
-                    *reinterpret_cast<uint4*>(act) = make_uint4(aw[0], aw[1], aw[2], aw[3]);
-                } else {
+                }
+                uint32_t wl = tap_weight_bits(wgt, (T*)nullptr), wh = wl << 16;
+                keep_rw(wl); keep_rw(wh);            // (packed 16-bit operands of v_dot2c must come from registers: see above)
+                const uint32_t r[4] = {q[j].x, q[j].y, q[j].z, q[j].w};
 #pragma unroll
-                    for (int e = 0; e < PER16; ++e) {
-                        float y = fmaf(to_f32(raw[e]), pa[e], pb[e]);
+                for (int i = 0; i < 4; ++i) {
+                    hA[2 * i] = dot2_acc(aw[i], wl, hA[2 * i], (T*)nullptr); hA[2 * i + 1] = dot2_acc(aw[i], wh, hA[2 * i + 1], (T*)nullptr);
+                    hR[2 * i] = dot2_acc(r[i], wl, hR[2 * i], (T*)nullptr); hR[2 * i + 1] = dot2_acc(r[i], wh, hR[2 * i + 1], (T*)nullptr);
+                }
+            } else {
+#pragma unroll
+                for (int e = 0; e < PER16; ++e) {
+                    const float xr = to_f32(raw[e]);
+                    float y = 0.f;
+                    if (x_in[j]) {
+                        y = fmaf(xr, pa[e], pb[e]);
                         if (silu) y = silu_f(y);
-                        from_f32(act[e], y);
+                        T ya; from_f32(ya, y); y = to_f32(ya);      // (the activated tensor is rounded to T before it is filtered)
+                    }
+                    hA[e] = fmaf(wgt, y, hA[e]); hR[e] = fmaf(wgt, xr, hR[e]);
+                }
+            }
+        }
+    };
+    const int oy0 = strip * DN_ROWS, oy1 = min(OH, oy0 + DN_ROWS);
+    float cA[PER16], cR[PER16];                     // carry: k0 h[2 oy - 1] + k1 h[2 oy]
+    {
+        float h0A[PER16], h0R[PER16], h1A[PER16], h1R[PER16];
+        hrow(2 * oy0 - 1, h0A, h0R);
+        hrow(2 * oy0, h1A, h1R);
+#pragma unroll
+        for (int e = 0; e < PER16; ++e) { cA[e] = fmaf(0.375f, h1A[e], 0.125f * h0A[e]); cR[e] = fmaf(0.375f, h1R[e], 0.125f * h0R[e]); }
+    }
+    for (int oy = oy0; oy < oy1; ++oy) {
+        float h2A[PER16], h2R[PER16], h3A[PER16], h3R[PER16];
+        hrow(2 * oy + 1, h2A, h2R);
+        hrow(2 * oy + 2, h3A, h3R);
+        float va[PER16], vr[PER16];
+#pragma unroll
+        for (int e = 0; e < PER16; ++e) {
+            va[e] = fmaf(0.125f, h3A[e], fmaf(0.375f, h2A[e], cA[e]));
+            vr[e] = fmaf(0.125f, h3R[e], fmaf(0.375f, h2R[e], cR[e]));
+            cA[e] = fmaf(0.375f, h3A[e], 0.125f * h2A[e]);
+            cR[e] = fmaf(0.375f, h3R[e], 0.125f * h2R[e]);
+        }
+        const long long o = (obase + (long long)oy * OW + ox) * C + c;
+        if constexpr (sizeof(T) == 2) {
+            *reinterpret_cast<uint4*>(out_act + o) = make_uint4(pack2(va[0], va[1], (T*)nullptr), pack2(va[2], va[3], (T*)nullptr),
+                                                                pack2(va[4], va[5], (T*)nullptr), pack2(va[6], va[7], (T*)nullptr));
+            if (out_raw) *reinterpret_cast<uint4*>(out_raw + o) = make_uint4(pack2(vr[0], vr[1], (T*)nullptr), pack2(vr[2], vr[3], (T*)nullptr),
+                                                                             pack2(vr[4], vr[5], (T*)nullptr), pack2(vr[6], vr[7], (T*)nullptr));
+        } else {
+            alignas(16) T oa[PER16];
+            alignas(16) T orr[PER16];
+#pragma unroll
+            for (int e = 0; e < PER16; ++e) { from_f32(oa[e], va[e]); from_f32(orr[e], vr[e]); }
+            *reinterpret_cast<uint4*>(out_act + o) = *reinterpret_cast<const uint4*>(oa);
+            if (out_raw) *reinterpret_cast<uint4*>(out_raw + o) = *reinterpret_cast<const uint4*>(orr);
+        }
+    }
+}
+
+// The same for x2 UP: out[2i] = 3/4 x[i] + 1/4 x[i - 1], out[2i + 1] = 3/4 x[i] + 1/4 x[i + 1] per axis (k = [1,3,3,1], gain 2 per
+// axis, zero boundary).  A thread owns one 16-byte channel slot of one INPUT column and walks down a strip of input rows: per
+// input row three loads (left, centre, right), each normalised + activated once, give the two horizontally up-sampled columns
+// (2 ix, 2 ix + 1) of both tensors; every pair of consecutive filtered rows (h[i], h[i + 1]) emits the output rows 2 i + 1 and
+// 2 i + 2.  The kernel is bound by its stores (two tensors of four times the input size: 8 x 16 B per thread and input row):
+// 4.1 TB/s, exactly what the LDS-tiled predecessor reached - a write-dominated stream does not get the copy rate on this part.
+constexpr int UP_COLS = 32, UP_ROWS = 16;           // input columns per workgroup / input rows per strip
+template <typename T>
+__global__ __launch_bounds__(256)
+void gn_apply_up_kernel(const T* __restrict__ xa, int Ca, const T* __restrict__ xb, int Cb,
+                        int H, int W, int G, const double* __restrict__ stats,
+                        const float* __restrict__ gamma, const float* __restrict__ beta, float eps,
+                        int silu, T* __restrict__ out_act, T* __restrict__ out_raw, int ncg, int nstrips) {
+    constexpr int PER16 = Elem<T>::PER16;
+    constexpr int CG = 8 * PER16;
+    __shared__ float gtab[2 * CG];
+    const int C = Ca + Cb, tid = threadIdx.x;
+    const int slot = tid & 7, col = tid >> 3;
+    const int OH = 2 * H, OW = 2 * W;
+    int t = blockIdx.y;
+    const int cg = t % ncg; t /= ncg;
+    const int strip = t % nstrips, b = t / nstrips;
+    const int gs = C / G;
+    if (tid < CG) {
+        const int cc = cg * CG + tid;
+        float sc = 0.f, sh = 0.f;
+        if (cc < C) {
+            const double n = (double)gs * H * W;
+            const int g = cc / gs;
+            const double m = stats[((long long)b * G + g) * 2] / n;
+            double var = stats[((long long)b * G + g) * 2 + 1] / n - m * m;
+            if (var < 0.0) var = 0.0;
+            const float pm = (float)m;
+            sc = (float)(1.0 / sqrt(var + (double)eps)) * gamma[cc];
+            sh = beta[cc] - pm * sc;
+        }
+        gtab[2 * tid] = sc; gtab[2 * tid + 1] = sh;
+    }
+    __syncthreads();
+    const int c = cg * CG + slot * PER16;
+    const int ix = blockIdx.x * UP_COLS + col;
+    if (c >= C || ix >= W) return;
+    float pa[PER16], pb[PER16];
+#pragma unroll
+    for (int e = 0; e < PER16; ++e) { pa[e] = gtab[2 * (slot * PER16 + e)]; pb[e] = gtab[2 * (slot * PER16 + e) + 1]; }
+    const T* const src = (c < Ca) ? xa + c : xb + (c - Ca);
+    const int cs = (c < Ca) ? Ca : Cb;
+    const long long ibase = (long long)b * H * W;
+    const long long obase = (long long)b * OH * OW;
+    const bool x_in[3] = {ix > 0, true, ix + 1 < W};
+    struct HRow { float eA[PER16], oA[PER16], eR[PER16], oR[PER16]; };    // columns 2 ix (even) / 2 ix + 1 (odd), activated / raw
+    auto hrow = [&](int iy, HRow& h) {
+#pragma unroll
+        for (int e = 0; e < PER16; ++e) { h.eA[e] = 0.f; h.oA[e] = 0.f; h.eR[e] = 0.f; h.oR[e] = 0.f; }
+        if (iy < 0 || iy >= H) return;
+        const T* const row = src + (ibase + (long long)iy * W) * cs;
+        uint4 q[3];
+#pragma unroll
+        for (int j = 0; j < 3; ++j)
+            q[j] = x_in[j] ? *reinterpret_cast<const uint4*>(row + (long long)(ix - 1 + j) * cs) : make_uint4(0u, 0u, 0u, 0u);
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+            // weights of this tap in the even / odd output column: left (1/4, 0), centre (3/4, 3/4), right (0, 1/4)
+            const float we = j == 0 ? 0.25f : (j == 1 ? 0.75f : 0.f), wo = j == 0 ? 0.f : (j == 1 ? 0.75f : 0.25f);
+            alignas(16) T raw[PER16];
+            *reinterpret_cast<uint4*>(raw) = q[j];
+            if constexpr (sizeof(T) == 2) {
+                uint32_t aw[4] = {0u, 0u, 0u, 0u};
+                if (x_in[j]) {
+#pragma unroll
+                    for (int e = 0; e < PER16; e += 2) {
+                        f32x2 y = __builtin_elementwise_fma(f32x2{to_f32(raw[e]), to_f32(raw[e + 1])}, f32x2{pa[e], pa[e + 1]}, f32x2{pb[e], pb[e + 1]});
+                        if (silu) y = silu2(y);
+                        aw[e / 2] = pack2(y.x, y.y, (T*)nullptr);
+                    }
+                }
+                const uint32_t r[4] = {q[j].x, q[j].y, q[j].z, q[j].w};
+                if (j != 2) {
+                    uint32_t wl = tap_weight_bits(we, (T*)nullptr), wh = wl << 16;
+                    keep_rw(wl); keep_rw(wh);
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        h.eA[2 * i] = dot2_acc(aw[i], wl, h.eA[2 * i], (T*)nullptr); h.eA[2 * i + 1] = dot2_acc(aw[i], wh, h.eA[2 * i + 1], (T*)nullptr);
+                        h.eR[2 * i] = dot2_acc(r[i], wl, h.eR[2 * i], (T*)nullptr); h.eR[2 * i + 1] = dot2_acc(r[i], wh, h.eR[2 * i + 1], (T*)nullptr);
+                    }
+                }
+                if (j != 0) {
+                    uint32_t wl = tap_weight_bits(wo, (T*)nullptr), wh = wl << 16;
+                    keep_rw(wl); keep_rw(wh);
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        h.oA[2 * i] = dot2_acc(aw[i], wl, h.oA[2 * i], (T*)nullptr); h.oA[2 * i + 1] = dot2_acc(aw[i], wh, h.oA[2 * i + 1], (T*)nullptr);
+                        h.oR[2 * i] = dot2_acc(r[i], wl, h.oR[2 * i], (T*)nullptr); h.oR[2 * i + 1] = dot2_acc(r[i], wh, h.oR[2 * i + 1], (T*)nullptr);
                     }
                 }
             } else {
-                *reinterpret_cast<uint4*>(act) = make_uint4(0u, 0u, 0u, 0u);
-            }
-            *reinterpret_cast<uint4*>(t_raw + rs_pos<RESAMPLE>(p) * 128 + slot * 16) = rawv[k];
-            *reinterpret_cast<uint4*>(t_act + rs_pos<RESAMPLE>(p) * 128 + slot * 16) = *reinterpret_cast<const uint4*>(act);
-        }
-        // ---- the next tile's loads fly under this tile's filter + stores ----
-        const TileId me = cur;
-        const int tn = t + 1;
-        const bool has_next = tn < t_end;
-        if (has_next) { cur = decode(tn); load_tile(cur); }
-        __syncthreads();
-        // ---- filter from LDS ----
-        const int c = me.cg * CG + slot * PER16;
-        if (c < C) {
-            const long long obase = (long long)me.b * OH * OW;
-            for (int u = tid; u < TOH * TOW * 8; u += 256) {
-                const int q = u >> 3;
-                const int oy_l = q / TOW, ox_l = q - oy_l * TOW;
-                const int oy = me.ty * TOH + oy_l, ox = me.tx * TOW + ox_l;
-                if (oy >= OH || ox >= OW) continue;
-                float va[PER16], vr[PER16];
 #pragma unroll
-                for (int e = 0; e < PER16; ++e) { va[e] = 0.f; vr[e] = 0.f; }
-                auto tap = [&](int py, int px, float wgt) {
-                    const uint4 qa = *reinterpret_cast<const uint4*>(t_act + rs_pos<RESAMPLE>(py * RS_IW + px) * 128 + slot * 16);
-                    const uint4 qr = *reinterpret_cast<const uint4*>(t_raw + rs_pos<RESAMPLE>(py * RS_IW + px) * 128 + slot * 16);
-                    if constexpr (sizeof(T) == 2) {
-                        // 16-bit data: one v_dot2c per channel and tap on the packed dwords (no unpack; exact, see dot2_acc)
-                        uint32_t wl = tap_weight_bits(wgt, (T*)nullptr), wh = wl << 16;
-                        // the weights must reach v_dot2c in REGISTERS: as a 32-bit literal of a packed-16-bit operand only the
-                        // low half is honoured (measured on gfx950: the (0, w) literal acted as (0, 0))
-                        keep_rw(wl); keep_rw(wh);
-                        const uint32_t a[4] = {qa.x, qa.y, qa.z, qa.w}, r[4] = {qr.x, qr.y, qr.z, qr.w};
-#pragma unroll
-                        for (int i = 0; i < 4; ++i) {
-                            va[2 * i] = dot2_acc(a[i], wl, va[2 * i], (T*)nullptr); va[2 * i + 1] = dot2_acc(a[i], wh, va[2 * i + 1], (T*)nullptr);
-                            vr[2 * i] = dot2_acc(r[i], wl, vr[2 * i], (T*)nullptr); vr[2 * i + 1] = dot2_acc(r[i], wh, vr[2 * i + 1], (T*)nullptr);
-                        }
-                    } else {
-                        alignas(16) T ra[PER16];
-                        alignas(16) T rr[PER16];
-                        *reinterpret_cast<uint4*>(ra) = qa;
-                        *reinterpret_cast<uint4*>(rr) = qr;
-#pragma unroll
-                        for (int e = 0; e < PER16; ++e) { va[e] = fmaf(wgt, to_f32(ra[e]), va[e]); vr[e] = fmaf(wgt, to_f32(rr[e]), vr[e]); }
+                for (int e = 0; e < PER16; ++e) {
+                    const float xr = to_f32(raw[e]);
+                    float y = 0.f;
+                    if (x_in[j]) {
+                        y = fmaf(xr, pa[e], pb[e]);
+                        if (silu) y = silu_f(y);
+                        T ya; from_f32(ya, y); y = to_f32(ya);
                     }
-                };
-                if (RESAMPLE == 1) {
-                    // input pixel (oy>>1, ox>>1) sits at tile coords (+1, +1) relative to the core origin
-                    const int py = (oy_l >> 1) + 1, px = (ox_l >> 1) + 1;
-                    const int ny = (oy_l & 1) ? py + 1 : py - 1, nx = (ox_l & 1) ? px + 1 : px - 1;
-                    tap(py, px, 0.5625f); tap(py, nx, 0.1875f); tap(ny, px, 0.1875f); tap(ny, nx, 0.0625f);
-                } else {
-                    // one filter row (4 taps x 2 tensors) in flight at a time: unrolling all 16 taps costs > 200 registers
-                    // and the occupancy this kernel lives on
-#pragma unroll 1
-                    for (int i = 0; i < 4; ++i) {
-                        const int py = 2 * oy_l + i, px = 2 * ox_l;
-                        if (i == 0 || i == 3) { tap(py, px, 0.015625f); tap(py, px + 1, 0.046875f); tap(py, px + 2, 0.046875f); tap(py, px + 3, 0.015625f); }
-                        else { tap(py, px, 0.046875f); tap(py, px + 1, 0.140625f); tap(py, px + 2, 0.140625f); tap(py, px + 3, 0.046875f); }
-                    }
-                }
-                const long long o = (obase + (long long)oy * OW + ox) * C + c;
-                if constexpr (sizeof(T) == 2) {
-                    *reinterpret_cast<uint4*>(out_act + o) = make_uint4(pack2(va[0], va[1], (T*)nullptr), pack2(va[2], va[3], (T*)nullptr),
-                                                                        pack2(va[4], va[5], (T*)nullptr), pack2(va[6], va[7], (T*)nullptr));
-                    if (out_raw) *reinterpret_cast<uint4*>(out_raw + o) = make_uint4(pack2(vr[0], vr[1], (T*)nullptr), pack2(vr[2], vr[3], (T*)nullptr),
-                                                                                     pack2(vr[4], vr[5], (T*)nullptr), pack2(vr[6], vr[7], (T*)nullptr));
-                } else {
-                    alignas(16) T oa[PER16];
-                    alignas(16) T orr[PER16];
-#pragma unroll
-                    for (int e = 0; e < PER16; ++e) { from_f32(oa[e], va[e]); from_f32(orr[e], vr[e]); }
-                    *reinterpret_cast<uint4*>(out_act + o) = *reinterpret_cast<const uint4*>(oa);
-                    if (out_raw) *reinterpret_cast<uint4*>(out_raw + o) = *reinterpret_cast<const uint4*>(orr);
+                    if (j != 2) { h.eA[e] = fmaf(we, y, h.eA[e]); h.eR[e] = fmaf(we, xr, h.eR[e]); }
+                    if (j != 0) { h.oA[e] = fmaf(wo, y, h.oA[e]); h.oR[e] = fmaf(wo, xr, h.oR[e]); }
                 }
             }
         }
-        if (!has_next) break;
-        t = tn;
+    };
+    auto store_row = [&](int oy, const HRow& a, float wa_, const HRow& bq, float wb_) {     // out[oy] = wa_ a + wb_ bq, both columns
+        const long long o0 = (obase + (long long)oy * OW + 2 * ix) * C + c;
+        float v[4][PER16];
+#pragma unroll
+        for (int e = 0; e < PER16; ++e) {
+            v[0][e] = fmaf(wb_, bq.eA[e], wa_ * a.eA[e]); v[1][e] = fmaf(wb_, bq.oA[e], wa_ * a.oA[e]);
+            v[2][e] = fmaf(wb_, bq.eR[e], wa_ * a.eR[e]); v[3][e] = fmaf(wb_, bq.oR[e], wa_ * a.oR[e]);
+        }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            T* const dst = (k < 2 ? out_act : out_raw);
+            if (dst == nullptr) continue;
+            alignas(16) T ov[PER16];
+            if constexpr (sizeof(T) == 2) {
+                *reinterpret_cast<uint4*>(ov) = make_uint4(pack2(v[k][0], v[k][1], (T*)nullptr), pack2(v[k][2], v[k][3], (T*)nullptr),
+                                                           pack2(v[k][4], v[k][5], (T*)nullptr), pack2(v[k][6], v[k][7], (T*)nullptr));
+            } else {
+#pragma unroll
+                for (int e = 0; e < PER16; ++e) from_f32(ov[e], v[k][e]);
+            }
+            *reinterpret_cast<uint4*>(dst + o0 + (k & 1) * C) = *reinterpret_cast<const uint4*>(ov);
+        }
+    };
+    const int iy0 = strip * UP_ROWS, iy1 = min(H, iy0 + UP_ROWS);
+    HRow h0, h1;
+    hrow(iy0 - 1, h0);
+    for (int i = iy0 - 1; i < iy1; ++i) {            // the pair (h[i], h[i + 1]) emits the output rows 2 i + 1 and 2 i + 2
+        hrow(i + 1, h1);
+        if (i >= iy0) store_row(2 * i + 1, h0, 0.75f, h1, 0.25f);
+        if (i + 1 < iy1) store_row(2 * i + 2, h1, 0.75f, h0, 0.25f);
+        h0 = h1;
     }
 }
 
@@ -461,17 +535,24 @@ static int gn_apply_t(const void* xa, int Ca, const void* xb, int Cb, int B, int
                       const double* stats, const float* gamma, const float* beta, float eps, int silu,
                       void* out_act, void* out_raw, hipStream_t st) {
     const GnGeom g = gn_geom(Ca + Cb);
-    if (R != 0) {
+    if (R == 2) {
         constexpr int CG = 8 * Elem<T>::PER16;
-        const int tiles_x = cdiv(W, 16), tiles_y = cdiv(H, 8), ncg = cdiv(Ca + Cb, CG);
-        const long long total = (long long)tiles_x * tiles_y * ncg * B;
-        STORM_CHECK(total > 0 && total < (1LL << 31), "storm_gn_apply: %lld tiles out of range", total);
-        // persistent: 3 workgroups fit a CU (46 KiB of LDS each); a few per slot so that the tail stays short
-        const long long cap = switches().resample_wgs > 0 ? switches().resample_wgs : 256LL * 3 * 4;   // (test hook: cap the persistent grid)
-        const long long grid = total < cap ? total : cap;
-        hipLaunchKernelGGL((gn_apply_resample_kernel<T, R == 0 ? 1 : R>), dim3((unsigned)grid), dim3(256), 0, st,
-                           (const T*)xa, Ca, (const T*)xb, Cb, H, W, G, stats, gamma, beta, eps, silu, (T*)out_act,
-                           (T*)out_raw, tiles_x, tiles_y, ncg, (int)total);
+        const int OH = H / 2, OW = W / 2;
+        const int ncg = cdiv(Ca + Cb, CG), nstrips = cdiv(OH, DN_ROWS);
+        const long long gy = (long long)ncg * nstrips * B;
+        STORM_CHECK(OH > 0 && OW > 0 && gy < 65536, "storm_gn_apply: down-sampling grid %lld out of range", gy);
+        hipLaunchKernelGGL((gn_apply_down_kernel<T>), dim3(cdiv(OW, DN_COLS), (unsigned)gy), dim3(256), 0, st,
+                           (const T*)xa, Ca, (const T*)xb, Cb, H, W, G, stats, gamma, beta, eps, silu, (T*)out_act, (T*)out_raw, ncg, nstrips);
+        STORM_LAUNCH_CHECK();
+        return STORM_OK;
+    }
+    if (R == 1) {
+        constexpr int CG = 8 * Elem<T>::PER16;
+        const int ncg = cdiv(Ca + Cb, CG), nstrips = cdiv(H, UP_ROWS);
+        const long long gy = (long long)ncg * nstrips * B;
+        STORM_CHECK(gy < 65536, "storm_gn_apply: up-sampling grid %lld out of range", gy);
+        hipLaunchKernelGGL((gn_apply_up_kernel<T>), dim3(cdiv(W, UP_COLS), (unsigned)gy), dim3(256), 0, st,
+                           (const T*)xa, Ca, (const T*)xb, Cb, H, W, G, stats, gamma, beta, eps, silu, (T*)out_act, (T*)out_raw, ncg, nstrips);
         STORM_LAUNCH_CHECK();
         return STORM_OK;
     }
