@@ -138,6 +138,8 @@ def profile_ops(net, Y, nfe_count):
                 flops += 2 * Bq * H * W * Cout * cin * nt
                 abytes += (Bq * H * W * cin + Cout * cin * nt) * esz
                 taps.append(nt)
+            if int(op.p[9].buf) >= 0:
+                abytes += Bq * H * W * outC * esz           # the residual / input-skip tensor added in the epilogue is read once too
             row.update(flops=flops, algorithmic_bytes=abytes, H=H, W=W, Cout=Cout, taps=taps, big=outC > 32, cin=[int(op.i[8]) + int(op.i[9])],
                        kernel=L.lib().storm_program_kernel_name(ops, k, code).decode())
         elif op.code == 6:                                  # GroupNorm-apply (+ SiLU) (+ FIR x2 of the activated AND the raw tensor)

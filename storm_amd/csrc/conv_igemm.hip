@@ -622,9 +622,11 @@ static int launch_conv(const storm_conv_args& a, hipStream_t st) {
 //   2: conv_igemm 256 cout x 256 px, 8 waves, 1 workgroup / CU, patch double-buffered through registers
 //   3: conv_pipe.hip, 256 cout x 256 px, 8 waves in two ping-pong groups, chunk-unrolled LDS-DMA pipeline (16-bit 3x3)
 //   4: conv_pipe128.hip, 128 cout x 512 px, the same pipeline for layers with <= 128 output channels (16-bit 3x3)
+//   6: conv_thin.hip, 8 input channels (stem, input-skip 1x1s): operands straight from global memory (16-bit)
 static int choose_variant(const storm_conv_args& a, bool any9) {
     const int forced = switches().conv_variant;                      // (test / A-B hook, storm_set_switch)
     if (forced >= 0) return forced;
+    if (conv_thin_supports(a)) return 6;
     const long long px_tiles = (long long)a.B * cdiv((long long)a.H * a.W, TILE_H * TILE_W);
     if (a.outC > 128 && px_tiles >= 512) return any9 && conv_pipe_supports(a) ? 3 : 2;
     // conv_pipe128: measured against this file's two-workgroup kernel on MI355X (tools/probe128.py, profiles/r02_pipe128_ab.txt) it
@@ -642,6 +644,7 @@ static int dispatch_conv(const storm_conv_args& a, hipStream_t st) {
     for (int s = 0; s < a.nseg; ++s) any9 = any9 || a.seg[s].ntaps == 9;
     const bool small = a.outC <= 32;
     const int variant = choose_variant(a, any9);
+    if (variant == 6 && conv_thin_supports(a)) return launch_conv_thin(a, st);
 #if defined(STORM_PROFILING)
     // work-skipping instantiations for tools/ (no MFMA, no fragment reads, ...): profiling build only
     const int abl = switches().conv_ablate;
@@ -686,6 +689,7 @@ static const char* kernel_name_of(const storm_conv_args& a) {
     const int taps = any9 ? 9 : 1;
     const char* shape;
     const int variant = a.outC <= 32 ? -1 : choose_variant(a, any9);
+    if (variant == 6 && conv_thin_supports(a)) return conv_thin_kernel_name(a.dtype, taps);
     if (a.outC <= 32) shape = "1, 1, 4, false, false";
     else if (any9 && variant == 3 && conv_pipe_supports(a)) return conv_pipe_kernel_name(a.dtype);
     else if (any9 && variant == 4 && conv_pipe128_supports(a)) return conv_pipe128_kernel_name(a.dtype);

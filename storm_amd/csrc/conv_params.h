@@ -184,4 +184,10 @@ bool conv_pipe128_supports(const storm_conv_args& a);
 int launch_conv_pipe128(const storm_conv_args& a, hipStream_t st);
 const char* conv_pipe128_kernel_name(int dtype);
 
+// defined in conv_thin.hip: convolutions over an 8-channel input (the stem, the input-skip 1x1s): operands straight from global
+// memory, no staging
+bool conv_thin_supports(const storm_conv_args& a);
+int launch_conv_thin(const storm_conv_args& a, hipStream_t st);
+const char* conv_thin_kernel_name(int dtype, int ntaps);
+
 }  // namespace storm

@@ -147,6 +147,41 @@ def test_conv_pipelined_kernels(dev, variant, case, switch):
         assert rel_l2(nchw(y)[:, :Cout], F.conv2d(q(x, dtype), q(w, dtype), padding=1)) < 6e-3
 
 
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("case", ["stem", "stem_ragged", "combine", "combine_ragged"])
+def test_conv_thin_input_kernel(dev, dtype, case, switch):
+    """conv_thin.hip - the convolutions over an 8-channel input (stem conv3x3 of ncsnpp.py:183, input-skip conv1x1 + h of
+    layerspp.py:44-59): operands straight from global memory.  Against F.conv2d and against the generic kernel (same statistics-
+    partial layout), ragged image sizes, 4 of the 8 input channels in use, 128 / 256 / 96 output channels."""
+    from storm_amd import ops
+    B, H, W, Cout, k, with_skip = {"stem": (2, 16, 64, 128, 3, False), "stem_ragged": (2, 19, 45, 96, 3, False),
+                                   "combine": (2, 8, 64, 256, 1, True), "combine_ragged": (1, 13, 37, 128, 1, True)}[case]
+    g = torch.Generator().manual_seed(77)
+    x = torch.randn(B, 8, H, W, generator=g)
+    x[:, 4:] = 0.0                                          # pack_input leaves channels 4-7 (6-7) zero
+    w = torch.randn(Cout, 8, k, k, generator=g) * 0.3
+    bias = torch.randn(Cout, generator=g)
+    outC = ops.round_up(Cout, 8)
+    skip = torch.randn(B, outC, H, W, generator=g) if with_skip else None
+    dd = lambda t: t.to(dtype).to(dev)
+    segs = [ops.Seg(dd(nhwc(x)), ops.pack_conv_weight(w.to(dev), dtype), k * k)]
+    kw = dict(bias=bias.to(dev), skip=dd(nhwc(skip)) if with_skip else None, scale=0.5 if with_skip else 1.0)
+    assert ops.conv_kernel_name(segs, Cout, **kw).startswith("storm::conv_thin_kernel")
+    y, part = ops.conv(segs, Cout, gn_partials=True, **kw)
+    ref = F.conv2d(q(x, dtype), q(w, dtype), bias, padding=k // 2)
+    if with_skip:
+        ref = (ref + q(skip, dtype)[:, :Cout]) * 0.5
+    yc = nchw(y.float().cpu())
+    assert rel_l2(yc[:, :Cout], ref) < (6e-3 if dtype == torch.bfloat16 else 1e-3)
+    switch("STORM_CONV_VARIANT", 0)
+    assert ops.conv_kernel_name(segs, Cout, **kw).startswith("storm::conv_igemm_kernel")
+    y0, part0 = ops.conv(segs, Cout, gn_partials=True, **kw)
+    assert rel_l2(yc, nchw(y0.float().cpu())) < 3e-3 and part.shape == part0.shape
+    assert torch.allclose(part.cpu(), part0.cpu(), rtol=2e-2, atol=2e-2 * float(part0.abs().max()))
+    st, sref = ops.gn_finalize(part).cpu(), ops.gn_stats(y).cpu()
+    assert torch.allclose(st, sref, rtol=2e-3, atol=2e-3 * float(sref.abs().max()))
+
+
 PIPE128_CASES = {
     # name: (B, H, W, Cout, (Ca, Cb) of the 3x3 operand, fused GroupNorm on it, (Sa, Sb) of the fused 1x1 shortcut or None, CUs)
     "plain": (2, 19, 45, 120, (72, 0), False, None, None),            # 3 chunks (the last ragged), ragged tile rows / columns
