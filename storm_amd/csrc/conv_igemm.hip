@@ -58,7 +58,7 @@ struct ConvCfg {
     static constexpr int PR = (WN >= 2 && NWAVES * 64 * WM * 128 <= MAIN_BYTES) ? 2 : 1;   // pixel rows staged per epilogue pass
     static constexpr int STAGE_BYTES = NWAVES * 32 * PR * WM * 128;
     static constexpr int LDS_BYTES = MAIN_BYTES > STAGE_BYTES ? MAIN_BYTES : STAGE_BYTES;
-    static constexpr int BLOCKS_PER_CU = (160 * 1024) / LDS_BYTES >= 2 ? 2 : 1;
+    static constexpr int BLOCKS_PER_CU = (160 * 1024) / LDS_BYTES >= 3 && BN == 32 ? 3 : ((160 * 1024) / LDS_BYTES >= 2 ? 2 : 1);   // (narrow-output tile: latency bound, a third workgroup fits)
     static constexpr int MIN_WAVES_PER_SIMD = BLOCKS_PER_CU * NWAVES / 4;
     static constexpr int PU = (NPIX * 8 + THREADS - 1) / THREADS;   // patch 16-B units per thread
     static constexpr int WU = BN * 8 / THREADS;                      // weight units per thread
