@@ -58,7 +58,7 @@ struct ConvCfg {
     static constexpr int PR = (WN >= 2 && NWAVES * 64 * WM * 128 <= MAIN_BYTES) ? 2 : 1;   // pixel rows staged per epilogue pass
     static constexpr int STAGE_BYTES = NWAVES * 32 * PR * WM * 128;
     static constexpr int LDS_BYTES = MAIN_BYTES > STAGE_BYTES ? MAIN_BYTES : STAGE_BYTES;
-    static constexpr int BLOCKS_PER_CU = (160 * 1024) / LDS_BYTES >= 3 && BN == 32 ? 3 : ((160 * 1024) / LDS_BYTES >= 2 ? 2 : 1);   // (narrow-output tile: latency bound, a third workgroup fits)
+    static constexpr int BLOCKS_PER_CU = (160 * 1024) / LDS_BYTES >= 2 ? 2 : 1;
     static constexpr int MIN_WAVES_PER_SIMD = BLOCKS_PER_CU * NWAVES / 4;
     static constexpr int PU = (NPIX * 8 + THREADS - 1) / THREADS;   // patch 16-B units per thread
     static constexpr int WU = BN * 8 / THREADS;                      // weight units per thread
@@ -623,6 +623,8 @@ static int launch_conv(const storm_conv_args& a, hipStream_t st) {
 //   3: conv_pipe.hip, 256 cout x 256 px, 8 waves in two ping-pong groups, chunk-unrolled LDS-DMA pipeline (16-bit 3x3)
 //   4: conv_pipe128.hip, 128 cout x 512 px, the same pipeline for layers with <= 128 output channels (16-bit 3x3)
 //   6: conv_thin.hip, 8 input channels (stem, input-skip 1x1s): operands straight from global memory (16-bit)
+//   7: conv_igemm 64 cout x 256 px, 4 waves (32x128 each), 2 workgroups / CU; LDS-DMA - for 3x3 layers with so few pixel tiles
+//      that 128-cout tiles leave CUs without work (the 32 x 64 level: 128 pixel tiles x 2 cout tiles on 256 CUs x 2 slots)
 static int choose_variant(const storm_conv_args& a, bool any9) {
     const int forced = switches().conv_variant;                      // (test / A-B hook, storm_set_switch)
     if (forced >= 0) return forced;
@@ -635,6 +637,9 @@ static int choose_variant(const storm_conv_args& a, bool any9) {
     // workgroups hide them at least as well.  (A stem-like layer with fewer than 32 input channels is HBM-bound either way.)
     if (a.outC > 32 && a.outC <= 128 && any9 && px_tiles >= 1024 && px_tiles <= 4096 && a.seg[0].Ca + a.seg[0].Cb >= 32 &&
         switches().conv_pipe128 != 0 && conv_pipe128_supports(a)) return 4;    // (A/B switch: 0 = conv_igemm for these layers)
+    // so few pixel tiles that 128-cout tiles do not give every CU its two workgroups (the 32 x 64 level of NCSN++ at 4 s: 128
+    // pixel tiles x 2 cout tiles): 64-cout tiles double the workgroups (measured +5 % on 256 -> 256 and 512 -> 256 @ 32 x 64 x 16)
+    if (any9 && a.outC >= 128 && px_tiles * cdiv(a.outC, 128) <= 256) return 7;
     return 0;
 }
 
@@ -667,6 +672,7 @@ static int dispatch_conv(const storm_conv_args& a, hipStream_t st) {
         if (variant == 3 && conv_pipe_supports(a)) return launch_conv_pipe(a, st);
         if (variant == 4 && conv_pipe128_supports(a)) return launch_conv_pipe128(a, st);
         if (variant == 2) return launch_conv<T, 9, 2, 4, 2, true>(a, st);
+        if (variant == 7) return launch_conv<T, 9, 1, 2, 2, false, true>(a, st);
 #if defined(STORM_PROFILING)                                          // A/B instantiations: 8-wave geometry, register staging
         if (variant == 1) return launch_conv<T, 9, 2, 2, 4, false>(a, st);
         if (switches().conv_dma == 0) return launch_conv<T, 9, 2, 2, 2, false, false>(a, st);
@@ -694,6 +700,7 @@ static const char* kernel_name_of(const storm_conv_args& a) {
     else if (any9 && variant == 3 && conv_pipe_supports(a)) return conv_pipe_kernel_name(a.dtype);
     else if (any9 && variant == 4 && conv_pipe128_supports(a)) return conv_pipe128_kernel_name(a.dtype);
     else if (variant == 2) shape = "2, 4, 2, true, false";
+    else if (any9 && variant == 7) shape = "1, 2, 2, false, true";
 #if defined(STORM_PROFILING)
     else if (variant == 1) shape = "2, 2, 4, false, false";
     else if (any9 && switches().conv_dma == 0) shape = "2, 2, 2, false, false";

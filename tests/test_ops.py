@@ -62,7 +62,7 @@ def test_conv_persistent_tile_loop(dev, dtype, k, switch):
     assert torch.allclose(st, sref, rtol=rtol, atol=rtol * float(sref.abs().max()))
 
 
-@pytest.mark.parametrize("variant", [3])
+@pytest.mark.parametrize("variant", [3, 7])
 @pytest.mark.parametrize("case", ["plain", "block_tail", "gn_fused", "ragged", "deep_k", "plain@8", "block_tail@8", "gn_fused@8",
                                   "plain:f16", "gn_fused:f16"])
 def test_conv_pipelined_kernels(dev, variant, case, switch):
@@ -195,6 +195,17 @@ PIPE128_CASES = {
     "gn_fused@8": (2, 35, 70, 40, (72, 56), True, None, 8),
     "gn_fused:f16": (2, 10, 36, 40, (72, 56), True, None, None),
 }
+
+
+def test_conv_dispatch_picks_the_64_cout_tile_when_128_cout_tiles_leave_cus_idle(dev):
+    """storm_conv's own choice (no switch): a 3x3 layer with > 128 output channels on so few pixel tiles that 128-cout tiles
+    give <= 256 workgroups runs the 64-cout tile of conv_igemm.hip; with many pixel tiles it does not."""
+    from storm_amd import ops
+    w = ops.pack_conv_weight(torch.zeros(256, 64, 3, 3, device=dev), torch.bfloat16)
+    small = [ops.Seg(torch.zeros(1, 32, 64, 64, dtype=torch.bfloat16, device=dev), w, 9)]
+    assert "1, 2, 2, false, true" in ops.conv_kernel_name(small, 256)
+    large = [ops.Seg(torch.zeros(16, 64, 128, 64, dtype=torch.bfloat16, device=dev), w, 9)]
+    assert "1, 2, 2, false, true" not in ops.conv_kernel_name(large, 256)
 
 
 @pytest.mark.parametrize("variant", [4])
