@@ -122,6 +122,26 @@ __device__ inline void load8(const half_t* p, float (&v)[8]) {
         v[2 * i + 1] = f16_bits_to_f32((uint16_t)(w[i] >> 16));
     }
 }
+// Eight elements as they sit in memory (16 B of 16-bit data, 32 B of fp32): fetched early, converted where they are used
+template <typename T> struct Raw8 { uint4 q; };
+template <> struct Raw8<float> { float4 a, b; };
+template <typename T> __device__ __forceinline__ void fetch8(const T* p, Raw8<T>& r) { r.q = *reinterpret_cast<const uint4*>(p); }
+__device__ __forceinline__ void fetch8(const float* p, Raw8<float>& r) {
+    r.a = *reinterpret_cast<const float4*>(p); r.b = *reinterpret_cast<const float4*>(p + 4);
+}
+__device__ __forceinline__ void unpack8(const Raw8<bf16_t>& r, float (&v)[8]) {
+    const uint32_t w[4] = {r.q.x, r.q.y, r.q.z, r.q.w};
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { v[2 * i] = __uint_as_float(w[i] << 16); v[2 * i + 1] = __uint_as_float(w[i] & 0xffff0000u); }
+}
+__device__ __forceinline__ void unpack8(const Raw8<half_t>& r, float (&v)[8]) {
+    const uint32_t w[4] = {r.q.x, r.q.y, r.q.z, r.q.w};
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { v[2 * i] = f16_bits_to_f32((uint16_t)(w[i] & 0xffffu)); v[2 * i + 1] = f16_bits_to_f32((uint16_t)(w[i] >> 16)); }
+}
+__device__ __forceinline__ void unpack8(const Raw8<float>& r, float (&v)[8]) {
+    v[0] = r.a.x; v[1] = r.a.y; v[2] = r.a.z; v[3] = r.a.w; v[4] = r.b.x; v[5] = r.b.y; v[6] = r.b.z; v[7] = r.b.w;
+}
 __device__ inline void store8(half_t* p, const float (&v)[8]) {
     uint32_t w[4];
 #pragma unroll

@@ -448,6 +448,47 @@ __device__ __forceinline__ void conv_tile(const ConvParams& a, const int vblock,
     for (int odd = 0; odd < 2; ++odd)
 #pragma unroll
         for (int h = 0; h < 2; ++h) srow[odd][h] = stage_off<WM>(odd * 8 + l8, 2 * c8 + h) - odd * 8 * (WM * 128);
+    // where iteration `it` of pass `pass` stores: validity and element offset inside this batch image (fits 32 bits)
+    auto locate = [&](int pass, int it, bool& ok, uint32_t& o) {
+        if constexpr (LPR == 8) {
+            const int trow = wn * WN + pass * PR + it / 4, nb = (it % 4) * RPI;          // (it is a compile-time constant)
+            if (TAPS == 9) {
+                const int gy = ty0 + trow;
+                ok = gy < imgH && gx0 + nb < imgW;
+                o = (uint32_t)(gy * imgW + tx0 + nb) * (uint32_t)outC + o_lane;
+            } else {
+                const int pix_u = (int)lin0 + trow * TILE_W + nb;
+                ok = pix_u + l8 < (int)npix;
+                o = (uint32_t)pix_u * (uint32_t)outC + o_lane;
+            }
+        } else {
+            const int row = it * RPI + lane / LPR;
+            const int trow = wn * WN + pass * PR + (row >> 5), n = row & 31;
+            int pix;
+            if (TAPS == 9) {
+                const int gy = ty0 + trow, gx = tx0 + n;
+                ok = gy < imgH && gx < imgW;
+                pix = gy * imgW + gx;
+            } else {
+                pix = (int)lin0 + trow * TILE_W + n;
+                ok = pix < (int)npix;
+            }
+            o = (uint32_t)(pix * outC + co);
+        }
+    };
+    // skip operands are fetched ONE PASS ahead, each into the registers its predecessor (same iteration, previous pass) has just
+    // left; the first pass's before the first staging write (fetched where it is used, every load exposed its memory latency)
+    constexpr int NIT = SROWS / RPI;
+    Raw8<T> skq[NIT];
+    auto skip_fetch = [&](int pass, int it) {
+        bool ok; uint32_t o;
+        locate(pass, it, ok, o);
+        if (ok && co_ok) fetch8(skip_b + o, skq[it]);
+    };
+    if (has_skip) {
+#pragma unroll
+        for (int it = 0; it < NIT; ++it) skip_fetch(0, it);
+    }
 #pragma unroll
     for (int pass = 0; pass < WN / PR; ++pass) {
         if (pass > 0) wave_sync();              // this wave's reads of the previous pass are done
@@ -473,41 +514,23 @@ __device__ __forceinline__ void conv_tile(const ConvParams& a, const int vblock,
             float4 v0, v1;
             bool ok;
             uint32_t o;
+            locate(pass, it, ok, o);
             if constexpr (LPR == 8) {
-                const int trow = wn * WN + pass * PR + it / 4, nb = (it % 4) * RPI;          // (it is a compile-time constant)
                 const char* const sp = stage + it * RPI * (WM * 128);
                 v0 = *reinterpret_cast<const float4*>(sp + srow[it & 1][0]);
                 v1 = *reinterpret_cast<const float4*>(sp + srow[it & 1][1]);
-                if (TAPS == 9) {
-                    const int gy = ty0 + trow;
-                    ok = gy < imgH && gx0 + nb < imgW;
-                    o = (uint32_t)(gy * imgW + tx0 + nb) * (uint32_t)outC + o_lane;
-                } else {
-                    const int pix_u = (int)lin0 + trow * TILE_W + nb;
-                    ok = pix_u + l8 < (int)npix;
-                    o = (uint32_t)pix_u * (uint32_t)outC + o_lane;
-                }
             } else {
                 const int row = it * RPI + lane / LPR;
                 v0 = *reinterpret_cast<const float4*>(stage + stage_off<WM>(row, 2 * c8));
                 v1 = *reinterpret_cast<const float4*>(stage + stage_off<WM>(row, 2 * c8 + 1));
-                const int trow = wn * WN + pass * PR + (row >> 5), n = row & 31;
-                int pix;                               // pixel index inside this batch image (fits 32 bits)
-                if (TAPS == 9) {
-                    const int gy = ty0 + trow, gx = tx0 + n;
-                    ok = gy < imgH && gx < imgW;
-                    pix = gy * imgW + gx;
-                } else {
-                    pix = (int)lin0 + trow * TILE_W + n;
-                    ok = pix < (int)npix;
-                }
-                o = (uint32_t)(pix * outC + co);
             }
             f32x2 v2[4] = {f32x2{v0.x, v0.y}, f32x2{v0.z, v0.w}, f32x2{v1.x, v1.y}, f32x2{v1.z, v1.w}};
+            const Raw8<T> skv = skq[it];
+            if (has_skip && pass + 1 < WN / PR) skip_fetch(pass + 1, it);
             if (ok && co_ok) {
                 if (has_skip) {
                     float sk[8];
-                    load8(skip_b + o, sk);
+                    unpack8(skv, sk);
 #pragma unroll
                     for (int i = 0; i < 4; ++i) v2[i] += f32x2{sk[2 * i], sk[2 * i + 1]};
                 }

@@ -591,6 +591,21 @@ void conv_pipe_kernel(const PipeParams a, const int n_ct, const int tiles_per_xc
         for (int odd = 0; odd < 2; ++odd)
 #pragma unroll
             for (int h = 0; h < 2; ++h) srow[odd][h] = stage_off<WM>(odd * 8 + l8, 2 * c8 + h) - odd * 8 * (WM * 128);
+        // skip operands are fetched ONE PASS ahead, each into the register its predecessor (same iteration, previous pass) has just
+        // left - the first pass's before the first staging write.  Fetched where they are used, every one of the 16 loads per tile
+        // and wave exposed its full memory latency (measured on 256 -> 256 @ 256 x 512: 2.50 ms with a skip operand against 1.93 ms
+        // without = 18 us per tile).
+        uint4 skq[SROWS / RPI];
+        auto skip_fetch = [&](int pass, int it) {
+            const int gy = e_ty0 + wn * WN + pass;
+            const uint32_t o_row = (uint32_t)(gy * imgW) * (uint32_t)outC;
+            skq[it] = (gy < imgH && gx0 + it * RPI < imgW && co_ok)
+                ? *reinterpret_cast<const uint4*>(skip_b + (o_row + (uint32_t)(it * RPI) * (uint32_t)outC + o_lane)) : make_uint4(0u, 0u, 0u, 0u);
+        };
+        if (has_skip && !(ABL & 2048)) {
+#pragma unroll
+            for (int it = 0; it < SROWS / RPI; ++it) skip_fetch(0, it);
+        }
 #pragma unroll
         for (int pass = 0; pass < WN / PR; ++pass) {
             if (pass > 0) wave_sync();
@@ -620,11 +635,13 @@ void conv_pipe_kernel(const PipeParams a, const int n_ct, const int tiles_per_xc
                     const float4 v0 = *reinterpret_cast<const float4*>(sp + srow[it & 1][0]);
                     const float4 v1 = *reinterpret_cast<const float4*>(sp + srow[it & 1][1]);
                     f32x2 v2[4] = {f32x2{v0.x, v0.y}, f32x2{v0.z, v0.w}, f32x2{v1.x, v1.y}, f32x2{v1.z, v1.w}};
+                    const uint4 skv = skq[it];
+                    if (has_skip && !(ABL & 2048) && pass + 1 < WN / PR) skip_fetch(pass + 1, it);
                     if (gx0 + it * RPI < imgW && co_ok && !(ABL & 2048)) {
                         const uint32_t o = o_row + (uint32_t)(it * RPI) * (uint32_t)outC + o_lane;
                         if (has_skip) {
                             alignas(16) T sk[8];
-                            *reinterpret_cast<uint4*>(sk) = *reinterpret_cast<const uint4*>(skip_b + o);
+                            *reinterpret_cast<uint4*>(sk) = skv;
 #pragma unroll
                             for (int i = 0; i < 4; ++i) v2[i] += f32x2{to_f32(sk[2 * i]), to_f32(sk[2 * i + 1])};
                         }

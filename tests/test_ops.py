@@ -63,8 +63,8 @@ def test_conv_persistent_tile_loop(dev, dtype, k, switch):
 
 
 @pytest.mark.parametrize("variant", [3, 7])
-@pytest.mark.parametrize("case", ["plain", "block_tail", "gn_fused", "ragged", "deep_k", "plain@8", "block_tail@8", "gn_fused@8",
-                                  "plain:f16", "gn_fused:f16"])
+@pytest.mark.parametrize("case", ["plain", "block_tail", "gn_fused", "ragged", "deep_k", "skip", "plain@8", "block_tail@8", "gn_fused@8",
+                                  "skip@8", "plain:f16", "gn_fused:f16"])
 def test_conv_pipelined_kernels(dev, variant, case, switch):
     """conv_pipe.hip (chunk-unrolled LDS-DMA pipeline, 256-cout tile) on shapes the default dispatch would give
     to conv_igemm.hip: plain 3x3, fused 1x1 shortcut over a concat, fused GroupNorm-apply operand, ragged sizes, many
@@ -86,6 +86,17 @@ def test_conv_pipelined_kernels(dev, variant, case, switch):
         y, part = ops.conv([ops.Seg(nhwc(x).to(dtype).to(dev), ops.pack_conv_weight(w.to(dev), dtype), 9)], Cout,
                            bias=b.to(dev), gn_partials=True)
         ref = F.conv2d(q(x, dtype), q(w, dtype), b, padding=1)
+        assert rel_l2(nchw(y.float().cpu())[:, :Cout], ref) < 6e-3
+        st, sref = ops.gn_finalize(part).cpu(), ops.gn_stats(y).cpu()
+        assert torch.allclose(st, sref, rtol=2e-3, atol=2e-3 * float(sref.abs().max()))
+    elif case == "skip":                               # identity shortcut of a residual block: skip operands are fetched a pass ahead
+        B, Cin, Cout, H, W = 2, 72, 288, 19, 45        # (ragged rows / columns / couts: fetches past the image are masked)
+        x = torch.randn(B, Cin, H, W, generator=g); w = torch.randn(Cout, Cin, 3, 3, generator=g) * 0.1
+        b = torch.randn(Cout, generator=g)
+        sk = torch.randn(B, Cout, H, W, generator=g)
+        y, part = ops.conv([ops.Seg(nhwc(x).to(dtype).to(dev), ops.pack_conv_weight(w.to(dev), dtype), 9)], Cout,
+                           bias=b.to(dev), skip=nhwc(sk).to(dtype).to(dev), scale=2 ** -0.5, gn_partials=True)
+        ref = (F.conv2d(q(x, dtype), q(w, dtype), b, padding=1) + q(sk, dtype)) * 2 ** -0.5
         assert rel_l2(nchw(y.float().cpu())[:, :Cout], ref) < 6e-3
         st, sref = ops.gn_finalize(part).cpu(), ops.gn_stats(y).cpu()
         assert torch.allclose(st, sref, rtol=2e-3, atol=2e-3 * float(sref.abs().max()))

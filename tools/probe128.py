@@ -16,6 +16,7 @@ p = argparse.ArgumentParser()
 p.add_argument("--reps", type=int, default=5)
 p.add_argument("--B", type=int, default=16)
 p.add_argument("--nogn", action="store_true", help="plain operand: no fused GroupNorm-apply + SiLU on the load")
+p.add_argument("--nosilu", action="store_true", help="fused GroupNorm affine without the SiLU (what the transcendentals cost)")
 p.add_argument("--only", type=int, default=-1)
 p.add_argument("--modes", default="", help="comma list of kernels to time (default: all)")
 args = p.parse_args()
@@ -39,7 +40,7 @@ for ci_, case in enumerate(CASES):
     x = rnd(B, H, W, cin).to(dt).to(dev)
     w = ops.pack_conv_weight((rnd(cout, cin, 3, 3) * 0.05).to(dev), dt)
     ss = ops.pack_gn_ss(1 + 0.1 * rnd(B, cin), 0.1 * rnd(B, cin)).to(dev)
-    segs = [ops.Seg(x, w, 9, gn_ss=None if args.nogn else ss, gn_silu=True)]
+    segs = [ops.Seg(x, w, 9, gn_ss=None if args.nogn else ss, gn_silu=not args.nosilu)]
     kw = dict(bias=rnd(cout).to(dev), tbias=rnd(B, cout).to(dev), gn_partials=True, scale=0.7)
     if sc:
         segs.append(ops.Seg(rnd(B, H, W, sc).to(dt).to(dev), ops.pack_conv_weight((rnd(cout, sc, 1, 1) * 0.05).to(dev), dt), 1))
