@@ -646,12 +646,14 @@ static int launch_conv(const storm_conv_args& a, hipStream_t st) {
 //   3: conv_pipe.hip, 256 cout x 256 px, 8 waves in two ping-pong groups, chunk-unrolled LDS-DMA pipeline (16-bit 3x3)
 //   4: conv_pipe128.hip, 128 cout x 512 px, the same pipeline for layers with <= 128 output channels (16-bit 3x3)
 //   6: conv_thin.hip, 8 input channels (stem, input-skip 1x1s): operands straight from global memory (16-bit)
+//   8: conv_narrow.hip, 3x3 to <= 4 output channels (the output pyramid): 36-row 1x1 GEMM over the haloed region + nine-point gather
 //   7: conv_igemm 64 cout x 256 px, 4 waves (32x128 each), 2 workgroups / CU; LDS-DMA - for 3x3 layers with so few pixel tiles
 //      that 128-cout tiles leave CUs without work (the 32 x 64 level: 128 pixel tiles x 2 cout tiles on 256 CUs x 2 slots)
 static int choose_variant(const storm_conv_args& a, bool any9) {
     const int forced = switches().conv_variant;                      // (test / A-B hook, storm_set_switch)
     if (forced >= 0) return forced;
     if (conv_thin_supports(a)) return 6;
+    if (conv_narrow_supports(a)) return 8;
     const long long px_tiles = (long long)a.B * cdiv((long long)a.H * a.W, TILE_H * TILE_W);
     if (a.outC > 128 && px_tiles >= 512) return any9 && conv_pipe_supports(a) ? 3 : 2;
     // conv_pipe128: measured against this file's two-workgroup kernel on MI355X (tools/probe128.py, profiles/r02_pipe128_ab.txt) it
@@ -673,6 +675,7 @@ static int dispatch_conv(const storm_conv_args& a, hipStream_t st) {
     const bool small = a.outC <= 32;
     const int variant = choose_variant(a, any9);
     if (variant == 6 && conv_thin_supports(a)) return launch_conv_thin(a, st);
+    if (variant == 8 && conv_narrow_supports(a)) return launch_conv_narrow(a, st);
 #if defined(STORM_PROFILING)
     // work-skipping instantiations for tools/ (no MFMA, no fragment reads, ...): profiling build only
     const int abl = switches().conv_ablate;
@@ -717,7 +720,9 @@ static const char* kernel_name_of(const storm_conv_args& a) {
     const char* tn = a.dtype == STORM_BF16 ? "storm::bf16_t" : a.dtype == STORM_F16 ? "storm::half_t" : "float";
     const int taps = any9 ? 9 : 1;
     const char* shape;
-    const int variant = a.outC <= 32 ? -1 : choose_variant(a, any9);
+    int variant = choose_variant(a, any9);
+    if (variant == 8 && conv_narrow_supports(a)) return conv_narrow_kernel_name(a.dtype, a.seg[0].Ca);
+    if (a.outC <= 32) variant = -1;
     if (variant == 6 && conv_thin_supports(a)) return conv_thin_kernel_name(a.dtype, taps);
     if (a.outC <= 32) shape = "1, 1, 4, false, false";
     else if (any9 && variant == 3 && conv_pipe_supports(a)) return conv_pipe_kernel_name(a.dtype);

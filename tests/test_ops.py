@@ -159,6 +159,50 @@ def test_conv_pipelined_kernels(dev, variant, case, switch):
 
 
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("case", ["c128_gn", "c256_gn_walk", "c128_plain", "c256_two_planes"])
+def test_conv_narrow_output_kernel(dev, dtype, case, switch):
+    """conv_narrow.hip - the 3x3 convolutions of the output pyramid (ncsnpp.py:389-410: conv3x3(act(GroupNorm(h))) -> 4 planes; 2 in
+    the discriminative net): one 36-row 1x1 GEMM over the haloed region + a nine-point gather.  Against F.conv2d and the generic
+    kernel; ragged image sizes (tiles cut by both image edges), several tiles and batch items per persistent workgroup ("walk": as if
+    the device had 3 CUs - the affine table is reloaded when the batch item changes), plain operand, missing output planes zero."""
+    from storm_amd import ops
+    C, B, H, W, Cout, gn, cus = {"c128_gn": (128, 2, 19, 45, 4, True, 0), "c256_gn_walk": (256, 3, 21, 37, 4, True, 3),
+                                 "c128_plain": (128, 1, 16, 32, 4, False, 0), "c256_two_planes": (256, 2, 9, 33, 2, True, 0)}[case]
+    g = torch.Generator().manual_seed(91)
+    dd = lambda t: t.to(dtype).to(dev)
+    x = torch.randn(B, C, H, W, generator=g)
+    w = torch.randn(Cout, C, 3, 3, generator=g) * 0.05
+    bias = torch.randn(Cout, generator=g)
+    xa = dd(nhwc(x))
+    ss, a_ref = None, q(x, dtype)
+    if gn:
+        gam, bet = 1 + 0.1 * torch.randn(C, generator=g), 0.1 * torch.randn(C, generator=g)
+        st = ops.gn_stats(xa).cpu()
+        n = (C // 32) * H * W
+        mean = st[:, :, 0] / n
+        rstd = 1.0 / torch.sqrt(st[:, :, 1] / n - mean * mean + 1e-6)
+        scale = (rstd.repeat_interleave(C // 32, 1) * gam[None].double()).float()
+        shift = (bet[None].double() - mean.repeat_interleave(C // 32, 1) * scale.double()).float()
+        ss = ops.pack_gn_ss(scale, shift).to(dev)
+        a_ref = NR.silu(q(x, dtype) * scale[:, :, None, None] + shift[:, :, None, None])
+    segs = [ops.Seg(xa, ops.pack_conv_weight(w.to(dev), dtype), 9, gn_ss=ss, gn_silu=True)]
+    kw = dict(bias=bias.to(dev), outC=8)
+    switch("STORM_CONV_VARIANT", 0)                               # the generic 32-cout tile
+    y_generic = ops.conv(segs, Cout, **kw)
+    assert ops.conv_kernel_name(segs, Cout, **kw).startswith("storm::conv_igemm_kernel")
+    switch("STORM_CONV_VARIANT", -1)
+    if cus:
+        switch("STORM_CONV_CUS", cus)
+    assert ops.conv_kernel_name(segs, Cout, **kw).startswith("storm::conv_narrow_kernel")
+    y = ops.conv(segs, Cout, **kw)
+    yc = nchw(y.float().cpu())
+    ref = F.conv2d(q(a_ref, dtype), q(w, dtype), bias, padding=1)
+    assert rel_l2(yc[:, :Cout], ref) < 6e-3
+    assert float(yc[:, Cout:].abs().max()) == 0.0
+    assert rel_l2(yc, nchw(y_generic.float().cpu())) < 4e-3
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
 @pytest.mark.parametrize("case", ["stem", "stem_ragged", "combine", "combine_ragged"])
 def test_conv_thin_input_kernel(dev, dtype, case, switch):
     """conv_thin.hip - the convolutions over an 8-channel input (stem conv3x3 of ncsnpp.py:183, input-skip conv1x1 + h of
