@@ -43,7 +43,8 @@ def build(force=False, verbose=False, profiling=False):
     cc = hipcc()
     bdir = os.path.join(CSRC, "build_prof" if profiling else "build")
     os.makedirs(bdir, exist_ok=True)
-    flags = FLAGS + (["-DSTORM_PROFILING"] if profiling else [])
+    # (STORM_EXTRA_DEFS: extra -D switches of one-off experiments, profiling build only)
+    flags = FLAGS + (["-DSTORM_PROFILING"] + os.environ.get("STORM_EXTRA_DEFS", "").split() if profiling else [])
 
     def compile_one(s):
         src, obj = os.path.join(CSRC, s + ".hip"), os.path.join(bdir, s + ".o")

@@ -75,8 +75,15 @@ __device__ inline float fast_silu(float y) { return y * hw_rcp(1.0f + hw_exp2(-1
 // the same on a channel pair: everything but the two transcendentals per element is a packed fp32 operation
 __device__ __forceinline__ f32x2 silu2(f32x2 y) {
     const f32x2 a = y * f32x2{-1.44269504088896341f, -1.44269504088896341f};
+#if defined(STORM_PROFILING) && defined(STORM_EXP_NOTRANS)
+    // experiment build (never the product): the same packed arithmetic WITHOUT the four transcendentals - what they cost inside
+    // the convolutions (profiles/r03_ubench.txt).  The result is not a SiLU.
+    const f32x2 d = a + f32x2{1.0f, 1.0f};
+    return y * d;
+#else
     const f32x2 d = f32x2{hw_exp2(a.x), hw_exp2(a.y)} + f32x2{1.0f, 1.0f};
     return y * f32x2{hw_rcp(d.x), hw_rcp(d.y)};
+#endif
 }
 
 __device__ __forceinline__ uint32_t pack2(float lo, float hi, bf16_t*) { return pack_bf16x2(lo, hi); }

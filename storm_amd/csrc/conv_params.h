@@ -40,8 +40,9 @@ __device__ __forceinline__ uint4 ld16(const void* base, uint32_t byte_off) {
 // y = act(x * scale + shift) on the 16-byte slot held in `v` (GroupNorm-apply + SiLU fused into the operand load: the
 // normalised tensor is never written to HBM).  ss = the slot's channels' scales in ss[0 .. PER16), shifts in ss[8 .. 8 + PER16)
 // (the table layout of storm_gn_finalize_ss), so channel pairs are adjacent registers and the affine, the exponent scaling,
-// the +1 and the final product are packed fp32 operations; the two transcendentals per element (v_exp_f32, v_rcp_f32:
-// quarter rate) are 70 % of what is left - this transform costs 11-30 % of a fused convolution's time.
+// the +1 and the final product are packed fp32 operations.  The transform costs 9-14 % of a fused convolution's time, and that is
+// the extra LDS pass, not this arithmetic: without the two transcendentals per element the kernels are 0-2 % faster
+// (profiles/r03_ubench.txt).
 __device__ __forceinline__ f32x2 gn_affine2(f32x2 x, const float (&ss)[16], int i) {
     return __builtin_elementwise_fma(x, f32x2{ss[2 * i], ss[2 * i + 1]}, f32x2{ss[8 + 2 * i], ss[8 + 2 * i + 1]});
 }
