@@ -125,6 +125,7 @@ def profile_ops(net, Y, nfe_count):
         for k in range(n):
             acc[k] += ms[k] / nfe_count
     rows = []
+    tname = {0: "float", 1: "storm::bf16_t", 2: "storm::half_t"}.get(code, "storm::bf16_t")
     for k in range(n):
         op = ops[k]
         row = dict(idx=k, code=int(op.code), ms=acc[k])
@@ -149,13 +150,13 @@ def profile_ops(net, Y, nfe_count):
             n_in = Bq * H * W * Cc
             n_out = n_in if rs == 0 else (2 * 4 * n_in if rs == 1 else 2 * n_in // 4)     # up / down: two output tensors
             row.update(algorithmic_bytes=(n_in + n_out) * esz, H=H, W=W, C=Cc, resample=rs,
-                       kernel="storm::gn_apply_kernel" if rs == 0 else f"storm::gn_apply_resample_kernel<{'up' if rs == 1 else 'down'}>")
+                       kernel=f"storm::gn_apply_kernel<{tname}, 0>" if rs == 0 else f"storm::gn_apply_{'up' if rs == 1 else 'down'}_kernel<{tname}>")
         elif op.code in (7, 8):                             # FIR x2 of the 8-channel pyramids
             Bq, H, W, Cc = [int(op.i[j]) for j in range(4)]
             esz = 4 if code == 0 else 2
             n_in = Bq * H * W * Cc
             row.update(algorithmic_bytes=(n_in + (4 * n_in if op.code == 7 else n_in // 4) + (4 * n_in if op.code == 7 else 0)) * esz,
-                       kernel="storm::fir_kernel<up>" if op.code == 7 else "storm::fir_kernel<down>")
+                       kernel=f"storm::fir_kernel<{tname}, {1 if op.code == 7 else 2}>")
         rows.append(row)
     return rows
 
@@ -329,9 +330,8 @@ def main():
             hb, hms = sum(r["algorithmic_bytes"] for r in hv), sum(r["ms"] for r in hv)
             htraffic = None
             if os.path.exists(tpath):
-                tkey = {"storm::gn_apply_resample_kernel<down>": "voidstorm::gn_apply_resample_kernel<storm::bf16_t,2>",
-                        "storm::gn_apply_resample_kernel<up>": "voidstorm::gn_apply_resample_kernel<storm::bf16_t,1>"}.get(hk)
-                htraffic = next((v.get("hbm_bytes_per_launch") for k, v in tj.items() if k.replace(" ", "") == tkey), None)
+                tkey = "void" + hk.replace(" ", "")                       # (rocprofv3 prints template kernels with their return type)
+                htraffic = next((v.get("hbm_bytes_per_launch") for k, v in tj.items() if k.replace(" ", "") in (tkey, tkey[4:])), None)
             result["roofline_hbm"] = {
                 "bound": "hbm", "kernel": hk, "achieved": hb / (hms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": hb / (hms * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": htraffic, "launches_per_nfe": len(hv),
