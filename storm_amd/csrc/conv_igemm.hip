@@ -688,7 +688,8 @@ static int dispatch_conv(const storm_conv_args& a, hipStream_t st) {
             case 8: return v2 ? launch_conv<T, 9, 2, 4, 2, true, false, 8>(a, st) : launch_conv<T, 9, 2, 2, 2, false, false, 8>(a, st);
             case 16: return v2 ? launch_conv<T, 9, 2, 4, 2, true, false, 16>(a, st) : launch_conv<T, 9, 2, 2, 2, false, false, 16>(a, st);
             case 32: return v2 ? launch_conv<T, 9, 2, 4, 2, true, false, 32>(a, st) : launch_conv<T, 9, 2, 2, 2, false, false, 32>(a, st);
-            case 64: return v2 ? launch_conv<T, 9, 2, 4, 2, true, false, 64>(a, st) : launch_conv<T, 9, 2, 2, 2, false, false, 64>(a, st);
+            case 64: return v2 ? launch_conv<T, 9, 2, 4, 2, true, false, 64>(a, st)
+                             : (switches().conv_dma ? launch_conv<T, 9, 2, 2, 2, false, true, 64>(a, st) : launch_conv<T, 9, 2, 2, 2, false, false, 64>(a, st));
             default: break;
         }
     }
