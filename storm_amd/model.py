@@ -357,8 +357,9 @@ class StochasticRegenerationModel(_Base):
                 sample, nfe = sampler()
             else:
                 sample = Y_denoised
-        if return_stft:                                     # (model.py:766-767)
-            return sample.squeeze(), Y.squeeze(), T_orig, float(peak[0])
+        if return_stft:                                     # (model.py:766-767; a batch gets every row's normalisation factor)
+            norm = float(peak[0]) if sample.shape[0] == 1 else peak.detach().reshape(-1).cpu()
+            return sample.squeeze(), Y.squeeze(), T_orig, norm
         x_hat = self.data_module.spec_to_wav(sample, T_orig, peak, lengths=lengths)
         return (x_hat, nfe) if return_nfe else x_hat
 
