@@ -34,6 +34,9 @@ template <> struct Mma<float> {
 __device__ __forceinline__ uint4 ld16(const void* base, uint32_t byte_off) {
     return *reinterpret_cast<const uint4*>(static_cast<const char*>(base) + byte_off);
 }
+__device__ __forceinline__ void st16(void* base, uint32_t byte_off, uint4 v) {
+    *reinterpret_cast<uint4*>(static_cast<char*>(base) + byte_off) = v;
+}
 
 
 

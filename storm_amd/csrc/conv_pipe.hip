@@ -595,14 +595,23 @@ void conv_pipe_kernel(const PipeParams a, const int n_ct, const int tiles_per_xc
         // left - the first pass's before the first staging write.  Fetched where they are used, every one of the 16 loads per tile
         // and wave exposed its full memory latency (measured on 256 -> 256 @ 256 x 512: 2.50 ms with a skip operand against 1.93 ms
         // without = 18 us per tile).
+        // The store loop in three instantiations, picked by uniform branches: a tile inside the image with all of its couts valid (no
+        // per-lane masks, no row / column tests, bf16 / fp16 output through base + 32-bit offset stores) with or without a skip
+        // operand, and the general one.  (One loop with the tests inside issued ~65 instructions per 8 pixels x 64 couts and wave,
+        // a third of them masks, branches and 64-bit address arithmetic - with all eight waves in their epilogues the matrix pipe idles.)
+        auto run_passes = [&](auto fast_, auto skipk_) {
+        constexpr bool FAST = decltype(fast_)::value;
+        constexpr int SKIPK = decltype(skipk_)::value;          // 1: skip operand, 0: none, -1: run-time
+        const bool skip_on = (SKIPK < 0 ? has_skip : SKIPK == 1) && !(ABL & 2048);
         uint4 skq[SROWS / RPI];
         auto skip_fetch = [&](int pass, int it) {
             const int gy = e_ty0 + wn * WN + pass;
             const uint32_t o_row = (uint32_t)(gy * imgW) * (uint32_t)outC;
-            skq[it] = (gy < imgH && gx0 + it * RPI < imgW && co_ok)
-                ? *reinterpret_cast<const uint4*>(skip_b + (o_row + (uint32_t)(it * RPI) * (uint32_t)outC + o_lane)) : make_uint4(0u, 0u, 0u, 0u);
+            const uint32_t o = o_row + (uint32_t)(it * RPI) * (uint32_t)outC + o_lane;
+            if (FAST) skq[it] = ld16(skip_b, o * (uint32_t)sizeof(T));
+            else skq[it] = (gy < imgH && gx0 + it * RPI < imgW && co_ok) ? *reinterpret_cast<const uint4*>(skip_b + o) : make_uint4(0u, 0u, 0u, 0u);
         };
-        if (has_skip && !(ABL & 2048)) {
+        if (skip_on) {
 #pragma unroll
             for (int it = 0; it < SROWS / RPI; ++it) skip_fetch(0, it);
         }
@@ -627,7 +636,7 @@ void conv_pipe_kernel(const PipeParams a, const int n_ct, const int tiles_per_xc
             // hand: `lane` is opaque to the compiler in this kernel, so the generic row / column arithmetic stayed 30 VALU
             // instructions per store - measured: 5.9 k of the epilogue's 12.1 k cycles per tile.)
             const int gy = e_ty0 + wn * WN + pass;
-            if (gy < imgH) {
+            if (FAST || gy < imgH) {
                 const uint32_t o_row = (uint32_t)(gy * imgW) * (uint32_t)outC;                    // (uniform)
 #pragma unroll
                 for (int it = 0; it < SROWS / RPI; ++it) {
@@ -636,10 +645,10 @@ void conv_pipe_kernel(const PipeParams a, const int n_ct, const int tiles_per_xc
                     const float4 v1 = *reinterpret_cast<const float4*>(sp + srow[it & 1][1]);
                     f32x2 v2[4] = {f32x2{v0.x, v0.y}, f32x2{v0.z, v0.w}, f32x2{v1.x, v1.y}, f32x2{v1.z, v1.w}};
                     const uint4 skv = skq[it];
-                    if (has_skip && !(ABL & 2048) && pass + 1 < WN / PR) skip_fetch(pass + 1, it);
-                    if (gx0 + it * RPI < imgW && co_ok && !(ABL & 2048)) {
+                    if (skip_on && pass + 1 < WN / PR) skip_fetch(pass + 1, it);
+                    if (FAST || (gx0 + it * RPI < imgW && co_ok && !(ABL & 2048))) {
                         const uint32_t o = o_row + (uint32_t)(it * RPI) * (uint32_t)outC + o_lane;
-                        if (has_skip) {
+                        if (skip_on) {
                             alignas(16) T sk[8];
                             *reinterpret_cast<uint4*>(sk) = skv;
 #pragma unroll
@@ -652,7 +661,11 @@ void conv_pipe_kernel(const PipeParams a, const int n_ct, const int tiles_per_xc
                             gsq2[i] = __builtin_elementwise_fma(v2[i], v2[i], gsq2[i]);
                         }
                         const float v[8] = {v2[0].x, v2[0].y, v2[1].x, v2[1].y, v2[2].x, v2[2].y, v2[3].x, v2[3].y};
-                        if (out_f32) store8(reinterpret_cast<float*>(out_b) + o, v);
+                        if (FAST) {
+                            st16(out_b, o * (uint32_t)sizeof(T), make_uint4(pack2(v[0], v[1], (T*)nullptr), pack2(v[2], v[3], (T*)nullptr),
+                                                                            pack2(v[4], v[5], (T*)nullptr), pack2(v[6], v[7], (T*)nullptr)));
+                        }
+                        else if (out_f32) store8(reinterpret_cast<float*>(out_b) + o, v);
                         else if (ABL & 4096) {                       // (profiling A/B: non-temporal output stores)
                             uint32_t w4[4];
 #pragma unroll
@@ -671,6 +684,13 @@ void conv_pipe_kernel(const PipeParams a, const int n_ct, const int tiles_per_xc
                 }
             }
         }
+        };
+        const bool interior = e_ty0 + TH <= imgH && e_tx0 + TILE_W <= imgW && e_cout0 + BN <= outC && !out_f32 &&
+                              !(ABL & (2048 | 4096 | 8192));
+        if (interior) {
+            if (has_skip) run_passes(std::true_type{}, IC<1>{});
+            else run_passes(std::true_type{}, IC<0>{});
+        } else run_passes(std::false_type{}, IC<-1>{});
         if (first) stamp(502);
 #pragma unroll
         for (int i = 0; i < 4; ++i) { gsum[2 * i] = gsum2[i].x; gsum[2 * i + 1] = gsum2[i].y; gsq[2 * i] = gsq2[i].x; gsq[2 * i + 1] = gsq2[i].y; }
