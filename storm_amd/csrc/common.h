@@ -88,6 +88,12 @@ __device__ __forceinline__ f32x2 silu2(f32x2 y) {
 
 __device__ __forceinline__ uint32_t pack2(float lo, float hi, bf16_t*) { return pack_bf16x2(lo, hi); }
 __device__ __forceinline__ uint32_t pack2(float lo, float hi, half_t*) { return pack_f16x2(lo, hi); }
+// eight values as one 16-byte vector of T (16-bit T only; the fp32 instantiation exists for generic code that never stores it)
+template <typename T> __device__ __forceinline__ uint4 pack8(const float (&v)[8]) {
+    if constexpr (sizeof(T) == 2) return make_uint4(pack2(v[0], v[1], (T*)nullptr), pack2(v[2], v[3], (T*)nullptr),
+                                                    pack2(v[4], v[5], (T*)nullptr), pack2(v[6], v[7], (T*)nullptr));
+    else return make_uint4(0u, 0u, 0u, 0u);
+}
 __device__ __forceinline__ uint32_t tap_weight_bits(float w, bf16_t*) { return f32_to_bf16_bits(w); }   // (exact for the FIR taps)
 __device__ __forceinline__ uint32_t tap_weight_bits(float w, half_t*) { return f32_to_f16_bits(w); }
 

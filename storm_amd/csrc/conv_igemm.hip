@@ -478,14 +478,22 @@ __device__ __forceinline__ void conv_tile(const ConvParams& a, const int vblock,
     };
     // skip operands are fetched ONE PASS ahead, each into the registers its predecessor (same iteration, previous pass) has just
     // left; the first pass's before the first staging write (fetched where it is used, every load exposed its memory latency)
+    // The store loop comes in three instantiations picked by uniform branches: a tile inside the image with all of its couts valid
+    // and a 16-bit output (no per-lane masks or range tests, stores through base + 32-bit offset) with / without a skip operand,
+    // and the general one.  With one wave per SIMD a workgroup issues a VALU instruction only every other slot
+    // (tools/ubench/valu_rate), so the epilogue of this kernel is bound by its instruction count.
     constexpr int NIT = SROWS / RPI;
+    auto run_passes = [&](auto fast_, auto skipk_) {
+    constexpr bool FAST = decltype(fast_)::value;
+    constexpr int SKIPK = decltype(skipk_)::value;          // 1: skip operand, 0: none, -1: run-time
+    const bool skip_on = SKIPK < 0 ? has_skip : SKIPK == 1;
     Raw8<T> skq[NIT];
     auto skip_fetch = [&](int pass, int it) {
         bool ok; uint32_t o;
         locate(pass, it, ok, o);
-        if (ok && co_ok) fetch8(skip_b + o, skq[it]);
+        if (FAST || (ok && co_ok)) fetch8(skip_b + o, skq[it]);
     };
-    if (has_skip) {
+    if (skip_on) {
 #pragma unroll
         for (int it = 0; it < NIT; ++it) skip_fetch(0, it);
     }
@@ -526,9 +534,9 @@ __device__ __forceinline__ void conv_tile(const ConvParams& a, const int vblock,
             }
             f32x2 v2[4] = {f32x2{v0.x, v0.y}, f32x2{v0.z, v0.w}, f32x2{v1.x, v1.y}, f32x2{v1.z, v1.w}};
             const Raw8<T> skv = skq[it];
-            if (has_skip && pass + 1 < WN / PR) skip_fetch(pass + 1, it);
-            if (ok && co_ok) {
-                if (has_skip) {
+            if (skip_on && pass + 1 < WN / PR) skip_fetch(pass + 1, it);
+            if (FAST || (ok && co_ok)) {
+                if (skip_on) {
                     float sk[8];
                     unpack8(skv, sk);
 #pragma unroll
@@ -541,11 +549,22 @@ __device__ __forceinline__ void conv_tile(const ConvParams& a, const int vblock,
                     gsq2[i] = __builtin_elementwise_fma(v2[i], v2[i], gsq2[i]);
                 }
                 const float v[8] = {v2[0].x, v2[0].y, v2[1].x, v2[1].y, v2[2].x, v2[2].y, v2[3].x, v2[3].y};
-                if (out_f32) store8(reinterpret_cast<float*>(out_b) + o, v);
+                if constexpr (FAST && sizeof(T) == 2) {
+                    st16(out_b, o * 2u, pack8<T>(v));
+                }
+                else if (out_f32) store8(reinterpret_cast<float*>(out_b) + o, v);
                 else store8(reinterpret_cast<T*>(out_b) + o, v);
             }
         }
     }
+    };
+    bool interior = sizeof(T) == 2 && !out_f32 && cout0 + BN <= outC;
+    if (TAPS == 9) interior = interior && ty0 + TILE_H <= imgH && tx0 + TILE_W <= imgW;
+    else interior = interior && lin0 + TILE_H * TILE_W <= npix;
+    if (interior) {
+        if (has_skip) run_passes(std::true_type{}, std::integral_constant<int, 1>{});
+        else run_passes(std::true_type{}, std::integral_constant<int, 0>{});
+    } else run_passes(std::false_type{}, std::integral_constant<int, -1>{});
     stamp(502);
     if (ABL & 64) { vm_wait<0>(); stamp(503); }
 #pragma unroll
