@@ -252,7 +252,7 @@ __device__ __forceinline__ void conv_tile(const ConvParams& a, const int vblock,
         }
         dma16(c.tsrd, (uint32_t)lane * 16u, 0u, smem + Cfg::OFF_SS, lane);
     };
-    auto patch_fixup = [&](const Chunk& c, char* dst) {          // fused GroupNorm-apply (+ SiLU), in place, own units
+    auto patch_fixup_t = [&](char* dst, auto silu_) {           // fused GroupNorm-apply (+ SiLU), in place, own units
 #pragma unroll
         for (int i = 0; i < Cfg::PUD; ++i) {
             const int k = wave_u + i * Cfg::NWAVES;
@@ -262,9 +262,12 @@ __device__ __forceinline__ void conv_tile(const ConvParams& a, const int vblock,
                 uint4* const q = reinterpret_cast<uint4*>(dst + k * 1024 + lane * 16);
                 float ss[16];
                 load_ss<PER16>(reinterpret_cast<const float*>(smem + Cfg::OFF_SS), slot, ss);
-                *q = gn_act_slot(*q, ss, c.gn_silu, (T*)nullptr);
+                *q = gn_act_slot_t<decltype(silu_)::value>(*q, ss, (T*)nullptr);
             }
         }
+    };
+    auto patch_fixup = [&](const Chunk& c, char* dst) {          // (one uniform branch per patch, not a select per channel pair)
+        if (c.gn_silu) patch_fixup_t(dst, std::true_type{}); else patch_fixup_t(dst, std::false_type{});
     };
 
     // per-lane fragment offsets: weights rows of mi are +32 rows (same swizzle) -> one VGPR + immediates; k-group j

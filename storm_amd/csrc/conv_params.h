@@ -78,6 +78,25 @@ __device__ __forceinline__ uint4 gn_act_slot(uint4 v, const float (&ss)[16], int
     }
     return make_uint4(__float_as_uint(x[0]), __float_as_uint(x[1]), __float_as_uint(x[2]), __float_as_uint(x[3]));
 }
+// the same with the activation as a compile-time choice: callers that branch ONCE per patch (uniformly) instead of selecting per
+// channel pair (as a run-time flag the compiler if-converts the SiLU: both results computed, eight v_cndmask per slot)
+template <bool SILU, typename T>
+__device__ __forceinline__ uint4 gn_act_slot_t(uint4 v, const float (&ss)[16], T* tag) {
+    if constexpr (sizeof(T) == 4) return gn_act_slot(v, ss, SILU ? 1 : 0, tag);
+    else {
+        uint32_t w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            f32x2 x;
+            if constexpr (Elem<T>::DT == STORM_BF16) x = f32x2{__uint_as_float(w[i] << 16), __uint_as_float(w[i] & 0xffff0000u)};
+            else x = f32x2{f16_bits_to_f32((uint16_t)(w[i] & 0xffffu)), f16_bits_to_f32((uint16_t)(w[i] >> 16))};
+            f32x2 y = gn_affine2(x, ss, i);
+            if (SILU) y = silu2(y);
+            w[i] = pack2(y.x, y.y, (T*)nullptr);
+        }
+        return make_uint4(w[0], w[1], w[2], w[3]);
+    }
+}
 // The PER16 scales / shifts of 16-byte slot `slot` of a chunk from its (scale, shift) table (global memory or its LDS image):
 // 16-bit operands: slot = one channel octet = 16 consecutive floats; fp32: half an octet.
 template <int PER16>
