@@ -75,7 +75,8 @@ STORM_HD int p_swz(int px, int slot) { return (slot ^ ((px >> 2) & 3)) << 4; }
 }  // namespace pipe128
 using namespace pipe128;
 
-template <typename T>
+// TRACE: profiling-only instantiation (libstorm_hip_prof.so, STORM_CONV_ABLATE=64): per-tile wave stamps for tools/pipe128_trace.py
+template <typename T, bool TRACE = false>
 __global__ __launch_bounds__(pipe128::THREADS, 2)
 void conv_pipe128_kernel(const PipeParams a, const int n_ct, const int tiles_per_xcd,
                          const int ntiles, const int tiles_x, const int tiles_per_img, const int total_vblocks) {
@@ -108,6 +109,16 @@ void conv_pipe128_kernel(const PipeParams a, const int n_ct, const int tiles_per
     const int wm = wave % WAVES_M, wn = wave / WAVES_M;
     const int grp = wave >> 2;                              // 0: leading (pixel rows 0-7), 1: lagging (rows 8-15), one interval behind
     const int lw = wave & 3;
+    unsigned long long* const trace_rec = TRACE && ap->trace ? ap->trace + ((long long)blockIdx.x * NWAVES + wave) * TRACE_SLOTS : nullptr;
+    int tstamp = 8;                                         // (profiling) next stamp slot: six per tile from slot 8
+    auto stamp = [&]() {
+        if (TRACE && trace_rec && tstamp < TRACE_SLOTS) {
+            const unsigned long long t = hw_memtime();
+            if ((threadIdx.x & 63) == 0) trace_rec[tstamp] = t;
+            ++tstamp;
+        }
+    };
+    if (TRACE && trace_rec && (threadIdx.x & 63) == 0) trace_rec[0] = hw_ids();
 
     f32x16 acc[WM][WN];
 
@@ -350,6 +361,7 @@ void conv_pipe128_kernel(const PipeParams a, const int n_ct, const int tiles_per
         // ---- tile start, part B: chunk 1 -> buffer 1 (after the previous tile's epilogue: it staged there); chunk 0 has landed;
         // fused GroupNorm transform of chunk 0 -------------------------------------------------------------------------
         STORM_RELAUNDER();
+        stamp();                                            // 0: tile start (part B)
         load_next(1);
         if (grp == 1) {
             issue_table(1);
@@ -365,6 +377,7 @@ void conv_pipe128_kernel(const PipeParams a, const int n_ct, const int tiles_per
         }
         load_next(2);
         raw_barrier();
+        stamp();                                            // 1: chunk 0 landed and transformed, main loop begins
         read_frags(fa0, fb0, 0, pbase[0], IC<0>{}, IC<0>{}, Prow9{});   // first k-group of phase 0
         if (grp == 1) raw_barrier();                        // the lagging group starts one interval later
 #pragma unroll
@@ -385,6 +398,7 @@ void conv_pipe128_kernel(const PipeParams a, const int n_ct, const int tiles_per
             chunk_change(ci);
         }
         if (grp == 0) raw_barrier();                        // balance the stagger: every wave has executed the same barriers
+        stamp();                                            // 2: main loop done
 
         // ---- hand-over: this tile's coordinates go to the epilogue; the next tile's first loads are issued -----------------
         vm_wait<0>();                                       // trailing (zero-fill) patch / ring loads landed ...
@@ -408,6 +422,7 @@ void conv_pipe128_kernel(const PipeParams a, const int n_ct, const int tiles_per
             tile_issue();
         }
         STORM_RELAUNDER();
+        stamp();                                            // 3: hand-over done (drain, barrier, next tile's first loads issued)
 
         // ---- epilogue: LDS transpose -> (bias, temb bias, skip, scale) -> wide stores (as conv_pipe.hip).  Staging lives in patch
         // buffers 1 and 2, the statistics scratch in ring slots 2, 3: the next tile's first loads are landing in buffer 0 /
@@ -517,6 +532,7 @@ void conv_pipe128_kernel(const PipeParams a, const int n_ct, const int tiles_per
                 }
             }
         }
+        stamp();                                            // 4: epilogue stores issued
 #pragma unroll
         for (int i = 0; i < 4; ++i) { gsum[2 * i] = gsum2[i].x; gsum[2 * i + 1] = gsum2[i].y; gsq[2 * i] = gsq2[i].x; gsq[2 * i + 1] = gsq2[i].y; }
         if (ap->gn_part != nullptr) {
@@ -549,6 +565,7 @@ void conv_pipe128_kernel(const PipeParams a, const int n_ct, const int tiles_per
                 dst[0] = s0; dst[1] = s1;
             }
         }
+        stamp();                                            // 5: statistics written
         if (!has_next) break;
         __syncthreads();                                    // the statistics scratch / staging of this tile is free again
     }
@@ -563,9 +580,9 @@ bool conv_pipe128_supports(const storm_conv_args& a) {
     return build_pipe_params(a, p, pipe128::KC);
 }
 
-template <typename T>
+template <typename T, bool TRACE = false>
 static int launch_pipe128(const storm_conv_args& a, hipStream_t st) {
-    auto kern = conv_pipe128_kernel<T>;
+    auto kern = conv_pipe128_kernel<T, TRACE>;
     static bool attr_set = false;                       // per instantiation; benign race (idempotent)
     if (!attr_set) {
         STORM_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, pipe128::LDS_BYTES));
@@ -573,6 +590,7 @@ static int launch_pipe128(const storm_conv_args& a, hipStream_t st) {
     }
     PipeParams prm;
     STORM_CHECK(a.outC <= pipe128::BN && build_pipe_params(a, prm, pipe128::KC), "storm_conv: convolution outside the 128-cout pipelined kernel's coverage");
+    if (TRACE) prm.trace = reinterpret_cast<unsigned long long*>(switches().conv_trace_ptr);
     const int tiles_x = cdiv(a.W, TILE_W);
     const int tiles_per_img = tiles_x * cdiv(a.H, pipe128::TH);
     const long long ntiles = (long long)a.B * tiles_per_img;
@@ -589,6 +607,9 @@ static int launch_pipe128(const storm_conv_args& a, hipStream_t st) {
 }
 
 int launch_conv_pipe128(const storm_conv_args& a, hipStream_t st) {
+#if defined(STORM_PROFILING)
+    if (switches().conv_ablate == 64 && a.dtype == STORM_BF16) return launch_pipe128<bf16_t, true>(a, st);
+#endif
     return a.dtype == STORM_F16 ? launch_pipe128<half_t>(a, st) : launch_pipe128<bf16_t>(a, st);
 }
 
