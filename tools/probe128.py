@@ -17,6 +17,7 @@ p.add_argument("--reps", type=int, default=5)
 p.add_argument("--B", type=int, default=16)
 p.add_argument("--nogn", action="store_true", help="plain operand: no fused GroupNorm-apply + SiLU on the load")
 p.add_argument("--nosilu", action="store_true", help="fused GroupNorm affine without the SiLU (what the transcendentals cost)")
+p.add_argument("--nostats", action="store_true", help="no fused GroupNorm statistics in the epilogue (what they cost)")
 p.add_argument("--only", type=int, default=-1)
 p.add_argument("--modes", default="", help="comma list of kernels to time (default: all)")
 args = p.parse_args()
@@ -41,7 +42,7 @@ for ci_, case in enumerate(CASES):
     w = ops.pack_conv_weight((rnd(cout, cin, 3, 3) * 0.05).to(dev), dt)
     ss = ops.pack_gn_ss(1 + 0.1 * rnd(B, cin), 0.1 * rnd(B, cin)).to(dev)
     segs = [ops.Seg(x, w, 9, gn_ss=None if args.nogn else ss, gn_silu=not args.nosilu)]
-    kw = dict(bias=rnd(cout).to(dev), tbias=rnd(B, cout).to(dev), gn_partials=True, scale=0.7)
+    kw = dict(bias=rnd(cout).to(dev), tbias=rnd(B, cout).to(dev), gn_partials=not args.nostats, scale=0.7)
     if sc:
         segs.append(ops.Seg(rnd(B, H, W, sc).to(dt).to(dev), ops.pack_conv_weight((rnd(cout, sc, 1, 1) * 0.05).to(dev), dt), 1))
     fl = 2 * B * H * W * cout * (cin * 9 + sc)
@@ -55,12 +56,13 @@ for ci_, case in enumerate(CASES):
     for sw, variant in MODES.items():
         L.check(lib.storm_set_switch(b"STORM_CONV_VARIANT", variant), "storm_set_switch")
         kn = ops.conv_kernel_name(segs, cout, bias=kw["bias"], tbias=kw["tbias"], scale=0.7)
+        unpack = (lambda r: r) if not args.nostats else (lambda r: (r, torch.zeros(1)))
         for _ in range(2):
-            y, part = ops.conv(segs, cout, **kw)
+            y, part = unpack(ops.conv(segs, cout, **kw))
         e0, e1 = ev(), ev()
         e0.record()
         for _ in range(args.reps):
-            y, part = ops.conv(segs, cout, **kw)
+            y, part = unpack(ops.conv(segs, cout, **kw))
         e1.record()
         torch.cuda.synchronize()
         ms = e0.elapsed_time(e1) / args.reps
