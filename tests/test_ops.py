@@ -202,6 +202,23 @@ def test_conv_narrow_output_kernel(dev, dtype, case, switch):
     assert rel_l2(yc, nchw(y_generic.float().cpu())) < 4e-3
 
 
+@pytest.mark.parametrize("shape", [(1, 1, 1, 128, 4), (2, 3, 5, 128, 1), (1, 2, 70, 256, 3), (1, 41, 3, 128, 4)])
+def test_conv_narrow_output_kernel_degenerate_images(dev, shape):
+    """conv_narrow.hip on images smaller than its 20 x 32-pixel tile in one or both directions (one pixel; one row band; one column
+    band), 1 / 3 / 4 output planes: every region fragment is mostly padding."""
+    from storm_amd import ops
+    B, H, W, C, Cout = shape
+    g = torch.Generator().manual_seed(3)
+    x = torch.randn(B, C, H, W, generator=g)
+    w = torch.randn(Cout, C, 3, 3, generator=g) * 0.05
+    b = torch.randn(Cout, generator=g)
+    segs = [ops.Seg(nhwc(x).to(torch.bfloat16).to(dev), ops.pack_conv_weight(w.to(dev), torch.bfloat16), 9)]
+    assert ops.conv_kernel_name(segs, Cout, bias=b.to(dev), outC=8).startswith("storm::conv_narrow_kernel")
+    y = nchw(ops.conv(segs, Cout, bias=b.to(dev), outC=8).float().cpu())
+    assert rel_l2(y[:, :Cout], F.conv2d(q(x, torch.bfloat16), q(w, torch.bfloat16), b, padding=1)) < 6e-3
+    assert float(y[:, Cout:].abs().max()) == 0.0
+
+
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
 @pytest.mark.parametrize("case", ["stem", "stem_ragged", "combine", "combine_ragged"])
 def test_conv_thin_input_kernel(dev, dtype, case, switch):
