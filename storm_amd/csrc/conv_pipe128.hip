@@ -614,7 +614,7 @@ int launch_conv_pipe128(const storm_conv_args& a, hipStream_t st) {
 }
 
 const char* conv_pipe128_kernel_name(int dtype) {
-    return dtype == STORM_F16 ? "storm::conv_pipe128_kernel<storm::half_t>" : "storm::conv_pipe128_kernel<storm::bf16_t>";
+    return dtype == STORM_F16 ? "storm::conv_pipe128_kernel<storm::half_t, false>" : "storm::conv_pipe128_kernel<storm::bf16_t, false>";
 }
 
 }  // namespace storm
