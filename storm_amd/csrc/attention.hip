@@ -141,10 +141,12 @@ void attention_kernel(const T* __restrict__ q, const T* __restrict__ k, const T*
         ps += __shfl_xor(ps, 32, 64);
         l_run = l_run * alpha + ps;
         m_run = m_new;
+        if (wave_any(alpha != 1.0f)) {               // after the first tiles the running maxima rarely move: 16 CT multiplications saved
 #pragma unroll
-        for (int t = 0; t < CT; ++t)
+            for (int t = 0; t < CT; ++t)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) o[t][r] *= alpha;
+                for (int r = 0; r < 16; ++r) o[t][r] *= alpha;
+        }
         // ---- O^T += V^T P^T: two k-groups of 16 keys, slot (h, e) <-> key 16 m + 4 h + (e & 3) + 8 (e >> 2) ---------------
 #pragma unroll
         for (int mk = 0; mk < 2; ++mk) {
@@ -258,10 +260,12 @@ void attention_f32_kernel(const float* __restrict__ q, const float* __restrict__
         ps += __shfl_xor(ps, 32, 64);
         l_run = l_run * alpha + ps;
         m_run = m_new;
+        if (wave_any(alpha != 1.0f)) {               // after the first tiles the running maxima rarely move: 16 CT multiplications saved
 #pragma unroll
-        for (int t = 0; t < CT; ++t)
+            for (int t = 0; t < CT; ++t)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) o[t][r] *= alpha;
+                for (int r = 0; r < 16; ++r) o[t][r] *= alpha;
+        }
 #pragma unroll
         for (int r = 0; r < 16; ++r) {                  // MFMA r contracts over the two keys acc_row(h = 0, r), acc_row(h = 1, r)
             const int key = cidx::acc_row(lane, r);

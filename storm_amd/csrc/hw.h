@@ -42,6 +42,8 @@ __device__ inline void wave_sync() {
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
+// wave vote: true in every lane if the predicate holds in any lane
+__device__ __forceinline__ bool wave_any(bool p) { return __builtin_amdgcn_ballot_w64(p) != 0ull; }
 
 // ---- opaque values: what the optimiser must not look through ------------------------------------------------------------
 // keep a wave-uniform value in an SGPR (stops re-materialisation from the kernarg segment inside a loop)
@@ -150,6 +152,11 @@ __device__ __forceinline__ u32x4 make_srd(const void* base, uint32_t bytes) {
 }
 #if defined(STORM_HOST_SIM)
 __device__ inline void wave_sync() { simrt::wave_rendezvous(); }
+__device__ inline bool wave_any(bool p) {
+    int in = p ? 1 : 0, out = 0;
+    simrt::wave_collective(&in, &out, sizeof(out), &simrt::any_fn, 0);
+    return out != 0;
+}
 __device__ __forceinline__ void dma16(u32x4 srd, uint32_t voff, uint32_t soff, char* lds_wave, int lane) {
     const uint64_t off = (uint64_t)voff + soff;
     const char* base = reinterpret_cast<const char*>(((uint64_t)srd[1] << 32) | srd[0]);
@@ -165,6 +172,7 @@ template <int N> __device__ __forceinline__ void vm_wait() {
 }
 #else
 __device__ inline void wave_sync() {}
+__device__ inline bool wave_any(bool p) { return p; }
 __device__ __forceinline__ void dma16(u32x4, uint32_t, uint32_t, char*, int) {}
 template <int N> __device__ __forceinline__ void vm_wait() {}
 #endif

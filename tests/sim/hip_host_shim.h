@@ -79,6 +79,13 @@ template <typename V> inline void shfl_xor_fn(const void* const* in, char (*out)
     }
 }
 }  // namespace simrt
+namespace simrt {
+inline void any_fn(const void* const* in, char (*out)[64], int nlanes, long long) {      // wave vote: OR over the lanes
+    int any = 0;
+    for (int l = 0; l < nlanes; ++l) any |= *static_cast<const int*>(in[l]);
+    for (int l = 0; l < nlanes; ++l) memcpy(out[l], &any, sizeof(any));
+}
+}  // namespace simrt
 template <typename V> inline V __shfl_xor(V v, int mask, int width = 64) {
     (void)width;
     V r;
