@@ -125,19 +125,24 @@ void attention_kernel(const T* __restrict__ q, const T* __restrict__ k, const T*
         }
         // ---- online softmax over this lane's 16 keys + its partner's 16 ------------------------------------------------
         float mx = -INFINITY;
+        if (j0 + BK <= L) {                               // (uniform) a full key tile: no masking
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int key = j0 + cidx::acc_row(lane, r);
-            s[r] = key < L ? s[r] * scale_log2e : -INFINITY;
-            mx = fmaxf(mx, s[r]);
+            for (int r = 0; r < 16; ++r) { s[r] *= scale_log2e; mx = fmaxf(mx, s[r]); }
+        } else {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int key = j0 + cidx::acc_row(lane, r);
+                s[r] = key < L ? s[r] * scale_log2e : -INFINITY;
+                mx = fmaxf(mx, s[r]);
+            }
         }
         mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
         const float m_new = fmaxf(m_run, mx);
-        const float alpha = exp2f(m_run - m_new);                    // (first tile: exp2(-inf) = 0 on a zero accumulator)
+        const float alpha = hw_exp2(m_run - m_new);                    // (first tile: exp2(-inf) = 0 on a zero accumulator)
         float ps = 0.f;
         float p[16];
 #pragma unroll
-        for (int r = 0; r < 16; ++r) { p[r] = exp2f(s[r] - m_new); ps += p[r]; }
+        for (int r = 0; r < 16; ++r) { p[r] = hw_exp2(s[r] - m_new); ps += p[r]; }
         ps += __shfl_xor(ps, 32, 64);
         l_run = l_run * alpha + ps;
         m_run = m_new;
@@ -245,18 +250,23 @@ void attention_f32_kernel(const float* __restrict__ q, const float* __restrict__
 #pragma unroll
         for (int g = 0; g < C / 2; ++g) s = __builtin_amdgcn_mfma_f32_32x32x2f32(kt[2 * g + h], qf[g], s, 0, 0, 0);
         float mx = -INFINITY;
+        if (j0 + BK <= L) {                               // (uniform) a full key tile: no masking
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int key = j0 + cidx::acc_row(lane, r);
-            s[r] = key < L ? s[r] * scale_log2e : -INFINITY;
-            mx = fmaxf(mx, s[r]);
+            for (int r = 0; r < 16; ++r) { s[r] *= scale_log2e; mx = fmaxf(mx, s[r]); }
+        } else {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int key = j0 + cidx::acc_row(lane, r);
+                s[r] = key < L ? s[r] * scale_log2e : -INFINITY;
+                mx = fmaxf(mx, s[r]);
+            }
         }
         mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
         const float m_new = fmaxf(m_run, mx);
-        const float alpha = exp2f(m_run - m_new);
+        const float alpha = hw_exp2(m_run - m_new);
         float ps = 0.f, p[16];
 #pragma unroll
-        for (int r = 0; r < 16; ++r) { p[r] = exp2f(s[r] - m_new); ps += p[r]; }
+        for (int r = 0; r < 16; ++r) { p[r] = hw_exp2(s[r] - m_new); ps += p[r]; }
         ps += __shfl_xor(ps, 32, 64);
         l_run = l_run * alpha + ps;
         m_run = m_new;
