@@ -94,10 +94,20 @@ void gn_finalize_kernel(const float* __restrict__ pa, int Ca, int tiles_a, const
         const int w = hi - lo;
         if (p == nullptr || w <= 0) continue;
         const float2* q = reinterpret_cast<const float2*>(p) + (long long)b * nt * Cs + lo;
-        for (int i = tid; i < nt * w; i += 256) {
-            const int t = i / w, k = i - t * w;
-            const float2 v = q[(long long)t * Cs + k];
-            s0 += (double)v.x; s1 += (double)v.y;
+        // (tile, channel) pairs tid, tid + 256, ...: ONE division per thread, then (t, k) advance by (256 / w, 256 % w) with a carry
+        const int dt = 256 / w, dk = 256 - dt * w;
+        int t = tid / w, k = tid - t * w;
+        const int n = nt * w;
+        for (int i = tid; i < n; i += 256 * 8) {          // eight loads in flight per thread (one at a time, the loop was a chain of round trips)
+            float2 v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                v[u] = (i + 256 * u < n) ? q[(long long)t * Cs + k] : make_float2(0.f, 0.f);
+                t += dt; k += dk;
+                if (k >= w) { k -= w; ++t; }
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) { s0 += (double)v[u].x; s1 += (double)v[u].y; }
         }
     }
     s0 = wave_sum_d(s0); s1 = wave_sum_d(s1);
