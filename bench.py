@@ -150,7 +150,8 @@ def profile_ops(net, Y, nfe_count):
             n_in = Bq * H * W * Cc
             n_out = n_in if rs == 0 else (2 * 4 * n_in if rs == 1 else 2 * n_in // 4)     # up / down: two output tensors
             row.update(algorithmic_bytes=(n_in + n_out) * esz, H=H, W=W, C=Cc, resample=rs,
-                       kernel=f"storm::gn_apply_kernel<{tname}, 0>" if rs == 0 else f"storm::gn_apply_{'up' if rs == 1 else 'down'}_kernel<{tname}>")
+                       kernel=f"storm::gn_apply_kernel<{tname}, 0>" if rs == 0 else
+                       f"storm::gn_apply_{'up' if rs == 1 else 'down'}_kernel<{tname}, {'true' if int(op.i[6]) else 'false'}>")
         elif op.code in (7, 8):                             # FIR x2 of the 8-channel pyramids
             Bq, H, W, Cc = [int(op.i[j]) for j in range(4)]
             esz = 4 if code == 0 else 2

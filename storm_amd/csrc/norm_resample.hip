@@ -227,12 +227,13 @@ __global__ void gn_apply_kernel(const T* __restrict__ xa, int Ca, const T* __res
 // barriers per 32 output pixels; git show 9dfa6dc:storm_amd/csrc/norm_resample.hip) ran at 1.7 TB/s with its waves parked half
 // of the time (profiles/r03a_pmc_summary.txt); this one measures 2.8 TB/s.
 constexpr int DN_COLS = 32, DN_ROWS = 16;           // output columns per workgroup / output rows per strip
-template <typename T>
+// SILU: the activation as a compile-time choice (as a run-time flag it is if-converted: both results computed, a select per value)
+template <typename T, bool SILU>
 __global__ __launch_bounds__(256)
 void gn_apply_down_kernel(const T* __restrict__ xa, int Ca, const T* __restrict__ xb, int Cb,
                           int H, int W, int G, const double* __restrict__ stats,
                           const float* __restrict__ gamma, const float* __restrict__ beta, float eps,
-                          int silu, T* __restrict__ out_act, T* __restrict__ out_raw, int ncg, int nstrips) {
+                          T* __restrict__ out_act, T* __restrict__ out_raw, int ncg, int nstrips) {
     constexpr int PER16 = Elem<T>::PER16;
     constexpr int CG = 8 * PER16;                   // channels per workgroup
     __shared__ float gtab[2 * CG];
@@ -293,7 +294,7 @@ void gn_apply_down_kernel(const T* __restrict__ xa, int Ca, const T* __restrict_
 #pragma unroll
                     for (int e = 0; e < PER16; e += 2) {
                         f32x2 y = __builtin_elementwise_fma(f32x2{to_f32(raw[e]), to_f32(raw[e + 1])}, f32x2{pa[e], pa[e + 1]}, f32x2{pb[e], pb[e + 1]});
-                        if (silu) y = silu2(y);
+                        if (SILU) y = silu2(y);
                         aw[e / 2] = pack2(y.x, y.y, (T*)nullptr);
                     }
                 }
@@ -312,7 +313,7 @@ void gn_apply_down_kernel(const T* __restrict__ xa, int Ca, const T* __restrict_
                     float y = 0.f;
                     if (x_in[j]) {
                         y = fmaf(xr, pa[e], pb[e]);
-                        if (silu) y = silu_f(y);
+                        if (SILU) y = silu_f(y);
                         T ya; from_f32(ya, y); y = to_f32(ya);      // (the activated tensor is rounded to T before it is filtered)
                     }
                     hA[e] = fmaf(wgt, y, hA[e]); hR[e] = fmaf(wgt, xr, hR[e]);
@@ -365,12 +366,12 @@ void gn_apply_down_kernel(const T* __restrict__ xa, int Ca, const T* __restrict_
 // 2 i + 2.  The kernel is bound by its stores (two tensors of four times the input size: 8 x 16 B per thread and input row):
 // 4.1 TB/s, exactly what the LDS-tiled predecessor reached - a write-dominated stream does not get the copy rate on this part.
 constexpr int UP_COLS = 32, UP_ROWS = 16;           // input columns per workgroup / input rows per strip
-template <typename T>
+template <typename T, bool SILU>
 __global__ __launch_bounds__(256)
 void gn_apply_up_kernel(const T* __restrict__ xa, int Ca, const T* __restrict__ xb, int Cb,
                         int H, int W, int G, const double* __restrict__ stats,
                         const float* __restrict__ gamma, const float* __restrict__ beta, float eps,
-                        int silu, T* __restrict__ out_act, T* __restrict__ out_raw, int ncg, int nstrips) {
+                        T* __restrict__ out_act, T* __restrict__ out_raw, int ncg, int nstrips) {
     constexpr int PER16 = Elem<T>::PER16;
     constexpr int CG = 8 * PER16;
     __shared__ float gtab[2 * CG];
@@ -430,7 +431,7 @@ void gn_apply_up_kernel(const T* __restrict__ xa, int Ca, const T* __restrict__ 
 #pragma unroll
                     for (int e = 0; e < PER16; e += 2) {
                         f32x2 y = __builtin_elementwise_fma(f32x2{to_f32(raw[e]), to_f32(raw[e + 1])}, f32x2{pa[e], pa[e + 1]}, f32x2{pb[e], pb[e + 1]});
-                        if (silu) y = silu2(y);
+                        if (SILU) y = silu2(y);
                         aw[e / 2] = pack2(y.x, y.y, (T*)nullptr);
                     }
                 }
@@ -460,7 +461,7 @@ void gn_apply_up_kernel(const T* __restrict__ xa, int Ca, const T* __restrict__ 
                     float y = 0.f;
                     if (x_in[j]) {
                         y = fmaf(xr, pa[e], pb[e]);
-                        if (silu) y = silu_f(y);
+                        if (SILU) y = silu_f(y);
                         T ya; from_f32(ya, y); y = to_f32(ya);
                     }
                     if (j != 2) { h.eA[e] = fmaf(we, y, h.eA[e]); h.eR[e] = fmaf(we, xr, h.eR[e]); }
@@ -551,8 +552,10 @@ static int gn_apply_t(const void* xa, int Ca, const void* xb, int Cb, int B, int
         const int ncg = cdiv(Ca + Cb, CG), nstrips = cdiv(OH, DN_ROWS);
         const long long gy = (long long)ncg * nstrips * B;
         STORM_CHECK(OH > 0 && OW > 0 && gy < 65536, "storm_gn_apply: down-sampling grid %lld out of range", gy);
-        hipLaunchKernelGGL((gn_apply_down_kernel<T>), dim3(cdiv(OW, DN_COLS), (unsigned)gy), dim3(256), 0, st,
-                           (const T*)xa, Ca, (const T*)xb, Cb, H, W, G, stats, gamma, beta, eps, silu, (T*)out_act, (T*)out_raw, ncg, nstrips);
+        if (silu) hipLaunchKernelGGL((gn_apply_down_kernel<T, true>), dim3(cdiv(OW, DN_COLS), (unsigned)gy), dim3(256), 0, st,
+                           (const T*)xa, Ca, (const T*)xb, Cb, H, W, G, stats, gamma, beta, eps, (T*)out_act, (T*)out_raw, ncg, nstrips);
+        else hipLaunchKernelGGL((gn_apply_down_kernel<T, false>), dim3(cdiv(OW, DN_COLS), (unsigned)gy), dim3(256), 0, st,
+                           (const T*)xa, Ca, (const T*)xb, Cb, H, W, G, stats, gamma, beta, eps, (T*)out_act, (T*)out_raw, ncg, nstrips);
         STORM_LAUNCH_CHECK();
         return STORM_OK;
     }
@@ -561,8 +564,10 @@ static int gn_apply_t(const void* xa, int Ca, const void* xb, int Cb, int B, int
         const int ncg = cdiv(Ca + Cb, CG), nstrips = cdiv(H, UP_ROWS);
         const long long gy = (long long)ncg * nstrips * B;
         STORM_CHECK(gy < 65536, "storm_gn_apply: up-sampling grid %lld out of range", gy);
-        hipLaunchKernelGGL((gn_apply_up_kernel<T>), dim3(cdiv(W, UP_COLS), (unsigned)gy), dim3(256), 0, st,
-                           (const T*)xa, Ca, (const T*)xb, Cb, H, W, G, stats, gamma, beta, eps, silu, (T*)out_act, (T*)out_raw, ncg, nstrips);
+        if (silu) hipLaunchKernelGGL((gn_apply_up_kernel<T, true>), dim3(cdiv(W, UP_COLS), (unsigned)gy), dim3(256), 0, st,
+                           (const T*)xa, Ca, (const T*)xb, Cb, H, W, G, stats, gamma, beta, eps, (T*)out_act, (T*)out_raw, ncg, nstrips);
+        else hipLaunchKernelGGL((gn_apply_up_kernel<T, false>), dim3(cdiv(W, UP_COLS), (unsigned)gy), dim3(256), 0, st,
+                           (const T*)xa, Ca, (const T*)xb, Cb, H, W, G, stats, gamma, beta, eps, (T*)out_act, (T*)out_raw, ncg, nstrips);
         STORM_LAUNCH_CHECK();
         return STORM_OK;
     }
