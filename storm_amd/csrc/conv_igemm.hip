@@ -744,7 +744,7 @@ static const char* kernel_name_of(const storm_conv_args& a) {
     const int taps = any9 ? 9 : 1;
     const char* shape;
     int variant = choose_variant(a, any9);
-    if (variant == 8 && conv_narrow_supports(a)) return conv_narrow_kernel_name(a.dtype, a.seg[0].Ca);
+    if (variant == 8 && conv_narrow_supports(a)) return conv_narrow_kernel_name(a);
     if (a.outC <= 32) variant = -1;
     if (variant == 6 && conv_thin_supports(a)) return conv_thin_kernel_name(a.dtype, taps);
     if (a.outC <= 32) shape = "1, 1, 4, false, false";

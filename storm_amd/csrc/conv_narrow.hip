@@ -37,8 +37,9 @@ struct Params {
 __host__ __device__ inline int lds_bytes(int C) { return Z_BYTES + (C / 8) * WROWS * 16 + C * 2 * 4; }
 }  // namespace narrow
 
-// CG = C / 64: 64-byte pieces per lane and pixel
-template <typename T, int CG>
+// CG = C / 64: 64-byte pieces per lane and pixel; SILU: the activation behind the fused GroupNorm affine (compile time: as a run-time
+// flag it is if-converted into a select per value)
+template <typename T, int CG, bool SILU>
 __global__ __launch_bounds__(narrow::THREADS, 1)
 void conv_narrow_kernel(const narrow::Params p) {
     using namespace narrow;
@@ -123,7 +124,7 @@ void conv_narrow_kernel(const narrow::Params p) {
                     if (gn) {
                         float ss[16];
                         load_ss<8>(SS, g8, ss);
-                        v = gn_act_slot(v, ss, p.silu, (T*)nullptr);
+                        v = gn_act_slot_t<SILU>(v, ss, (T*)nullptr);
                         if (!cur.valid) v = make_uint4(0u, 0u, 0u, 0u);      // (zero padding applies to the ACTIVATED tensor)
                     }
                     Frag bf, a0, a1;
@@ -173,9 +174,9 @@ bool conv_narrow_supports(const storm_conv_args& a) {
     return (long long)a.H * a.W * g.Ca < (1LL << 31) && a.H >= 1 && a.W >= 1;
 }
 
-template <typename T, int CG>
+template <typename T, int CG, bool SILU>
 static int launch_narrow(const storm_conv_args& a, hipStream_t st) {
-    auto kern = conv_narrow_kernel<T, CG>;
+    auto kern = conv_narrow_kernel<T, CG, SILU>;
     const int lds = narrow::lds_bytes(CG * 64);
     static bool attr_set = false;                       // per instantiation; benign race (idempotent)
     if (!attr_set) {
@@ -199,15 +200,24 @@ static int launch_narrow(const storm_conv_args& a, hipStream_t st) {
     return STORM_OK;
 }
 
-int launch_conv_narrow(const storm_conv_args& a, hipStream_t st) {
-    const bool c256 = a.seg[0].Ca == 256;
-    if (a.dtype == STORM_F16) return c256 ? launch_narrow<half_t, 4>(a, st) : launch_narrow<half_t, 2>(a, st);
-    return c256 ? launch_narrow<bf16_t, 4>(a, st) : launch_narrow<bf16_t, 2>(a, st);
+template <typename T, int CG>
+static int launch_narrow_t(const storm_conv_args& a, hipStream_t st) {
+    const bool silu = a.seg[0].gn_ss != nullptr && a.seg[0].gn_silu != 0;        // (without a fused GroupNorm operand the flag is unused)
+    return silu ? launch_narrow<T, CG, true>(a, st) : launch_narrow<T, CG, false>(a, st);
 }
 
-const char* conv_narrow_kernel_name(int dtype, int C) {
-    if (dtype == STORM_F16) return C == 256 ? "storm::conv_narrow_kernel<storm::half_t, 4>" : "storm::conv_narrow_kernel<storm::half_t, 2>";
-    return C == 256 ? "storm::conv_narrow_kernel<storm::bf16_t, 4>" : "storm::conv_narrow_kernel<storm::bf16_t, 2>";
+int launch_conv_narrow(const storm_conv_args& a, hipStream_t st) {
+    const bool c256 = a.seg[0].Ca == 256;
+    if (a.dtype == STORM_F16) return c256 ? launch_narrow_t<half_t, 4>(a, st) : launch_narrow_t<half_t, 2>(a, st);
+    return c256 ? launch_narrow_t<bf16_t, 4>(a, st) : launch_narrow_t<bf16_t, 2>(a, st);
+}
+
+const char* conv_narrow_kernel_name(const storm_conv_args& a) {
+    static thread_local char buf[96];
+    const bool silu = a.seg[0].gn_ss != nullptr && a.seg[0].gn_silu != 0;
+    snprintf(buf, sizeof(buf), "storm::conv_narrow_kernel<storm::%s, %d, %s>", a.dtype == STORM_F16 ? "half_t" : "bf16_t", a.seg[0].Ca / 64,
+             silu ? "true" : "false");
+    return buf;
 }
 
 }  // namespace storm

@@ -215,6 +215,6 @@ const char* conv_thin_kernel_name(int dtype, int ntaps);
 // defined in conv_narrow.hip: 3x3 convolutions to <= 4 output channels (the output pyramid): one 36-row 1x1 GEMM + a nine-point gather
 bool conv_narrow_supports(const storm_conv_args& a);
 int launch_conv_narrow(const storm_conv_args& a, hipStream_t st);
-const char* conv_narrow_kernel_name(int dtype, int C);
+const char* conv_narrow_kernel_name(const storm_conv_args& a);
 
 }  // namespace storm
