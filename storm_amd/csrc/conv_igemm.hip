@@ -667,6 +667,7 @@ static int launch_conv(const storm_conv_args& a, hipStream_t st) {
 //   2: conv_igemm 256 cout x 256 px, 8 waves, 1 workgroup / CU, patch double-buffered through registers
 //   3: conv_pipe.hip, 256 cout x 256 px, 8 waves in two ping-pong groups, chunk-unrolled LDS-DMA pipeline (16-bit 3x3)
 //   4: conv_pipe128.hip, 128 cout x 512 px, the same pipeline for layers with <= 128 output channels (16-bit 3x3)
+//   5: conv_duo.hip, 128 cout x 256 px, 4 waves, two workgroups / CU, single-stream phases (16-bit 3x3, <= 128 output channels)
 //   6: conv_thin.hip, 8 input channels (stem, input-skip 1x1s): operands straight from global memory (16-bit)
 //   8: conv_narrow.hip, 3x3 to <= 4 output channels (the output pyramid): 36-row 1x1 GEMM over the haloed region + nine-point gather
 //   7: conv_igemm 64 cout x 256 px, 4 waves (32x128 each), 2 workgroups / CU; LDS-DMA - for 3x3 layers with so few pixel tiles
@@ -720,6 +721,7 @@ static int dispatch_conv(const storm_conv_args& a, hipStream_t st) {
         if (small) return launch_conv<T, 9, 1, 1, 4, false>(a, st);
         if (variant == 3 && conv_pipe_supports(a)) return launch_conv_pipe(a, st);
         if (variant == 4 && conv_pipe128_supports(a)) return launch_conv_pipe128(a, st);
+        if (variant == 5 && conv_duo_supports(a)) return launch_conv_duo(a, st);
         if (variant == 2) return launch_conv<T, 9, 2, 4, 2, true>(a, st);
         if (variant == 7) return launch_conv<T, 9, 1, 2, 2, false, true>(a, st);
 #if defined(STORM_PROFILING)                                          // A/B instantiations: 8-wave geometry, register staging
@@ -750,6 +752,7 @@ static const char* kernel_name_of(const storm_conv_args& a) {
     if (a.outC <= 32) shape = "1, 1, 4, false, false";
     else if (any9 && variant == 3 && conv_pipe_supports(a)) return conv_pipe_kernel_name(a.dtype);
     else if (any9 && variant == 4 && conv_pipe128_supports(a)) return conv_pipe128_kernel_name(a.dtype);
+    else if (any9 && variant == 5 && conv_duo_supports(a)) return conv_duo_kernel_name(a.dtype);
     else if (variant == 2) shape = "2, 4, 2, true, false";
     else if (any9 && variant == 7) shape = "1, 2, 2, false, true";
 #if defined(STORM_PROFILING)

@@ -206,6 +206,11 @@ const char* conv_pipe_kernel_name(int dtype);
 bool conv_pipe128_supports(const storm_conv_args& a);
 int launch_conv_pipe128(const storm_conv_args& a, hipStream_t st);
 const char* conv_pipe128_kernel_name(int dtype);
+// defined in conv_duo.hip: <= 128 output channels, 128 couts x 256 pixels per 4-wave workgroup, two workgroups per CU, one instruction
+// stream and one barrier per phase (staging and the fused GroupNorm transform in the MFMA gaps)
+bool conv_duo_supports(const storm_conv_args& a);
+int launch_conv_duo(const storm_conv_args& a, hipStream_t st);
+const char* conv_duo_kernel_name(int dtype);
 
 // defined in conv_thin.hip: convolutions over an 8-channel input (the stem, the input-skip 1x1s): operands straight from global
 // memory, no staging

@@ -47,7 +47,7 @@
 // pre-read.
 #include <cstdlib>
 #include <cstring>
-#include "conv_pipe_common.h"
+#include "conv_epilogue.h"
 
 namespace storm {
 using namespace cidx;
@@ -535,189 +535,18 @@ void conv_pipe_kernel(const PipeParams a, const int n_ct, const int tiles_per_xc
             __syncthreads();
             continue;
         }
-    // ---- epilogue: LDS transpose -> (bias, temb bias, skip, scale) -> wide stores (as conv_igemm.hip).  Staging lives in
-        // patch buffer 1 (waves 0-4) and ring slots 2, 3 (waves 5-7): the next tile's first loads are landing in buffer 0 /
-        // slots 0, 1 meanwhile.
-        constexpr int SROWS = 32 * PR;
-        constexpr int WSTAGE = SROWS * WM * 128;
+        // ---- epilogue (conv_epilogue.h).  Staging lives in patch buffer 1 (waves 0-4) and ring slots 2, 3 (waves 5-7; the statistics
+        // scratch behind them): the next tile's first loads are landing in buffer 0 / slots 0, 1 meanwhile.
+        constexpr int WSTAGE = 32 * PR * WM * 128;
         static_assert(5 * WSTAGE <= PATCH_BYTES && 3 * WSTAGE + WAVES_N * BN * 8 <= 2 * WPHASE, "epilogue staging beside the next tile's loads");
         char* const stage = smem + (wave < 5 ? PATCH_BYTES + wave * WSTAGE : OFF_RING + 2 * WPHASE + (wave - 5) * WSTAGE);
-        constexpr int LPR = WM * 4;                 // lanes per staged row (8 couts each)
-        constexpr int RPI = 64 / LPR;               // rows per read iteration
-        // epilogue parameters: read ONCE per tile and pinned in SGPRs (through the kernarg pointer the compiler re-loaded the
-        // output pointer / strides inside the store loop: a scalar load + s_waitcnt lgkmcnt(0) and a 64-bit multiply per store)
-        const int outC = pin(ap->outC), skipC = outC, out_f32 = pin(ap->out_f32);
-        const bool has_skip = ap->skip != nullptr;
-        char* const out_b = as_global(reinterpret_cast<unsigned long long>(ap->out) +
-                                      (unsigned long long)((long long)e_b * ap->out_bstride * (out_f32 ? 4 : (int)sizeof(T))));
-        const int c8 = lane & (LPR - 1);
-        const int co = e_cout0 + wm * WM * 32 + c8 * 8;
-        float badd[8];
-#pragma unroll
-        for (int e = 0; e < 8; ++e) badd[e] = 0.f;
-        if (co + 8 <= ap->Cout) {
-            if (ap->bias) { float bb[8]; load8(ap->bias + co, bb);
-#pragma unroll
-                for (int e = 0; e < 8; ++e) badd[e] += bb[e]; }
-            if (ap->tbias) { float bb[8]; load8(ap->tbias + (long long)e_b * ap->tbias_stride + co, bb);
-#pragma unroll
-                for (int e = 0; e < 8; ++e) badd[e] += bb[e]; }
-        } else {
-#pragma unroll
-            for (int e = 0; e < 8; ++e)
-                if (co + e < ap->Cout) {
-                    if (ap->bias) badd[e] += ap->bias[co + e];
-                    if (ap->tbias) badd[e] += ap->tbias[(long long)e_b * ap->tbias_stride + co + e];
-                }
-        }
-        const bool co_ok = co < outC;
-        const T* const skip_b = reinterpret_cast<const T*>(ap->skip) + (long long)e_b * ap->skip_bstride;
-        // out = (acc + bias + temb bias + skip) * scale, evaluated as packed fma: (acc [+ skip]) * scale + (bias * scale);
-        // channel pairs stay in adjacent registers from the staging read to the bf16 pack (v_pk_fma_f32 / v_pk_add_f32)
-        f32x2 badd2[4], gsum2[4], gsq2[4];
-        const f32x2 scale2 = {ap->scale, ap->scale};
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            badd2[i] = f32x2{badd[2 * i] * ap->scale, badd[2 * i + 1] * ap->scale};
-            gsum2[i] = f32x2{0.f, 0.f}; gsq2[i] = f32x2{0.f, 0.f};
-        }
+        const epi::TileAt et = {e_tile, e_b, e_ty0, e_tx0, e_cout0};
         float gsum[8], gsq[8];
-        static_assert(PR == 1 && LPR == 8 && RPI == 8 && WM == 2, "store loop index math");
-        const int l8 = (lane >> 3) & 7;                         // the pixel (of the 8 per iteration) this lane stores
-        const int gx0 = e_tx0 + l8;
-        const uint32_t o_lane = (uint32_t)(gx0 * outC + co);
-        int srow[2][2];                                         // staged row it * 8 + l8, slots 2 c8 / 2 c8 + 1: stage_off<WM> without its `it * 8` rows
-#pragma unroll
-        for (int odd = 0; odd < 2; ++odd)
-#pragma unroll
-            for (int h = 0; h < 2; ++h) srow[odd][h] = stage_off<WM>(odd * 8 + l8, 2 * c8 + h) - odd * 8 * (WM * 128);
-        // skip operands are fetched ONE PASS ahead, each into the register its predecessor (same iteration, previous pass) has just
-        // left - the first pass's before the first staging write.  Fetched where they are used, every one of the 16 loads per tile
-        // and wave exposed its full memory latency (measured on 256 -> 256 @ 256 x 512: 2.50 ms with a skip operand against 1.93 ms
-        // without = 18 us per tile).
-        // The store loop in three instantiations, picked by uniform branches: a tile inside the image with all of its couts valid (no
-        // per-lane masks, no row / column tests, bf16 / fp16 output through base + 32-bit offset stores) with or without a skip
-        // operand, and the general one.  (One loop with the tests inside issued ~65 instructions per 8 pixels x 64 couts and wave,
-        // a third of them masks, branches and 64-bit address arithmetic - with all eight waves in their epilogues the matrix pipe idles.)
-        auto run_passes = [&](auto fast_, auto skipk_) {
-        constexpr bool FAST = decltype(fast_)::value;
-        constexpr int SKIPK = decltype(skipk_)::value;          // 1: skip operand, 0: none, -1: run-time
-        const bool skip_on = (SKIPK < 0 ? has_skip : SKIPK == 1) && !(ABL & 2048);
-        uint4 skq[SROWS / RPI];
-        auto skip_fetch = [&](int pass, int it) {
-            const int gy = e_ty0 + wn * WN + pass;
-            const uint32_t o_row = (uint32_t)(gy * imgW) * (uint32_t)outC;
-            const uint32_t o = o_row + (uint32_t)(it * RPI) * (uint32_t)outC + o_lane;
-            if (FAST) skq[it] = ld16(skip_b, o * (uint32_t)sizeof(T));
-            else skq[it] = (gy < imgH && gx0 + it * RPI < imgW && co_ok) ? *reinterpret_cast<const uint4*>(skip_b + o) : make_uint4(0u, 0u, 0u, 0u);
-        };
-        if (skip_on) {
-#pragma unroll
-            for (int it = 0; it < SROWS / RPI; ++it) skip_fetch(0, it);
-        }
-#pragma unroll
-        for (int pass = 0; pass < WN / PR; ++pass) {
-            if (pass > 0) wave_sync();
-#pragma unroll
-            for (int nn = 0; nn < PR; ++nn)
-#pragma unroll
-                for (int mi = 0; mi < WM; ++mi)
-#pragma unroll
-                    for (int g = 0; g < 4; ++g) {
-                        const int row = nn * 32 + (lane & 31);
-                        const f32x16& c = acc[mi][pass * PR + nn];
-                        *reinterpret_cast<float4*>(stage + stage_off<WM>(row, stage_wslot(lane, mi, g))) =
-                            make_float4(c[4 * g], c[4 * g + 1], c[4 * g + 2], c[4 * g + 3]);
-                    }
-            wave_sync();
-            // store loop: a pass is ONE pixel row of the tile (PR = 1), an iteration 8 of its pixels x 64 couts per wave.  Everything
-            // that does not depend on the lane is scalar: the row's validity, the element offset of (row, 8 * it) - the lane adds
-            // its own (pixel l8, cout octet c8) offset, and the staged row's swizzle has two variants (it even / odd).  (Written out by
-            // hand: `lane` is opaque to the compiler in this kernel, so the generic row / column arithmetic stayed 30 VALU
-            // instructions per store - measured: 5.9 k of the epilogue's 12.1 k cycles per tile.)
-            const int gy = e_ty0 + wn * WN + pass;
-            if (FAST || gy < imgH) {
-                const uint32_t o_row = (uint32_t)(gy * imgW) * (uint32_t)outC;                    // (uniform)
-#pragma unroll
-                for (int it = 0; it < SROWS / RPI; ++it) {
-                    const char* const sp = stage + it * RPI * (WM * 128);
-                    const float4 v0 = *reinterpret_cast<const float4*>(sp + srow[it & 1][0]);
-                    const float4 v1 = *reinterpret_cast<const float4*>(sp + srow[it & 1][1]);
-                    f32x2 v2[4] = {f32x2{v0.x, v0.y}, f32x2{v0.z, v0.w}, f32x2{v1.x, v1.y}, f32x2{v1.z, v1.w}};
-                    const uint4 skv = skq[it];
-                    if (skip_on && pass + 1 < WN / PR) skip_fetch(pass + 1, it);
-                    if (FAST || (gx0 + it * RPI < imgW && co_ok && !(ABL & 2048))) {
-                        const uint32_t o = o_row + (uint32_t)(it * RPI) * (uint32_t)outC + o_lane;
-                        if (skip_on) {
-                            alignas(16) T sk[8];
-                            *reinterpret_cast<uint4*>(sk) = skv;
-#pragma unroll
-                            for (int i = 0; i < 4; ++i) v2[i] += f32x2{to_f32(sk[2 * i]), to_f32(sk[2 * i + 1])};
-                        }
-#pragma unroll
-                        for (int i = 0; i < 4; ++i) {
-                            v2[i] = __builtin_elementwise_fma(v2[i], scale2, badd2[i]);
-                            gsum2[i] += v2[i];
-                            gsq2[i] = __builtin_elementwise_fma(v2[i], v2[i], gsq2[i]);
-                        }
-                        const float v[8] = {v2[0].x, v2[0].y, v2[1].x, v2[1].y, v2[2].x, v2[2].y, v2[3].x, v2[3].y};
-                        if (FAST) {
-                            st16(out_b, o * (uint32_t)sizeof(T), make_uint4(pack2(v[0], v[1], (T*)nullptr), pack2(v[2], v[3], (T*)nullptr),
-                                                                            pack2(v[4], v[5], (T*)nullptr), pack2(v[6], v[7], (T*)nullptr)));
-                        }
-                        else if (out_f32) store8(reinterpret_cast<float*>(out_b) + o, v);
-                        else if (ABL & 4096) {                       // (profiling A/B: non-temporal output stores)
-                            uint32_t w4[4];
-#pragma unroll
-                            for (int i = 0; i < 4; ++i) w4[i] = sizeof(T) == 2 && Elem<T>::DT == STORM_BF16 ? pack_bf16x2(v[2 * i], v[2 * i + 1]) : pack_f16x2(v[2 * i], v[2 * i + 1]);
-                            typedef uint32_t u32x4_nt __attribute__((ext_vector_type(4)));
-                            u32x4_nt val = {w4[0], w4[1], w4[2], w4[3]};
-                            __builtin_nontemporal_store(val, reinterpret_cast<u32x4_nt*>(reinterpret_cast<T*>(out_b) + o));
-                        }
-                        else if (ABL & 8192) {                       // (profiling: all of the epilogue's arithmetic, no global store)
-#pragma unroll
-                            for (int e = 0; e < 8; ++e) keep(v[e]);
-                            keep(o);
-                        }
-                        else store8(reinterpret_cast<T*>(out_b) + o, v);
-                    }
-                }
-            }
-        }
-        };
-        const bool interior = e_ty0 + TH <= imgH && e_tx0 + TILE_W <= imgW && e_cout0 + BN <= outC && !out_f32 &&
-                              !(ABL & (2048 | 4096 | 8192));
-        if (interior) {
-            if (has_skip) run_passes(std::true_type{}, IC<1>{});
-            else run_passes(std::true_type{}, IC<0>{});
-        } else run_passes(std::false_type{}, IC<-1>{});
+        epi::store_tile<T, WM, WN, (ABL & (2048 | 4096 | 8192))>(acc, stage, ap, et, wm, wn, lane, imgH, imgW, BN, TH, gsum, gsq);
         if (first) stamp(502);
-#pragma unroll
-        for (int i = 0; i < 4; ++i) { gsum[2 * i] = gsum2[i].x; gsum[2 * i + 1] = gsum2[i].y; gsq[2 * i] = gsq2[i].x; gsq[2 * i + 1] = gsq2[i].y; }
-        if (ap->gn_part != nullptr) {
-#pragma unroll
-            for (int off = LPR; off < 64; off <<= 1)
-#pragma unroll
-                for (int e = 0; e < 8; ++e) { gsum[e] += __shfl_xor(gsum[e], off, 64); gsq[e] += __shfl_xor(gsq[e], off, 64); }
-            __syncthreads();
-            float* red = reinterpret_cast<float*>(smem + OFF_RING + 2 * WPHASE + 3 * WSTAGE);   // [WAVES_N][BN][2]
-            if (lane < LPR) {
-#pragma unroll
-                for (int e = 0; e < 8; ++e) {
-                    const int chl = wm * WM * 32 + lane * 8 + e;
-                    red[(wn * BN + chl) * 2] = gsum[e];
-                    red[(wn * BN + chl) * 2 + 1] = gsq[e];
-                }
-            }
-            __syncthreads();
-            if (tid < BN && e_cout0 + tid < ap->outC) {
-                float s0 = 0.f, s1 = 0.f;
-#pragma unroll
-                for (int w = 0; w < WAVES_N; ++w) { s0 += red[(w * BN + tid) * 2]; s1 += red[(w * BN + tid) * 2 + 1]; }
-                float* dst = ap->gn_part + ((long long)e_tile * ap->outC + e_cout0 + tid) * 2;
-                dst[0] = s0; dst[1] = s1;
-            }
-        }
+        if (ap->gn_part != nullptr)
+            epi::write_stats<WM, WN, WAVES_N, BN, TH>(gsum, gsq, reinterpret_cast<float*>(smem + OFF_RING + 2 * WPHASE + 3 * WSTAGE), ap, et, wm, wn, lane, tid,
+                                                      imgH, tiles_x, tiles_per_img);
         if (!has_next) break;
         first = false;
         __syncthreads();                                    // the statistics scratch / staging of this tile is free again

@@ -32,7 +32,7 @@
 // ((64-channel chunk, tap, k-group)), so outputs agree with those kernels to rounding, not bit for bit.
 #include <cstdlib>
 #include <cstring>
-#include "conv_pipe_common.h"
+#include "conv_epilogue.h"
 
 namespace storm {
 using namespace cidx;
@@ -424,147 +424,17 @@ void conv_pipe128_kernel(const PipeParams a, const int n_ct, const int tiles_per
         STORM_RELAUNDER();
         stamp();                                            // 3: hand-over done (drain, barrier, next tile's first loads issued)
 
-        // ---- epilogue: LDS transpose -> (bias, temb bias, skip, scale) -> wide stores (as conv_pipe.hip).  Staging lives in patch
-        // buffers 1 and 2, the statistics scratch in ring slots 2, 3: the next tile's first loads are landing in buffer 0 /
-        // table 0 / ring slots 0, 1 meanwhile.
-        constexpr int SROWS = 32 * PR;
-        char* const stage = smem + PATCH_BYTES + wave * WSTAGE;
-        constexpr int LPR = WM * 4;                 // lanes per staged row (8 couts each)
-        constexpr int RPI = 64 / LPR;               // rows per read iteration
-        // epilogue parameters: read ONCE per tile and pinned in SGPRs (through the kernarg pointer the compiler re-loaded the
-        // output pointer / strides inside the store loop: a scalar load + s_waitcnt lgkmcnt(0) and a 64-bit multiply per store)
-        const int outC = pin(ap->outC), skipC = outC, out_f32 = pin(ap->out_f32);
-        const bool has_skip = ap->skip != nullptr;
-        char* const out_b = as_global(reinterpret_cast<unsigned long long>(ap->out) +
-                                      (unsigned long long)((long long)e_b * ap->out_bstride * (out_f32 ? 4 : (int)sizeof(T))));
-        const int c8 = lane & (LPR - 1);
-        const int co = e_cout0 + wm * WM * 32 + c8 * 8;
-        float badd[8];
-#pragma unroll
-        for (int e = 0; e < 8; ++e) badd[e] = 0.f;
-        if (co + 8 <= ap->Cout) {
-            if (ap->bias) { float bb[8]; load8(ap->bias + co, bb);
-#pragma unroll
-                for (int e = 0; e < 8; ++e) badd[e] += bb[e]; }
-            if (ap->tbias) { float bb[8]; load8(ap->tbias + (long long)e_b * ap->tbias_stride + co, bb);
-#pragma unroll
-                for (int e = 0; e < 8; ++e) badd[e] += bb[e]; }
-        } else {
-#pragma unroll
-            for (int e = 0; e < 8; ++e)
-                if (co + e < ap->Cout) {
-                    if (ap->bias) badd[e] += ap->bias[co + e];
-                    if (ap->tbias) badd[e] += ap->tbias[(long long)e_b * ap->tbias_stride + co + e];
-                }
-        }
-        const bool co_ok = co < outC;
-        const T* const skip_b = reinterpret_cast<const T*>(ap->skip) + (long long)e_b * ap->skip_bstride;
-        // out = (acc + bias + temb bias + skip) * scale as packed fma: (acc [+ skip]) * scale + (bias * scale)
-        f32x2 badd2[4], gsum2[4], gsq2[4];
-        const f32x2 scale2 = {ap->scale, ap->scale};
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            badd2[i] = f32x2{badd[2 * i] * ap->scale, badd[2 * i + 1] * ap->scale};
-            gsum2[i] = f32x2{0.f, 0.f}; gsq2[i] = f32x2{0.f, 0.f};
-        }
+        // ---- epilogue (conv_epilogue.h).  Staging lives in patch buffers 1 and 2, the statistics scratch in ring slots 2, 3: the next
+        // tile's first loads are landing in buffer 0 / table 0 / ring slots 0, 1 meanwhile.  GroupNorm partials go out in the 8 x 32
+        // pixel tile layout every conv kernel writes (storm_conv_tiles): this tile is two of them - pixel rows 0-7 (wave rows wn = 0, 1)
+        // and rows 8-15 (wn = 2, 3).
+        const epi::TileAt et = {e_tile, e_b, e_ty0, e_tx0, e_cout0};
         float gsum[8], gsq[8];
-        static_assert(PR == 1 && WM == 2, "store loop index math");
-        const int l8 = (lane >> 3) & 7;                         // the pixel (of the 8 per iteration) this lane stores
-        const int gx0 = e_tx0 + l8;
-        const uint32_t o_lane = (uint32_t)(gx0 * outC + co);
-        int srow[2][2];                                         // staged row it * 8 + l8, slots 2 c8 / 2 c8 + 1 (see conv_pipe.hip)
-#pragma unroll
-        for (int odd = 0; odd < 2; ++odd)
-#pragma unroll
-            for (int h = 0; h < 2; ++h) srow[odd][h] = stage_off<WM>(odd * 8 + l8, 2 * c8 + h) - odd * 8 * (WM * 128);
-#pragma unroll
-        for (int pass = 0; pass < WN / PR; ++pass) {
-            // a pass is ONE pixel row of the tile: its validity and element offset are scalar, the lane adds its own (pixel, cout octet)
-            // offset (conv_pipe.hip); skip operands are fetched ONE store ahead (the first under the staging writes)
-            const int gy = e_ty0 + wn * WN + pass;
-            const bool row_ok = gy < imgH;
-            const uint32_t o_row = (uint32_t)(gy * imgW) * (uint32_t)outC;
-            auto skip_fetch = [&](int it) {
-                uint4 q = make_uint4(0u, 0u, 0u, 0u);
-                if (row_ok && gx0 + it * RPI < imgW && co_ok) q = *reinterpret_cast<const uint4*>(skip_b + (o_row + (uint32_t)(it * RPI) * (uint32_t)outC + o_lane));
-                return q;
-            };
-            uint4 sk_next = make_uint4(0u, 0u, 0u, 0u);
-            if (has_skip) sk_next = skip_fetch(0);
-            if (pass > 0) wave_sync();
-#pragma unroll
-            for (int nn = 0; nn < PR; ++nn)
-#pragma unroll
-                for (int mi = 0; mi < WM; ++mi)
-#pragma unroll
-                    for (int g = 0; g < 4; ++g) {
-                        const int row = nn * 32 + (lane & 31);
-                        const f32x16& c = acc[mi][pass * PR + nn];
-                        *reinterpret_cast<float4*>(stage + stage_off<WM>(row, stage_wslot(lane, mi, g))) =
-                            make_float4(c[4 * g], c[4 * g + 1], c[4 * g + 2], c[4 * g + 3]);
-                    }
-            wave_sync();
-#pragma unroll
-            for (int it = 0; it < SROWS / RPI; ++it) {
-                const uint4 sk_cur = sk_next;
-                if (has_skip && it + 1 < SROWS / RPI) sk_next = skip_fetch(it + 1);
-                const char* const sp = stage + it * RPI * (WM * 128);
-                const float4 v0 = *reinterpret_cast<const float4*>(sp + srow[it & 1][0]);
-                const float4 v1 = *reinterpret_cast<const float4*>(sp + srow[it & 1][1]);
-                f32x2 v2[4] = {f32x2{v0.x, v0.y}, f32x2{v0.z, v0.w}, f32x2{v1.x, v1.y}, f32x2{v1.z, v1.w}};
-                if (row_ok && gx0 + it * RPI < imgW && co_ok) {
-                    if (has_skip) {
-                        alignas(16) T sk[8];
-                        *reinterpret_cast<uint4*>(sk) = sk_cur;
-#pragma unroll
-                        for (int i = 0; i < 4; ++i) v2[i] += f32x2{to_f32(sk[2 * i]), to_f32(sk[2 * i + 1])};
-                    }
-#pragma unroll
-                    for (int i = 0; i < 4; ++i) {
-                        v2[i] = __builtin_elementwise_fma(v2[i], scale2, badd2[i]);
-                        gsum2[i] += v2[i];
-                        gsq2[i] = __builtin_elementwise_fma(v2[i], v2[i], gsq2[i]);
-                    }
-                    const float v[8] = {v2[0].x, v2[0].y, v2[1].x, v2[1].y, v2[2].x, v2[2].y, v2[3].x, v2[3].y};
-                    const uint32_t o = o_row + (uint32_t)(it * RPI) * (uint32_t)outC + o_lane;
-                    if (out_f32) store8(reinterpret_cast<float*>(out_b) + o, v);
-                    else store8(reinterpret_cast<T*>(out_b) + o, v);
-                }
-            }
-        }
+        epi::store_tile<T, WM, WN>(acc, smem + PATCH_BYTES + wave * WSTAGE, ap, et, wm, wn, lane, imgH, imgW, BN, TH, gsum, gsq);
         stamp();                                            // 4: epilogue stores issued
-#pragma unroll
-        for (int i = 0; i < 4; ++i) { gsum[2 * i] = gsum2[i].x; gsum[2 * i + 1] = gsum2[i].y; gsq[2 * i] = gsq2[i].x; gsq[2 * i + 1] = gsq2[i].y; }
-        if (ap->gn_part != nullptr) {
-            // GroupNorm partials in the 8 x 32 pixel tile layout every conv kernel writes (storm_conv_tiles): this tile is two of
-            // them - pixel rows 0-7 (wave rows wn = 0, 1) and rows 8-15 (wn = 2, 3)
-#pragma unroll
-            for (int off = LPR; off < 64; off <<= 1)
-#pragma unroll
-                for (int e = 0; e < 8; ++e) { gsum[e] += __shfl_xor(gsum[e], off, 64); gsq[e] += __shfl_xor(gsq[e], off, 64); }
-            __syncthreads();
-            float* red = reinterpret_cast<float*>(smem + OFF_RING + 2 * WPHASE);   // [WAVES_N][BN][2]
-            if (lane < LPR) {
-#pragma unroll
-                for (int e = 0; e < 8; ++e) {
-                    const int chl = wm * WM * 32 + lane * 8 + e;
-                    red[(wn * BN + chl) * 2] = gsum[e];
-                    red[(wn * BN + chl) * 2 + 1] = gsq[e];
-                }
-            }
-            __syncthreads();
-            const int half = tid / BN, ch = tid % BN;
-            const int tiles_y8 = (imgH + TILE_H - 1) / TILE_H;
-            const int trem = e_tile - e_b * tiles_per_img;
-            const int ty8 = 2 * (trem / tiles_x) + half;
-            if (tid < 2 * BN && ty8 < tiles_y8 && e_cout0 + ch < ap->outC) {
-                const float s0 = red[((2 * half) * BN + ch) * 2] + red[((2 * half + 1) * BN + ch) * 2];
-                const float s1 = red[((2 * half) * BN + ch) * 2 + 1] + red[((2 * half + 1) * BN + ch) * 2 + 1];
-                const long long t8 = ((long long)e_b * tiles_y8 + ty8) * tiles_x + trem % tiles_x;
-                float* dst = ap->gn_part + (t8 * ap->outC + e_cout0 + ch) * 2;
-                dst[0] = s0; dst[1] = s1;
-            }
-        }
+        if (ap->gn_part != nullptr)
+            epi::write_stats<WM, WN, WAVES_N, BN, TH>(gsum, gsq, reinterpret_cast<float*>(smem + OFF_RING + 2 * WPHASE), ap, et, wm, wn, lane, tid,
+                                                      imgH, tiles_x, tiles_per_img);
         stamp();                                            // 5: statistics written
         if (!has_next) break;
         __syncthreads();                                    // the statistics scratch / staging of this tile is free again

@@ -11,12 +11,12 @@ ROOT = os.path.dirname(os.path.dirname(HERE))
 CSRC = os.path.join(ROOT, "storm_amd", "csrc")
 OUT = os.path.join(HERE, "libstorm_sim.so")
 CXX = os.environ.get("STORM_SIM_CXX", "/opt/rocm/lib/llvm/bin/clang++")
-SOURCES = ["abi", "conv_igemm", "conv_pipe", "conv_pipe128", "conv_thin", "conv_narrow", "attention", "ncsnpp_graph", "norm_resample", "elementwise", "sde", "spectral", "program"]
+SOURCES = ["abi", "conv_igemm", "conv_pipe", "conv_pipe128", "conv_duo", "conv_thin", "conv_narrow", "attention", "ncsnpp_graph", "norm_resample", "elementwise", "sde", "spectral", "program"]
 
 
 def build(force=False):
     srcs = [os.path.join(CSRC, s + ".hip") for s in SOURCES] + [os.path.join(HERE, "simrt.cpp")]
-    deps = srcs + [os.path.join(CSRC, "common.h"), os.path.join(CSRC, "conv_index.h"), os.path.join(CSRC, "conv_params.h"),
+    deps = srcs + [os.path.join(CSRC, "common.h"), os.path.join(CSRC, "conv_index.h"), os.path.join(CSRC, "conv_params.h"), os.path.join(CSRC, "conv_pipe_common.h"), os.path.join(CSRC, "conv_epilogue.h"), os.path.join(CSRC, "hw.h"),
                    os.path.join(HERE, "hip_host_shim.h"), os.path.join(ROOT, "include", "storm_hip.h")]
     if not force and os.path.exists(OUT) and all(os.path.getmtime(OUT) >= os.path.getmtime(d) for d in deps):
         return OUT

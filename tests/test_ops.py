@@ -280,11 +280,12 @@ def test_conv_dispatch_picks_the_64_cout_tile_when_128_cout_tiles_leave_cus_idle
     assert "1, 2, 2, false, true" not in ops.conv_kernel_name(large, 256)
 
 
-@pytest.mark.parametrize("variant", [4])
+@pytest.mark.parametrize("variant", [4, 5])
 @pytest.mark.parametrize("case", list(PIPE128_CASES))
 def test_conv_pipelined_128cout_kernel(dev, case, variant, switch):
-    """The pipelined kernel for <= 128 output channels - conv_pipe128.hip (variant 4: 128 couts x 16 x 32 pixels, 8 waves, triple-
-    buffered patches, 32-channel chunks): plain 3x3, fused 1x1 shortcut over a concat, fused GroupNorm-apply operand, ragged
+    """The pipelined kernels for <= 128 output channels - conv_pipe128.hip (variant 4: 128 couts x 16 x 32 pixels, 8 waves, triple-
+    buffered patches, 32-channel chunks) and conv_duo.hip (variant 5: 128 couts x 8 x 32 pixels, 4 waves, two workgroups per CU,
+    staging and the fused GroupNorm transform inside the MFMA stream, one barrier per phase): plain 3x3, fused 1x1 shortcut over a concat, fused GroupNorm-apply operand, ragged
     sizes, 1 .. 8 nine-tap chunks, persistent tile walk, GroupNorm partials in the 8-row tile layout - on shapes the default
     dispatch would give to conv_igemm.hip."""
     from storm_amd import ops
@@ -326,7 +327,8 @@ def test_conv_pipelined_128cout_kernel(dev, case, variant, switch):
     switch("STORM_CONV_VARIANT", variant)
     if cus:
         switch("STORM_CONV_CUS", cus)
-    assert ops.conv_kernel_name(segs, Co, bias=bias.to(dev), tbias=tbd[:, 8:], skip=skip, scale=0.5).startswith("storm::conv_pipe128_kernel")
+    assert ops.conv_kernel_name(segs, Co, bias=bias.to(dev), tbias=tbd[:, 8:], skip=skip, scale=0.5).startswith(
+        {4: "storm::conv_pipe128_kernel", 5: "storm::conv_duo_kernel"}[variant])
     y, part = ops.conv(segs, Co, bias=bias.to(dev), tbias=tbd[:, 8:], skip=skip, scale=0.5, gn_partials=True)
     yc = nchw(y.float().cpu())
     assert rel_l2(yc[:, :Co], ref) < (1e-2 if gn else 6e-3)
