@@ -55,6 +55,12 @@ def parse():
     p.add_argument("--stream", type=int, default=0, metavar="N",
                    help="configs[4]: a step = N synthetic utterances of 2-10 s (seeded lengths), micro-batched by padded frame count "
                         "(<= --batch per launch, ragged rows) instead of one equal-length batch")
+    p.add_argument("--dist-world1", action="store_true",
+                   help="with ONE rank: initialise the RCCL process group anyway and run the barrier / gather lines through it (dry run of the "
+                        "N-rank path on one GPU; the driver launches the real one)")
+    p.add_argument("--include-h2d", action="store_true",
+                   help="also time the step from HOST wavs (pinned): H2D of the batch, the sampler, D2H of the result (SURVEY 8(d)); reported "
+                        "beside `value`, never as it")
     p.add_argument("--selftest-cpu", action="store_true",
                    help="(tests) run the launch / sharding / timing skeleton with a stand-in step on CPU ranks (gloo)")
     return p.parse_args()
@@ -202,9 +208,10 @@ def main():
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     dist = None
-    if world > 1:
+    if world > 1 or args.dist_world1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
         assert dist.get_world_size() == args.gpus
 
@@ -245,9 +252,21 @@ def main():
             nfes.append(n_ * yb.shape[0])
         return out, sum(nfes) / args.stream                 # mean score evaluations per utterance
 
-    elapsed, per_rank, (out, nfe) = D.timed_steps(step, args.steps, args.warmup, sync=torch.cuda.synchronize)
+    elapsed, per_rank, (out, nfe) = D.timed_steps(step, args.steps, args.warmup, sync=torch.cuda.synchronize, single_rank_group=args.dist_world1)
     assert torch.isfinite(out).all(), "non-finite output"
     value = units * world * args.steps / elapsed
+    h2d = None
+    if args.include_h2d and not args.stream:               # the same step from host memory: H2D + sampler + D2H inside the timed region
+        wav_host = wav.cpu().pin_memory()
+        out_host = torch.empty(out.shape, dtype=out.dtype).pin_memory()
+
+        def step_host(i):
+            o, n_ = model.enhance_batch(wav_host.to(dev, non_blocking=True), seed=1000 * rank + i, return_nfe=True, **skw)
+            out_host.copy_(o, non_blocking=True)
+            return o, n_
+        el_h, _, _ = D.timed_steps(step_host, args.steps, 0, sync=torch.cuda.synchronize, single_rank_group=args.dist_world1)
+        h2d = {"value_from_host_wavs": units * world * args.steps / el_h, "ms_per_step": 1e3 * el_h / args.steps,
+               "bytes_per_step": 2 * args.batch * L * 4, "note": "pinned host wavs -> H2D -> sampler -> D2H of the enhanced wavs, all inside the timed region"}
 
     cfg_name = {("ncsnpp", 4.0, 30): "configs[1]" if world == 1 else "configs[2]", ("ncsnpplarge", 8.0, 50): "configs[3]"}.get(
         (args.backbone, float(args.seconds), args.N), "custom")
@@ -267,6 +286,10 @@ def main():
         "nfe_per_s": value * nfe, "ms_per_nfe_batch": None if args.stream else 1e3 * elapsed / args.steps / nfe,
         "per_rank_s": [round(t, 4) for t in per_rank],
     }
+    if h2d is not None:
+        result["from_host"] = h2d
+    if args.dist_world1:
+        result["process_group"] = {"backend": dist.get_backend(), "world_size": dist.get_world_size()}
 
     if rank == 0 and not args.no_roofline and not args.stream:
         Y, _, _ = model._prepare(wav)

@@ -321,6 +321,61 @@ def gen_f12(ref):
     np.savez_compressed(os.path.join(OUT, "f12_ode_rows.npz"), **f12)
 
 
+def gen_f13(ref):
+    """F13: the product of the path at FULL width and FULL length of the sampler - ScoreModel.enhance (model.py:273-310) with the seeded
+    27.8 M `ncsnpp`, one 1-s utterance (16 000 samples -> 126 -> 128 frames), N = 30 reverse steps, `reverse_diffusion` + `ald` x 1 = 60
+    score evaluations inside pc_sampler (sampling/__init__.py:54-66), with RECORDED noise (61 draws, regenerated on both sides from
+    a seed; their SHA-256 is stored).  Stores the reference's wav and the sampler's final spectrogram (the tensor enhance hands to
+    to_audio).  This is what pins a bf16 / fp16 60-evaluation run against the REFERENCE instead of against the engine's own fp32 run."""
+    print("F13 full-width 60-evaluation enhance (about ten minutes)")
+    torch.set_num_threads(16)
+    M, DM = ref["model"], ref["data_module"].SpecsDataModule
+    N, steps, seed_w, seed_n, seed_wav = 30, 1, 11, 1313, 1301
+    cfg = NR.NCSNppConfig(input_channels=4)
+    sd = NR.seeded_state_dict(cfg, seed=seed_w)
+    m = M.ScoreModel(backbone="ncsnpp", sde="ouve", data_module_cls=DM, theta=1.5, sigma_min=0.05, sigma_max=0.5,
+                     spec_factor=0.15, spec_abs_exponent=0.5)
+    m.dnn.load_state_dict(sd)
+    m.eval(no_ema=True)
+    ywav = torch.randn(1, 16000, generator=torch.Generator().manual_seed(seed_wav)) * 0.1
+    Ysh = FR.wav_to_spec(ywav)[0].shape
+    gn = torch.Generator().manual_seed(seed_n)
+    noises = [SR.complex_randn(Ysh, gn) for _ in range(1 + N * (steps + 1))]
+    nhash = hashlib.sha256(b"".join(c2np(n).tobytes() for n in noises)).hexdigest()
+    it = iter(noises)
+    orig = torch.randn_like
+    final = {}
+    istft_orig = m._istft if hasattr(m, "_istft") else None
+    torch.randn_like = lambda x, *a, **k: next(it).to(x.dtype)
+    to_audio_orig = m.to_audio
+
+    def to_audio_spy(spec, length=None):                  # the sampler's final state, as enhance() hands it to the back end
+        final["spec"] = spec.detach().clone()
+        return to_audio_orig(spec, length)
+    m.to_audio = to_audio_spy
+    try:
+        with torch.no_grad():
+            xh_ref = m.enhance(ywav.clone(), N=N, corrector="ald", corrector_steps=steps, snr=0.5)
+    finally:
+        torch.randn_like = orig
+        m.to_audio = to_audio_orig
+    Y, nfac, T0 = FR.wav_to_spec(ywav)
+    it = iter(noises)
+    with torch.no_grad():
+        samp, nfe = SR.pc_sample(SR.OUVE(1.5, 0.05, 0.5, N=N),
+                                 lambda x, t, y: -NR.ncsnpp_forward(sd, cfg, torch.cat([x, y], 1), t),
+                                 Y, lambda: next(it), corrector_steps=steps, snr=0.5)
+    xh_or = FR.spec_to_wav(samp, nfac, T0)
+    check("F13 enhance wav (60 evaluations, 27.8 M)", xh_or, xh_ref, 1e-4)
+    fs = final["spec"].reshape(samp.shape) if "spec" in final else None
+    if fs is not None:
+        check("F13 final sampler state", samp, fs, 1e-4)
+    np.savez_compressed(os.path.join(OUT, "f13_full_sampler.npz"), wav_in=ywav.numpy(), out=xh_ref.numpy(),
+                        final_spec=c2np(fs if fs is not None else samp), nfe=np.array(N * (steps + 1)), N=np.array(N),
+                        seeds=np.array([seed_w, seed_n, seed_wav]), noise_hash=np.array(nhash), sdhash=np.array(sd_hash(sd)),
+                        noise_shape=np.array(list(Ysh)))
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
     if "--only-f9" in sys.argv:
@@ -332,7 +387,7 @@ def main():
     if "--only-f8" in sys.argv:
         gen_f8(import_reference())
         return
-    for flag, fn in (("--only-f10", gen_f10), ("--only-f11", gen_f11), ("--only-f12", gen_f12)):
+    for flag, fn in (("--only-f10", gen_f10), ("--only-f11", gen_f11), ("--only-f12", gen_f12), ("--only-f13", gen_f13)):
         if flag in sys.argv:
             fn(import_reference())
             return
@@ -581,6 +636,7 @@ def main():
     gen_f10(ref)
     gen_f11(ref)
     gen_f12(ref)
+    gen_f13(ref)
     for fn in sorted(os.listdir(OUT)):
         print(f"  {fn}: {os.path.getsize(os.path.join(OUT, fn))/1024:.0f} KiB")
     print("golden fixtures written to", OUT)

@@ -155,7 +155,7 @@ class NCSNpp(nn.Module):
         self.compute_dtype = torch.float32
         self.negate_output = False        # ScoreModel folds the "score = -dnn(...)" sign into the output head
         self._handles = {}                # dtype code -> (engine handle, arena tensor, params version, device)
-        self._workspaces = {}             # (device, dtype) -> ONE grow-only scratch tensor (the workspace holds no state between calls)
+        self._workspaces = {}             # (device, dtype, stream) -> ONE grow-only scratch tensor (the workspace holds no state between calls)
         self._param_version = 0
         self.register_load_state_dict_post_hook(lambda m, keys: m.invalidate())
 
@@ -233,12 +233,12 @@ class NCSNpp(nn.Module):
 
     def _get_workspace(self, h, B, F, T, dtype_code, device):
         """Scratch for one forward at (B, F, T).  The workspace carries nothing from one call to the next, so there is ONE
-        buffer per (device, dtype), grown to the largest size seen: a ragged stream (17 frame buckets x tail batch sizes)
-        holds the memory of its biggest micro-batch, not the sum over shapes."""
+        buffer per (device, dtype, stream), grown to the largest size seen: a ragged stream (17 frame buckets x tail batch sizes)
+        holds the memory of its biggest micro-batch, not the sum over shapes; two streams driving one module never share scratch."""
         n = L.lib().storm_ncsnpp_workspace_bytes(h, B, F, T)
         if n < 0:
             raise L.StormError(f"storm_ncsnpp_workspace_bytes: {L.lib().storm_last_error().decode()}")
-        key = (str(device), dtype_code)
+        key = (str(device), dtype_code, L.stream())
         ws = self._workspaces.get(key)
         if ws is None or ws.numel() < n:
             self._workspaces.pop(key, None)

@@ -80,8 +80,10 @@ void time_embedding_kernel(const float* __restrict__ t, const float* __restrict_
 }
 
 // ---- dense: out[b][n] = W[n][:] . x[b][:] + bias[n]; one wave per output row n ------------
-// The weight row is read ONCE (K <= 64 * DENSE_KMAX) and all batch rows are accumulated side by side, so a wave has one memory
-// round trip instead of B dependent ones (the first version: 40 us for the 22 Dense_0 layers of a forward, latency bound).
+// The weight row is read ONCE per 8 batch rows (K <= 64 * DENSE_KMAX: once per wave) and the batch rows are accumulated side by side,
+// so a wave has one memory round trip instead of B dependent ones (the first version: 40 us for the 22 Dense_0 layers of a forward,
+// latency bound).  Wider rows (nf > 128: K = 4 nf > 512) walk the row in pieces of 64 * DENSE_KMAX columns; a lane's summation order
+// (k = lane, lane + 64, ...) is the same for every K.
 constexpr int DENSE_KMAX = 8, DENSE_BT = 8;
 __global__ void dense_kernel(const float* __restrict__ x, const float* __restrict__ W,
                              const float* __restrict__ bias, float* __restrict__ out, int B, int N, int K) {
@@ -89,19 +91,22 @@ __global__ void dense_kernel(const float* __restrict__ x, const float* __restric
     const int n = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
     if (n >= N) return;
     const float* w = W + (long long)n * K;
-    float wr[DENSE_KMAX];
-#pragma unroll
-    for (int i = 0; i < DENSE_KMAX; ++i) wr[i] = lane + 64 * i < K ? w[lane + 64 * i] : 0.f;
     const float bn = bias[n];
     for (int b0 = 0; b0 < B; b0 += DENSE_BT) {
         float acc[DENSE_BT];
 #pragma unroll
-        for (int j = 0; j < DENSE_BT; ++j) {
-            acc[j] = 0.f;
-            const int b = b0 + j < B ? b0 + j : B - 1;
+        for (int j = 0; j < DENSE_BT; ++j) acc[j] = 0.f;
+        for (int k0 = 0; k0 < K; k0 += 64 * DENSE_KMAX) {
+            float wr[DENSE_KMAX];
 #pragma unroll
-            for (int i = 0; i < DENSE_KMAX; ++i)
-                if (64 * i < K) acc[j] = fmaf(wr[i], lane + 64 * i < K ? x[(long long)b * K + lane + 64 * i] : 0.f, acc[j]);
+            for (int i = 0; i < DENSE_KMAX; ++i) wr[i] = k0 + lane + 64 * i < K ? w[k0 + lane + 64 * i] : 0.f;
+#pragma unroll
+            for (int j = 0; j < DENSE_BT; ++j) {
+                const int b = b0 + j < B ? b0 + j : B - 1;
+#pragma unroll
+                for (int i = 0; i < DENSE_KMAX; ++i)
+                    if (k0 + 64 * i < K) acc[j] = fmaf(wr[i], k0 + lane + 64 * i < K ? x[(long long)b * K + k0 + lane + 64 * i] : 0.f, acc[j]);
+            }
         }
 #pragma unroll
         for (int j = 0; j < DENSE_BT; ++j) {
@@ -185,7 +190,6 @@ extern "C" int storm_time_embedding(const float* t, const float* gfp_W, const fl
 extern "C" int storm_dense(const float* x, const float* W, const float* bias, float* out, int B, int N, int K,
                            storm_stream_t s) {
     STORM_CHECK(x && W && bias && out && B > 0 && N > 0 && K > 0, "storm_dense: bad arguments");
-    STORM_CHECK(K <= 64 * DENSE_KMAX, "storm_dense: K=%d exceeds %d", K, 64 * DENSE_KMAX);
     hipLaunchKernelGGL(dense_kernel, dim3(cdiv(N, 4)), dim3(256), 0, (hipStream_t)s, x, W, bias, out, B, N, K);
     STORM_LAUNCH_CHECK();
     return STORM_OK;

@@ -510,6 +510,9 @@ struct storm_ncsnpp {
     std::map<std::tuple<int, int, int>, std::shared_ptr<Program>> programs;
     std::map<std::tuple<int, int, int>, unsigned long long> last_use;
     unsigned long long tick = 0;
+    // programs whose op list has been handed out through storm_ncsnpp_program (profilers hold the raw pointer): pinned for the life of
+    // the handle, whatever the cache evicts or storm_ncsnpp_set_fusion drops
+    std::vector<std::shared_ptr<Program>> exported;
     std::mutex mu;
     static constexpr size_t MAX_PROGRAMS = 64;
 };
@@ -643,11 +646,17 @@ extern "C" long long storm_ncsnpp_workspace_bytes(storm_ncsnpp* h, int B, int F,
     return p->ws_bytes;
 }
 
-// the planned op list (for profilers: storm_program_run_timed / storm_program_kernel_name); owned by the handle: valid until the
-// handle is destroyed, its fusion switches change, or MAX_PROGRAMS other shapes have been planned since
+// the planned op list (for profilers: storm_program_run_timed / storm_program_kernel_name); owned by the handle and valid until the
+// handle is destroyed: a program handed out here is pinned (neither the LRU eviction nor storm_ncsnpp_set_fusion frees it)
 extern "C" int storm_ncsnpp_program(storm_ncsnpp* h, int B, int F, int T, const storm_op** ops, int* n_ops, long long* flops) {
     std::shared_ptr<Program> p;
     if (int rc = get_program(h, B, F, T, &p)) return rc;
+    {
+        std::lock_guard<std::mutex> lk(h->mu);
+        bool have = false;
+        for (const auto& e : h->exported) have = have || e.get() == p.get();
+        if (!have) h->exported.push_back(p);
+    }
     if (ops) *ops = p->ops.data();
     if (n_ops) *n_ops = (int)p->ops.size();
     if (flops) *flops = p->flops;

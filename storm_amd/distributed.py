@@ -34,13 +34,14 @@ def self_launch(n_procs, script, argv):
     os.execv(sys.executable, cmd)
 
 
-def timed_steps(step, steps, warmup, sync=None, group_ready=True):
+def timed_steps(step, steps, warmup, sync=None, group_ready=True, single_rank_group=False):
     """The bench contract's timed region: `warmup` untimed steps, then EXACTLY `steps` steps bracketed by
     (device sync, barrier, device sync) on both sides; returns (seconds = MAX over ranks, last step's result).
-    `sync` = torch.cuda.synchronize on a GPU rank, None on CPU."""
+    `sync` = torch.cuda.synchronize on a GPU rank, None on CPU.  single_rank_group: run the barrier / gather lines through an
+    initialised one-rank group too (bench.py --dist-world1: the N-rank code path exercised on one GPU)."""
     import time
     import torch.distributed as dist
-    multi = group_ready and dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
+    multi = group_ready and dist.is_available() and dist.is_initialized() and (dist.get_world_size() > 1 or single_rank_group)
 
     def fence():
         if sync is not None:

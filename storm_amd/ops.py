@@ -389,6 +389,10 @@ def rk_combine_rows(x64, K, coef, h_rows, want64=False):
     the complex128 solver state, K complex64 stages; returns the complex64 rounding (the next network input), with
     want64=True (out64, out32)."""
     B = x64.shape[0]
+    if B > RK_MAX_ROWS:                      # the kernels take their step sizes as a 128-entry argument array: larger batches in row blocks
+        parts = [rk_combine_rows(x64[i:i + RK_MAX_ROWS], [k[i:i + RK_MAX_ROWS] for k in K], coef, h_rows[i:i + RK_MAX_ROWS], want64)
+                 for i in range(0, B, RK_MAX_ROWS)]
+        return (torch.cat([p[0] for p in parts]), torch.cat([p[1] for p in parts])) if want64 else torch.cat(parts)
     out32 = torch.empty(x64.shape, dtype=torch.complex64, device=x64.device)
     out64 = torch.empty_like(x64) if want64 else None
     cf = (C.c_double * len(K))(*[float(c) for c in coef])
@@ -402,6 +406,11 @@ def rk_scaled_sumsq_rows(xa, xb, K, coef, h_rows, atol, rtol, mode=None):
     v = h_b sum coef[j] K[j] (mode None), K[0] (-1), K[0] - K[1] (-2) or xa itself (-3); xa / xb complex128, K complex64.
     A row's value does not depend on the other rows of the batch."""
     B = xa.shape[0]
+    if B > RK_MAX_ROWS:                      # (row blocks, as rk_combine_rows: a row's value does not depend on the others)
+        return torch.cat([rk_scaled_sumsq_rows(xa[i:i + RK_MAX_ROWS], xb[i:i + RK_MAX_ROWS] if xb is not None else None,
+                                               [k[i:i + RK_MAX_ROWS] for k in K], coef,
+                                               h_rows[i:i + RK_MAX_ROWS] if h_rows is not None else None, atol, rtol, mode)
+                          for i in range(0, B, RK_MAX_ROWS)])
     key = (str(xa.device), "rows")
     need = RK_ROW_BLOCKS * B
     if key not in _rk_scratch or _rk_scratch[key].numel() < need:

@@ -77,7 +77,8 @@ def get_ode_sampler(sde, score_fn, y, inverse_scaler=None, denoise=True, rtol=1e
                 return [math.sqrt(sum(s[b] for b in ids) / (n_row * len(ids))) for ids in groups]
 
             zz, sd, off = noise.next(yy)
-            x32 = (sde.prior_sampling(yy.shape, yy, z=zz, seed=sd, offset=off) if z is None else z).contiguous()
+            # (a caller's start state is cloned: accepted rows are copied into x32 in place, and the caller may reuse z)
+            x32 = sde.prior_sampling(yy.shape, yy, z=zz, seed=sd, offset=off).contiguous() if z is None else z.contiguous().clone()
             x = x32.to(torch.complex128)                      # the solver state is complex128, as in scipy (module docstring)
             t_end, direction = float(eps), -1.0
             t = [float(sde.T)] * G

@@ -63,7 +63,7 @@ def evaluate_model(model, num_eval_files, spec=False, audio=False, discriminativ
         if batched:
             x_hat = model.enhance_batch(y, lengths=lens if len(set(lens)) > 1 else None, **kw)
         else:
-            x_hat = model.enhance(y[:1]).reshape(1, -1)
+            x_hat = model.enhance(y[:1], **kw).reshape(1, -1)         # (N / snr / corrector_steps ... reach the model here too: util/inference.py:49)
         x_hat = x_hat.reshape(len(ids), -1).float().to(dev)
         if len(set(lens)) == 1:                                             # one launch for the whole micro-batch
             sdr[ids] = si_sdr_batch(x.contiguous(), x_hat.contiguous()).double().cpu()

@@ -129,3 +129,27 @@ def test_langevin_group_norms_two_ranks(tmp_path):
     assert out.returncode == 0, out.stderr[-2000:]
     sn, zn, sn_ref, zn_ref = json.loads([l for l in out.stdout.splitlines() if l.startswith("RESULT ")][0][7:])
     assert abs(sn - sn_ref) < 1e-6 and abs(zn - zn_ref) < 1e-6
+
+
+@pytest.mark.gpu
+def test_bench_under_the_driver_launch_line_with_an_rccl_group_of_one():
+    """The driver starts the multi-GPU bench as `python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1
+    --master-port P bench.py --gpus N ...`.  On the one GPU a test box has, run exactly that line with N = 1 and --dist-world1, so that
+    bench.py's own init_process_group("nccl", device_id=...), the barrier / all_gather_object fences of distributed.timed_steps and the
+    leave-together barrier execute on ROCm / RCCL before the driver runs them at N = 8; and the --include-h2d variant of the step."""
+    import json
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env["HSA_ENABLE_IPC_MODE_LEGACY"] = "0"
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1",
+           "--master-port", "29577", os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "1", "--warmup", "0", "--N", "2", "--batch", "2",
+           "--seconds", "1", "--no-cpu-baseline", "--no-roofline", "--dist-world1", "--include-h2d"]
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=env, cwd=ROOT)
+    assert out.returncode == 0, out.stdout[-1500:] + out.stderr[-2500:]
+    line = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(line) == 1
+    r = json.loads(line[0])
+    assert r["n_gpus"] == 1 and r["process_group"] == {"backend": "nccl", "world_size": 1}
+    assert r["config"]["nfe_per_utterance"] == 4 and len(r["per_rank_s"]) == 1
+    assert r["from_host"]["value_from_host_wavs"] > 0 and r["from_host"]["bytes_per_step"] == 2 * 2 * 16000 * 4

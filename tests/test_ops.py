@@ -491,6 +491,11 @@ def test_time_embedding_and_dense(dev):
     Wd, bd = torch.randn(37, 4 * nf, generator=g) * 0.2, torch.randn(37, generator=g)
     o = ops.dense(at, Wd.to(dev), bd.to(dev)).cpu()
     assert rel_l2(o, F.linear(at.cpu(), Wd, bd)) < 2e-6
+    # rows wider than one register tile of the kernel (nf = 192 / 256 -> K = 4 nf = 768 / 1024; --nf is a reference flag), ragged K
+    for K in (768, 1024, 520):
+        xw, Ww, bw = torch.randn(11, K, generator=g), torch.randn(21, K, generator=g) * 0.05, torch.randn(21, generator=g)
+        ow = ops.dense(xw.to(dev), Ww.to(dev), bw.to(dev)).cpu()
+        assert rel_l2(ow, F.linear(xw, Ww, bw)) < 2e-6
 
 
 # ---------------------------------------------------------------- SDE steps ---------------

@@ -123,6 +123,67 @@ def test_ode_per_row_control_equals_the_reference_per_utterance_runs(dev, golden
     assert coupled.nfev_rows == [nc] * 3 and not torch.equal(xc.cpu(), x.cpu())
 
 
+def f13_noises(g):
+    """the 61 recorded draws of fixture F13, regenerated from their seed (oracle/make_golden.py::gen_f13; SHA-256 checked)"""
+    import hashlib
+    gen = torch.Generator().manual_seed(int(g["seeds"][1]))
+    shape = tuple(int(v) for v in g["noise_shape"])
+    zs = [SR.complex_randn(shape, gen) for _ in range(1 + int(g["N"]) * 2)]
+    assert hashlib.sha256(b"".join(z.numpy().tobytes() for z in zs)).hexdigest() == str(g["noise_hash"])
+    return zs
+
+
+def test_f13_fixture_inputs_regenerate(golden):
+    """F13 (the reference's full-width, 60-evaluation ScoreModel.enhance) stores seeds instead of 16 MB of noise: the draws and the
+    27.8 M weights regenerate bit for bit here (hashes), so the GPU test below feeds the engine what the reference consumed."""
+    import hashlib
+    g = golden["f13_full_sampler"]
+    assert len(f13_noises(g)) == 61 and int(g["nfe"]) == 60
+    sd = NR.seeded_state_dict(NR.NCSNppConfig(input_channels=4), seed=int(g["seeds"][0]))
+    h = hashlib.sha256()
+    for k in sorted(sd):
+        h.update(k.encode())
+        h.update(sd[k].detach().contiguous().numpy().tobytes())
+    assert h.hexdigest() == str(g["sdhash"])
+    wav = torch.randn(1, 16000, generator=torch.Generator().manual_seed(int(g["seeds"][2]))) * 0.1
+    assert torch.equal(wav, T(g["wav_in"]))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("prec,tol_wav,tol_spec", [("fp32", 1e-3, 1e-3), ("bf16", 5e-2, 5e-2), ("fp16", 2e-2, 2e-2)])
+def test_full_width_60_evaluation_sampler_vs_reference_golden(golden, prec, tol_wav, tol_spec):
+    """The product of the path against the REFERENCE at full width and full sampler length (fixture F13): ScoreModel.enhance of the
+    seeded 27.8 M `ncsnpp` on a 1-s utterance, N = 30 reverse steps + 1 ald corrector step each = 60 score evaluations
+    (model.py:273-310, sampling/__init__.py:54-66), under the noise the reference consumed - at batch 16 (the same row 16 times, so
+    the production kernel selection of the bench batch is active and every row must reproduce the reference), in the parity
+    precision and in the two 16-bit operand precisions: what 60 chained evaluations of a 1e-2 network error amount to, measured
+    against the reference instead of against the engine's own fp32 run."""
+    from tests.backend import setup_backend
+    from storm_amd.model import ScoreModel
+    dev = setup_backend("hip")
+    g = golden["f13_full_sampler"]
+    m = ScoreModel(backbone="ncsnpp", sde="ouve", theta=1.5, sigma_min=0.05, sigma_max=0.5, spec_factor=0.15, spec_abs_exponent=0.5)
+    m.dnn.load_state_dict(NR.seeded_state_dict(NR.NCSNppConfig(input_channels=4), seed=int(g["seeds"][0])))
+    m._error_loading_ema = True
+    m = m.eval().to(dev)
+    m.set_precision(prec)
+    B = 16
+    zs = [z.to(dev).expand(B, -1, -1, -1).contiguous() for z in f13_noises(g)]
+    it = iter(zs)
+    wav = T(g["wav_in"]).to(dev).expand(B, -1).contiguous()
+    Y, peak, T_orig = m._prepare(wav)                         # (enhance_batch, opened up to read the sampler's final state as well)
+    sampler = m.get_pc_sampler("reverse_diffusion", "ald", Y, N=int(g["N"]), corrector_steps=1, snr=0.5, intermediate=False,
+                               langevin_per_row=True, noise_fn=lambda: next(it))
+    sample, nfe = sampler()
+    x = m.data_module.spec_to_wav(sample, T_orig, peak)
+    assert nfe == int(g["nfe"]) == 60 and x.shape == (B, 16000)
+    e_spec = [rel_l2(sample[b].reshape(-1).cpu(), T(g["final_spec"]).reshape(-1)) for b in range(B)]
+    e_wav = [rel_l2(x[b].float().cpu(), g["out"]) for b in range(B)]
+    print(f"F13 60-evaluation enhance, {prec}, batch {B}: wav rel-L2 vs reference {max(e_wav):.3e} (final spectrogram {max(e_spec):.3e})")
+    assert max(e_wav) < tol_wav and max(e_spec) < tol_spec
+    assert all(torch.equal(x[b], x[0]) for b in range(1, B))          # identical rows in, identical rows out (no batch coupling in ald)
+
+
 @pytest.mark.gpu
 def test_bf16_sampler_drift_over_a_full_run():
     """BASELINE.json configs[1] numerics: the FULL 30-step PC run (reverse_diffusion + 1 ald step = 60 score evaluations of

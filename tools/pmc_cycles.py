@@ -15,12 +15,13 @@ for f in glob.glob(root + "/**/*counter_collection.csv", recursive=True):
         k = r["Kernel_Name"]
         if not any(p_ in k for p_ in pats):
             continue
-        acc[(k.split("(")[0][-44:], r["Grid_Size"])][r["Counter_Name"]].append(float(r["Counter_Value"]))
+        acc[(k.split("(")[0].replace("storm::", "").replace("void ", ""), r["Grid_Size"])][r["Counter_Name"]].append(float(r["Counter_Value"]))
 for (k, grid), c in sorted(acc.items()):
     med = {n: sorted(v)[len(v) // 2] for n, v in c.items()}
     gui = med.get("GRBM_GUI_ACTIVE", 0) / 8.0                    # summed over the 8 XCDs
     busy = med.get("SQ_VALU_MFMA_BUSY_CYCLES", 0)
-    line = f"{tag:10s} grid {int(grid) // 512:5d} wgs: cycles/launch {gui:10.0f}"
+    n_disp = len(next(iter(c.values())))
+    line = f"{tag:8s} {k[:64]:64s} grid {int(grid):8d} threads x{n_disp:4d}: cycles/launch {gui:10.0f}"
     if busy and gui:
         line += f"  mfma-busy {busy / (gui * 1024):5.3f}"
     for n in ("SQ_WAVE_CYCLES", "SQ_WAIT_ANY", "SQ_WAIT_INST_ANY", "SQ_ACTIVE_INST_ANY"):
