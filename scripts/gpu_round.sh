@@ -1,13 +1,15 @@
 #!/bin/bash
 # One GPU-box visit: smoke, the -m gpu suite, the default bench line (roofline + roofline_hbm + cpu_baseline), rocprofv3
-# kernel stats of the same bench command, HBM-traffic PMC passes (-> conv_traffic.json), SQ counters; the other configs' lines.
+# kernel stats of the same bench command (socket power / clock sampled beside the bench line), HBM-traffic PMC passes (-> conv_traffic.json), SQ counters; the other configs' lines.
 TAG=${1:-r04a}
 mkdir -p gpurun_out
 export TMPDIR=/tmp
 python -c "import __graft_entry__ as g; g.build(); g.smoke()" > gpurun_out/smoke_$TAG.log 2>&1; echo "smoke rc=$?" >> gpurun_out/smoke_$TAG.log; tail -2 gpurun_out/smoke_$TAG.log
 timeout 1500 python -m pytest tests -m gpu -q --tb=short > gpurun_out/pytest_gpu_$TAG.log 2>&1; tail -3 gpurun_out/pytest_gpu_$TAG.log
 grep -h "rel-L2\|nfev\|vs reference" gpurun_out/pytest_gpu_$TAG.log | head -20
-timeout 900 python bench.py --ops-json gpurun_out/ops_$TAG.json > gpurun_out/bench_$TAG.json 2> gpurun_out/bench_$TAG.err; head -c 400 gpurun_out/bench_$TAG.json; echo
+python tools/power_trace.py gpurun_out/power_$TAG.csv & PT=$!
+timeout 900 python bench.py --include-h2d --ops-json gpurun_out/ops_$TAG.json > gpurun_out/bench_$TAG.json 2> gpurun_out/bench_$TAG.err; head -c 400 gpurun_out/bench_$TAG.json; echo
+kill $PT; sleep 0.3; python tools/power_trace.py --summary gpurun_out/power_$TAG.csv | tee gpurun_out/power_summary_$TAG.txt
 if [ "$2" != "short" ]; then
 timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_$TAG -o trace -- python bench.py --steps 1 --warmup 0 --no-cpu-baseline > gpurun_out/prof_bench_$TAG.json 2> gpurun_out/prof_$TAG.err
 f=$(find gpurun_out/prof_$TAG -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && head -8 "$f"
