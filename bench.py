@@ -327,6 +327,12 @@ def main():
             "avg_launch_algorithmic_bytes": sum(r["algorithmic_bytes"] for r in big) / len(big),
             "nfe_ms_profiled": total_ms, "ms_by_op_kind": {k: round(v, 3) for k, v in by_kind.items()},
             "conv3x3_by_kernel": by_kernel,
+            # the dominant kernel's launches by layer resolution: the few-tile levels (< 512 pixel tiles of 8 x 32: one workgroup's serial
+            # K loop bounds them, not the matrix pipe) pull its launch average down - `achieved` / `frac` above are over ALL its launches
+            "dominant_by_resolution": {f"{h}x{w}": {"launches_per_nfe": len(v), "ms_per_nfe": round(sum(r["ms"] for r in v), 3),
+                                                    "tflops": round(sum(r["flops"] for r in v) / (sum(r["ms"] for r in v) * 1e-3) / 1e12, 1)}
+                                       for (h, w), v in sorted({(r["H"], r["W"]): [q for q in big if (q["H"], q["W"]) == (r["H"], r["W"])] for r in big}.items(),
+                                                               reverse=True)},
             "all_3x3_tflops": sum(r["flops"] for r in all3) / (sum(r["ms"] for r in all3) * 1e-3) / 1e12,
             "all_conv_tflops": sum(r["flops"] for r in all_conv) / (sum(r["ms"] for r in all_conv) * 1e-3) / 1e12,
             "method": f"HIP events per op on the launch stream (storm_program_run_timed) over {args.profile_nfe} score "
