@@ -22,8 +22,9 @@ p = argparse.ArgumentParser()
 p.add_argument("--seconds", type=float, default=4.0)
 p.add_argument("--modes", default="idle,igemm,duo,p128,pipe,zeros")
 p.add_argument("--cin", type=int, default=128)
+p.add_argument("--dtype", default="bf16", choices=["bf16", "fp16"])
 args = p.parse_args()
-dev, dt = torch.device("cuda:0"), torch.bfloat16
+dev, dt = torch.device("cuda:0"), (torch.bfloat16 if args.dtype == "bf16" else torch.float16)
 g = torch.Generator().manual_seed(0)
 rnd = lambda *s: torch.randn(*s, generator=g)  # noqa: E731
 samples, stop = [], False
@@ -94,7 +95,7 @@ def run(mode):
         v = sorted(s[k] for s in late if k in s)
         return v[len(v) // 2] if v else float("nan")
     fl = 2 * B * H * W * cout * cin * 9
-    line = f"{mode:6s} power {med('W'):7.1f} W  sclk {med('sclk'):6.0f} MHz  T {med('T'):5.1f} C  ({len(late)} samples)"
+    line = f"{args.dtype} {mode:6s} power {med('W'):7.1f} W  sclk {med('sclk'):6.0f} MHz  T {med('T'):5.1f} C  ({len(late)} samples)"
     if n:
         line += f"  | {kn.split('<')[0][7:]:20s} first-to-last mean {ms_tot / n:.3f} ms, settled {last:.3f} ms = {fl / last / 1e9:5.0f} TF/s"
     print(line, flush=True)
