@@ -23,6 +23,8 @@ p.add_argument("--seconds", type=float, default=4.0)
 p.add_argument("--modes", default="idle,igemm,duo,p128,pipe,zeros")
 p.add_argument("--cin", type=int, default=128)
 p.add_argument("--dtype", default="bf16", choices=["bf16", "fp16"])
+p.add_argument("--abl", default="", help="comma list of STORM_CONV_ABLATE values (profiling library, STORM_LIB=...): every mode is run once per value")
+p.add_argument("--nogn", action="store_true", help="plain operand")
 args = p.parse_args()
 dev, dt = torch.device("cuda:0"), (torch.bfloat16 if args.dtype == "bf16" else torch.float16)
 g = torch.Generator().manual_seed(0)
@@ -65,7 +67,7 @@ def run(mode):
     x = (torch.zeros(B, H, W, cin) if mode == "zeros" else rnd(B, H, W, cin)).to(dt).to(dev)
     w = ops.pack_conv_weight(((torch.zeros if mode == "zeros" else rnd)(cout, cin, 3, 3) * 0.05).to(dev), dt)
     ss = ops.pack_gn_ss(1 + 0.1 * rnd(B, cin), 0.1 * rnd(B, cin)).to(dev)
-    segs = [ops.Seg(x, w, 9, gn_ss=ss, gn_silu=True)]
+    segs = [ops.Seg(x, w, 9, gn_ss=None if args.nogn else ss, gn_silu=True)]
     kw = dict(bias=rnd(cout).to(dev), tbias=rnd(B, cout).to(dev), gn_partials=True, scale=0.7)
     variant = {"igemm": 0, "duo": 5, "p128": 4, "pipe": -1, "zeros": 0}.get(mode, -1)
     L.check(L.lib().storm_set_switch(b"STORM_CONV_VARIANT", variant), "storm_set_switch")
@@ -104,4 +106,11 @@ def run(mode):
 
 
 for m in args.modes.split(","):
-    run(m)
+    if args.abl:
+        for a in args.abl.split(","):
+            L.check(L.lib().storm_set_switch(b"STORM_CONV_ABLATE", int(a)), "storm_set_switch")
+            print(f"STORM_CONV_ABLATE={a}: ", end="")
+            run(m)
+        L.lib().storm_set_switch(b"STORM_CONV_ABLATE", 0)
+    else:
+        run(m)
