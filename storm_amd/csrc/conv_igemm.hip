@@ -670,6 +670,7 @@ static int launch_conv(const storm_conv_args& a, hipStream_t st) {
 //   5: conv_duo.hip, 128 cout x 256 px, 4 waves, two workgroups / CU, single-stream phases (16-bit 3x3, <= 128 output channels)
 //   6: conv_thin.hip, 8 input channels (stem, input-skip 1x1s): operands straight from global memory (16-bit)
 //   8: conv_narrow.hip, 3x3 to <= 4 output channels (the output pyramid): 36-row 1x1 GEMM over the haloed region + nine-point gather
+//   9: conv_pipe.hip with 128 cout x 256 px per 8-wave workgroup (64 x 64 per wave): the pipelined kernel for 128 ... 511 pixel tiles
 //   7: conv_igemm 64 cout x 256 px, 4 waves (32x128 each), 2 workgroups / CU; LDS-DMA - for 3x3 layers with so few pixel tiles
 //      that 128-cout tiles leave CUs without work (the 32 x 64 level: 128 pixel tiles x 2 cout tiles on 256 CUs x 2 slots)
 static int choose_variant(const storm_conv_args& a, bool any9) {
@@ -682,7 +683,8 @@ static int choose_variant(const storm_conv_args& a, bool any9) {
     // 128 ... 511 pixel tiles (the 32 x 64 level of NCSN++ at batch 16, 32 x 128 of ncsnpplarge at batch 8): the pipelined kernel on HALF
     // the CUs still beats the 64-cout tiles on all of them (profiles/r04_probe_small.txt: 59.5 vs 62.3 us on 256 -> 256, 101 vs 112 on
     // 512 -> 256) - a lone 4-wave workgroup issues too slowly to use its CU; below 128 tiles the 64-cout tiles win
-    if (a.outC > 128 && px_tiles >= 128 && any9 && conv_pipe_supports(a)) return 3;
+    // ... and the same kernel with 128-cout tiles (<128, 8>: twice the workgroups, half the MFMAs per phase and wave) shortens the chain
+    if (a.outC > 128 && px_tiles >= 128 && any9 && conv_pipe_supports(a)) return 9;
     // conv_pipe128: measured against this file's two-workgroup kernel on MI355X (tools/probe128.py, profiles/r02_pipe128_ab.txt) it
     // wins 13-20 % at 4 of its tiles per CU (128 x 256 x 16) and ties or loses (0 ... -10 %) at 16 tiles per CU (256 x 512 x 16):
     // with K this short the exposed epilogue and the fused GroupNorm transform weigh the same in both kernels and two resident
@@ -724,6 +726,7 @@ static int dispatch_conv(const storm_conv_args& a, hipStream_t st) {
     if (any9) {
         if (small) return launch_conv<T, 9, 1, 1, 4, false>(a, st);
         if (variant == 3 && conv_pipe_supports(a)) return launch_conv_pipe(a, st);
+        if (variant == 9 && conv_pipe_supports(a)) return launch_conv_pipe_half(a, st);
         if (variant == 4 && conv_pipe128_supports(a)) return launch_conv_pipe128(a, st);
         if (variant == 5 && conv_duo_supports(a)) return launch_conv_duo(a, st);
         if (variant == 2) return launch_conv<T, 9, 2, 4, 2, true>(a, st);
@@ -754,7 +757,7 @@ static const char* kernel_name_of(const storm_conv_args& a) {
     if (a.outC <= 32) variant = -1;
     if (variant == 6 && conv_thin_supports(a)) return conv_thin_kernel_name(a.dtype, taps);
     if (a.outC <= 32) shape = "1, 1, 4, false, false";
-    else if (any9 && variant == 3 && conv_pipe_supports(a)) return conv_pipe_kernel_name(a.dtype);
+    else if (any9 && (variant == 3 || variant == 9) && conv_pipe_supports(a)) return conv_pipe_kernel_name(a.dtype, variant == 9);
     else if (any9 && variant == 4 && conv_pipe128_supports(a)) return conv_pipe128_kernel_name(a.dtype);
     else if (any9 && variant == 5 && conv_duo_supports(a)) return conv_duo_kernel_name(a.dtype);
     else if (variant == 2) shape = "2, 4, 2, true, false";

@@ -201,7 +201,8 @@ struct PipeParams {
 // defined in conv_pipe.hip: software-pipelined 3x3 kernel (bf16 / fp16 operands), 256 output channels per workgroup
 bool conv_pipe_supports(const storm_conv_args& a);
 int launch_conv_pipe(const storm_conv_args& a, hipStream_t st);
-const char* conv_pipe_kernel_name(int dtype);
+int launch_conv_pipe_half(const storm_conv_args& a, hipStream_t st);      // 128 output channels per workgroup (few pixel tiles)
+const char* conv_pipe_kernel_name(int dtype, bool half_tile);
 // defined in conv_pipe128.hip: the same pipeline for layers with <= 128 output channels (128 couts x 512 pixels per workgroup)
 bool conv_pipe128_supports(const storm_conv_args& a);
 int launch_conv_pipe128(const storm_conv_args& a, hipStream_t st);

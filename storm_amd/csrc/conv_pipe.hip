@@ -5,7 +5,11 @@
 // per CU (2 waves / SIMD, 256 registers each) and for an instruction stream in which nothing but MFMAs, fragment
 // reads and DMA issues is left:
 //   * tile: BN output channels x (TH x 32) pixels; every wave owns 64 couts x (4 x 32) pixels = 8 accumulator tiles
-//     of v_mfma_f32_32x32x16_bf16.   <256, 8>: wave grid 4 (cout) x 2 (pixel rows);  <128, 16>: 2 x 4.
+//     of v_mfma_f32_32x32x16_bf16.   <256, 8>: wave grid 4 (cout) x 2 (pixel rows).
+//     <128, 8> (round 4): 128 couts x 256 pixels, wave grid 2 x 4, a wave owns 64 couts x (2 x 32) pixels = 4 accumulator tiles and
+//     issues 8 MFMAs per phase instead of 16 - for layers with 128 ... 511 pixel tiles (the 32 x 64 level at batch 16), where the
+//     256-cout tile leaves half of the CUs without a workgroup and the launch time is the serial chain of phases per workgroup.
+//     Same chunk order, same phases, same epilogue: results are bit-identical to <256, 8>.
 //   * the K dimension is a HOST-BUILT list of chunk descriptors (conv_params.h: 64 channels of one source tensor
 //     under all of its taps), and the body of a chunk is compile-time unrolled over its taps (two bodies: nine taps,
 //     one tap).  Tap offsets, pixel rows and k-groups are instruction immediates; the per-phase scalar work is one
@@ -76,9 +80,15 @@ template <int BN_, int TH_> struct PCfg {
     static constexpr int OFF_RING = 2 * PATCH_BYTES;
     static constexpr int OFF_SS = OFF_RING + RINGB;
     static constexpr int MAIN_BYTES = OFF_SS + 2 * 1024;
-    static constexpr int STAGE_BYTES = NWAVES * 32 * PR * WM * 128;
-    static constexpr int LDS_BYTES = MAIN_BYTES > STAGE_BYTES ? MAIN_BYTES : STAGE_BYTES;
-    static_assert(WN == 4, "wave tile is 64 couts x 4 pixel rows");
+    static constexpr int WSTAGE = 32 * PR * WM * 128;         // one wave's epilogue staging (one pixel row x 64 couts, fp32)
+    // Epilogue staging beside the next tile's landing loads: waves 0-4 in patch buffer 1; waves 5-7 + the statistics scratch in ring
+    // slots 2, 3 when they fit there (<256, 8>: 2 x 16 KiB), else in a region of their own behind the main image (<128, 8>)
+    static constexpr int TAIL_BYTES = 3 * WSTAGE + WAVES_N * BN * 8;
+    static constexpr bool TAIL_IN_RING = TAIL_BYTES <= 2 * WPHASE;
+    static constexpr int OFF_TAIL = TAIL_IN_RING ? OFF_RING + 2 * WPHASE : MAIN_BYTES;
+    static constexpr int LDS_BYTES = TAIL_IN_RING ? MAIN_BYTES : MAIN_BYTES + TAIL_BYTES;
+    static_assert(WN == 4 || WN == 2, "wave tile is 64 couts x 4 (or 2) pixel rows");
+    static_assert(5 * WSTAGE <= PATCH_BYTES, "epilogue staging of waves 0-4 inside patch buffer 1");
     static_assert(LDS_BYTES <= 160 * 1024, "LDS budget");
     static_assert((WPHASE & (WPHASE - 1)) == 0, "ring rotation by mask");
     static_assert(PATCH_BYTES % 256 == 0, "k-group XOR must stay inside the slot field");
@@ -384,6 +394,18 @@ void conv_pipe_kernel(const PipeParams a, const int n_ct, const int tiles_per_xc
                 };
                 typedef IC<2 * h + 1> K1;
 #define STORM_SB() __builtin_amdgcn_sched_barrier(0)
+                if constexpr (WM * WN == 4) {
+                // <128, 8>: four MFMAs per k-group (fa[i / 2], fb[i % 2]); the same rule - one or two reads per MFMA gap, a fragment
+                // register is refilled right after the last MFMA that reads it
+                mma_part(fa0, fb0, 0, 1); read_a(fa1[0], ring_rd, K1{}, IC<0>{}); read_b(fb1[0], pb, K1{}, Poff{}, Prow{}, IC<0>{}); STORM_SB();
+                mma_part(fa0, fb0, 1, 2); read_b(fb1[1], pb, K1{}, Poff{}, Prow{}, IC<1>{}); read_a(fa1[1], ring_rd, K1{}, IC<1>{}); STORM_SB();
+                mma_part(fa0, fb0, 2, 3); next_a(IC<0>{}); STORM_SB();          // fa0[0]: last used by MFMA 1
+                mma_part(fa0, fb0, 3, 4); next_b(IC<0>{}); STORM_SB();          // fb0[0]: last used by MFMA 2
+                mma_part(fa1, fb1, 0, 1); next_b(IC<1>{}); next_a(IC<1>{}); STORM_SB();   // fb0[1], fa0[1]: last used by MFMA 3
+                mma_part(fa1, fb1, 1, WM * WN); STORM_SB();
+                stamp(sb + (h ? 10 : 6));
+                raw_barrier();
+                } else {
                 // fragment registers are refilled as early as the MFMAs release them, so that every LDS read of the interval
                 // has returned by MFMA 12: the wave then ARRIVES at the interval barrier and issues its last four MFMAs behind
                 // it - the barrier's latency (~95 cycles) and the partner group's start-up hide under them
@@ -406,6 +428,7 @@ void conv_pipe_kernel(const PipeParams a, const int n_ct, const int tiles_per_xc
                     mma_part(fa1, fb1, 1, WM * WN); STORM_SB();
                     stamp(sb + (h ? 10 : 6));
                     raw_barrier();
+                }
                 }
 #undef STORM_SB
             } else {
@@ -536,16 +559,16 @@ void conv_pipe_kernel(const PipeParams a, const int n_ct, const int tiles_per_xc
             continue;
         }
         // ---- epilogue (conv_epilogue.h).  Staging lives in patch buffer 1 (waves 0-4) and ring slots 2, 3 (waves 5-7; the statistics
-        // scratch behind them): the next tile's first loads are landing in buffer 0 / slots 0, 1 meanwhile.
-        constexpr int WSTAGE = 32 * PR * WM * 128;
-        static_assert(5 * WSTAGE <= PATCH_BYTES && 3 * WSTAGE + WAVES_N * BN * 8 <= 2 * WPHASE, "epilogue staging beside the next tile's loads");
-        char* const stage = smem + (wave < 5 ? PATCH_BYTES + wave * WSTAGE : OFF_RING + 2 * WPHASE + (wave - 5) * WSTAGE);
+        // scratch behind them; <128, 8>: a region behind the main image, PCfg::OFF_TAIL): the next tile's first loads are landing in
+        // buffer 0 / slots 0, 1 meanwhile.
+        constexpr int WSTAGE = Cfg::WSTAGE;
+        char* const stage = smem + (wave < 5 ? PATCH_BYTES + wave * WSTAGE : Cfg::OFF_TAIL + (wave - 5) * WSTAGE);
         const epi::TileAt et = {e_tile, e_b, e_ty0, e_tx0, e_cout0};
         float gsum[8], gsq[8];
         epi::store_tile<T, WM, WN, (ABL & (2048 | 4096 | 8192))>(acc, stage, ap, et, wm, wn, lane, imgH, imgW, BN, TH, gsum, gsq);
         if (first) stamp(502);
         if (ap->gn_part != nullptr)
-            epi::write_stats<WM, WN, WAVES_N, BN, TH>(gsum, gsq, reinterpret_cast<float*>(smem + OFF_RING + 2 * WPHASE + 3 * WSTAGE), ap, et, wm, wn, lane, tid,
+            epi::write_stats<WM, WN, WAVES_N, BN, TH>(gsum, gsq, reinterpret_cast<float*>(smem + Cfg::OFF_TAIL + 3 * WSTAGE), ap, et, wm, wn, lane, tid,
                                                       imgH, tiles_x, tiles_per_img);
         if (!has_next) break;
         first = false;
@@ -671,7 +694,17 @@ int launch_conv_pipe(const storm_conv_args& a, hipStream_t st) {
     return launch_pipe<bf16_t, 256, 8, 0>(a, st);
 }
 
-const char* conv_pipe_kernel_name(int dtype) {
+// <128, 8>: the same kernel with 128 output channels per workgroup (choose_variant 9: layers with 128 ... 511 pixel tiles)
+int launch_conv_pipe_half(const storm_conv_args& a, hipStream_t st) {
+    if (a.dtype == STORM_F16) return launch_pipe<half_t, 128, 8, 0>(a, st);
+#if defined(STORM_PROFILING)
+    if (switches().conv_ablate == 64) return launch_pipe<bf16_t, 128, 8, 64>(a, st);
+#endif
+    return launch_pipe<bf16_t, 128, 8, 0>(a, st);
+}
+
+const char* conv_pipe_kernel_name(int dtype, bool half_tile) {
+    if (half_tile) return dtype == STORM_F16 ? "storm::conv_pipe_kernel<storm::half_t, 128, 8, 0>" : "storm::conv_pipe_kernel<storm::bf16_t, 128, 8, 0>";
     return dtype == STORM_F16 ? "storm::conv_pipe_kernel<storm::half_t, 256, 8, 0>" : "storm::conv_pipe_kernel<storm::bf16_t, 256, 8, 0>";
 }
 

@@ -62,12 +62,12 @@ def test_conv_persistent_tile_loop(dev, dtype, k, switch):
     assert torch.allclose(st, sref, rtol=rtol, atol=rtol * float(sref.abs().max()))
 
 
-@pytest.mark.parametrize("variant", [3, 7])
+@pytest.mark.parametrize("variant", [3, 7, 9])
 @pytest.mark.parametrize("case", ["plain", "block_tail", "gn_fused", "ragged", "deep_k", "skip", "plain@8", "block_tail@8", "gn_fused@8",
                                   "skip@8", "plain:f16", "gn_fused:f16"])
 def test_conv_pipelined_kernels(dev, variant, case, switch):
-    """conv_pipe.hip (chunk-unrolled LDS-DMA pipeline, 256-cout tile) on shapes the default dispatch would give
-    to conv_igemm.hip: plain 3x3, fused 1x1 shortcut over a concat, fused GroupNorm-apply operand, ragged sizes, many
+    """conv_pipe.hip (chunk-unrolled LDS-DMA pipeline, 256-cout tile; variant 9: its 128-cout tile for layers with few pixel
+    tiles) on shapes the default dispatch would give to conv_igemm.hip: plain 3x3, fused 1x1 shortcut over a concat, fused GroupNorm-apply operand, ragged sizes, many
     K-chunks; "@8": as if the device had 8 CUs, so every persistent workgroup walks several tiles (next-tile prefetch
     before the epilogue, staging beside the landing loads)."""
     from storm_amd import ops
@@ -156,6 +156,43 @@ def test_conv_pipelined_kernels(dev, variant, case, switch):
         x = torch.randn(B, Cin, H, W, generator=g); w = torch.randn(Cout, Cin, 3, 3, generator=g) * 0.2
         y = ops.conv([ops.Seg(nhwc(x).to(dtype).to(dev), ops.pack_conv_weight(w.to(dev), dtype), 9)], Cout).float().cpu()
         assert rel_l2(nchw(y)[:, :Cout], F.conv2d(q(x, dtype), q(w, dtype), padding=1)) < 6e-3
+
+
+@pytest.mark.parametrize("cus", [0, 8])
+def test_conv_pipe_half_tile_equals_full_tile_bit_for_bit(dev, cus, switch):
+    """conv_pipe_kernel<T, 128, 8> (variant 9: 128 couts per workgroup, a wave owns 64 couts x 64 pixels) walks the same chunk
+    descriptors in the same order as <T, 256, 8>: the output is bit-identical (the GroupNorm partials to fp32 rounding) - 2 + 1 nine-tap chunks over a
+    concat with a fused GroupNorm operand, 2 one-tap chunks of a fused shortcut, ragged rows / columns / couts, with and without
+    the persistent tile walk."""
+    from storm_amd import ops
+    dtype = torch.bfloat16
+    g = torch.Generator().manual_seed(77)
+    B, C0, Ca, Cb, Sa, Co, H, W = 2, 8, 104, 56, 72, 264, 11, 37
+    x0 = torch.randn(B, C0, H, W, generator=g)
+    wa, wb = torch.randn(Ca, C0, 3, 3, generator=g) * 0.4, torch.randn(Cb, C0, 1, 1, generator=g) * 0.7
+    w = torch.randn(Co, Ca + Cb, 3, 3, generator=g) * 0.05
+    sa = torch.randn(B, Sa, H, W, generator=g)
+    w2 = torch.randn(Co, Sa, 1, 1, generator=g) * 0.1
+    bias, tb = torch.randn(Co, generator=g), torch.randn(B, Co, generator=g)
+    gam, bet = 1 + 0.1 * torch.randn(Ca + Cb, generator=g), 0.1 * torch.randn(Ca + Cb, generator=g)
+    x0d = nhwc(x0).to(dtype).to(dev)
+    xa, pa = ops.conv([ops.Seg(x0d, ops.pack_conv_weight(wa.to(dev), dtype), 9)], Ca, gn_partials=True)
+    xb, pb = ops.conv([ops.Seg(x0d, ops.pack_conv_weight(wb.to(dev), dtype), 1)], Cb, gn_partials=True)
+    _, ss = ops.gn_finalize(pa, pb, gamma=gam.to(dev), beta=bet.to(dev), count=H * W)
+    segs = [ops.Seg(xa, ops.pack_conv_weight(w.to(dev), dtype), 9, src_b=xb, gn_ss=ss, gn_silu=True),
+            ops.Seg(nhwc(sa).to(dtype).to(dev), ops.pack_conv_weight(w2.to(dev), dtype), 1)]
+    kw = dict(bias=bias.to(dev), tbias=tb.to(dev), scale=0.5)
+    if cus:
+        switch("STORM_CONV_CUS", cus)
+    out = {}
+    for variant in (3, 9):
+        switch("STORM_CONV_VARIANT", variant)
+        assert ops.conv_kernel_name(segs, Co, **kw).endswith({3: "256, 8, 0>", 9: "128, 8, 0>"}[variant])
+        out[variant] = ops.conv(segs, Co, gn_partials=True, **kw)
+    assert torch.equal(out[3][0], out[9][0])
+    # (the statistics partials of an 8-row tile are summed over 4 wave rows of 2 pixel rows instead of 2 x 4: fp32 rounding apart)
+    assert torch.allclose(out[3][1], out[9][1], rtol=2e-5, atol=2e-5 * float(out[3][1].abs().max()))
+
 
 
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
