@@ -680,11 +680,12 @@ static int choose_variant(const storm_conv_args& a, bool any9) {
     if (conv_narrow_supports(a)) return 8;
     const long long px_tiles = (long long)a.B * cdiv((long long)a.H * a.W, TILE_H * TILE_W);
     if (a.outC > 128 && px_tiles >= 512) return any9 && conv_pipe_supports(a) ? 3 : 2;
-    // 128 ... 511 pixel tiles (the 32 x 64 level of NCSN++ at batch 16, 32 x 128 of ncsnpplarge at batch 8): the pipelined kernel on HALF
-    // the CUs still beats the 64-cout tiles on all of them (profiles/r04_probe_small.txt: 59.5 vs 62.3 us on 256 -> 256, 101 vs 112 on
-    // 512 -> 256) - a lone 4-wave workgroup issues too slowly to use its CU; below 128 tiles the 64-cout tiles win
-    // ... and the same kernel with 128-cout tiles (<128, 8>: twice the workgroups, half the MFMAs per phase and wave) shortens the chain
-    if (a.outC > 128 && px_tiles >= 128 && any9 && conv_pipe_supports(a)) return 9;
+    // fewer than 512 pixel tiles (the 32 x 64 level of NCSN++ at batch 16; 32 x 128 ... 4 x 16 of ncsnpplarge at batch 8): the launch time is the
+    // serial chain of phases per workgroup, not throughput.  conv_pipe with 128-cout tiles (<128, 8>: twice the workgroups of its
+    // 256-cout tile, half the MFMAs per phase and wave) against the 256-cout tile / the generic 64-cout tiles on all CUs, same box
+    // (profiles/r04_probe_small_half.txt): 256 -> 256 @ 16 x 32 x 64: 48.6 vs 66.7 / 72.1 us, 512 -> 256: 84.0 vs 109 / 133;
+    // 8 x 16 x 64: 38.2 vs 52.7 / 43.7; 8 x 8 x 32: 36.1 vs 51.0 / 41.1; 8 x 4 x 16: 31.8 vs 46.9 / 37.7
+    if (a.outC > 128 && any9 && conv_pipe_supports(a)) return 9;
     // conv_pipe128: measured against this file's two-workgroup kernel on MI355X (tools/probe128.py, profiles/r02_pipe128_ab.txt) it
     // wins 13-20 % at 4 of its tiles per CU (128 x 256 x 16) and ties or loses (0 ... -10 %) at 16 tiles per CU (256 x 512 x 16):
     // with K this short the exposed epilogue and the fused GroupNorm transform weigh the same in both kernels and two resident

@@ -306,15 +306,19 @@ PIPE128_CASES = {
 }
 
 
-def test_conv_dispatch_picks_the_64_cout_tile_when_128_cout_tiles_leave_cus_idle(dev):
-    """storm_conv's own choice (no switch): a 3x3 layer with > 128 output channels on so few pixel tiles that 128-cout tiles
-    give <= 256 workgroups runs the 64-cout tile of conv_igemm.hip; with many pixel tiles it does not."""
+def test_conv_dispatch_with_few_pixel_tiles(dev):
+    """storm_conv's own choice (no switch) for a 3x3 layer with > 128 output channels: with fewer than 512 pixel tiles the pipelined
+    kernel's 128-cout tile (16-bit operands; fp32: the 64-cout tile of conv_igemm.hip when 128-cout tiles would give <= 256
+    workgroups), with many pixel tiles its 256-cout tile."""
     from storm_amd import ops
     w = ops.pack_conv_weight(torch.zeros(256, 64, 3, 3, device=dev), torch.bfloat16)
     small = [ops.Seg(torch.zeros(1, 32, 64, 64, dtype=torch.bfloat16, device=dev), w, 9)]
-    assert "1, 2, 2, false, true" in ops.conv_kernel_name(small, 256)
+    assert ops.conv_kernel_name(small, 256) == "storm::conv_pipe_kernel<storm::bf16_t, 128, 8, 0>"
     large = [ops.Seg(torch.zeros(16, 64, 128, 64, dtype=torch.bfloat16, device=dev), w, 9)]
-    assert "1, 2, 2, false, true" not in ops.conv_kernel_name(large, 256)
+    assert ops.conv_kernel_name(large, 256) == "storm::conv_pipe_kernel<storm::bf16_t, 256, 8, 0>"
+    w32 = ops.pack_conv_weight(torch.zeros(256, 64, 3, 3, device=dev), torch.float32)
+    small32 = [ops.Seg(torch.zeros(1, 32, 64, 64, dtype=torch.float32, device=dev), w32, 9)]
+    assert "1, 2, 2, false, true" in ops.conv_kernel_name(small32, 256)
 
 
 @pytest.mark.parametrize("variant", [4, 5])
