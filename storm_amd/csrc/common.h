@@ -32,7 +32,6 @@ struct Switches {
     int conv_persist = 0;       // STORM_CONV_PERSIST (profiling build)
     int conv_dma = 1;           // STORM_CONV_DMA (profiling build): 0 = register staging in conv_igemm's 128-cout kernel
     int conv_ablate = 0;        // STORM_CONV_ABLATE (profiling build): work-skipping instantiations
-    int side_stream = 1;        // STORM_SIDE_STREAM: 0 = the time embedding + Dense_0 ops stay on the launch stream (program.hip)
     unsigned long long conv_trace_ptr = 0;   // STORM_CONV_TRACE_PTR (profiling build): device buffer of tools/conv_trace.py
 };
 Switches& switches();

@@ -38,57 +38,13 @@ static void conv_args_of(const storm_op& op, void* const* p, int dtype, storm_co
     a.seg[0].gn_silu = op.f[1] != 0.f;
 }
 
-// The time embedding (GFP + two Linear layers) and the 22 concatenated Dense_0 layers depend on t only, not on the input: two
-// latency-bound launches (~45 us each at batch 16: chains of dependent matrix-vector products) that the planner emits ahead of
-// the stem convolution.  They run on a SIDE stream, forked from the launch stream where the program starts and joined in front of
-// the first convolution that adds a time bias, under memset + input packing + stem conv + its GroupNorm finalize on the launch
-// stream (~190 us).  Everything is ordered in the launch stream again from the join on, so the C-ABI contract ("the call's work is
-// enqueued on s") holds.  One side stream and one event pair per host thread and device.
-namespace {
-struct Side { hipStream_t st = nullptr; hipEvent_t fork{}, join{}; bool ok = false, tried = false; };
-Side& side_of_this_thread() {
-    constexpr int MAX_DEV = 16;
-    static thread_local Side sd[MAX_DEV];
-    int dev = 0;
-    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= MAX_DEV) dev = 0;
-    Side& q = sd[dev];
-    if (!q.tried) {
-        q.tried = true;
-        q.ok = hipStreamCreateWithFlags(&q.st, hipStreamNonBlocking) == hipSuccess &&
-               hipEventCreateWithFlags(&q.fork, hipEventDisableTiming) == hipSuccess &&
-               hipEventCreateWithFlags(&q.join, hipEventDisableTiming) == hipSuccess;
-    }
-    return q;
-}
-}  // namespace
-
 static int run_ops(const storm_op* ops, int n_ops, void* const* bufs, int n_bufs, int dtype, storm_stream_t s,
                    hipEvent_t* ev) {
     STORM_CHECK(ops && bufs && n_ops >= 0, "storm_program_run: bad arguments");
     hipStream_t st = (hipStream_t)s;
-    const storm_stream_t s_main = s;
-    Side* side = nullptr;                                   // (per-op timing keeps everything on the launch stream)
-    if (ev == nullptr && switches().side_stream != 0) { Side& q = side_of_this_thread(); if (q.ok) side = &q; }
-    bool forked = false;
     for (int k = 0; k < n_ops; ++k) {
         if (ev) STORM_HIP(hipEventRecord(ev[k], st));
         const storm_op& op = ops[k];
-        s = s_main;
-        if (side != nullptr) {
-            if (op.code == STORM_OP_TEMB && k + 1 < n_ops && ops[k + 1].code == STORM_OP_DENSE && !forked) {
-                STORM_HIP(hipEventRecord(side->fork, st));              // earlier work on the launch stream (the previous evaluation's
-                STORM_HIP(hipStreamWaitEvent(side->st, side->fork, 0)); // readers of these buffers, the producer of t) comes first
-                forked = true;
-            }
-            if (forked && (op.code == STORM_OP_TEMB || op.code == STORM_OP_DENSE)) s = (storm_stream_t)side->st;
-            else if (forked && op.code != STORM_OP_MEMSET && op.code != STORM_OP_PACK_INPUT &&
-                     !(op.code == STORM_OP_CONV && op.p[8].buf < 0) && op.code != STORM_OP_GN_FINALIZE) {
-                // the first op that is not one of the independent ones: join (conservative - a conv with a time bias, or anything
-                // that might read the embedding)
-                STORM_HIP(hipStreamWaitEvent(st, side->join, 0));
-                forked = false; side = nullptr;
-            }
-        }
         bool ok = true;
         void* p[STORM_OP_NPTR];
         for (int j = 0; j < STORM_OP_NPTR; ++j) p[j] = resolve(op.p[j], bufs, n_bufs, ok);
@@ -111,7 +67,6 @@ static int run_ops(const storm_op* ops, int n_ops, void* const* bufs, int n_bufs
             case STORM_OP_DENSE:
                 rc = storm_dense((const float*)p[0], (const float*)p[1], (const float*)p[2], (float*)p[3], (int)i[0],
                                  (int)i[1], (int)i[2], s);
-                if (rc == STORM_OK && forked && s != s_main) STORM_HIP(hipEventRecord(side->join, side->st));
                 break;
             case STORM_OP_CONV: {
                 storm_conv_args a;
@@ -159,7 +114,6 @@ static int run_ops(const storm_op* ops, int n_ops, void* const* bufs, int n_bufs
         }
         if (rc != STORM_OK) return rc;
     }
-    if (forked) STORM_HIP(hipStreamWaitEvent(st, side->join, 0));    // (a program that ends before its first time-bias conv)
     if (ev) STORM_HIP(hipEventRecord(ev[n_ops], st));
     return STORM_OK;
 }

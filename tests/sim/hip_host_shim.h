@@ -171,11 +171,6 @@ inline hipError_t hipEventDestroy(hipEvent_t) { return hipSuccess; }
 inline hipError_t hipEventRecord(hipEvent_t, hipStream_t) { return hipSuccess; }
 inline hipError_t hipEventSynchronize(hipEvent_t) { return hipSuccess; }
 inline hipError_t hipEventElapsedTime(float* ms, hipEvent_t, hipEvent_t) { *ms = 0.f; return hipSuccess; }
-// (the simulator executes every launch synchronously: a second stream and cross-stream waits are no-ops)
-constexpr unsigned hipStreamNonBlocking = 1u, hipEventDisableTiming = 2u;
-inline hipError_t hipStreamCreateWithFlags(hipStream_t* s, unsigned) { static int dummy; *s = &dummy; return hipSuccess; }
-inline hipError_t hipEventCreateWithFlags(hipEvent_t* e, unsigned) { *e = 0; return hipSuccess; }
-inline hipError_t hipStreamWaitEvent(hipStream_t, hipEvent_t, unsigned) { return hipSuccess; }
 #define hipLaunchKernelGGL(kern, grid, block, lds, stream, ...) \
     simrt::launch((grid), (block), (size_t)(lds), [=]() { (kern)(__VA_ARGS__); })
 
