@@ -686,11 +686,14 @@ static int choose_variant(const storm_conv_args& a, bool any9) {
     // (profiles/r04_probe_small_half.txt): 256 -> 256 @ 16 x 32 x 64: 48.6 vs 66.7 / 72.1 us, 512 -> 256: 84.0 vs 109 / 133;
     // 8 x 16 x 64: 38.2 vs 52.7 / 43.7; 8 x 8 x 32: 36.1 vs 51.0 / 41.1; 8 x 4 x 16: 31.8 vs 46.9 / 37.7
     if (a.outC > 128 && any9 && conv_pipe_supports(a)) return 9;
-    // conv_pipe128: measured against this file's two-workgroup kernel on MI355X (tools/probe128.py, profiles/r02_pipe128_ab.txt) it
-    // wins 13-20 % at 4 of its tiles per CU (128 x 256 x 16) and ties or loses (0 ... -10 %) at 16 tiles per CU (256 x 512 x 16):
-    // with K this short the exposed epilogue and the fused GroupNorm transform weigh the same in both kernels and two resident
-    // workgroups hide them at least as well.  (A stem-like layer with fewer than 32 input channels is HBM-bound either way.)
-    if (a.outC > 32 && a.outC <= 128 && any9 && px_tiles >= 1024 && px_tiles <= 4096 && a.seg[0].Ca + a.seg[0].Cb >= 32 &&
+    // conv_pipe128: measured against this file's two-workgroup kernel on MI355X, each kernel sustained in its own process, alternating
+    // (profiles/r04_duo_fair_ab.txt, profiles/r04_half_fair_ab.txt: two boxes).  The three structures stay within 5 % of each other
+    // (the part runs these layers at its power cap); conv_pipe128 is ahead on both boxes where its per-tile fixed cost is
+    // amortised - 4 of its tiles per CU (128 x 256 x 16: +0 ... +20 %) and, at 16 tiles per CU (256 x 512 x 16), the layers with >= 256
+    // input channels (384 -> 128: +2.6 / +4.6 %, 256 -> 128: +0.7 / +3.2 %) - and behind or level on 128 -> 128 there (-3 / 0 %), with or
+    // without the fused 1x1 shortcut.  (A stem-like layer with fewer than 32 input channels is HBM-bound either way.)
+    const int cin9 = a.seg[0].Ca + a.seg[0].Cb;
+    if (a.outC > 32 && a.outC <= 128 && any9 && px_tiles >= 1024 && (px_tiles <= 4096 || cin9 >= 256) && cin9 >= 32 &&
         switches().conv_pipe128 != 0 && conv_pipe128_supports(a)) return 4;    // (A/B switch: 0 = conv_igemm for these layers)
     // so few pixel tiles that 128-cout tiles do not give every CU its two workgroups (the 32 x 64 level of NCSN++ at 4 s: 128
     // pixel tiles x 2 cout tiles): 64-cout tiles double the workgroups (measured +5 % on 256 -> 256 and 512 -> 256 @ 32 x 64 x 16)

@@ -838,16 +838,17 @@ def test_spec_transform_standalone(dev, e, fac):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("shortcut", [0, 128])
-def test_conv_pipe128_bench_layer_vs_generic_kernel(shortcut, switch):
-    """The two layers of BASELINE.json configs[1] the dispatcher gives to conv_pipe128.hip (128 -> 128 @ 128 x 256, batch 16, fused
-    GroupNorm operand + temb bias + statistics epilogue, with / without the fused 1x1 shortcut) at FULL size: same output as the
-    generic kernel up to the accumulation order (bf16 outputs: a few values differ by one rounding), same statistics partials."""
+@pytest.mark.parametrize("shortcut,H,W,cin", [(0, 128, 256, 128), (128, 128, 256, 128), (0, 256, 512, 384), (0, 256, 512, 256)])
+def test_conv_pipe128_bench_layer_vs_generic_kernel(shortcut, H, W, cin, switch):
+    """The layers of BASELINE.json configs[1] the dispatcher gives to conv_pipe128.hip (128 -> 128 @ 128 x 256, batch 16, fused
+    GroupNorm operand + temb bias + statistics epilogue, with / without the fused 1x1 shortcut; 384 -> 128 and 256 -> 128 @ 256 x 512)
+    at FULL size: same output as the generic kernel up to the accumulation order (bf16 outputs: a few values differ by one rounding),
+    same statistics partials."""
     from storm_amd import ops
     from tests.backend import setup_backend
     dev = setup_backend("hip")
     g = torch.Generator().manual_seed(7)
-    B, H, W, cin, cout, dt = 16, 128, 256, 128, 128, torch.bfloat16
+    B, cout, dt = 16, 128, torch.bfloat16
     rnd = lambda *s: torch.randn(*s, generator=g)
     x = rnd(B, H, W, cin).to(dt).to(dev)
     ss = ops.pack_gn_ss(1 + 0.1 * rnd(B, cin), 0.1 * rnd(B, cin)).to(dev)

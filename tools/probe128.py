@@ -48,7 +48,7 @@ for ci_, case in enumerate(CASES):
     fl = 2 * B * H * W * cout * (cin * 9 + sc)
     out = {}
     lib = L.lib()
-    MODES = {"duo": 5, "p128": 4, "igemm": 0} if cout <= 128 else {"pipe": -1, "igemm": 2}
+    MODES = {"duo": 5, "p128": 4, "half": 9, "igemm": 0} if cout <= 128 else {"pipe": 3, "half": 9, "igemm": 2}
     if args.modes:
         MODES = {k: v for k, v in MODES.items() if k in args.modes.split(",")}
         if not MODES:
