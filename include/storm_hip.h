@@ -108,9 +108,15 @@ typedef struct storm_conv_args {
     int dtype;                  /* STORM_F32 / STORM_BF16 operands + activations          */
     float* gn_part;             /* optional fused GroupNorm statistics: per-tile (sum, sumsq) of
                                    the output, fp32 [B][storm_conv_tiles()][outC][2]; NULL = off */
+    void* splitk_ws;            /* optional scratch of storm_conv_splitk_bytes() bytes (16-byte aligned): lets a 3x3 layer with
+                                   so few pixel tiles that most CUs would idle split its K loop over workgroups (fp32 slabs,
+                                   summed in a fixed order: bit-reproducible).  NULL / too small = the unsplit kernel       */
+    long long splitk_ws_bytes;
 } storm_conv_args;
 
 int storm_conv(const storm_conv_args* a, storm_stream_t s);
+/* scratch bytes with which storm_conv would split K for this call; 0 = it would not (most layers) */
+long long storm_conv_splitk_bytes(const storm_conv_args* a);
 /* number of pixel tiles per batch item the kernel will use for this call (size of gn_part) */
 int storm_conv_tiles(const storm_conv_args* a);
 /* name (as rocprofv3 prints it) of the kernel storm_conv launches for these arguments: lets a profiler or
@@ -314,7 +320,7 @@ enum {
     STORM_OP_FIR_DOWN = 8, STORM_OP_SOFTMAX = 9, STORM_OP_OUTPUT_HEAD = 10, STORM_OP_GN_FINALIZE = 11,
     STORM_OP_ATTENTION = 12
 };
-#define STORM_OP_NPTR 12
+#define STORM_OP_NPTR 13
 #define STORM_OP_NINT 24
 #define STORM_OP_NFLT 4
 typedef struct storm_ref { int32_t buf; int32_t pad_; int64_t off; } storm_ref; /* buf<0: NULL; byte offset */

@@ -18,7 +18,7 @@ F32, BF16, F16 = 0, 1, 2
 _TORCH2DT = {torch.float32: F32, torch.bfloat16: BF16, torch.float16: F16}
 _DT2TORCH = {F32: torch.float32, BF16: torch.bfloat16, F16: torch.float16}
 
-OP_NPTR, OP_NINT, OP_NFLT = 12, 24, 4
+OP_NPTR, OP_NINT, OP_NFLT = 13, 24, 4
 
 
 class StormError(RuntimeError):
@@ -38,7 +38,8 @@ class ConvArgs(C.Structure):
                 ("out", C.c_void_p), ("outC", C.c_int), ("Cout", C.c_int), ("out_bstride", C.c_longlong),
                 ("bias", C.c_void_p), ("tbias", C.c_void_p), ("tbias_stride", C.c_int),
                 ("skip", C.c_void_p), ("skip_bstride", C.c_longlong), ("scale", C.c_float),
-                ("out_f32", C.c_int), ("dtype", C.c_int), ("gn_part", C.c_void_p)]
+                ("out_f32", C.c_int), ("dtype", C.c_int), ("gn_part", C.c_void_p),
+                ("splitk_ws", C.c_void_p), ("splitk_ws_bytes", C.c_longlong)]
 
 
 class NcsnppConfig(C.Structure):
@@ -69,6 +70,7 @@ _SIGNATURES = {
     "storm_pack_matrix": ([_vp, _vp, _i, _i, _i, _i, _i, _i, _vp], C.c_int),
     "storm_conv": ([C.POINTER(ConvArgs), _vp], C.c_int),
     "storm_conv_tiles": ([C.POINTER(ConvArgs)], C.c_int),
+    "storm_conv_splitk_bytes": ([C.POINTER(ConvArgs)], C.c_longlong),
     "storm_conv_kernel_name": ([C.POINTER(ConvArgs)], C.c_char_p),
     "storm_gn_finalize": ([_vp, _i, _i, _vp, _i, _i, _i, _i, _vp, _vp], C.c_int),
     "storm_gn_finalize_ss": ([_vp, _i, _i, _vp, _i, _i, _i, _i, _ll, _vp, _vp, _f, _vp, _vp, _vp], C.c_int),

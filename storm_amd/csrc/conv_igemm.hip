@@ -671,11 +671,33 @@ static int launch_conv(const storm_conv_args& a, hipStream_t st) {
 //   6: conv_thin.hip, 8 input channels (stem, input-skip 1x1s): operands straight from global memory (16-bit)
 //   8: conv_narrow.hip, 3x3 to <= 4 output channels (the output pyramid): 36-row 1x1 GEMM over the haloed region + nine-point gather
 //   9: conv_pipe.hip with 128 cout x 256 px per 8-wave workgroup (64 x 64 per wave): the pipelined kernel for 128 ... 511 pixel tiles
+//  10: conv_pipe.hip split-K: the 128-cout tile with K cut into 2 / 4 / 8 slices on as many workgroups (fp32 slabs in the caller's
+//      scratch) + one combine launch - 3x3 layers whose 128-cout tiles would occupy <= 64 CUs (needs storm_conv_args.splitk_ws)
 //   7: conv_igemm 64 cout x 256 px, 4 waves (32x128 each), 2 workgroups / CU; LDS-DMA - for 3x3 layers with so few pixel tiles
 //      that 128-cout tiles leave CUs without work (the 32 x 64 level: 128 pixel tiles x 2 cout tiles on 256 CUs x 2 slots)
+// K slices storm_conv would use for this call (0 = none), whatever scratch the caller brought
+static int splitk_slices_of(const storm_conv_args& a) {
+    const int forced = switches().conv_variant;
+    if (forced >= 0 && forced != 10) return 0;
+    bool any9 = false;
+    for (int s = 0; s < a.nseg; ++s) any9 = any9 || a.seg[s].ntaps == 9;
+    if (!any9 || a.dtype == STORM_F32 || !conv_pipe_supports(a)) return 0;
+    const int S = conv_splitk_slices(a);
+    if (S == 0 && forced == 10 && !a.out_f32) {                    // (tests: force a split wherever there are two nine-tap chunks)
+        const int n9 = cdiv(a.seg[0].Ca, 64) + (a.seg[0].Cb ? cdiv(a.seg[0].Cb, 64) : 0);
+        return n9 >= 4 ? 4 : n9 >= 2 ? 2 : 0;
+    }
+    return S;
+}
+
 static int choose_variant(const storm_conv_args& a, bool any9) {
     const int forced = switches().conv_variant;                      // (test / A-B hook, storm_set_switch)
-    if (forced >= 0) return forced;
+    if (forced >= 0 && forced != 10) return forced;
+    if (any9) {
+        const int S = splitk_slices_of(a);
+        if (S >= 2 && a.splitk_ws != nullptr && a.splitk_ws_bytes >= conv_splitk_bytes(a, S)) return 10;
+    }
+    if (forced == 10) return conv_pipe_supports(a) ? 9 : 0;        // (forced split without scratch / with one chunk: the unsplit tile)
     if (conv_thin_supports(a)) return 6;
     if (conv_narrow_supports(a)) return 8;
     const long long px_tiles = (long long)a.B * cdiv((long long)a.H * a.W, TILE_H * TILE_W);
@@ -731,6 +753,7 @@ static int dispatch_conv(const storm_conv_args& a, hipStream_t st) {
         if (small) return launch_conv<T, 9, 1, 1, 4, false>(a, st);
         if (variant == 3 && conv_pipe_supports(a)) return launch_conv_pipe(a, st);
         if (variant == 9 && conv_pipe_supports(a)) return launch_conv_pipe_half(a, st);
+        if (variant == 10) return launch_conv_pipe_splitk(a, splitk_slices_of(a), st);
         if (variant == 4 && conv_pipe128_supports(a)) return launch_conv_pipe128(a, st);
         if (variant == 5 && conv_duo_supports(a)) return launch_conv_duo(a, st);
         if (variant == 2) return launch_conv<T, 9, 2, 4, 2, true>(a, st);
@@ -761,6 +784,7 @@ static const char* kernel_name_of(const storm_conv_args& a) {
     if (a.outC <= 32) variant = -1;
     if (variant == 6 && conv_thin_supports(a)) return conv_thin_kernel_name(a.dtype, taps);
     if (a.outC <= 32) shape = "1, 1, 4, false, false";
+    else if (any9 && variant == 10) return a.dtype == STORM_F16 ? "storm::conv_pipe_splitk_kernel<storm::half_t, 128, 8>" : "storm::conv_pipe_splitk_kernel<storm::bf16_t, 128, 8>";
     else if (any9 && (variant == 3 || variant == 9) && conv_pipe_supports(a)) return conv_pipe_kernel_name(a.dtype, variant == 9);
     else if (any9 && variant == 4 && conv_pipe128_supports(a)) return conv_pipe128_kernel_name(a.dtype);
     else if (any9 && variant == 5 && conv_duo_supports(a)) return conv_duo_kernel_name(a.dtype);
@@ -785,6 +809,11 @@ extern "C" int storm_conv_tiles(const storm_conv_args* ap) {
     using namespace storm::cidx;
     if (any9) return storm::cdiv(ap->W, TILE_W) * storm::cdiv(ap->H, TILE_H);
     return storm::cdiv((long long)ap->H * ap->W, TILE_H * TILE_W);
+}
+
+extern "C" long long storm_conv_splitk_bytes(const storm_conv_args* ap) {
+    if (ap == nullptr || ap->nseg < 1 || ap->nseg > 2 || ap->B <= 0 || ap->H <= 0 || ap->W <= 0) return 0;
+    return storm::conv_splitk_bytes(*ap, storm::splitk_slices_of(*ap));
 }
 
 extern "C" int storm_conv(const storm_conv_args* ap, storm_stream_t s) {

@@ -189,10 +189,12 @@ struct WRunDesc {                     // 32 bytes: the weight matrix of a run, [
 struct PipeParams {
     ChunkDesc chunk[MAX_CHUNKS + 1];  // [nchunks] = terminator (prefetch target of the last chunk)
     WRunDesc wrun[4];
-    int nchunks, nchunks9, B, H, W, pad_;   // nchunks9: the leading nine-tap chunks (one-tap chunks follow)
+    int nchunks, nchunks9, B, H, W;   // nchunks9: the leading nine-tap chunks (one-tap chunks follow)
+    int kslices;                      // split-K instantiation only: K slices per (pixel tile, cout tile), each on its own workgroup
     void* out; int outC, Cout; long long out_bstride;
     const float* bias; const float* tbias; int tbias_stride, out_f32;
-    const void* skip; long long skip_bstride; float scale; int pad2_;
+    const void* skip; long long skip_bstride; float scale;
+    int split_nct;                    // split-K instantiation only: cout tiles of the layer (the kernel's n_ct argument = split_nct * kslices)
     float* gn_part;
     unsigned long long* trace;        // profiling build (-DSTORM_PROFILING) only
 };
@@ -202,6 +204,12 @@ struct PipeParams {
 bool conv_pipe_supports(const storm_conv_args& a);
 int launch_conv_pipe(const storm_conv_args& a, hipStream_t st);
 int launch_conv_pipe_half(const storm_conv_args& a, hipStream_t st);      // 128 output channels per workgroup (few pixel tiles)
+// split-K (choose_variant 10): the 128-cout tile with the nine-tap chunks of the K loop cut into `slices` contiguous ranges, one workgroup
+// per (pixel tile, cout tile, slice) writing an fp32 slab into a.splitk_ws, then one combine launch (fixed summation order: slice 0, 1, ...)
+// that applies bias / temb bias / skip / scale, rounds, and writes the GroupNorm partials.  conv_splitk_slices: 0 = no split for this layer.
+int conv_splitk_slices(const storm_conv_args& a);
+long long conv_splitk_bytes(const storm_conv_args& a, int slices);
+int launch_conv_pipe_splitk(const storm_conv_args& a, int slices, hipStream_t st);
 const char* conv_pipe_kernel_name(int dtype, bool half_tile);
 // defined in conv_pipe128.hip: the same pipeline for layers with <= 128 output channels (128 couts x 512 pixels per workgroup)
 bool conv_pipe128_supports(const storm_conv_args& a);

@@ -108,10 +108,12 @@ using namespace pipe;
 // ABL: profiling-only instantiations (built with -DSTORM_PROFILING into libstorm_hip_prof.so, never in the product
 // library): 8 no weight DMA after the prologue, 16 no fragment reads, 32 no MFMAs, 128 no patch DMA / transform,
 // 64 wave-timeline stamps (tools/conv_trace.py).
-template <typename T, int BN, int TH, int ABL>
-__global__ __launch_bounds__(pipe::THREADS, 2)
-void conv_pipe_kernel(const PipeParams a, const int n_ct, const int tiles_per_xcd,
-                      const int ntiles, const int tiles_x, const int tiles_per_img, const int total_vblocks) {
+// SPLIT: the workgroup id carries a K slice as well - (pixel tile, cout tile, slice); a workgroup walks only its slice's chunk
+// descriptors (the nine-tap chunks in `kslices` contiguous ranges, the one-tap chunks with the last range) and stores its raw fp32
+// accumulators as slab `slice` of the output (the host points a.out at the slabs: fp32, no bias / skip / statistics).
+template <typename T, int BN, int TH, int ABL, bool SPLIT>
+__device__ __forceinline__ void conv_pipe_body(const PipeParams& a, const int n_ct, const int tiles_per_xcd,
+                                               const int ntiles, const int tiles_x, const int tiles_per_img, const int total_vblocks) {
     typedef PCfg<BN, TH> Cfg;
     constexpr bool TRACE = (ABL & 64) != 0;
     constexpr int WM = Cfg::WM, WN = Cfg::WN, WAVES_M = Cfg::WAVES_M, WAVES_N = Cfg::WAVES_N, NWD = Cfg::NWD;
@@ -132,6 +134,8 @@ void conv_pipe_kernel(const PipeParams a, const int n_ct, const int tiles_per_xc
     while (vb < total_vblocks && block_map(vb, n_ct, tiles_per_xcd).tile >= ntiles) vb += gridDim.x;   // (padding ids of the XCD map)
     if (vb >= total_vblocks) return;
     int tile, b, ty0, tx0, cout0;                           // the tile whose loads are being ISSUED (= computed, until the hand-over)
+    int nchunks = pin(ap->nchunks), n9 = pin(ap->nchunks9); // chunks of this workgroup's K loop (SPLIT: of its slice, from descriptor c0 on)
+    int c0 = 0, eb_off = 0;
     auto decode = [&](int v) {
         const BlockMap bm = block_map(v, n_ct, tiles_per_xcd);
         tile = bm.tile;
@@ -139,7 +143,17 @@ void conv_pipe_kernel(const PipeParams a, const int n_ct, const int tiles_per_xc
         const int trem = bm.tile - b * tiles_per_img;
         ty0 = (trem / tiles_x) * TH;
         tx0 = (trem % tiles_x) * TILE_W;
-        cout0 = bm.ct * BN;
+        int ct = bm.ct;
+        if constexpr (SPLIT) {
+            const int nct = ap->split_nct, S = ap->kslices, n9all = ap->nchunks9;
+            const int slice = ct / nct;
+            ct -= slice * nct;
+            c0 = slice * n9all / S;
+            n9 = (slice + 1) * n9all / S - c0;
+            nchunks = slice == S - 1 ? ap->nchunks - c0 : n9;
+            eb_off = slice * ap->B;                         // slab `slice` = "batch items" slice * B ... of the fp32 output
+        }
+        cout0 = ct * BN;
     };
     decode(vb);
     const int imgH = pin(ap->H), imgW = pin(ap->W);         // (two SGPRs for the whole kernel: read in the pipelined loop)
@@ -202,7 +216,7 @@ void conv_pipe_kernel(const PipeParams a, const int n_ct, const int tiles_per_xc
     int nx_C2 = 0, nx_cbeg2 = 0, nx_cvalid = 0, nx_ntaps = 9, nx_gn = 0, nx_silu = 0, nx_wrun = 0, nx_wsoff = 0, nx_neww = 0;
     int w_soff = 0, w_tapbytes = 0;
     auto load_next = [&](int i) {                           // descriptor i -> nx_* (scalar loads from the kernarg segment)
-        const ChunkDesc& d = ap->chunk[i < nchunks_k ? i : nchunks_k];
+        const ChunkDesc& d = ap->chunk[SPLIT ? (i < nchunks ? c0 + i : nchunks_k) : (i < nchunks_k ? i : nchunks_k)];
         nx_srd = make_srd(reinterpret_cast<const char*>(d.src + (unsigned long long)b * d.bstride), d.src_bytes);
         nx_gn = d.ss != 0ull;
         nx_ss_srd = make_srd(reinterpret_cast<const char*>(nx_gn ? d.ss + (unsigned long long)b * d.ss_bstride : d.src),
@@ -478,7 +492,6 @@ void conv_pipe_kernel(const PipeParams a, const int n_ct, const int tiles_per_xc
             for (int i = 0; i < NSLOT; ++i) issue_slot(i, 0);
         }
     };
-    const int nchunks = pin(ap->nchunks), n9 = pin(ap->nchunks9);
     // chunk change: the fetched buffer becomes current; descriptor of the chunk after the next.  Lane-derived address
     // math is re-laundered so that none of it is hoisted out of the loops and kept in registers.
     auto chunk_change = [&](int ci) {
@@ -529,7 +542,7 @@ void conv_pipe_kernel(const PipeParams a, const int n_ct, const int tiles_per_xc
         vm_wait<0>();                                       // trailing ring / patch re-loads landed ...
         raw_barrier();                                      // ... and every wave is done reading: all of LDS is free
         if (first) stamp(501);
-        const int e_tile = tile, e_b = b, e_ty0 = ty0, e_tx0 = tx0, e_cout0 = cout0;
+        const int e_tile = tile, e_b = b + eb_off, e_ty0 = ty0, e_tx0 = tx0, e_cout0 = cout0;
         STORM_RELAUNDER();
         int nvb = vb + gridDim.x;
         while (nvb < total_vblocks && block_map(nvb, n_ct, tiles_per_xcd).tile >= ntiles) nvb += gridDim.x;
@@ -578,6 +591,20 @@ void conv_pipe_kernel(const PipeParams a, const int n_ct, const int tiles_per_xc
 }
 
 #undef STORM_RELAUNDER
+
+// (the parameter block must stay the kernels' FIRST argument: the body reads it in place through the kernarg segment pointer)
+template <typename T, int BN, int TH, int ABL>
+__global__ __launch_bounds__(pipe::THREADS, 2)
+void conv_pipe_kernel(const PipeParams a, const int n_ct, const int tiles_per_xcd,
+                      const int ntiles, const int tiles_x, const int tiles_per_img, const int total_vblocks) {
+    conv_pipe_body<T, BN, TH, ABL, false>(a, n_ct, tiles_per_xcd, ntiles, tiles_x, tiles_per_img, total_vblocks);
+}
+template <typename T, int BN, int TH>
+__global__ __launch_bounds__(pipe::THREADS, 2)
+void conv_pipe_splitk_kernel(const PipeParams a, const int n_ct, const int tiles_per_xcd,
+                             const int ntiles, const int tiles_x, const int tiles_per_img, const int total_vblocks) {
+    conv_pipe_body<T, BN, TH, 0, true>(a, n_ct, tiles_per_xcd, ntiles, tiles_x, tiles_per_img, total_vblocks);
+}
 
 // ---- host side ---------------------------------------------------------------------------------------------------
 // The K loop as chunk descriptors (declared in conv_pipe_common.h).
@@ -701,6 +728,143 @@ int launch_conv_pipe_half(const storm_conv_args& a, hipStream_t st) {
     if (switches().conv_ablate == 64) return launch_pipe<bf16_t, 128, 8, 64>(a, st);
 #endif
     return launch_pipe<bf16_t, 128, 8, 0>(a, st);
+}
+
+// ---- split-K (few-tile layers) ---------------------------------------------------------------------------------------------
+// ncsnpplarge at configs[3] runs 44 of its 99 3x3 launches on 16 x 64 ... 4 x 16 pixel images (x 8 utterances): 64 ... 16 workgroups of
+// the 128-cout tile, each walking the layer's whole K loop - 72 or 144 phases of ~0.36 us that nothing shortens but a split of K.
+// Measured before it was built (tools/probe_splitk.py, profiles/r04_probe_splitk.txt: the slices emulated by the existing kernel over
+// B * S images of Cin / S channels with fp32 output, the combine as a torch.sum over the slabs): 512 -> 256 @ 8 x 8 x 32 62.7 -> 23.3 us,
+// 256 -> 256 @ 8 x 4 x 16 32.0 -> 17.5 us, 256 -> 256 @ 8 x 16 x 64 38.2 -> 31.0 us; nothing at 256 workgroups (16 x 32 x 64).
+// Two launches, no cross-workgroup hand-off inside a launch: the slices write fp32 slabs [slice][B][H][W][outC] (the launch above
+// in its SPLIT instantiation), then ONE combine pass sums them in slice order (bit-reproducible), applies the epilogue of
+// conv_epilogue.h - (sum + skip) * scale + (bias + temb bias) * scale, rounded to the activation type - and writes the GroupNorm
+// partials in the 8 x 32 tile layout every conv kernel uses.  32 pixels x 8 channel octets per workgroup: a wave reads whole 256-byte
+// rows of a slab, the statistics are reduced over the pixels in a fixed order (lane exchanges, then the four waves through LDS).
+template <typename T>
+__global__ __launch_bounds__(256)
+void splitk_combine_kernel(const float* __restrict__ slabs, const int S, const long long slab_stride, const int H, const int W, const int outC,
+                           const int Cout, const float* __restrict__ bias, const float* __restrict__ tbias, const int tbias_stride,
+                           const T* __restrict__ skip, const long long skip_bstride, const float scale, T* __restrict__ out,
+                           const long long out_bstride, float* __restrict__ gn_part, const int tiles_x, const int tiles_y8) {
+    __shared__ float red[4][64][2];
+    const int t8 = blockIdx.x, tpi = tiles_x * tiles_y8;
+    const int b = t8 / tpi, trem = t8 - b * tpi;
+    const int ty0 = (trem / tiles_x) * TILE_H, tx0 = (trem % tiles_x) * TILE_W;
+    const int tid = threadIdx.x, oct = tid & 7, px = tid >> 3, wave = tid >> 6;
+    const int co = blockIdx.y * 64 + oct * 8, gx = tx0 + px;
+    const bool ok = co < outC && gx < W;
+    float badd[8], gsum[8], gsq[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        badd[e] = 0.f; gsum[e] = 0.f; gsq[e] = 0.f;
+        if (ok && co + e < Cout) {
+            if (bias) badd[e] += bias[co + e];
+            if (tbias) badd[e] += tbias[(long long)b * tbias_stride + co + e];
+        }
+        badd[e] *= scale;
+    }
+    const long long img = (long long)H * W * outC;
+    for (int r = 0; r < TILE_H; ++r) {
+        const int gy = ty0 + r;
+        if (!ok || gy >= H) continue;
+        const long long o = ((long long)gy * W + gx) * outC + co;
+        float v[8];
+        load8(slabs + (long long)b * img + o, v);
+        for (int s = 1; s < S; ++s) {                       // fixed order: slice 0, 1, ...
+            float u[8];
+            load8(slabs + s * slab_stride + (long long)b * img + o, u);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] += u[e];
+        }
+        if (skip != nullptr) {
+            float u[8];
+            load8(skip + (long long)b * skip_bstride + o, u);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] += u[e];
+        }
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            v[e] = fmaf(v[e], scale, badd[e]);
+            gsum[e] += v[e];
+            gsq[e] = fmaf(v[e], v[e], gsq[e]);
+        }
+        store8(out + (long long)b * out_bstride + o, v);
+    }
+    if (gn_part == nullptr) return;
+#pragma unroll
+    for (int off = 8; off < 64; off <<= 1)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { gsum[e] += __shfl_xor(gsum[e], off, 64); gsq[e] += __shfl_xor(gsq[e], off, 64); }
+    if ((tid & 63) < 8) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { red[wave][oct * 8 + e][0] = gsum[e]; red[wave][oct * 8 + e][1] = gsq[e]; }
+    }
+    __syncthreads();
+    if (tid < 64 && blockIdx.y * 64 + tid < outC) {
+        const float s0 = ((red[0][tid][0] + red[1][tid][0]) + red[2][tid][0]) + red[3][tid][0];
+        const float s1 = ((red[0][tid][1] + red[1][tid][1]) + red[2][tid][1]) + red[3][tid][1];
+        float* dst = gn_part + ((long long)t8 * outC + blockIdx.y * 64 + tid) * 2;
+        dst[0] = s0; dst[1] = s1;
+    }
+}
+
+// K slices for a layer, 0 = no split: only where the 128-cout tiles leave three quarters of the CUs without a workgroup (<= 64 of them;
+// at 128 ... 256 workgroups the split measured slower), a power of two <= 8, at least one nine-tap chunk per slice, <= 256 workgroups.
+int conv_splitk_slices(const storm_conv_args& a) {
+    if (!conv_pipe_supports(a) || a.outC <= 128 || a.out_f32) return 0;
+    const long long px_tiles = (long long)a.B * cdiv(a.W, TILE_W) * cdiv(a.H, TILE_H);
+    const long long wgs = px_tiles * cdiv(a.outC, 128);
+    if (wgs > 64) return 0;
+    const int n9 = cdiv(a.seg[0].Ca, KC) + (a.seg[0].Cb ? cdiv(a.seg[0].Cb, KC) : 0);
+    int S = 8;
+    while (S > 1 && (S > n9 || wgs * S > 256)) S >>= 1;
+    return S >= 2 ? S : 0;
+}
+long long conv_splitk_bytes(const storm_conv_args& a, int slices) {
+    return slices < 2 ? 0 : (long long)slices * a.B * a.H * a.W * a.outC * 4;
+}
+
+template <typename T>
+static int launch_splitk(const storm_conv_args& a, const int S, hipStream_t st) {
+    constexpr int BN = 128, TH = 8;
+    typedef PCfg<BN, TH> Cfg;
+    auto kern = conv_pipe_splitk_kernel<T, BN, TH>;
+    static bool attr_set = false;
+    if (!attr_set) {
+        STORM_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, Cfg::LDS_BYTES));
+        attr_set = true;
+    }
+    PipeParams prm;
+    STORM_CHECK(build_pipe_params(a, prm, KC), "storm_conv: convolution outside the pipelined kernel's coverage");
+    STORM_CHECK(S >= 2 && S <= prm.nchunks9 && a.splitk_ws != nullptr && a.splitk_ws_bytes >= conv_splitk_bytes(a, S) && !a.out_f32,
+                "storm_conv: split-K launch with %d slices of %d nine-tap chunks, workspace %lld bytes", S, prm.nchunks9, a.splitk_ws_bytes);
+    const long long img = (long long)a.H * a.W * a.outC;
+    prm.out = a.splitk_ws; prm.out_f32 = 1; prm.out_bstride = img;                // slab s = "batch items" s * B ...
+    prm.bias = nullptr; prm.tbias = nullptr; prm.skip = nullptr; prm.scale = 1.0f; prm.gn_part = nullptr;
+    const int tiles_x = cdiv(a.W, TILE_W), tiles_y = cdiv(a.H, TH);
+    const int tiles_per_img = tiles_x * tiles_y;
+    const long long ntiles = (long long)a.B * tiles_per_img;
+    const int n_ct = cdiv(a.outC, BN);
+    prm.kslices = S; prm.split_nct = n_ct;
+    const int tiles_per_xcd = cdiv(ntiles, 8);
+    const long long vblocks = 8LL * tiles_per_xcd * n_ct * S;
+    const long long resident = (device_cus() + 7) / 8 * 8;
+    const long long grid = vblocks < resident ? vblocks : resident;
+    hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(THREADS), Cfg::LDS_BYTES, st, prm, n_ct * S, tiles_per_xcd, (int)ntiles,
+                       tiles_x, tiles_per_img, (int)vblocks);
+    STORM_LAUNCH_CHECK();
+    hipLaunchKernelGGL(splitk_combine_kernel<T>, dim3((unsigned)ntiles, (unsigned)cdiv(a.outC, 64)), dim3(256), 0, st,
+                       static_cast<const float*>(a.splitk_ws), S, (long long)a.B * img, a.H, a.W, a.outC, a.Cout, a.bias, a.tbias,
+                       a.tbias_stride, static_cast<const T*>(a.skip), a.skip_bstride, a.scale, static_cast<T*>(a.out), a.out_bstride,
+                       a.gn_part, tiles_x, tiles_y);
+    STORM_LAUNCH_CHECK();
+    return STORM_OK;
+}
+
+int launch_conv_pipe_splitk(const storm_conv_args& a, int slices, hipStream_t st) {
+    if (a.dtype == STORM_F16) return launch_splitk<half_t>(a, slices, st);
+    return launch_splitk<bf16_t>(a, slices, st);
 }
 
 const char* conv_pipe_kernel_name(int dtype, bool half_tile) {

@@ -307,6 +307,23 @@ struct Program {
             out.part = arena.alloc((long long)B * out.tiles * outC * 2 * 4);
             ws(ops.back(), 10, out.part);
         }
+        {   // few-tile 3x3 layers: scratch for storm_conv's split of K over workgroups - live for this op only (the stream orders
+            // every later writer of the region behind it)
+            storm_conv_args q;
+            memset(&q, 0, sizeof(q));
+            q.nseg = (int)segs.size(); q.B = B; q.H = H; q.W = W; q.outC = outC; q.Cout = Cout; q.out_f32 = k.out_f32; q.dtype = dtype;
+            for (size_t g = 0; g < segs.size(); ++g) {
+                const Seg& s = segs[g];
+                storm_conv_seg& sg = q.seg[g];
+                sg.src_a = &q; sg.w = &q;                       // (shape query: the pointers only have to be non-NULL)
+                sg.Ca = s.a_is_act ? s.a.C : s.a_C; sg.Cb = s.has_b ? s.b.C : 0; if (s.has_b) sg.src_b = &q;
+                sg.CinP = s.CinP; sg.w_rows = s.rows; sg.ntaps = s.taps; sg.w_bstride = s.w_bstride;
+                sg.w_tapstride = s.w_tapstride >= 0 ? s.w_tapstride : (long long)s.CinP * s.rows;
+                sg.bstride_a = (long long)H * W * sg.Ca; sg.bstride_b = (long long)H * W * sg.Cb;
+            }
+            const long long nb = storm_conv_splitk_bytes(&q);
+            if (nb > 0) { const long long off = arena.alloc(nb); ws(ops.back(), 12, off); arena.release(off); }
+        }
         return out;
     }
 

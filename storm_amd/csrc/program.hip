@@ -36,6 +36,10 @@ static void conv_args_of(const storm_op& op, void* const* p, int dtype, storm_co
     a.gn_part = (float*)p[10];
     a.seg[0].gn_ss = (const float*)p[11];
     a.seg[0].gn_silu = op.f[1] != 0.f;
+    if (p[12] != nullptr) {                                 // the planner sized this scratch with the same query
+        a.splitk_ws = p[12];
+        a.splitk_ws_bytes = storm_conv_splitk_bytes(&a);
+    }
 }
 
 static int run_ops(const storm_op* ops, int n_ops, void* const* bufs, int n_bufs, int dtype, storm_stream_t s,

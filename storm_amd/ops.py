@@ -101,6 +101,10 @@ def conv(segs, Cout, gn_partials=False, **kw):
         tiles = L.lib().storm_conv_tiles(C.byref(a))
         part = torch.zeros((a.B, tiles, a.outC, 2), dtype=torch.float32, device=out.device)
         a.gn_part = L.ptr(part)
+    need = L.lib().storm_conv_splitk_bytes(C.byref(a))      # few-tile 3x3 layers: scratch for the split of K over workgroups
+    if need > 0:
+        ws = torch.empty((need,), dtype=torch.uint8, device=out.device)
+        a.splitk_ws, a.splitk_ws_bytes = L.ptr(ws), need
     L.check(L.lib().storm_conv(C.byref(a), L.stream()), "storm_conv")
     return (out, part) if gn_partials else out
 
@@ -108,6 +112,8 @@ def conv(segs, Cout, gn_partials=False, **kw):
 def conv_kernel_name(segs, Cout, **kw):
     """name of the kernel storm_conv launches for these arguments (storm_conv_kernel_name)"""
     a, _ = _conv_args(segs, Cout, **kw)
+    if L.lib().storm_conv_splitk_bytes(C.byref(a)) > 0:     # (as conv() would call it: with the split-K scratch)
+        a.splitk_ws, a.splitk_ws_bytes = 16, L.lib().storm_conv_splitk_bytes(C.byref(a))
     return L.lib().storm_conv_kernel_name(C.byref(a)).decode()
 
 

@@ -323,7 +323,52 @@ class Program:
             out.tiles = (-(-W // 32)) * (-(-H // 8)) if any9 else -(-(H * W) // 256)
             out.part = self.arena.alloc(self.B * out.tiles * outC * 2 * 4)
             self._ws(op, 10, out.part)
+        nb = self.splitk_bytes(segs, H, W, outC, out_f32)
+        if nb > 0:                                  # scratch of the split-K launch: live for this op only
+            off = self.arena.alloc(nb)
+            self._ws(op, 12, off)
+            self.arena.release(off)
         return out
+
+    def splitk_bytes(self, segs, H, W, outC, out_f32):
+        """conv_pipe.hip: conv_splitk_slices / conv_splitk_bytes restated - a 16-bit 3x3 layer with > 128 output channels whose
+        128-cout tiles would occupy <= 64 workgroups splits its nine-tap chunks (64 channels each) into 2 / 4 / 8 slices, at most
+        256 workgroups, one fp32 slab [B][H][W][outC] per slice."""
+        if self.esize != 2 or out_f32 or outC <= 128 or segs[0]["taps"] != 9:
+            return 0
+        # what the pipelined kernel covers (build_pipe_params): a nine-tap segment first, then at most one one-tap segment without
+        # a fused GroupNorm, shared weights, <= 4 weight runs, <= 36 chunks, images and weight matrices below 2 GiB
+        runs = chunks = 0
+        for g, s in enumerate(segs):
+            if s["taps"] not in (9, 1) or s.get("w_bstride", 0) != 0 or (g > 0 and s["taps"] == 9):
+                return 0
+            if s["taps"] == 1 and s.get("gn") is not None:
+                return 0
+            a = s["a"]
+            Ca = a.C if isinstance(a, Act) else a[2]
+            Cb = s["b"].C if s.get("b") is not None else 0
+            tapstride = s.get("w_tapstride", s["CinP"] * s["rows"])
+            for part, Cc in enumerate((Ca, Cb)):
+                if part == 1 and Cb == 0:
+                    break
+                runs += 1
+                chunks += -(-Cc // 64)
+                wc0 = 0 if part == 0 else Ca
+                if H * W * Cc * 2 >= 2 ** 31 or (s["taps"] * tapstride - wc0) * 2 >= 2 ** 31:
+                    return 0
+        if runs > 4 or chunks > 36:
+            return 0
+        a0 = segs[0]["a"]
+        Ca0 = a0.C if isinstance(a0, Act) else a0[2]
+        Cb0 = segs[0]["b"].C if segs[0].get("b") is not None else 0
+        wgs = self.B * (-(-W // 32)) * (-(-H // 8)) * (-(-outC // 128))
+        if wgs > 64:
+            return 0
+        n9 = -(-Ca0 // 64) + (-(-Cb0 // 64) if Cb0 else 0)
+        S = 8
+        while S > 1 and (S > n9 or wgs * S > 256):
+            S >>= 1
+        return S * self.B * H * W * outC * 4 if S >= 2 else 0
 
     def wseg(self, a, key, taps, b=None, gn=None):
         e = self.layout.entries[key]

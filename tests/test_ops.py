@@ -306,6 +306,73 @@ PIPE128_CASES = {
 }
 
 
+@pytest.mark.parametrize("case", ["natural", "natural@8", "deep_k", "deep_k@8", "natural:f16", "one_slice_pair"])
+def test_conv_split_k(dev, case, switch):
+    """Split-K for 3x3 layers whose 128-cout tiles would leave most CUs idle (conv_pipe.hip: conv_pipe_splitk_kernel + splitk_combine_kernel;
+    ncsnpp.py:460-470 - the deep levels of ncsnpplarge): K slices on separate workgroups write fp32 slabs, one combine pass sums them in
+    slice order and applies bias / temb bias / skip / scale / rounding / GroupNorm partials.  "natural": the dispatcher's own choice
+    (> 128 couts, few tiles) with ragged rows / columns / couts and a skip operand; "deep_k": 3 + 2 nine-tap chunks over a concat with a
+    fused GroupNorm operand + 3 + 2 one-tap chunks of a fused shortcut (they ride with the last slice); "@8": eight resident workgroups
+    walk all (tile, cout tile, slice) blocks; against the unsplit tile (variant 9), F.conv2d, and itself (bit-reproducible)."""
+    from storm_amd import ops
+    cus = 0
+    if case.endswith("@8"):
+        cus, case = 8, case[:-2]
+    dtype = torch.bfloat16
+    if case.endswith(":f16"):
+        dtype, case = torch.float16, case[:-4]
+    g = torch.Generator().manual_seed(91)
+    dd = lambda t: nhwc(t).to(dtype).to(dev)
+    if case in ("natural", "one_slice_pair"):
+        B, Cin, Cout, outC, H, W = (2, 256, 280, 288, 9, 33) if case == "natural" else (1, 128, 96, 96, 5, 20)
+        x = torch.randn(B, Cin, H, W, generator=g); w = torch.randn(Cout, Cin, 3, 3, generator=g) * 0.05
+        bias, tb = torch.randn(Cout, generator=g), torch.randn(B, Cout, generator=g)
+        sk = torch.randn(B, outC, H, W, generator=g)
+        segs = [ops.Seg(dd(x), ops.pack_conv_weight(w.to(dev), dtype), 9)]
+        kw = dict(bias=bias.to(dev), tbias=tb.to(dev), skip=dd(sk), scale=2 ** -0.5, outC=outC)
+        ref = (F.conv2d(q(x, dtype), q(w, dtype), bias, padding=1) + tb[:, :, None, None] + q(sk, dtype)[:, :Cout]) * 2 ** -0.5
+        tol_ref = 6e-3
+    else:
+        B, C0, Ca, Cb, Sa, Sb, Co, H, W = 1, 8, 136, 88, 136, 72, 264, 9, 33
+        x0 = torch.randn(B, C0, H, W, generator=g)
+        wa, wb = torch.randn(Ca, C0, 3, 3, generator=g) * 0.4, torch.randn(Cb, C0, 1, 1, generator=g) * 0.7
+        w = torch.randn(Co, Ca + Cb, 3, 3, generator=g) * 0.05
+        sa, sb = torch.randn(B, Sa, H, W, generator=g), torch.randn(B, Sb, H, W, generator=g)
+        w2 = torch.randn(Co, Sa + Sb, 1, 1, generator=g) * 0.1
+        bias = torch.randn(Co, generator=g)
+        gam, bet = 1 + 0.1 * torch.randn(Ca + Cb, generator=g), 0.1 * torch.randn(Ca + Cb, generator=g)
+        xa, pa = ops.conv([ops.Seg(dd(x0), ops.pack_conv_weight(wa.to(dev), dtype), 9)], Ca, gn_partials=True)
+        xb, pb = ops.conv([ops.Seg(dd(x0), ops.pack_conv_weight(wb.to(dev), dtype), 1)], Cb, gn_partials=True)
+        _, ss = ops.gn_finalize(pa, pb, gamma=gam.to(dev), beta=bet.to(dev), count=H * W)
+        segs = [ops.Seg(xa, ops.pack_conv_weight(w.to(dev), dtype), 9, src_b=xb, gn_ss=ss, gn_silu=True),
+                ops.Seg(dd(sa), ops.pack_conv_weight(w2.to(dev), dtype), 1, src_b=dd(sb))]
+        kw = dict(bias=bias.to(dev), scale=0.5)
+        xcat = torch.cat([nchw(xa.float().cpu()), nchw(xb.float().cpu())], 1)
+        a = NR.silu(NR.group_norm(xcat, gam, bet))
+        ref = (F.conv2d(q(a, dtype), q(w, dtype), padding=1) + F.conv2d(q(torch.cat([sa, sb], 1), dtype), q(w2, dtype))
+               + bias[None, :, None, None]) * 0.5
+        Cout, tol_ref = Co, 1e-2
+    if cus:
+        switch("STORM_CONV_CUS", cus)
+    switch("STORM_CONV_VARIANT", 9)
+    y9, part9 = ops.conv(segs, Cout, gn_partials=True, **kw)
+    switch("STORM_CONV_VARIANT", 10 if case == "one_slice_pair" else -1)      # (96 couts on one cout tile: only a forced split applies)
+    assert ops.conv_kernel_name(segs, Cout, **kw).startswith("storm::conv_pipe_splitk_kernel")
+    y, part = ops.conv(segs, Cout, gn_partials=True, **kw)
+    y2, part2 = ops.conv(segs, Cout, gn_partials=True, **kw)
+    assert torch.equal(y, y2) and torch.equal(part, part2)
+    yc = nchw(y.float().cpu())
+    assert rel_l2(yc[:, :Cout], ref) < tol_ref
+    if yc.shape[1] > Cout:                                  # padding channels: (0 + skip) * scale, as every conv kernel writes them
+        assert torch.equal(y[..., Cout:], y9[..., Cout:])
+    assert rel_l2(yc, nchw(y9.float().cpu())) < 2e-3        # (another fp32 summation order: a few values round the other way)
+    assert part.shape == part9.shape
+    assert torch.allclose(part.cpu(), part9.cpu(), rtol=2e-2, atol=2e-2 * float(part9.abs().max()))
+    if y.shape[-1] % ops.gn_groups(y.shape[-1]) == 0:
+        st, sref = ops.gn_finalize(part).cpu(), ops.gn_stats(y).cpu()
+        assert torch.allclose(st, sref, rtol=2e-3, atol=2e-3 * float(sref.abs().max()))
+
+
 def test_conv_dispatch_with_few_pixel_tiles(dev):
     """storm_conv's own choice (no switch) for a 3x3 layer with > 128 output channels: with fewer than 512 pixel tiles the pipelined
     kernel's 128-cout tile (16-bit operands; fp32: the 64-cout tile of conv_igemm.hip when 128-cout tiles would give <= 256

@@ -23,7 +23,7 @@ for (B, H, W, cin) in [(8, 64, 256, 256), (8, 32, 128, 256), (8, 32, 128, 512), 
     kw = dict(bias=rnd(cout).to(dev), tbias=rnd(B, cout).to(dev), gn_partials=True, scale=0.7)
     fl = 2 * B * H * W * cout * cin * 9
     line = f"{B}x{H}x{W} {cin}->{cout}"
-    for variant in (-1, 7, 3, 9):
+    for variant in (-1, 7, 9, 10):
         L.check(L.lib().storm_set_switch(b"STORM_CONV_VARIANT", variant), "set")
         try:
             for _ in range(3):
