@@ -765,31 +765,65 @@ void splitk_combine_kernel(const float* __restrict__ slabs, const int S, const l
         badd[e] *= scale;
     }
     const long long img = (long long)H * W * outC;
-    for (int r = 0; r < TILE_H; ++r) {
-        const int gy = ty0 + r;
-        if (!ok || gy >= H) continue;
-        const long long o = ((long long)gy * W + gx) * outC + co;
-        float v[8];
-        load8(slabs + (long long)b * img + o, v);
-        for (int s = 1; s < S; ++s) {                       // fixed order: slice 0, 1, ...
-            float u[8];
-            load8(slabs + s * slab_stride + (long long)b * img + o, u);
+    const float* const sl = slabs + (long long)b * img;
+    // a launch this small is a chain of memory round trips unless the loads are in flight together: two pixel rows per step, all
+    // slabs of both rows (and the skip operand) issued before the first sum; rows past the image read the tile's first valid
+    // address and are dropped
+    constexpr int RB = 2;
+#pragma unroll 1
+    for (int r0 = 0; r0 < TILE_H; r0 += RB) {
+        bool valid[RB];
+        long long o[RB];
+        float v[RB][8], sk[RB][8];
 #pragma unroll
-            for (int e = 0; e < 8; ++e) v[e] += u[e];
+        for (int j = 0; j < RB; ++j) {
+            const int gy = ty0 + r0 + j;
+            valid[j] = ok && gy < H;
+            o[j] = valid[j] ? ((long long)gy * W + gx) * outC + co : 0;
+            load8(sl + o[j], v[j]);
+        }
+        if (S == 4) {                                       // (the common cases unrolled: every load issued up front)
+            float u[RB][3][8];
+#pragma unroll
+            for (int j = 0; j < RB; ++j)
+#pragma unroll
+                for (int s = 1; s < 4; ++s) load8(sl + s * slab_stride + o[j], u[j][s - 1]);
+#pragma unroll
+            for (int j = 0; j < RB; ++j)
+#pragma unroll
+                for (int s = 1; s < 4; ++s)
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) v[j][e] += u[j][s - 1][e];
+        } else {
+            for (int s = 1; s < S; ++s) {                   // fixed order: slice 0, 1, ...
+                float u[RB][8];
+#pragma unroll
+                for (int j = 0; j < RB; ++j) load8(sl + s * slab_stride + o[j], u[j]);
+#pragma unroll
+                for (int j = 0; j < RB; ++j)
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) v[j][e] += u[j][e];
+            }
         }
         if (skip != nullptr) {
-            float u[8];
-            load8(skip + (long long)b * skip_bstride + o, u);
 #pragma unroll
-            for (int e = 0; e < 8; ++e) v[e] += u[e];
+            for (int j = 0; j < RB; ++j) load8(skip + (long long)b * skip_bstride + o[j], sk[j]);
+#pragma unroll
+            for (int j = 0; j < RB; ++j)
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v[j][e] += sk[j][e];
         }
 #pragma unroll
-        for (int e = 0; e < 8; ++e) {
-            v[e] = fmaf(v[e], scale, badd[e]);
-            gsum[e] += v[e];
-            gsq[e] = fmaf(v[e], v[e], gsq[e]);
+        for (int j = 0; j < RB; ++j) {
+            if (!valid[j]) continue;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                v[j][e] = fmaf(v[j][e], scale, badd[e]);
+                gsum[e] += v[j][e];
+                gsq[e] = fmaf(v[j][e], v[j][e], gsq[e]);
+            }
+            store8(out + (long long)b * out_bstride + o[j], v[j]);
         }
-        store8(out + (long long)b * out_bstride + o, v);
     }
     if (gn_part == nullptr) return;
 #pragma unroll
@@ -810,14 +844,19 @@ void splitk_combine_kernel(const float* __restrict__ slabs, const int S, const l
 }
 
 // K slices for a layer, 0 = no split: only where the 128-cout tiles leave three quarters of the CUs without a workgroup (<= 64 of them;
-// at 128 ... 256 workgroups the split measured slower), a power of two <= 8, at least one nine-tap chunk per slice, <= 256 workgroups.
+// at 128 ... 256 workgroups the split measured slower), 4 or 2, at least one nine-tap chunk per slice.  Measured on the built kernels
+// (tools/probe_splitk_s.py, profiles/r04_probe_splitk_s.txt; unsplit -> 4 slices): 256 -> 256 @ 8 x 16 x 64 39.2 -> 37.9 us, 512 -> 256
+// 67.9 -> 43.8; @ 8 x 8 x 32 36.7 -> 25.1 and 63.7 -> 32.2; @ 8 x 4 x 16 32.2 -> 25.3 and 55.3 -> 26.5; one utterance @ 32 x 64 38.2 -> 25.5.
 int conv_splitk_slices(const storm_conv_args& a) {
     if (!conv_pipe_supports(a) || a.outC <= 128 || a.out_f32) return 0;
     const long long px_tiles = (long long)a.B * cdiv(a.W, TILE_W) * cdiv(a.H, TILE_H);
     const long long wgs = px_tiles * cdiv(a.outC, 128);
     if (wgs > 64) return 0;
     const int n9 = cdiv(a.seg[0].Ca, KC) + (a.seg[0].Cb ? cdiv(a.seg[0].Cb, KC) : 0);
-    int S = 8;
+    const int forced = switches().splitk;                    // (A/B hook)
+    if (forced == 1) return 0;
+    if (forced >= 2) return forced <= n9 ? forced : 0;
+    int S = 4;                                               // (8 slices measured behind 4 wherever both apply, profiles/r04_probe_splitk_s.txt)
     while (S > 1 && (S > n9 || wgs * S > 256)) S >>= 1;
     return S >= 2 ? S : 0;
 }

@@ -332,8 +332,8 @@ class Program:
 
     def splitk_bytes(self, segs, H, W, outC, out_f32):
         """conv_pipe.hip: conv_splitk_slices / conv_splitk_bytes restated - a 16-bit 3x3 layer with > 128 output channels whose
-        128-cout tiles would occupy <= 64 workgroups splits its nine-tap chunks (64 channels each) into 2 / 4 / 8 slices, at most
-        256 workgroups, one fp32 slab [B][H][W][outC] per slice."""
+        128-cout tiles would occupy <= 64 workgroups splits its nine-tap chunks (64 channels each) into 4 (or 2) slices, one fp32
+        slab [B][H][W][outC] per slice."""
         if self.esize != 2 or out_f32 or outC <= 128 or segs[0]["taps"] != 9:
             return 0
         # what the pipelined kernel covers (build_pipe_params): a nine-tap segment first, then at most one one-tap segment without
@@ -365,7 +365,7 @@ class Program:
         if wgs > 64:
             return 0
         n9 = -(-Ca0 // 64) + (-(-Cb0 // 64) if Cb0 else 0)
-        S = 8
+        S = 4
         while S > 1 and (S > n9 or wgs * S > 256):
             S >>= 1
         return S * self.B * H * W * outC * 4 if S >= 2 else 0
