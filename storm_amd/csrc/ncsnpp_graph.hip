@@ -322,7 +322,10 @@ struct Program {
                 sg.bstride_a = (long long)H * W * sg.Ca; sg.bstride_b = (long long)H * W * sg.Cb;
             }
             const long long nb = storm_conv_splitk_bytes(&q);
-            if (nb > 0) { const long long off = arena.alloc(nb); ws(ops.back(), 12, off); arena.release(off); }
+            if (nb > 0) {                                       // f[2] = the slabs the scratch holds (the interpreter sizes it from that)
+                const long long off = arena.alloc(nb); ws(ops.back(), 12, off); arena.release(off);
+                ops.back().f[2] = (float)(nb / ((long long)B * H * W * outC * 4));
+            }
         }
         return out;
     }

@@ -36,9 +36,9 @@ static void conv_args_of(const storm_op& op, void* const* p, int dtype, storm_co
     a.gn_part = (float*)p[10];
     a.seg[0].gn_ss = (const float*)p[11];
     a.seg[0].gn_silu = op.f[1] != 0.f;
-    if (p[12] != nullptr) {                                 // the planner sized this scratch with the same query
+    if (p[12] != nullptr) {                                 // split-K scratch: f[2] fp32 slabs [B][H][W][outC] (storm_conv_splitk_bytes at plan time)
         a.splitk_ws = p[12];
-        a.splitk_ws_bytes = storm_conv_splitk_bytes(&a);
+        a.splitk_ws_bytes = (long long)op.f[2] * a.B * hw * a.outC * 4;
     }
 }
 

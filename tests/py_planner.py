@@ -328,6 +328,7 @@ class Program:
             off = self.arena.alloc(nb)
             self._ws(op, 12, off)
             self.arena.release(off)
+            op.f[2] = float(nb // (self.B * H * W * outC * 4))
         return out
 
     def splitk_bytes(self, segs, H, W, outC, out_f32):
