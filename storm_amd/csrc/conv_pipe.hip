@@ -843,22 +843,21 @@ void splitk_combine_kernel(const float* __restrict__ slabs, const int S, const l
     }
 }
 
-// K slices for a layer, 0 = no split: only where the 128-cout tiles leave three quarters of the CUs without a workgroup (<= 64 of them;
-// at 128 ... 256 workgroups the split measured slower), 4 or 2, at least one nine-tap chunk per slice.  Measured on the built kernels
-// (tools/probe_splitk_s.py, profiles/r04_probe_splitk_s.txt; unsplit -> 4 slices): 256 -> 256 @ 8 x 16 x 64 39.2 -> 37.9 us, 512 -> 256
-// 67.9 -> 43.8; @ 8 x 8 x 32 36.7 -> 25.1 and 63.7 -> 32.2; @ 8 x 4 x 16 32.2 -> 25.3 and 55.3 -> 26.5; one utterance @ 32 x 64 38.2 -> 25.5.
+// K slices for a layer, 0 = no split.  The rule looks at ONE image only - its 128-cout tiles (pixel tiles x cout tiles <= 8: images up
+// to 16 x 64 / 32 x 32 pixels at 256 couts) - never at the batch size: a split changes the fp32 summation order, and an utterance must
+// come out the same alone, in a batch, or on another rank (test_batch_independence_and_determinism).  At configs[3]'s 8 utterances per
+// GPU that is <= 64 workgroups unsplit; at 128 ... 256 workgroups (the 32 x 64 level at batch 16) the split measured slower.  4 slices,
+// 2 when there are fewer than four 64-channel chunks: 8 measured behind 4 wherever both apply (profiles/r04_probe_splitk_s.txt;
+// unsplit -> 4 slices): 256 -> 256 @ 8 x 16 x 64 39.2 -> 37.9 us, 512 -> 256 67.9 -> 43.8; @ 8 x 8 x 32 36.7 -> 25.1 and 63.7 -> 32.2;
+// @ 8 x 4 x 16 32.2 -> 25.3 and 55.3 -> 26.5.
 int conv_splitk_slices(const storm_conv_args& a) {
     if (!conv_pipe_supports(a) || a.outC <= 128 || a.out_f32) return 0;
-    const long long px_tiles = (long long)a.B * cdiv(a.W, TILE_W) * cdiv(a.H, TILE_H);
-    const long long wgs = px_tiles * cdiv(a.outC, 128);
-    if (wgs > 64) return 0;
     const int n9 = cdiv(a.seg[0].Ca, KC) + (a.seg[0].Cb ? cdiv(a.seg[0].Cb, KC) : 0);
     const int forced = switches().splitk;                    // (A/B hook)
     if (forced == 1) return 0;
     if (forced >= 2) return forced <= n9 ? forced : 0;
-    int S = 4;                                               // (8 slices measured behind 4 wherever both apply, profiles/r04_probe_splitk_s.txt)
-    while (S > 1 && (S > n9 || wgs * S > 256)) S >>= 1;
-    return S >= 2 ? S : 0;
+    if ((long long)cdiv(a.W, TILE_W) * cdiv(a.H, TILE_H) * cdiv(a.outC, 128) > 8) return 0;
+    return n9 >= 4 ? 4 : n9 >= 2 ? 2 : 0;
 }
 long long conv_splitk_bytes(const storm_conv_args& a, int slices) {
     return slices < 2 ? 0 : (long long)slices * a.B * a.H * a.W * a.outC * 4;

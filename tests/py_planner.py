@@ -332,9 +332,9 @@ class Program:
         return out
 
     def splitk_bytes(self, segs, H, W, outC, out_f32):
-        """conv_pipe.hip: conv_splitk_slices / conv_splitk_bytes restated - a 16-bit 3x3 layer with > 128 output channels whose
-        128-cout tiles would occupy <= 64 workgroups splits its nine-tap chunks (64 channels each) into 4 (or 2) slices, one fp32
-        slab [B][H][W][outC] per slice."""
+        """conv_pipe.hip: conv_splitk_slices / conv_splitk_bytes restated - a 16-bit 3x3 layer with > 128 output channels and at most
+        8 128-cout tiles PER IMAGE splits its nine-tap chunks (64 channels each) into 4 (or 2) slices, one fp32 slab [B][H][W][outC]
+        per slice."""
         if self.esize != 2 or out_f32 or outC <= 128 or segs[0]["taps"] != 9:
             return 0
         # what the pipelined kernel covers (build_pipe_params): a nine-tap segment first, then at most one one-tap segment without
@@ -362,13 +362,10 @@ class Program:
         a0 = segs[0]["a"]
         Ca0 = a0.C if isinstance(a0, Act) else a0[2]
         Cb0 = segs[0]["b"].C if segs[0].get("b") is not None else 0
-        wgs = self.B * (-(-W // 32)) * (-(-H // 8)) * (-(-outC // 128))
-        if wgs > 64:
+        if (-(-W // 32)) * (-(-H // 8)) * (-(-outC // 128)) > 8:      # per image, never the batch size: results must not depend on it
             return 0
         n9 = -(-Ca0 // 64) + (-(-Cb0 // 64) if Cb0 else 0)
-        S = 4
-        while S > 1 and (S > n9 or wgs * S > 256):
-            S >>= 1
+        S = 4 if n9 >= 4 else 2 if n9 >= 2 else 0
         return S * self.B * H * W * outC * 4 if S >= 2 else 0
 
     def wseg(self, a, key, taps, b=None, gn=None):

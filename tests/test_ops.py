@@ -324,7 +324,7 @@ def test_conv_split_k(dev, case, switch):
     g = torch.Generator().manual_seed(91)
     dd = lambda t: nhwc(t).to(dtype).to(dev)
     if case in ("natural", "one_slice_pair"):
-        B, Cin, Cout, outC, H, W = (2, 256, 280, 288, 9, 33) if case == "natural" else (1, 128, 96, 96, 5, 20)
+        B, Cin, Cout, outC, H, W = (2, 256, 280, 288, 9, 20) if case == "natural" else (1, 128, 96, 96, 5, 20)
         x = torch.randn(B, Cin, H, W, generator=g); w = torch.randn(Cout, Cin, 3, 3, generator=g) * 0.05
         bias, tb = torch.randn(Cout, generator=g), torch.randn(B, Cout, generator=g)
         sk = torch.randn(B, outC, H, W, generator=g)
@@ -333,7 +333,7 @@ def test_conv_split_k(dev, case, switch):
         ref = (F.conv2d(q(x, dtype), q(w, dtype), bias, padding=1) + tb[:, :, None, None] + q(sk, dtype)[:, :Cout]) * 2 ** -0.5
         tol_ref = 6e-3
     else:
-        B, C0, Ca, Cb, Sa, Sb, Co, H, W = 1, 8, 136, 88, 136, 72, 264, 9, 33
+        B, C0, Ca, Cb, Sa, Sb, Co, H, W = 1, 8, 136, 88, 136, 72, 264, 9, 20
         x0 = torch.randn(B, C0, H, W, generator=g)
         wa, wb = torch.randn(Ca, C0, 3, 3, generator=g) * 0.4, torch.randn(Cb, C0, 1, 1, generator=g) * 0.7
         w = torch.randn(Co, Ca + Cb, 3, 3, generator=g) * 0.05
