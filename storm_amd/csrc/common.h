@@ -32,6 +32,7 @@ struct Switches {
     int conv_persist = 0;       // STORM_CONV_PERSIST (profiling build)
     int conv_dma = 1;           // STORM_CONV_DMA (profiling build): 0 = register staging in conv_igemm's 128-cout kernel
     int conv_ablate = 0;        // STORM_CONV_ABLATE (profiling build): work-skipping instantiations
+    int gn_wide = 1;            // STORM_GN_WIDE: 0 = the GroupNorm + FIR kernels with 8 slots (128 B) of a pixel per workgroup (A/B)
     int splitk = 0;             // STORM_SPLITK: 0 = the dispatcher's K slices for few-tile 3x3 layers, 1 = never split, 2 / 4 / 8 = that many (A/B)
     unsigned long long conv_trace_ptr = 0;   // STORM_CONV_TRACE_PTR (profiling build): device buffer of tools/conv_trace.py
 };

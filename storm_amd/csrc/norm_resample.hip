@@ -226,19 +226,24 @@ __global__ void gn_apply_kernel(const T* __restrict__ xa, int Ca, const T* __res
 // keep 8 KiB of loads in flight each - the LDS-tiled predecessor (10 x 18-pixel tiles staged once, 3 workgroups per CU, two
 // barriers per 32 output pixels; git show 9dfa6dc:storm_amd/csrc/norm_resample.hip) ran at 1.7 TB/s with its waves parked half
 // of the time (profiles/r03a_pmc_summary.txt); this one measures 2.8 TB/s.
-constexpr int DN_COLS = 32, DN_ROWS = 16;           // output columns per workgroup / output rows per strip
+constexpr int DN_ROWS = 16;                         // output rows per strip
+// NS = 16-byte slots of a pixel per workgroup (256 / NS output columns).  Round 3 used 8 everywhere (one 128-byte line per pixel and
+// wave access); with NS = 32 a wave reads / writes 512 contiguous bytes per pixel - whole DRAM bursts of one page instead of 128-byte
+// pieces 1 KiB apart that other workgroups complete at another time (round 4: the write stream of the up-sampling kernel was at 4.1 TB/s
+// where a plain fill reaches 6.9, profiles/r04d_hbm_probe.txt).
 // SILU: the activation as a compile-time choice (as a run-time flag it is if-converted: both results computed, a select per value)
-template <typename T, bool SILU>
+template <typename T, bool SILU, int NS>
 __global__ __launch_bounds__(256)
 void gn_apply_down_kernel(const T* __restrict__ xa, int Ca, const T* __restrict__ xb, int Cb,
                           int H, int W, int G, const double* __restrict__ stats,
                           const float* __restrict__ gamma, const float* __restrict__ beta, float eps,
                           T* __restrict__ out_act, T* __restrict__ out_raw, int ncg, int nstrips) {
     constexpr int PER16 = Elem<T>::PER16;
-    constexpr int CG = 8 * PER16;                   // channels per workgroup
+    constexpr int CG = NS * PER16;                  // channels per workgroup
+    constexpr int DN_COLS = 256 / NS;               // output columns per workgroup
     __shared__ float gtab[2 * CG];
     const int C = Ca + Cb, tid = threadIdx.x;
-    const int slot = tid & 7, col = tid >> 3;
+    const int slot = tid % NS, col = tid / NS;
     const int OH = H / 2, OW = W / 2;
     int t = blockIdx.y;                             // (channel group, strip, batch item)
     const int cg = t % ncg; t /= ncg;
@@ -365,18 +370,19 @@ void gn_apply_down_kernel(const T* __restrict__ xa, int Ca, const T* __restrict_
 // (2 ix, 2 ix + 1) of both tensors; every pair of consecutive filtered rows (h[i], h[i + 1]) emits the output rows 2 i + 1 and
 // 2 i + 2.  The kernel is bound by its stores (two tensors of four times the input size: 8 x 16 B per thread and input row):
 // 4.1 TB/s, exactly what the LDS-tiled predecessor reached - a write-dominated stream does not get the copy rate on this part.
-constexpr int UP_COLS = 32, UP_ROWS = 16;           // input columns per workgroup / input rows per strip
-template <typename T, bool SILU>
+constexpr int UP_ROWS = 16;                         // input rows per strip
+template <typename T, bool SILU, int NS>
 __global__ __launch_bounds__(256)
 void gn_apply_up_kernel(const T* __restrict__ xa, int Ca, const T* __restrict__ xb, int Cb,
                         int H, int W, int G, const double* __restrict__ stats,
                         const float* __restrict__ gamma, const float* __restrict__ beta, float eps,
                         T* __restrict__ out_act, T* __restrict__ out_raw, int ncg, int nstrips) {
     constexpr int PER16 = Elem<T>::PER16;
-    constexpr int CG = 8 * PER16;
+    constexpr int CG = NS * PER16;
+    constexpr int UP_COLS = 256 / NS;               // input columns per workgroup
     __shared__ float gtab[2 * CG];
     const int C = Ca + Cb, tid = threadIdx.x;
-    const int slot = tid & 7, col = tid >> 3;
+    const int slot = tid % NS, col = tid / NS;
     const int OH = 2 * H, OW = 2 * W;
     int t = blockIdx.y;
     const int cg = t % ncg; t /= ncg;
@@ -546,28 +552,31 @@ static int gn_apply_t(const void* xa, int Ca, const void* xb, int Cb, int B, int
                       const double* stats, const float* gamma, const float* beta, float eps, int silu,
                       void* out_act, void* out_raw, hipStream_t st) {
     const GnGeom g = gn_geom(Ca + Cb);
+    // slots of a pixel per workgroup: the widest of 32 / 16 / 8 that tiles the channel count (256 channels of 16-bit data: 32)
+    const int slots = (Ca + Cb) / Elem<T>::PER16;
+    const int NSr = switches().gn_wide == 0 ? 8 : (slots % 32 == 0 ? 32 : slots % 16 == 0 ? 16 : 8);
     if (R == 2) {
-        constexpr int CG = 8 * Elem<T>::PER16;
         const int OH = H / 2, OW = W / 2;
-        const int ncg = cdiv(Ca + Cb, CG), nstrips = cdiv(OH, DN_ROWS);
+        const int ncg = cdiv(Ca + Cb, NSr * Elem<T>::PER16), nstrips = cdiv(OH, DN_ROWS);
         const long long gy = (long long)ncg * nstrips * B;
         STORM_CHECK(OH > 0 && OW > 0 && gy < 65536, "storm_gn_apply: down-sampling grid %lld out of range", gy);
-        if (silu) hipLaunchKernelGGL((gn_apply_down_kernel<T, true>), dim3(cdiv(OW, DN_COLS), (unsigned)gy), dim3(256), 0, st,
-                           (const T*)xa, Ca, (const T*)xb, Cb, H, W, G, stats, gamma, beta, eps, (T*)out_act, (T*)out_raw, ncg, nstrips);
-        else hipLaunchKernelGGL((gn_apply_down_kernel<T, false>), dim3(cdiv(OW, DN_COLS), (unsigned)gy), dim3(256), 0, st,
-                           (const T*)xa, Ca, (const T*)xb, Cb, H, W, G, stats, gamma, beta, eps, (T*)out_act, (T*)out_raw, ncg, nstrips);
+#define STORM_GN_DOWN(SILU_, NS_) hipLaunchKernelGGL((gn_apply_down_kernel<T, SILU_, NS_>), dim3(cdiv(OW, 256 / NS_), (unsigned)gy), dim3(256), 0, st, \
+                           (const T*)xa, Ca, (const T*)xb, Cb, H, W, G, stats, gamma, beta, eps, (T*)out_act, (T*)out_raw, ncg, nstrips)
+        if (silu) { if (NSr == 32) STORM_GN_DOWN(true, 32); else if (NSr == 16) STORM_GN_DOWN(true, 16); else STORM_GN_DOWN(true, 8); }
+        else { if (NSr == 32) STORM_GN_DOWN(false, 32); else if (NSr == 16) STORM_GN_DOWN(false, 16); else STORM_GN_DOWN(false, 8); }
+#undef STORM_GN_DOWN
         STORM_LAUNCH_CHECK();
         return STORM_OK;
     }
     if (R == 1) {
-        constexpr int CG = 8 * Elem<T>::PER16;
-        const int ncg = cdiv(Ca + Cb, CG), nstrips = cdiv(H, UP_ROWS);
+        const int ncg = cdiv(Ca + Cb, NSr * Elem<T>::PER16), nstrips = cdiv(H, UP_ROWS);
         const long long gy = (long long)ncg * nstrips * B;
         STORM_CHECK(gy < 65536, "storm_gn_apply: up-sampling grid %lld out of range", gy);
-        if (silu) hipLaunchKernelGGL((gn_apply_up_kernel<T, true>), dim3(cdiv(W, UP_COLS), (unsigned)gy), dim3(256), 0, st,
-                           (const T*)xa, Ca, (const T*)xb, Cb, H, W, G, stats, gamma, beta, eps, (T*)out_act, (T*)out_raw, ncg, nstrips);
-        else hipLaunchKernelGGL((gn_apply_up_kernel<T, false>), dim3(cdiv(W, UP_COLS), (unsigned)gy), dim3(256), 0, st,
-                           (const T*)xa, Ca, (const T*)xb, Cb, H, W, G, stats, gamma, beta, eps, (T*)out_act, (T*)out_raw, ncg, nstrips);
+#define STORM_GN_UP(SILU_, NS_) hipLaunchKernelGGL((gn_apply_up_kernel<T, SILU_, NS_>), dim3(cdiv(W, 256 / NS_), (unsigned)gy), dim3(256), 0, st, \
+                           (const T*)xa, Ca, (const T*)xb, Cb, H, W, G, stats, gamma, beta, eps, (T*)out_act, (T*)out_raw, ncg, nstrips)
+        if (silu) { if (NSr == 32) STORM_GN_UP(true, 32); else if (NSr == 16) STORM_GN_UP(true, 16); else STORM_GN_UP(true, 8); }
+        else { if (NSr == 32) STORM_GN_UP(false, 32); else if (NSr == 16) STORM_GN_UP(false, 16); else STORM_GN_UP(false, 8); }
+#undef STORM_GN_UP
         STORM_LAUNCH_CHECK();
         return STORM_OK;
     }
