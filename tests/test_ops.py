@@ -306,14 +306,15 @@ PIPE128_CASES = {
 }
 
 
-@pytest.mark.parametrize("case", ["natural", "natural@8", "deep_k", "deep_k@8", "natural:f16", "one_slice_pair"])
+@pytest.mark.parametrize("case", ["natural", "natural@8", "deep_k", "deep_k@8", "natural:f16", "one_slice_pair", "three_chunks", "tiny_images"])
 def test_conv_split_k(dev, case, switch):
     """Split-K for 3x3 layers whose 128-cout tiles would leave most CUs idle (conv_pipe.hip: conv_pipe_splitk_kernel + splitk_combine_kernel;
     ncsnpp.py:460-470 - the deep levels of ncsnpplarge): K slices on separate workgroups write fp32 slabs, one combine pass sums them in
     slice order and applies bias / temb bias / skip / scale / rounding / GroupNorm partials.  "natural": the dispatcher's own choice
     (> 128 couts, few tiles) with ragged rows / columns / couts and a skip operand; "deep_k": 3 + 2 nine-tap chunks over a concat with a
     fused GroupNorm operand + 3 + 2 one-tap chunks of a fused shortcut (they ride with the last slice); "@8": eight resident workgroups
-    walk all (tile, cout tile, slice) blocks; against the unsplit tile (variant 9), F.conv2d, and itself (bit-reproducible)."""
+    walk all (tile, cout tile, slice) blocks; "three_chunks": uneven slices; "tiny_images": images smaller than a tile; against the
+    unsplit tile (variant 9), F.conv2d, and itself (bit-reproducible)."""
     from storm_amd import ops
     cus = 0
     if case.endswith("@8"):
@@ -323,8 +324,11 @@ def test_conv_split_k(dev, case, switch):
         dtype, case = torch.float16, case[:-4]
     g = torch.Generator().manual_seed(91)
     dd = lambda t: nhwc(t).to(dtype).to(dev)
-    if case in ("natural", "one_slice_pair"):
-        B, Cin, Cout, outC, H, W = (2, 256, 280, 288, 9, 20) if case == "natural" else (1, 128, 96, 96, 5, 20)
+    if case in ("natural", "one_slice_pair", "three_chunks", "tiny_images"):
+        # three_chunks: 136 input channels = 3 chunks (the last one ragged) -> 2 slices of 1 and 2 chunks; tiny_images: 8 images of 4 x 16
+        # pixels (half a tile high, half a tile wide: the deepest level of ncsnpplarge at configs[3])
+        B, Cin, Cout, outC, H, W = {"natural": (2, 256, 280, 288, 9, 20), "one_slice_pair": (1, 128, 96, 96, 5, 20),
+                                    "three_chunks": (2, 136, 160, 160, 9, 20), "tiny_images": (8, 256, 256, 256, 4, 16)}[case]
         x = torch.randn(B, Cin, H, W, generator=g); w = torch.randn(Cout, Cin, 3, 3, generator=g) * 0.05
         bias, tb = torch.randn(Cout, generator=g), torch.randn(B, Cout, generator=g)
         sk = torch.randn(B, outC, H, W, generator=g)
