@@ -115,7 +115,9 @@ typedef struct storm_conv_args {
 } storm_conv_args;
 
 int storm_conv(const storm_conv_args* a, storm_stream_t s);
-/* scratch bytes with which storm_conv would split K for this call; 0 = it would not (most layers) */
+/* scratch bytes with which storm_conv would split K for this call; 0 = it would not (most layers).  No counterpart in the
+ * reference: a scheduling aid for ddpm_conv3x3 (layers.py:119-126) on the 16 x 64 ... 4 x 16 pixel levels of ncsnpplarge
+ * (ncsnpp.py:460-470), where one launch is otherwise a serial K loop on a few workgroups. */
 long long storm_conv_splitk_bytes(const storm_conv_args* a);
 /* number of pixel tiles per batch item the kernel will use for this call (size of gn_part) */
 int storm_conv_tiles(const storm_conv_args* a);
