@@ -526,11 +526,12 @@ def test_groupnorm_golden(dev, golden):
 
 @pytest.mark.parametrize("dtype", DTYPES)
 @pytest.mark.parametrize("resample", [1, 2])
-@pytest.mark.parametrize("shape", [(2, 24, 6, 10), (2, 72, 20, 36), (1, 160, 38, 70)])
-def test_groupnorm_fir_fused(dev, dtype, resample, shape):
+@pytest.mark.parametrize("shape", [(2, 24, 6, 10), (2, 72, 20, 36), (1, 160, 38, 70), (1, 128, 6, 20), (2, 256, 10, 12)])
+def test_groupnorm_fir_fused(dev, dtype, resample, shape, switch):
     """h = FIR(SiLU(GN(x))) and x = FIR(x) of a BigGAN up/down block in one pass (layerspp.py:243-255); second / third shape: two
     and three channel groups (the last ragged), several row strips and column blocks per image - every thread walks down a strip
-    with the rows it shares with the previous output row carried in registers."""
+    with the rows it shares with the previous output row carried in registers; the last two: the channel counts of the networks, which
+    run with 16 / 32 slots of a pixel per workgroup (same bits as the 8-slot layout, STORM_GN_WIDE = 0)."""
     from storm_amd import ops
     g = torch.Generator().manual_seed(5)
     B, C, H, W = shape
@@ -542,6 +543,9 @@ def test_groupnorm_fir_fused(dev, dtype, resample, shape):
     fir = NR.fir_up2 if resample == 1 else NR.fir_down2
     assert rel_l2(nchw(act.float().cpu()), fir(NR.silu(NR.group_norm(q(x, dtype), gam, bet)))) < tol(dtype, 2e-6, 5e-3)
     assert rel_l2(nchw(raw.float().cpu()), fir(q(x, dtype))) < tol(dtype, 2e-6, 5e-3)
+    switch("STORM_GN_WIDE", 0)
+    act8, raw8 = ops.gn_apply(xa, st, gam.to(dev), bet.to(dev), resample=resample)
+    assert torch.equal(act, act8) and torch.equal(raw, raw8)
 
 
 def test_fir_golden(dev, golden):
