@@ -672,7 +672,7 @@ static int launch_conv(const storm_conv_args& a, hipStream_t st) {
 //   8: conv_narrow.hip, 3x3 to <= 4 output channels (the output pyramid): 36-row 1x1 GEMM over the haloed region + nine-point gather
 //   9: conv_pipe.hip with 128 cout x 256 px per 8-wave workgroup (64 x 64 per wave): the pipelined kernel for 128 ... 511 pixel tiles
 //  10: conv_pipe.hip split-K: the 128-cout tile with K cut into 4 (or 2) slices on as many workgroups (fp32 slabs in the caller's
-//      scratch) + one combine launch - 3x3 layers whose 128-cout tiles would occupy <= 64 CUs (needs storm_conv_args.splitk_ws)
+//      scratch) + one combine launch - 3x3 layers with at most 8 128-cout tiles per image (needs storm_conv_args.splitk_ws)
 //   7: conv_igemm 64 cout x 256 px, 4 waves (32x128 each), 2 workgroups / CU; LDS-DMA - for 3x3 layers with so few pixel tiles
 //      that 128-cout tiles leave CUs without work (the 32 x 64 level: 128 pixel tiles x 2 cout tiles on 256 CUs x 2 slots)
 // K slices storm_conv would use for this call (0 = none), whatever scratch the caller brought
