@@ -32,6 +32,8 @@ struct Switches {
     int conv_persist = 0;       // STORM_CONV_PERSIST (profiling build)
     int conv_dma = 1;           // STORM_CONV_DMA (profiling build): 0 = register staging in conv_igemm's 128-cout kernel
     int conv_ablate = 0;        // STORM_CONV_ABLATE (profiling build): work-skipping instantiations
+    int gn_rows = 0;            // STORM_GN_ROWS (experiment): rows per strip of the GroupNorm + FIR kernels (0 = 16)
+    int gn_nt = 5;              // STORM_GN_NT: non-temporal output stores - bit 0 gn_apply_up, bit 1 gn_apply_down (no gain: off), bit 2 conv_thin (A/B: profiles/r04_gnexp.txt)
     int gn_wide = 1;            // STORM_GN_WIDE: 0 = the GroupNorm + FIR kernels with 8 slots (128 B) of a pixel per workgroup (A/B)
     int splitk = 0;             // STORM_SPLITK: 0 = the dispatcher's K slices for few-tile 3x3 layers, 1 = never split, 2 / 4 / 8 = that many (A/B)
     unsigned long long conv_trace_ptr = 0;   // STORM_CONV_TRACE_PTR (profiling build): device buffer of tools/conv_trace.py
@@ -166,6 +168,12 @@ __device__ inline void store8(half_t* p, const float (&v)[8]) {
 __device__ inline void store8(float* p, const float (&v)[8]) {
     *reinterpret_cast<float4*>(p) = make_float4(v[0], v[1], v[2], v[3]);
     *reinterpret_cast<float4*>(p + 4) = make_float4(v[4], v[5], v[6], v[7]);
+}
+// 16 bytes that will not be read again before they leave the caches (streaming outputs far larger than the L2): non-temporal
+typedef uint32_t u32x4_nt_t __attribute__((ext_vector_type(4)));
+__device__ inline void store16_nt(void* p, uint4 q) {
+    u32x4_nt_t val = {q.x, q.y, q.z, q.w};
+    __builtin_nontemporal_store(val, reinterpret_cast<u32x4_nt_t*>(p));
 }
 __device__ inline void store8(bf16_t* p, const float (&v)[8]) {
     uint32_t w[4];

@@ -26,7 +26,7 @@ struct Params {
     const void* src; const void* w; void* out; const float* bias; const void* skip; float* gn_part;
     long long src_bstride, out_bstride, skip_bstride;       // elements
     int B, H, W, outC, Cout, w_rows, tiles_x, tiles_per_img;
-    float scale;
+    float scale; int nt;                                    // nt: non-temporal output stores (the stem's 537 MB are read next from HBM anyway)
 };
 }  // namespace thin
 
@@ -143,7 +143,9 @@ void conv_thin_kernel(const thin::Params p) {
                         gsq2[i] = __builtin_elementwise_fma(v2[i], v2[i], gsq2[i]);
                     }
                     const float v[8] = {v2[0].x, v2[0].y, v2[1].x, v2[1].y, v2[2].x, v2[2].y, v2[3].x, v2[3].y};
-                    store8(out_b + o, v);
+                    if (p.nt) store16_nt(out_b + o, make_uint4(pack2(v[0], v[1], (T*)nullptr), pack2(v[2], v[3], (T*)nullptr),
+                                                                pack2(v[4], v[5], (T*)nullptr), pack2(v[6], v[7], (T*)nullptr)));
+                    else store8(out_b + o, v);
                 }
             }
         }
@@ -198,6 +200,7 @@ static int launch_thin(const storm_conv_args& a, hipStream_t st) {
     const storm_conv_seg& g = a.seg[0];
     p.src = g.src_a; p.w = g.w; p.out = a.out; p.bias = a.bias; p.skip = a.skip; p.gn_part = a.gn_part;
     p.src_bstride = g.bstride_a; p.out_bstride = a.out_bstride; p.skip_bstride = a.skip_bstride;
+    p.nt = (switches().gn_nt >> 2) & 1;
     p.B = a.B; p.H = a.H; p.W = a.W; p.outC = a.outC; p.Cout = a.Cout; p.w_rows = g.w_rows; p.scale = a.scale;
     p.tiles_x = cdiv(a.W, TILE_W);
     p.tiles_per_img = TAPS == 9 ? p.tiles_x * cdiv(a.H, TILE_H) : cdiv((long long)a.H * a.W, TILE_H * TILE_W);

@@ -237,7 +237,7 @@ __global__ __launch_bounds__(256)
 void gn_apply_down_kernel(const T* __restrict__ xa, int Ca, const T* __restrict__ xb, int Cb,
                           int H, int W, int G, const double* __restrict__ stats,
                           const float* __restrict__ gamma, const float* __restrict__ beta, float eps,
-                          T* __restrict__ out_act, T* __restrict__ out_raw, int ncg, int nstrips) {
+                          T* __restrict__ out_act, T* __restrict__ out_raw, int ncg, int nstrips, int nt_stores) {
     constexpr int PER16 = Elem<T>::PER16;
     constexpr int CG = NS * PER16;                  // channels per workgroup
     constexpr int DN_COLS = 256 / NS;               // output columns per workgroup
@@ -326,7 +326,8 @@ void gn_apply_down_kernel(const T* __restrict__ xa, int Ca, const T* __restrict_
             }
         }
     };
-    const int oy0 = strip * DN_ROWS, oy1 = min(OH, oy0 + DN_ROWS);
+    const int dn_rows = (OH + nstrips - 1) / nstrips;
+    const int oy0 = strip * dn_rows, oy1 = min(OH, oy0 + dn_rows);
     float cA[PER16], cR[PER16];                     // carry: k0 h[2 oy - 1] + k1 h[2 oy]
     {
         float h0A[PER16], h0R[PER16], h1A[PER16], h1R[PER16];
@@ -349,10 +350,12 @@ void gn_apply_down_kernel(const T* __restrict__ xa, int Ca, const T* __restrict_
         }
         const long long o = (obase + (long long)oy * OW + ox) * C + c;
         if constexpr (sizeof(T) == 2) {
-            *reinterpret_cast<uint4*>(out_act + o) = make_uint4(pack2(va[0], va[1], (T*)nullptr), pack2(va[2], va[3], (T*)nullptr),
-                                                                pack2(va[4], va[5], (T*)nullptr), pack2(va[6], va[7], (T*)nullptr));
-            if (out_raw) *reinterpret_cast<uint4*>(out_raw + o) = make_uint4(pack2(vr[0], vr[1], (T*)nullptr), pack2(vr[2], vr[3], (T*)nullptr),
-                                                                             pack2(vr[4], vr[5], (T*)nullptr), pack2(vr[6], vr[7], (T*)nullptr));
+            const uint4 qa = make_uint4(pack2(va[0], va[1], (T*)nullptr), pack2(va[2], va[3], (T*)nullptr),
+                                        pack2(va[4], va[5], (T*)nullptr), pack2(va[6], va[7], (T*)nullptr));
+            const uint4 qr = make_uint4(pack2(vr[0], vr[1], (T*)nullptr), pack2(vr[2], vr[3], (T*)nullptr),
+                                        pack2(vr[4], vr[5], (T*)nullptr), pack2(vr[6], vr[7], (T*)nullptr));
+            if (nt_stores) { store16_nt(out_act + o, qa); if (out_raw) store16_nt(out_raw + o, qr); }
+            else { *reinterpret_cast<uint4*>(out_act + o) = qa; if (out_raw) *reinterpret_cast<uint4*>(out_raw + o) = qr; }
         } else {
             alignas(16) T oa[PER16];
             alignas(16) T orr[PER16];
@@ -376,7 +379,7 @@ __global__ __launch_bounds__(256)
 void gn_apply_up_kernel(const T* __restrict__ xa, int Ca, const T* __restrict__ xb, int Cb,
                         int H, int W, int G, const double* __restrict__ stats,
                         const float* __restrict__ gamma, const float* __restrict__ beta, float eps,
-                        T* __restrict__ out_act, T* __restrict__ out_raw, int ncg, int nstrips) {
+                        T* __restrict__ out_act, T* __restrict__ out_raw, int ncg, int nstrips, int nt_stores) {
     constexpr int PER16 = Elem<T>::PER16;
     constexpr int CG = NS * PER16;
     constexpr int UP_COLS = 256 / NS;               // input columns per workgroup
@@ -496,10 +499,12 @@ void gn_apply_up_kernel(const T* __restrict__ xa, int Ca, const T* __restrict__ 
 #pragma unroll
                 for (int e = 0; e < PER16; ++e) from_f32(ov[e], v[k][e]);
             }
-            *reinterpret_cast<uint4*>(dst + o0 + (k & 1) * C) = *reinterpret_cast<const uint4*>(ov);
+            if (nt_stores) store16_nt(dst + o0 + (k & 1) * C, *reinterpret_cast<const uint4*>(ov));
+            else *reinterpret_cast<uint4*>(dst + o0 + (k & 1) * C) = *reinterpret_cast<const uint4*>(ov);
         }
     };
-    const int iy0 = strip * UP_ROWS, iy1 = min(H, iy0 + UP_ROWS);
+    const int up_rows = (H + nstrips - 1) / nstrips;
+    const int iy0 = strip * up_rows, iy1 = min(H, iy0 + up_rows);
     HRow h0, h1;
     hrow(iy0 - 1, h0);
     for (int i = iy0 - 1; i < iy1; ++i) {            // the pair (h[i], h[i + 1]) emits the output rows 2 i + 1 and 2 i + 2
@@ -557,11 +562,11 @@ static int gn_apply_t(const void* xa, int Ca, const void* xb, int Cb, int B, int
     const int NSr = switches().gn_wide == 0 ? 8 : (slots % 32 == 0 ? 32 : slots % 16 == 0 ? 16 : 8);
     if (R == 2) {
         const int OH = H / 2, OW = W / 2;
-        const int ncg = cdiv(Ca + Cb, NSr * Elem<T>::PER16), nstrips = cdiv(OH, DN_ROWS);
+        const int ncg = cdiv(Ca + Cb, NSr * Elem<T>::PER16), nstrips = cdiv(OH, switches().gn_rows > 0 ? switches().gn_rows : DN_ROWS);
         const long long gy = (long long)ncg * nstrips * B;
         STORM_CHECK(OH > 0 && OW > 0 && gy < 65536, "storm_gn_apply: down-sampling grid %lld out of range", gy);
 #define STORM_GN_DOWN(SILU_, NS_) hipLaunchKernelGGL((gn_apply_down_kernel<T, SILU_, NS_>), dim3(cdiv(OW, 256 / NS_), (unsigned)gy), dim3(256), 0, st, \
-                           (const T*)xa, Ca, (const T*)xb, Cb, H, W, G, stats, gamma, beta, eps, (T*)out_act, (T*)out_raw, ncg, nstrips)
+                           (const T*)xa, Ca, (const T*)xb, Cb, H, W, G, stats, gamma, beta, eps, (T*)out_act, (T*)out_raw, ncg, nstrips, (switches().gn_nt >> 1) & 1)
         if (silu) { if (NSr == 32) STORM_GN_DOWN(true, 32); else if (NSr == 16) STORM_GN_DOWN(true, 16); else STORM_GN_DOWN(true, 8); }
         else { if (NSr == 32) STORM_GN_DOWN(false, 32); else if (NSr == 16) STORM_GN_DOWN(false, 16); else STORM_GN_DOWN(false, 8); }
 #undef STORM_GN_DOWN
@@ -569,11 +574,11 @@ static int gn_apply_t(const void* xa, int Ca, const void* xb, int Cb, int B, int
         return STORM_OK;
     }
     if (R == 1) {
-        const int ncg = cdiv(Ca + Cb, NSr * Elem<T>::PER16), nstrips = cdiv(H, UP_ROWS);
+        const int ncg = cdiv(Ca + Cb, NSr * Elem<T>::PER16), nstrips = cdiv(H, switches().gn_rows > 0 ? switches().gn_rows : UP_ROWS);
         const long long gy = (long long)ncg * nstrips * B;
         STORM_CHECK(gy < 65536, "storm_gn_apply: up-sampling grid %lld out of range", gy);
 #define STORM_GN_UP(SILU_, NS_) hipLaunchKernelGGL((gn_apply_up_kernel<T, SILU_, NS_>), dim3(cdiv(W, 256 / NS_), (unsigned)gy), dim3(256), 0, st, \
-                           (const T*)xa, Ca, (const T*)xb, Cb, H, W, G, stats, gamma, beta, eps, (T*)out_act, (T*)out_raw, ncg, nstrips)
+                           (const T*)xa, Ca, (const T*)xb, Cb, H, W, G, stats, gamma, beta, eps, (T*)out_act, (T*)out_raw, ncg, nstrips, switches().gn_nt & 1)
         if (silu) { if (NSr == 32) STORM_GN_UP(true, 32); else if (NSr == 16) STORM_GN_UP(true, 16); else STORM_GN_UP(true, 8); }
         else { if (NSr == 32) STORM_GN_UP(false, 32); else if (NSr == 16) STORM_GN_UP(false, 16); else STORM_GN_UP(false, 8); }
 #undef STORM_GN_UP
