@@ -847,7 +847,7 @@ void splitk_combine_kernel(const float* __restrict__ slabs, const int S, const l
 // to 16 x 64 / 32 x 32 pixels at 256 couts) - never at the batch size: a split changes the fp32 summation order, and an utterance must
 // come out the same alone, in a batch, or on another rank (test_batch_independence_and_determinism).  At configs[3]'s 8 utterances per
 // GPU that is <= 64 workgroups unsplit; at 128 ... 256 workgroups (the 32 x 64 level at batch 16) the split measured slower.  4 slices,
-// 2 when there are fewer than four 64-channel chunks: 8 measured behind 4 wherever both apply (profiles/r04e_probe_splitk_s.txt;
+// 2 when there are fewer than four 64-channel chunks: 8 measured behind 4 wherever both apply (profiles/r04f_probe_splitk_s.txt;
 // unsplit -> 4 slices): 256 -> 256 @ 8 x 16 x 64 39.2 -> 37.9 us, 512 -> 256 67.9 -> 43.8; @ 8 x 8 x 32 36.7 -> 25.1 and 63.7 -> 32.2;
 // @ 8 x 4 x 16 32.2 -> 25.3 and 55.3 -> 26.5.
 int conv_splitk_slices(const storm_conv_args& a) {

@@ -230,7 +230,7 @@ constexpr int DN_ROWS = 16;                         // output rows per strip
 // NS = 16-byte slots of a pixel per workgroup (256 / NS output columns).  Round 3 used 8 everywhere (one 128-byte line per pixel and
 // wave access); with NS = 32 a wave reads / writes 512 contiguous bytes per pixel - whole DRAM bursts of one page instead of 128-byte
 // pieces 1 KiB apart that other workgroups complete at another time (round 4: the write stream of the up-sampling kernel was at 4.1 TB/s
-// where a plain fill reaches 6.9, profiles/r04e_hbm_probe.txt).
+// where a plain fill reaches 6.9, profiles/r04f_hbm_probe.txt).
 // SILU: the activation as a compile-time choice (as a run-time flag it is if-converted: both results computed, a select per value)
 template <typename T, bool SILU, int NS>
 __global__ __launch_bounds__(256)
