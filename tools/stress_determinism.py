@@ -11,7 +11,27 @@ from oracle import ncsnpp_ref as NR  # noqa: E402  (test infrastructure: seeded 
 from storm_amd.model import ScoreModel  # noqa: E402
 
 reps = int(sys.argv[1]) if len(sys.argv) > 1 else 10
+large = len(sys.argv) > 2 and sys.argv[2] == "large"     # ncsnpplarge at configs[3]'s shape: the split-K launch pairs of its deep levels
 dev = torch.device("cuda:0")
+if large:
+    m = ScoreModel(backbone="ncsnpplarge", sde="ouve", theta=1.5, sigma_min=0.05, sigma_max=0.5, spec_factor=0.15, spec_abs_exponent=0.5)
+    m.dnn.load_state_dict(NR.seeded_state_dict(NR.NCSNppConfig(**NR.NAMED_CONFIGS["ncsnpplarge"]), seed=7))
+    m._error_loading_ema = True
+    m = m.eval().to(dev)
+    m.set_precision("bf16")
+    g = torch.Generator().manual_seed(0)
+    x = torch.randn(8, 1, 256, 1024, dtype=torch.complex64, generator=g).to(dev)
+    y = torch.randn(8, 1, 256, 1024, dtype=torch.complex64, generator=g).to(dev)
+    t = torch.linspace(0.1, 0.9, 8).to(dev)
+    bad = 0
+    with torch.no_grad():
+        ref = m(x, t, y).clone()
+        for i in range(reps):
+            if not torch.equal(m(x, t, y), ref):
+                bad += 1
+                print("forward repetition", i, "differs")
+    print("ncsnpplarge 8 x 256 x 1024: finite:", bool(torch.isfinite(ref.abs()).all()), " RESULT", "FAIL" if bad else "PASS")
+    sys.exit(1 if bad else 0)
 m = ScoreModel(backbone="ncsnpp", sde="ouve", theta=1.5, sigma_min=0.05, sigma_max=0.5, spec_factor=0.15, spec_abs_exponent=0.5)
 m.dnn.load_state_dict(NR.seeded_state_dict(NR.NCSNppConfig(), seed=7))
 m._error_loading_ema = True
