@@ -58,9 +58,12 @@ def parse():
     p.add_argument("--dist-world1", action="store_true",
                    help="with ONE rank: initialise the RCCL process group anyway and run the barrier / gather lines through it (dry run of the "
                         "N-rank path on one GPU; the driver launches the real one)")
-    p.add_argument("--include-h2d", action="store_true",
-                   help="also time the step from HOST wavs (pinned): H2D of the batch, the sampler, D2H of the result (SURVEY 8(d)); reported "
-                        "beside `value`, never as it")
+    p.add_argument("--no-h2d", action="store_true",
+                   help="skip the second timed pass from HOST wavs (pinned: H2D of the batch, the sampler, D2H of the result - SURVEY 8(d)), "
+                        "which is reported as `from_host` beside `value`, never as it")
+    p.add_argument("--include-h2d", action="store_true", help="(accepted for old command lines: the from-host pass is now the default)")
+    p.add_argument("--graph", default="auto", choices=["auto", "on", "off"],
+                   help="HIP-graph replay of the score evaluations (storm_ncsnpp_set_graph): auto = the library's rule (small batches)")
     p.add_argument("--selftest-cpu", action="store_true",
                    help="(tests) run the launch / sharding / timing skeleton with a stand-in step on CPU ranks (gloo)")
     return p.parse_args()
@@ -209,6 +212,8 @@ def main():
     assert torch.cuda.is_available(), "bench.py needs a GPU (no CPU fallback)"
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
+    from storm_amd import distributed as D
+    pinned = D.pin_to_gpu_numa(local) if world > 1 else None    # (one rank: the whole host is ours)
     dist = None
     if world > 1 or args.dist_world1:
         import torch.distributed as dist
@@ -217,7 +222,6 @@ def main():
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
         assert dist.get_world_size() == args.gpus
 
-    from storm_amd import distributed as D
     from storm_amd.model import ScoreModel
     model = ScoreModel(backbone=args.backbone, sde="ouve", theta=1.5, sigma_min=0.05, sigma_max=0.5,
                        spec_factor=0.15, spec_abs_exponent=0.5)
@@ -226,6 +230,7 @@ def main():
     model.eval()
     model = model.to(dev)
     model.set_precision(args.precision)
+    model.dnn.set_graph({"auto": -1, "on": 1, "off": 0}[args.graph])
 
     L = int(args.seconds * 16000)
     g = torch.Generator().manual_seed(1234 + rank)
@@ -258,7 +263,7 @@ def main():
     assert torch.isfinite(out).all(), "non-finite output"
     value = units * world * args.steps / elapsed
     h2d = None
-    if args.include_h2d and not args.stream:               # the same step from host memory: H2D + sampler + D2H inside the timed region
+    if not args.no_h2d and not args.stream:                 # the same step from host memory: H2D + sampler + D2H inside the timed region
         wav_host = wav.cpu().pin_memory()
         out_host = torch.empty(out.shape, dtype=out.dtype).pin_memory()
 
@@ -287,11 +292,24 @@ def main():
                    "pc_steps": args.N, "nfe_per_utterance": nfe, "parallelism": f"utterance-sharded x{world}"},
         "nfe_per_s": value * nfe, "ms_per_nfe_batch": None if args.stream else 1e3 * elapsed / args.steps / nfe,
         "per_rank_s": [round(t, 4) for t in per_rank],
+        # the reference's own performance figure (model.py:304-308): processing time / audio duration.  `rtf` = latency of a call over the
+        # duration of ONE of its utterances (the whole batch returns together); `rtf_per_audio_second` = GPU-seconds per second of audio
+        "rtf": None if args.stream else elapsed / args.steps / args.seconds,
+        "rtf_per_audio_second": None if args.stream else elapsed / args.steps / (args.seconds * args.batch),
+        "graph": {"mode": args.graph, "hip_graph_launches": model.dnn.graph_launches()},
+        # what the barrier / gather lines of the timed region ran through: the RCCL group the launcher's ranks formed, or nothing (one rank)
+        "process_group": ({"backend": dist.get_backend(), "world_size": dist.get_world_size()} if dist is not None
+                          else {"backend": None, "world_size": 1}),
+        "from_host": h2d,
     }
-    if h2d is not None:
-        result["from_host"] = h2d
-    if args.dist_world1:
-        result["process_group"] = {"backend": dist.get_backend(), "world_size": dist.get_world_size()}
+    if pinned is not None:
+        result["cpu_affinity"] = {"numa_cpus": len(pinned), "first": pinned[0], "last": pinned[-1]}
+    if dist is not None:
+        # every rank leaves the group HERE, right behind the timed region's closing fence: ranks 1.. exit, rank 0 profiles alone
+        # (parked in an RCCL barrier they would spin on their GPUs for as long as rank 0's per-op profile takes)
+        dist.barrier()
+        dist.destroy_process_group()
+        dist = None
 
     if rank == 0 and not args.no_roofline and not args.stream:
         Y, _, _ = model._prepare(wav)
@@ -390,9 +408,6 @@ def main():
 
     if rank == 0:
         print(json.dumps(result))
-    if dist is not None:
-        dist.barrier()                     # rank 0 profiles after the timed region: leave together
-        dist.destroy_process_group()
 
 
 if __name__ == "__main__":

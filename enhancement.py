@@ -48,12 +48,16 @@ def main():
     p.add_argument("--precision", choices=("fp32", "bf16", "fp16"), default="fp32")
     p.add_argument("--batch", type=int, default=16)
     p.add_argument("--seed", type=int, default=None, help="Philox seed of the sampler noise (default: drawn from torch's RNG, as the reference)")
+    p.add_argument("--dist-world1", action="store_true", help="with ONE rank: form the RCCL process group anyway (dry run of the sharded path on one GPU)")
     args = p.parse_args()
 
     from storm_amd import distributed as D
     from storm_amd.model import DiscriminativeModel, ScoreModel, StochasticRegenerationModel
-    rank, world, local = D.init()
+    local = int(os.environ.get("LOCAL_RANK", 0))
     torch.cuda.set_device(local)
+    rank, world, local = D.init(single_rank_group=args.dist_world1)
+    if world > 1:
+        D.pin_to_gpu_numa(local)                            # this rank's launch thread next to its GPU
     os.makedirs(args.enhanced_dir, exist_ok=True)
     model_cls = {"storm": StochasticRegenerationModel, "score-only": ScoreModel, "denoiser-only": DiscriminativeModel}[args.mode]
     model = model_cls.load_from_checkpoint(args.ckpt, base_dir="", batch_size=1, num_workers=0, kwargs=dict(gpu=False))
@@ -86,7 +90,7 @@ def main():
             outs = [x_hat[k, :lens[k]] for k in range(len(ids))]
         for i, x in zip(ids, outs):
             write_wav(os.path.join(args.enhanced_dir, os.path.basename(files[i])), x.float().reshape(-1), 16000)
-    D.barrier()
+    D.finish()
 
 
 if __name__ == "__main__":

@@ -37,7 +37,13 @@ enum { STORM_OK = 0, STORM_ERR_INVALID = -1, STORM_ERR_HIP = -2, STORM_ERR_UNSUP
 enum { STORM_F32 = 0, STORM_BF16 = 1, STORM_F16 = 2 };    /* activation / operand dtype (fp32 accumulation always) */
 
 const char* storm_last_error(void);
+/* Bumped whenever a public struct changes size or layout (2: storm_conv_args gained splitk_ws / splitk_ws_bytes, storm_op 13 pointer
+ * slots).  A host compiled against another header must not call in: check storm_abi_version() == STORM_ABI_VERSION and
+ * storm_abi_struct_bytes(0 / 1) == sizeof(storm_conv_args) / sizeof(storm_op) once at load time.  Callers zero-initialise
+ * storm_conv_args (memset) before filling it: every optional pointer is "absent" as NULL. */
+#define STORM_ABI_VERSION 2
 int storm_abi_version(void);
+long long storm_abi_struct_bytes(int which);   /* 0: storm_conv_args, 1: storm_op, 2: storm_conv_seg, 3: storm_ncsnpp_config */
 /* Test / tool hook, not part of the drop-in surface: the launchers' A/B switches (forced kernel family, pretend-small device for
  * persistent tile walks, ...) are a table filled once from the environment variables of the same names when the library is
  * first used; these two calls read / change an entry afterwards (names: STORM_CONV_VARIANT, STORM_CONV_PIPE128,
@@ -376,6 +382,15 @@ void storm_ncsnpp_destroy(storm_ncsnpp* h);
 /* A/B switches of the planner (all on by default): GroupNorm statistics from conv epilogues, GroupNorm apply in conv operand
  * loads, fused attention kernel */
 int storm_ncsnpp_set_fusion(storm_ncsnpp* h, int fuse_stats, int fuse_apply, int fused_attention);
+/* HIP-graph replay of this handle's evaluations (the reference's own operating point is ONE utterance per
+ * call, enhancement.py:66-72, where an evaluation is ~120 short launches): mode 0 = eager launches, 1 = replay, -1 (default) = the
+ * library's rule (replay for small batches).  The first call per (shape, workspace address) runs eagerly, the second records the runs
+ * of ops that touch only the workspace and the weights, later calls are one hipGraphLaunch per run + the three ops that read the
+ * caller's tensors (input packing, time embedding, output head).  A replayed evaluation executes exactly the eager kernels with the
+ * eager arguments: results are bit-identical.  A workspace passed to a graph-mode call must stay allocated while the handle lives
+ * or until the same address is passed again (the recorded kernels point into it). */
+int storm_ncsnpp_set_graph(storm_ncsnpp* h, int mode);
+long long storm_ncsnpp_graph_launches(storm_ncsnpp* h);    /* hipGraphLaunch calls this handle has made (diagnostics: 0 = everything ran eagerly) */
 /* bytes of scratch one forward at (B, F, T) needs (liveness-planned; 5.2 GB at B = 16, 256 x 512, bf16); -1 on error */
 long long storm_ncsnpp_workspace_bytes(storm_ncsnpp* h, int B, int F, int T);
 /* out[b] = dnn(cat[parts...], t) (negate != 0: its negative = the score, model.py:131-132).  parts: n device pointers to

@@ -321,23 +321,23 @@ def gen_f12(ref):
     np.savez_compressed(os.path.join(OUT, "f12_ode_rows.npz"), **f12)
 
 
-def gen_f13(ref):
-    """F13: the product of the path at FULL width and FULL length of the sampler - ScoreModel.enhance (model.py:273-310) with the seeded
-    27.8 M `ncsnpp`, one 1-s utterance (16 000 samples -> 126 -> 128 frames), N = 30 reverse steps, `reverse_diffusion` + `ald` x 1 = 60
-    score evaluations inside pc_sampler (sampling/__init__.py:54-66), with RECORDED noise (61 draws, regenerated on both sides from
-    a seed; their SHA-256 is stored).  Stores the reference's wav and the sampler's final spectrogram (the tensor enhance hands to
-    to_audio).  This is what pins a bf16 / fp16 60-evaluation run against the REFERENCE instead of against the engine's own fp32 run."""
-    print("F13 full-width 60-evaluation enhance (about ten minutes)")
+def _full_sampler_fixture(ref, tag, fname, nsamples, seeds, what):
+    """ScoreModel.enhance (model.py:273-310) of the seeded 27.8 M `ncsnpp` on ONE utterance of `nsamples` samples: N = 30 reverse steps,
+    `reverse_diffusion` + `ald` x 1 = 60 score evaluations inside pc_sampler (sampling/__init__.py:54-66), with RECORDED noise (61 draws,
+    regenerated on both sides from a seed; their SHA-256 is stored).  Stores the reference's wav and the sampler's final spectrogram (the
+    tensor enhance hands to to_audio), and checks the oracle restatement against both on the way."""
+    print(f"{tag} full-width 60-evaluation enhance, {what}")
     torch.set_num_threads(16)
     M, DM = ref["model"], ref["data_module"].SpecsDataModule
-    N, steps, seed_w, seed_n, seed_wav = 30, 1, 11, 1313, 1301
+    N, steps = 30, 1
+    seed_w, seed_n, seed_wav = seeds
     cfg = NR.NCSNppConfig(input_channels=4)
     sd = NR.seeded_state_dict(cfg, seed=seed_w)
     m = M.ScoreModel(backbone="ncsnpp", sde="ouve", data_module_cls=DM, theta=1.5, sigma_min=0.05, sigma_max=0.5,
                      spec_factor=0.15, spec_abs_exponent=0.5)
     m.dnn.load_state_dict(sd)
     m.eval(no_ema=True)
-    ywav = torch.randn(1, 16000, generator=torch.Generator().manual_seed(seed_wav)) * 0.1
+    ywav = torch.randn(1, nsamples, generator=torch.Generator().manual_seed(seed_wav)) * 0.1
     Ysh = FR.wav_to_spec(ywav)[0].shape
     gn = torch.Generator().manual_seed(seed_n)
     noises = [SR.complex_randn(Ysh, gn) for _ in range(1 + N * (steps + 1))]
@@ -345,7 +345,6 @@ def gen_f13(ref):
     it = iter(noises)
     orig = torch.randn_like
     final = {}
-    istft_orig = m._istft if hasattr(m, "_istft") else None
     torch.randn_like = lambda x, *a, **k: next(it).to(x.dtype)
     to_audio_orig = m.to_audio
 
@@ -366,14 +365,26 @@ def gen_f13(ref):
                                  lambda x, t, y: -NR.ncsnpp_forward(sd, cfg, torch.cat([x, y], 1), t),
                                  Y, lambda: next(it), corrector_steps=steps, snr=0.5)
     xh_or = FR.spec_to_wav(samp, nfac, T0)
-    check("F13 enhance wav (60 evaluations, 27.8 M)", xh_or, xh_ref, 1e-4)
+    check(f"{tag} enhance wav (60 evaluations, 27.8 M)", xh_or, xh_ref, 1e-4)
     fs = final["spec"].reshape(samp.shape) if "spec" in final else None
     if fs is not None:
-        check("F13 final sampler state", samp, fs, 1e-4)
-    np.savez_compressed(os.path.join(OUT, "f13_full_sampler.npz"), wav_in=ywav.numpy(), out=xh_ref.numpy(),
+        check(f"{tag} final sampler state", samp, fs, 1e-4)
+    np.savez_compressed(os.path.join(OUT, fname), wav_in=ywav.numpy(), out=xh_ref.numpy(),
                         final_spec=c2np(fs if fs is not None else samp), nfe=np.array(N * (steps + 1)), N=np.array(N),
                         seeds=np.array([seed_w, seed_n, seed_wav]), noise_hash=np.array(nhash), sdhash=np.array(sd_hash(sd)),
                         noise_shape=np.array(list(Ysh)))
+
+
+def gen_f13(ref):
+    """F13: the product of the path at FULL width and FULL length of the sampler on a 1-s utterance (16 000 samples -> 126 -> 128
+    frames).  This is what pins a bf16 / fp16 60-evaluation run against the REFERENCE instead of against the engine's own fp32 run."""
+    _full_sampler_fixture(ref, "F13", "f13_full_sampler.npz", 16000, (11, 1313, 1301), "1-s utterance (about ten minutes)")
+
+
+def gen_f14(ref):
+    """F14: the same at the BENCH length - BASELINE.json configs[1]'s utterance: 4 s = 64 000 samples -> 501 -> 512 frames, i.e. the
+    reference's own 60-evaluation `enhance` at the shape bench.py times (about 40 minutes on 8 cores: 2 x 60 CPU evaluations)."""
+    _full_sampler_fixture(ref, "F14", "f14_full_sampler_4s.npz", 64000, (12, 1414, 1402), "4-s utterance = the bench length (about 40 minutes)")
 
 
 def main():
@@ -387,7 +398,7 @@ def main():
     if "--only-f8" in sys.argv:
         gen_f8(import_reference())
         return
-    for flag, fn in (("--only-f10", gen_f10), ("--only-f11", gen_f11), ("--only-f12", gen_f12), ("--only-f13", gen_f13)):
+    for flag, fn in (("--only-f10", gen_f10), ("--only-f11", gen_f11), ("--only-f12", gen_f12), ("--only-f13", gen_f13), ("--only-f14", gen_f14)):
         if flag in sys.argv:
             fn(import_reference())
             return
@@ -637,6 +648,7 @@ def main():
     gen_f11(ref)
     gen_f12(ref)
     gen_f13(ref)
+    gen_f14(ref)
     for fn in sorted(os.listdir(OUT)):
         print(f"  {fn}: {os.path.getsize(os.path.join(OUT, fn))/1024:.0f} KiB")
     print("golden fixtures written to", OUT)

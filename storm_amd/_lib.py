@@ -19,6 +19,7 @@ _TORCH2DT = {torch.float32: F32, torch.bfloat16: BF16, torch.float16: F16}
 _DT2TORCH = {F32: torch.float32, BF16: torch.bfloat16, F16: torch.float16}
 
 OP_NPTR, OP_NINT, OP_NFLT = 13, 24, 4
+ABI_VERSION = 2                  # include/storm_hip.h: STORM_ABI_VERSION
 
 
 class StormError(RuntimeError):
@@ -63,6 +64,7 @@ class Op(C.Structure):
 _vp, _i, _ll, _f, _u64 = C.c_void_p, C.c_int, C.c_longlong, C.c_float, C.c_uint64
 _SIGNATURES = {
     "storm_abi_version": ([], C.c_int),
+    "storm_abi_struct_bytes": ([_i], C.c_longlong),
     "storm_set_switch": ([C.c_char_p, _ll], C.c_int),
     "storm_get_switch": ([C.c_char_p], C.c_longlong),
     "storm_device_info": ([C.c_char_p, _i, C.POINTER(C.c_int), C.POINTER(C.c_size_t)], C.c_int),
@@ -110,6 +112,8 @@ _SIGNATURES = {
     "storm_ncsnpp_create": ([C.POINTER(NcsnppConfig), C.POINTER(_vp), _i, _i, _vp, _vp, C.POINTER(_vp)], C.c_int),
     "storm_ncsnpp_destroy": ([_vp], None),
     "storm_ncsnpp_set_fusion": ([_vp, _i, _i, _i], C.c_int),
+    "storm_ncsnpp_set_graph": ([_vp, _i], C.c_int),
+    "storm_ncsnpp_graph_launches": ([_vp], C.c_longlong),
     "storm_ncsnpp_workspace_bytes": ([_vp, _i, _i, _i], C.c_longlong),
     "storm_ncsnpp_forward": ([_vp, C.POINTER(_vp), _i, _vp, _vp, _vp, _ll, _i, _i, _i, _i, _vp], C.c_int),
     "storm_ncsnpp_program": ([_vp, _i, _i, _i, C.POINTER(C.POINTER(Op)), C.POINTER(C.c_int), C.POINTER(C.c_longlong)], C.c_int),
@@ -130,6 +134,12 @@ def _bind(path):
     for name, (args, res) in _SIGNATURES.items():
         fn = getattr(lib, name)
         fn.argtypes, fn.restype = args, res
+    # the structures above mirror include/storm_hip.h by hand: refuse a library built from another header
+    if lib.storm_abi_version() != ABI_VERSION:
+        raise StormError(f"{path}: ABI version {lib.storm_abi_version()}, this binding is written for {ABI_VERSION}")
+    for which, cls in ((0, ConvArgs), (1, Op), (2, ConvSeg), (3, NcsnppConfig)):
+        if lib.storm_abi_struct_bytes(which) != C.sizeof(cls):
+            raise StormError(f"{path}: sizeof({cls.__name__}) = {C.sizeof(cls)} here, {lib.storm_abi_struct_bytes(which)} in the library")
     return lib
 
 

@@ -156,6 +156,7 @@ class NCSNpp(nn.Module):
         self.negate_output = False        # ScoreModel folds the "score = -dnn(...)" sign into the output head
         self._handles = {}                # dtype code -> (engine handle, arena tensor, params version, device)
         self._workspaces = {}             # (device, dtype, stream) -> ONE grow-only scratch tensor (the workspace holds no state between calls)
+        self._graph_mode = -1             # storm_ncsnpp_set_graph: -1 = the library's rule (replay for small batches), 0 eager, 1 replay
         self._param_version = 0
         self.register_load_state_dict_post_hook(lambda m, keys: m.invalidate())
 
@@ -170,6 +171,20 @@ class NCSNpp(nn.Module):
         L.dt(dtype)
         self.compute_dtype = dtype
         return self
+
+    MAX_WORKSPACES = 4                    # streams (per device and dtype) whose scratch is kept; least recently used out
+
+    def set_graph(self, mode):
+        """HIP-graph replay of the score evaluations (include/storm_hip.h: storm_ncsnpp_set_graph): "auto" / -1 = the library's rule
+        (small batches), 0 / False = eager launches, 1 / True = replay.  Results are bit-identical either way."""
+        self._graph_mode = -1 if mode in ("auto", -1, None) else int(bool(mode))
+        for h, _, _, _ in self._handles.values():
+            L.check(L.lib().storm_ncsnpp_set_graph(h, self._graph_mode), "storm_ncsnpp_set_graph")
+        return self
+
+    def graph_launches(self):
+        """hipGraphLaunch calls made so far by this module's engine handles (0 = every evaluation ran as eager launches)"""
+        return sum(int(L.lib().storm_ncsnpp_graph_launches(h)) for h, _, _, _ in self._handles.values())
 
     def invalidate(self):
         """Call after changing parameters in place (e.g. EMA swap): the engine re-packs its weight arena lazily."""
@@ -228,6 +243,7 @@ class NCSNpp(nn.Module):
                                             int(os.environ.get("STORM_FUSED_ATTENTION", "1") != "0")), "storm_ncsnpp_set_fusion")
         if not L.is_sim():
             torch.cuda.current_stream().synchronize()    # the fp32 staging copies die with this scope
+        L.check(lib.storm_ncsnpp_set_graph(h, self._graph_mode), "storm_ncsnpp_set_graph")
         self._handles[dtype_code] = (h, arena, self._param_version, device)
         return h
 
@@ -239,12 +255,15 @@ class NCSNpp(nn.Module):
         if n < 0:
             raise L.StormError(f"storm_ncsnpp_workspace_bytes: {L.lib().storm_last_error().decode()}")
         key = (str(device), dtype_code, L.stream())
-        ws = self._workspaces.get(key)
+        ws = self._workspaces.pop(key, None)           # (re-inserted below: the dict is kept in least-recently-used order)
         if ws is None or ws.numel() < n:
-            self._workspaces.pop(key, None)
             ws = None                                  # (release the old buffer before asking the allocator for the larger one)
+            # a raw stream handle outlives nothing: scratch of streams that are gone (or whose handle was recycled) must not pile up -
+            # keep the few most recently used, drop the rest before growing
+            while len(self._workspaces) >= self.MAX_WORKSPACES:
+                self._workspaces.pop(next(iter(self._workspaces)))
             ws = torch.empty(n, dtype=torch.uint8, device=device)
-            self._workspaces[key] = ws
+        self._workspaces[key] = ws
         return ws
 
     def workspace_bytes(self, B, F, T, dtype=None, device=None):

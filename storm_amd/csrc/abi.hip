@@ -19,7 +19,7 @@ struct SwitchName { const char* name; int Switches::*field; };
 const SwitchName kSwitches[] = {
     {"STORM_CONV_VARIANT", &Switches::conv_variant}, {"STORM_CONV_PIPE128", &Switches::conv_pipe128}, 
     {"STORM_CONV_CUS", &Switches::conv_cus}, {"STORM_CONV_PERSIST", &Switches::conv_persist},
-    {"STORM_CONV_DMA", &Switches::conv_dma}, {"STORM_CONV_ABLATE", &Switches::conv_ablate}, {"STORM_SPLITK", &Switches::splitk}, {"STORM_GN_WIDE", &Switches::gn_wide}, {"STORM_GN_ROWS", &Switches::gn_rows}, {"STORM_GN_NT", &Switches::gn_nt},
+    {"STORM_CONV_DMA", &Switches::conv_dma}, {"STORM_CONV_ABLATE", &Switches::conv_ablate}, {"STORM_SPLITK", &Switches::splitk}, {"STORM_GN_WIDE", &Switches::gn_wide}, {"STORM_GN_ROWS", &Switches::gn_rows}, {"STORM_GN_NT", &Switches::gn_nt}, {"STORM_GRAPH", &Switches::graph},
 };
 }  // namespace
 
@@ -64,7 +64,16 @@ extern "C" long long storm_get_switch(const char* name) {
 }
 
 extern "C" const char* storm_last_error(void) { return storm::g_err; }
-extern "C" int storm_abi_version(void) { return 1; }
+extern "C" int storm_abi_version(void) { return STORM_ABI_VERSION; }
+extern "C" long long storm_abi_struct_bytes(int which) {
+    switch (which) {
+        case 0: return (long long)sizeof(storm_conv_args);
+        case 1: return (long long)sizeof(storm_op);
+        case 2: return (long long)sizeof(storm_conv_seg);
+        case 3: return (long long)sizeof(storm_ncsnpp_config);
+        default: return -1;
+    }
+}
 extern "C" int storm_device_info(char* name, int name_len, int* n_cu, size_t* hbm_bytes) {
     int dev = 0;
     STORM_HIP(hipGetDevice(&dev));

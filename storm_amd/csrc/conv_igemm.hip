@@ -755,7 +755,9 @@ static int dispatch_conv(const storm_conv_args& a, hipStream_t st) {
         if (variant == 9 && conv_pipe_supports(a)) return launch_conv_pipe_half(a, st);
         if (variant == 10) return launch_conv_pipe_splitk(a, splitk_slices_of(a), st);
         if (variant == 4 && conv_pipe128_supports(a)) return launch_conv_pipe128(a, st);
+#if defined(STORM_WITH_DUO)                                          // conv_duo.hip: profiling library and the test simulator only (a tie)
         if (variant == 5 && conv_duo_supports(a)) return launch_conv_duo(a, st);
+#endif
         if (variant == 2) return launch_conv<T, 9, 2, 4, 2, true>(a, st);
         if (variant == 7) return launch_conv<T, 9, 1, 2, 2, false, true>(a, st);
 #if defined(STORM_PROFILING)                                          // A/B instantiations: 8-wave geometry, register staging
@@ -787,7 +789,9 @@ static const char* kernel_name_of(const storm_conv_args& a) {
     else if (any9 && variant == 10) return a.dtype == STORM_F16 ? "storm::conv_pipe_splitk_kernel<storm::half_t, 128, 8>" : "storm::conv_pipe_splitk_kernel<storm::bf16_t, 128, 8>";
     else if (any9 && (variant == 3 || variant == 9) && conv_pipe_supports(a)) return conv_pipe_kernel_name(a.dtype, variant == 9);
     else if (any9 && variant == 4 && conv_pipe128_supports(a)) return conv_pipe128_kernel_name(a.dtype);
+#if defined(STORM_WITH_DUO)
     else if (any9 && variant == 5 && conv_duo_supports(a)) return conv_duo_kernel_name(a.dtype);
+#endif
     else if (variant == 2) shape = "2, 4, 2, true, false";
     else if (any9 && variant == 7) shape = "1, 2, 2, false, true";
 #if defined(STORM_PROFILING)

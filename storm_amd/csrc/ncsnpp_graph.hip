@@ -11,6 +11,7 @@
 // Host code only (plus two trivial fill kernels).  The planner mirrors, op for op, what tests/py_planner.py restates in
 // Python (tests compare the two op lists bit for bit).
 #include <algorithm>
+#include <atomic>
 #include <map>
 #include <memory>
 #include <mutex>
@@ -224,6 +225,15 @@ struct Program {
     const Cfg& cfg; const Layout& lay; int B, F, T; bool fuse_stats = true, fuse_apply = true, fused_attention = true;
     int dtype, esize; std::vector<storm_op> ops; Arena arena; long long flops = 0, ws_bytes = 0;
     long long stats_off = 0, stats_bytes = 0, stats_cursor = 0, dense_out = 0;
+    // HIP-graph replay of the evaluation (storm_ncsnpp_set_graph): the maximal runs of ops that touch only the workspace and the weight
+    // arena, instantiated once per workspace address.  state: 0 = first call (runs eagerly: lazy kernel attributes / code-object loads
+    // must not happen inside a capture), 1 = captured, -1 = capture failed on this runtime (eager from then on).
+    struct GraphSeg { int first, last; hipGraphExec_t exec; };
+    struct GraphSet {
+        int state = 0; std::vector<GraphSeg> segs; unsigned long long used = 0;
+        ~GraphSet() { for (auto& sg : segs) if (sg.exec) (void)hipGraphExecDestroy(sg.exec); }
+    };
+    std::map<void*, std::shared_ptr<GraphSet>> graphs;
     Program(const Cfg& c, const Layout& l, int B_, int F_, int T_) : cfg(c), lay(l), B(B_), F(F_), T(T_), dtype(l.dtype), esize(l.esize) {}
 
     storm_op& op(int code) {
@@ -535,6 +545,11 @@ struct storm_ncsnpp {
     std::vector<std::shared_ptr<Program>> exported;
     std::mutex mu;
     static constexpr size_t MAX_PROGRAMS = 64;
+    int graph_mode = -1;             // storm_ncsnpp_set_graph: 0 eager, 1 replay, -1 = the library's rule (graph_wanted)
+    hipStream_t cap_stream = nullptr;   // captures are recorded on a private stream (the caller's may be the legacy default stream, which cannot capture)
+    unsigned long long gtick = 0;
+    std::atomic<long long> graph_launches{0};   // hipGraphLaunch calls so far (storm_ncsnpp_graph_launches: did the replay really run?)
+    static constexpr size_t MAX_GRAPH_WS = 4;   // workspaces (addresses) with instantiated graphs per program
 };
 
 static int to_cfg(const storm_ncsnpp_config* c, Cfg& out) {
@@ -624,6 +639,8 @@ extern "C" int storm_ncsnpp_create(const storm_ncsnpp_config* c, const void* con
 
 extern "C" void storm_ncsnpp_destroy(storm_ncsnpp* h) {
     if (!h) return;
+    h->programs.clear(); h->exported.clear();               // (graph executables go with their programs)
+    if (h->cap_stream) (void)hipStreamDestroy(h->cap_stream);
     if (h->owns_arena && h->arena) (void)hipFree(h->arena);
     delete h;
 }
@@ -632,9 +649,21 @@ extern "C" int storm_ncsnpp_set_fusion(storm_ncsnpp* h, int fuse_stats, int fuse
     STORM_CHECK(h != nullptr, "storm_ncsnpp_set_fusion: null handle");
     h->fuse_stats = fuse_stats != 0; h->fuse_apply = fuse_apply != 0 && fuse_stats != 0; h->fused_attention = fused_attention != 0;
     std::lock_guard<std::mutex> lk(h->mu);
-    h->programs.clear(); h->last_use.clear();
+    h->programs.clear(); h->last_use.clear();                  // (and with them their recorded graphs)
     return STORM_OK;
 }
+
+// HIP-graph replay of the evaluations of this handle: 0 = eager launches, 1 = replay (the first call per (shape, workspace address) runs
+// eagerly, the second records, later ones are one hipGraphLaunch per recorded run + the few ops that read the caller's tensors),
+// -1 = the library's rule (graph_wanted: small batches).  A replayed evaluation launches exactly the kernels the eager one does.
+extern "C" int storm_ncsnpp_set_graph(storm_ncsnpp* h, int mode) {
+    STORM_CHECK(h != nullptr && mode >= -1 && mode <= 1, "storm_ncsnpp_set_graph: bad arguments");
+    std::lock_guard<std::mutex> lk(h->mu);
+    h->graph_mode = mode;
+    return STORM_OK;
+}
+
+extern "C" long long storm_ncsnpp_graph_launches(storm_ncsnpp* h) { return h ? h->graph_launches.load(std::memory_order_relaxed) : -1; }
 
 // The returned program stays alive for as long as the caller holds the shared_ptr (an eviction by another thread only drops
 // the cache's reference).
@@ -685,6 +714,90 @@ extern "C" int storm_ncsnpp_program(storm_ncsnpp* h, int B, int F, int T, const 
 
 extern "C" const void* storm_ncsnpp_arena(storm_ncsnpp* h) { return h ? h->arena : nullptr; }
 
+// ---- one evaluation: eager launches, or HIP-graph replay ---------------------------------------------------------------------
+// ops [a, b) of the program; `negate` is a run-time argument of THE CALL: the cached op list is shared by every caller of the
+// handle, so the output head (the last op) runs from a local copy instead of being patched in place
+static int run_range(const Program& p, int a, int b, void* const* bufs, int dtype, int negate, storm_stream_t s) {
+    const int n = (int)p.ops.size();
+    const int be = b == n ? n - 1 : b;
+    if (be > a) if (int rc = storm_program_run(p.ops.data() + a, be - a, bufs, N_BUFS, dtype, s)) return rc;
+    if (b == n && a < n) {
+        storm_op head = p.ops[n - 1];
+        head.i[4] = negate ? 1 : 0;
+        return storm_program_run(&head, 1, bufs, N_BUFS, dtype, s);
+    }
+    return STORM_OK;
+}
+
+// The library's rule when nobody chose (storm_ncsnpp_set_graph(h, -1)): replay where an evaluation is a chain of SHORT launches - the
+// one-to-four-utterance calls of the reference's own operating point (enhancement.py:66-72 is a batch-1 loop) and the ragged stream's
+// tail batches.  At the bench batch the launches are long and the stream is gap-free either way.
+static int graph_wanted(const Program& p) { return (long long)p.B * p.F * p.T <= 4LL * 256 * 640 ? 1 : 0; }
+
+// maximal runs (>= 4 ops) of ops that reference nothing but the workspace and the weight arena: their kernel arguments depend on
+// (program, workspace address) only, so one instantiated graph serves every later call with that workspace
+static std::vector<std::pair<int, int>> graph_ranges(const Program& p) {
+    std::vector<std::pair<int, int>> r;
+    const int n = (int)p.ops.size();
+    int a = -1;
+    for (int k = 0; k <= n; ++k) {
+        bool internal = k < n - 1;                              // (the output head carries `negate`: always eager)
+        if (internal)
+            for (int j = 0; j < STORM_OP_NPTR; ++j) { const int b = p.ops[k].p[j].buf; internal = internal && (b < 0 || b == BUF_WS || b == BUF_PARAMS); }
+        if (internal) { if (a < 0) a = k; }
+        else { if (a >= 0 && k - a >= 4) r.push_back({a, k}); a = -1; }
+    }
+    return r;
+}
+
+static int forward_replay(storm_ncsnpp* h, Program& p, void* const* bufs, int negate, storm_stream_t s) {
+    std::shared_ptr<Program::GraphSet> g;
+    bool capture = false;
+    {
+        std::lock_guard<std::mutex> lk(h->mu);
+        auto it = p.graphs.find(bufs[BUF_WS]);
+        if (it == p.graphs.end()) {
+            if (p.graphs.size() >= storm_ncsnpp::MAX_GRAPH_WS) {
+                auto old = p.graphs.begin();
+                for (auto u = p.graphs.begin(); u != p.graphs.end(); ++u) if (u->second->used < old->second->used) old = u;
+                p.graphs.erase(old);
+            }
+            it = p.graphs.emplace(bufs[BUF_WS], std::make_shared<Program::GraphSet>()).first;
+        }
+        g = it->second;
+        g->used = ++h->gtick;
+        if (g->state == 0) g->state = 2;                        // this call runs eagerly (warm-up), the next one records
+        else if (g->state == 2) {
+            capture = true;
+            if (h->cap_stream == nullptr && hipStreamCreateWithFlags(&h->cap_stream, hipStreamNonBlocking) != hipSuccess) { h->cap_stream = nullptr; g->state = -1; capture = false; }
+        }
+        if (capture) {
+            // recorded under the handle's lock (once per program and workspace): nothing executes here, the launches below do
+            g->state = 1;
+            for (const auto& r : graph_ranges(p)) {
+                hipGraph_t gr = nullptr; hipGraphExec_t ex = nullptr;
+                bool ok = hipStreamBeginCapture(h->cap_stream, hipStreamCaptureModeThreadLocal) == hipSuccess;
+                const int rc = ok ? storm_program_run(p.ops.data() + r.first, r.second - r.first, bufs, N_BUFS, h->dtype, (storm_stream_t)h->cap_stream) : STORM_ERR_HIP;
+                if (ok) ok = hipStreamEndCapture(h->cap_stream, &gr) == hipSuccess && gr != nullptr;
+                ok = ok && rc == STORM_OK && hipGraphInstantiate(&ex, gr, nullptr, nullptr, 0) == hipSuccess;
+                if (gr) (void)hipGraphDestroy(gr);
+                if (!ok) { (void)hipGetLastError(); g->segs.clear(); g->state = -1; break; }
+                g->segs.push_back({r.first, r.second, ex});
+            }
+        }
+    }
+    const int n = (int)p.ops.size();
+    if (g->state != 1) return run_range(p, 0, n, bufs, h->dtype, negate, s);
+    int k = 0;
+    for (const auto& sg : g->segs) {
+        if (int rc = run_range(p, k, sg.first, bufs, h->dtype, negate, s)) return rc;
+        STORM_HIP(hipGraphLaunch(sg.exec, (hipStream_t)s));
+        h->graph_launches.fetch_add(1, std::memory_order_relaxed);
+        k = sg.last;
+    }
+    return run_range(p, k, n, bufs, h->dtype, negate, s);
+}
+
 // parts: n_parts device pointers to complex64 [B][F][T] tensors (x, y[, y_denoised]) - torch.cat([x, y], 1) of the reference
 // never materialises; t: fp32 [B] (NULL for a discriminative net); out: complex64 [B][F][T]; negate: score = -dnn(...)
 // (model.py:131-132) folded into the output head.
@@ -700,11 +813,8 @@ extern "C" int storm_ncsnpp_forward(storm_ncsnpp* h, const void* const* parts, i
     bufs[BUF_WS] = ws; bufs[BUF_PARAMS] = h->arena;
     for (int j = 0; j < n_parts; ++j) { STORM_CHECK(parts[j] != nullptr, "storm_ncsnpp_forward: input %d is NULL", j); bufs[BUF_IN0 + j] = const_cast<void*>(parts[j]); }
     bufs[BUF_T] = const_cast<float*>(t); bufs[BUF_OUT] = out;
-    // `negate` is a run-time argument of THIS call: the cached op list is shared by every caller of the handle, so the output
-    // head runs from a local copy instead of being patched in place
-    const int n = (int)p->ops.size();
-    if (int rc = storm_program_run(p->ops.data(), n - 1, bufs, N_BUFS, h->dtype, s)) return rc;
-    storm_op head = p->ops[n - 1];
-    head.i[4] = negate ? 1 : 0;
-    return storm_program_run(&head, 1, bufs, N_BUFS, h->dtype, s);
+    int mode = switches().graph >= 0 ? switches().graph : h->graph_mode;
+    if (mode < 0) mode = graph_wanted(*p);
+    if (mode == 0) return run_range(*p, 0, (int)p->ops.size(), bufs, h->dtype, negate, s);
+    return forward_replay(h, *p, bufs, negate, s);
 }

@@ -141,7 +141,7 @@ extern "C" int storm_program_run_timed(const storm_op* ops, int n_ops, void* con
     if (rc == STORM_OK)
         for (int k = 0; k < n_ops; ++k)
             if (hipEventElapsedTime(&ms[k], ev[k], ev[k + 1]) != hipSuccess) { storm::set_error("hipEventElapsedTime failed"); rc = STORM_ERR_HIP; break; }
-    for (int k = 0; k < created; ++k) hipEventDestroy(ev[k]);
+    for (int k = 0; k < created; ++k) (void)hipEventDestroy(ev[k]);
     delete[] ev;
     return rc;
 }

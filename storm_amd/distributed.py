@@ -7,16 +7,54 @@ import os
 import torch
 
 
-def init(backend=None):
-    """Initialise torch.distributed from the torchrun environment; returns (rank, world, local_rank)."""
+def init(backend=None, single_rank_group=False):
+    """Initialise torch.distributed from the torchrun environment; returns (rank, world, local_rank).  single_rank_group: form the
+    group even when the launcher started ONE rank (the N-rank code path - RCCL init, barrier - exercised on a one-GPU box)."""
     import torch.distributed as dist
     rank, world = int(os.environ.get("RANK", 0)), int(os.environ.get("WORLD_SIZE", 1))
     local = int(os.environ.get("LOCAL_RANK", 0))
-    if world > 1 and not dist.is_initialized():
+    if (world > 1 or single_rank_group) and not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29534")
         backend = backend or ("nccl" if torch.cuda.is_available() else "gloo")
-        dist.init_process_group(backend, rank=rank, world_size=world)
+        kw = dict(device_id=torch.device("cuda", local)) if backend == "nccl" else {}
+        dist.init_process_group(backend, rank=rank, world_size=world, **kw)
     return rank, world, local
+
+
+def parse_cpulist(text):
+    """'0-3,8,10-11' (the format of /sys/devices/system/node/node*/cpulist) -> [0, 1, 2, 3, 8, 10, 11]"""
+    cpus = []
+    for part in text.strip().split(","):
+        if not part:
+            continue
+        lo, _, hi = part.partition("-")
+        cpus.extend(range(int(lo), int(hi or lo) + 1))
+    return cpus
+
+
+def pin_to_gpu_numa(local_rank, sysfs="/sys"):
+    """Pin this rank's launch thread(s) to the CPUs of its GPU's NUMA node: on an 8-GPU node the sampler's host loop (one C-ABI
+    call per score evaluation + the fused SDE updates) otherwise migrates across sockets and its dispatch latency with it.
+    Best effort - returns the CPU list it pinned to, or None when the topology is not exposed (containers, single-node boxes with
+    numa_node = -1) or the platform has no sched_setaffinity."""
+    try:
+        prop = torch.cuda.get_device_properties(local_rank)
+        bdf = f"{getattr(prop, 'pci_domain_id', 0):04x}:{prop.pci_bus_id:02x}:{prop.pci_device_id:02x}.0"
+        with open(os.path.join(sysfs, "bus/pci/devices", bdf, "numa_node")) as f:
+            node = int(f.read().strip())
+        if node < 0:
+            return None
+        with open(os.path.join(sysfs, "devices/system/node", f"node{node}", "cpulist")) as f:
+            cpus = parse_cpulist(f.read())
+        allowed = os.sched_getaffinity(0)
+        cpus = [c for c in cpus if c in allowed]
+        if not cpus:
+            return None
+        os.sched_setaffinity(0, cpus)
+        return cpus
+    except (OSError, AttributeError, ValueError, RuntimeError, AssertionError):
+        return None
 
 
 def self_launch(n_procs, script, argv):
@@ -128,3 +166,11 @@ def barrier():
     import torch.distributed as dist
     if dist.is_available() and dist.is_initialized():
         dist.barrier()
+
+
+def finish():
+    """Leave the process group together (last line of a sharded tool)."""
+    import torch.distributed as dist
+    if dist.is_available() and dist.is_initialized():
+        dist.barrier()
+        dist.destroy_process_group()

@@ -22,3 +22,36 @@ def golden():
         def __getitem__(self, name):
             return np.load(os.path.join(GOLDEN, name + ".npz"), allow_pickle=False)
     return G()
+
+
+# ---- measured parity errors as an artefact -----------------------------------------------------------------------------------
+# The golden tests PRINT what they measured ("... rel-L2 vs reference 1.08e-06 ..."); a quiet run keeps only "N passed".  Every
+# such line of a passing or failing test is collected here and written to gpurun_out/parity.json (STORM_PARITY_JSON overrides
+# the path) when the session ends: scripts/gpu_round.sh copies it to profiles/rNN_parity.json, so the measured numbers - not only
+# the bounds the assertions hold them to - survive the GPU box.
+_PARITY = []
+
+
+def pytest_runtest_logreport(report):
+    import re
+    if report.when != "call":
+        return
+    for line in (getattr(report, "capstdout", "") or "").splitlines():
+        if "rel-L2" in line or "nfev" in line:
+            nums = [float(v) for v in re.findall(r"(?<![\w.])\d+\.\d+e[-+]\d+", line)]
+            _PARITY.append({"test": report.nodeid, "outcome": report.outcome, "line": line.strip(), "values": nums})
+
+
+def pytest_sessionfinish(session, exitstatus):
+    import json
+    if not _PARITY or hasattr(session.config, "workerinput"):          # (xdist workers forward their reports to the controller)
+        return
+    path = os.environ.get("STORM_PARITY_JSON") or os.path.join(ROOT, "gpurun_out", "parity.json")
+    try:
+        os.makedirs(os.path.dirname(path), exist_ok=True)
+        import torch
+        dev = torch.cuda.get_device_name(0) if torch.cuda.is_available() else "cpu (host simulation of the kernel sources)"
+        with open(path, "w") as f:
+            json.dump({"device": dev, "exitstatus": int(exitstatus), "records": _PARITY}, f, indent=1)
+    except OSError:
+        pass

@@ -27,7 +27,7 @@ def build(force=False):
     for s in srcs:
         o = os.path.join(bdir, os.path.basename(s) + ".o")
         objs.append(o)
-        cmd = [CXX, "-x", "c++", "-std=c++17", "-O2", "-g", "-fPIC", "-DSTORM_HOST_SIM", "-I", HERE, "-I", CSRC,
+        cmd = [CXX, "-x", "c++", "-std=c++17", "-O2", "-g", "-fPIC", "-DSTORM_HOST_SIM", "-DSTORM_WITH_DUO", "-I", HERE, "-I", CSRC,
                "-Wno-unknown-attributes", "-Wno-unknown-pragmas", "-Wno-pass-failed", "-c", s, "-o", o]
         procs.append((s, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)))
     for s, p in procs:

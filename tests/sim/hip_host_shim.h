@@ -171,6 +171,18 @@ inline hipError_t hipEventDestroy(hipEvent_t) { return hipSuccess; }
 inline hipError_t hipEventRecord(hipEvent_t, hipStream_t) { return hipSuccess; }
 inline hipError_t hipEventSynchronize(hipEvent_t) { return hipSuccess; }
 inline hipError_t hipEventElapsedTime(float* ms, hipEvent_t, hipEvent_t) { *ms = 0.f; return hipSuccess; }
+// HIP graphs do not exist on the simulator: a capture attempt fails and storm_ncsnpp_forward stays on its eager path
+typedef void* hipGraph_t;
+typedef void* hipGraphExec_t;
+enum { hipStreamNonBlocking = 1, hipStreamCaptureModeThreadLocal = 1 };
+inline hipError_t hipStreamCreateWithFlags(hipStream_t* s, unsigned) { *s = nullptr; return 1; }
+inline hipError_t hipStreamDestroy(hipStream_t) { return hipSuccess; }
+inline hipError_t hipStreamBeginCapture(hipStream_t, int) { return 1; }
+inline hipError_t hipStreamEndCapture(hipStream_t, hipGraph_t* g) { *g = nullptr; return 1; }
+inline hipError_t hipGraphInstantiate(hipGraphExec_t*, hipGraph_t, void*, void*, size_t) { return 1; }
+inline hipError_t hipGraphDestroy(hipGraph_t) { return hipSuccess; }
+inline hipError_t hipGraphExecDestroy(hipGraphExec_t) { return hipSuccess; }
+inline hipError_t hipGraphLaunch(hipGraphExec_t, hipStream_t) { return 1; }
 #define hipLaunchKernelGGL(kern, grid, block, lds, stream, ...) \
     simrt::launch((grid), (block), (size_t)(lds), [=]() { (kern)(__VA_ARGS__); })
 

@@ -22,7 +22,7 @@ def test_library_builds_and_exports_every_declared_symbol():
     missing = [n for n in names if not hasattr(lib, n)]
     assert not missing, missing
     lib.storm_abi_version.restype = ctypes.c_int
-    assert lib.storm_abi_version() == 1
+    assert lib.storm_abi_version() == 2
     lib.storm_last_error.restype = ctypes.c_char_p
     assert lib.storm_last_error() is not None
 

@@ -131,6 +131,17 @@ def test_langevin_group_norms_two_ranks(tmp_path):
     assert abs(sn - sn_ref) < 1e-6 and abs(zn - zn_ref) < 1e-6
 
 
+def test_numa_pinning_helpers(tmp_path):
+    """bench.py / enhancement.py pin a rank's launch thread to its GPU's NUMA node (8-GPU nodes): the cpulist parser, and the
+    best-effort contract - no GPU / no topology in sysfs -> None, nothing changed."""
+    from storm_amd import distributed as D
+    assert D.parse_cpulist("0-3,8,10-11\n") == [0, 1, 2, 3, 8, 10, 11]
+    assert D.parse_cpulist("5") == [5] and D.parse_cpulist("") == []
+    before = os.sched_getaffinity(0)
+    assert D.pin_to_gpu_numa(0, sysfs=str(tmp_path)) is None
+    assert os.sched_getaffinity(0) == before
+
+
 @pytest.mark.gpu
 def test_bench_under_the_driver_launch_line_with_an_rccl_group_of_one():
     """The driver starts the multi-GPU bench as `python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1

@@ -125,9 +125,13 @@ def test_enhancement_cli(tmp_path):
     wavs = [0.1 * torch.randn(6000, generator=g), 0.1 * torch.randn(6000, generator=g)]
     for i, w in enumerate(wavs):
         wavfile.write(os.path.join(noisy, f"u{i}.wav"), 16000, w.numpy().astype(np.float32))
-    env = dict(os.environ, PYTHONPATH=root)
-    r = subprocess.run([sys.executable, os.path.join(root, "enhancement.py"), "--test_dir", noisy, "--enhanced_dir", out,
-                        "--ckpt", path, "--mode", "score-only", "--N", "2", "--corrector", "ald", "--seed", "123"],
+    # under the launcher line a multi-GPU user types, with ONE rank and --dist-world1: D.init() forms an RCCL group (device_id bound), the
+    # files are sharded over its ranks and D.finish() leaves through an RCCL barrier - the sharded CLI path executed on ROCm
+    env = {k: v for k, v in dict(os.environ, PYTHONPATH=root, HSA_ENABLE_IPC_MODE_LEGACY="0").items()
+           if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1",
+                        "--master-port", "29578", os.path.join(root, "enhancement.py"), "--test_dir", noisy, "--enhanced_dir", out,
+                        "--ckpt", path, "--mode", "score-only", "--N", "2", "--corrector", "ald", "--seed", "123", "--dist-world1"],
                        env=env, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stderr[-2000:]
     got = []
