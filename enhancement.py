@@ -48,6 +48,7 @@ def main():
     p.add_argument("--precision", choices=("fp32", "bf16", "fp16"), default="fp32")
     p.add_argument("--batch", type=int, default=16)
     p.add_argument("--seed", type=int, default=None, help="Philox seed of the sampler noise (default: drawn from torch's RNG, as the reference)")
+    p.add_argument("--streams", type=int, default=1, help="micro-batches in flight at once on this GPU (own HIP stream + host thread each)")
     p.add_argument("--dist-world1", action="store_true", help="with ONE rank: form the RCCL process group anyway (dry run of the sharded path on one GPU)")
     args = p.parse_args()
 
@@ -74,7 +75,7 @@ def main():
         lengths.append(y.shape[1])
     mine = D.shard_indices(len(files), rank, world, lengths)
     # micro-batches of utterances that share a padded frame count (different lengths welcome): equal to per-file runs
-    for batch in D.bucket_by_frames([lengths[i] for i in mine], args.batch):
+    def run(batch):
         ids = [mine[k] for k in batch]
         lens = [lengths[i] for i in ids]
         y = torch.zeros(len(ids), max(lens))
@@ -88,6 +89,9 @@ def main():
             x_hat = model.enhance_batch(y, corrector=args.corrector, N=args.N, corrector_steps=args.corrector_steps, snr=args.snr,
                                         lengths=ragged, **kw)
             outs = [x_hat[k, :lens[k]] for k in range(len(ids))]
+        return ids, outs
+
+    for ids, outs in D.run_concurrent(run, D.bucket_by_frames([lengths[i] for i in mine], args.batch), args.streams):
         for i, x in zip(ids, outs):
             write_wav(os.path.join(args.enhanced_dir, os.path.basename(files[i])), x.float().reshape(-1), 16000)
     D.finish()

@@ -404,6 +404,8 @@ int storm_ncsnpp_forward(storm_ncsnpp* h, const void* const* parts, int n_parts,
 /* the planned op list of (B, F, T) (owned by the handle) for storm_program_run_timed / storm_program_kernel_name, the packed
  * arena, and the algorithmic FLOPs of one forward */
 int storm_ncsnpp_program(storm_ncsnpp* h, int B, int F, int T, const storm_op** ops, int* n_ops, long long* flops);
+/* a program handed out above stays valid (pinned) until the handle is destroyed or the caller releases it: */
+int storm_ncsnpp_release_program(storm_ncsnpp* h, const storm_op* ops);
 const void* storm_ncsnpp_arena(storm_ncsnpp* h);
 
 #ifdef __cplusplus

@@ -117,6 +117,7 @@ _SIGNATURES = {
     "storm_ncsnpp_workspace_bytes": ([_vp, _i, _i, _i], C.c_longlong),
     "storm_ncsnpp_forward": ([_vp, C.POINTER(_vp), _i, _vp, _vp, _vp, _ll, _i, _i, _i, _i, _vp], C.c_int),
     "storm_ncsnpp_program": ([_vp, _i, _i, _i, C.POINTER(C.POINTER(Op)), C.POINTER(C.c_int), C.POINTER(C.c_longlong)], C.c_int),
+    "storm_ncsnpp_release_program": ([_vp, C.POINTER(Op)], C.c_int),
     "storm_ncsnpp_arena": ([_vp], _vp),
     "storm_program_kernel_name": ([C.POINTER(Op), _i, _i], C.c_char_p),
     "storm_program_run_timed": ([C.POINTER(Op), _i, C.POINTER(_vp), _i, _i, _vp, C.POINTER(C.c_float)], C.c_int),

@@ -9,6 +9,7 @@ call.  There is no PyTorch/CPU execution path.
 """
 import math
 import os
+import threading
 
 import numpy as np
 import torch
@@ -156,6 +157,7 @@ class NCSNpp(nn.Module):
         self.negate_output = False        # ScoreModel folds the "score = -dnn(...)" sign into the output head
         self._handles = {}                # dtype code -> (engine handle, arena tensor, params version, device)
         self._workspaces = {}             # (device, dtype, stream) -> ONE grow-only scratch tensor (the workspace holds no state between calls)
+        self._lock = threading.RLock()    # handle / scratch bookkeeping (host threads driving different streams share the module)
         self._graph_mode = -1             # storm_ncsnpp_set_graph: -1 = the library's rule (replay for small batches), 0 eager, 1 replay
         self._param_version = 0
         self.register_load_state_dict_post_hook(lambda m, keys: m.invalidate())
@@ -279,6 +281,12 @@ class NCSNpp(nn.Module):
         L.check(L.lib().storm_ncsnpp_program(h, B, F, T, C.byref(ops), C.byref(n), C.byref(fl)), "storm_ncsnpp_program")
         return ops, n.value, fl.value
 
+    def release_program(self, ops, dtype=None):
+        """unpin an op list obtained from program() (a profiler that sweeps many shapes calls this per shape)"""
+        code = L.dt(dtype or self.compute_dtype)
+        h = self._get_handle(code, next(self.parameters()).device)
+        L.check(L.lib().storm_ncsnpp_release_program(h, ops), "storm_ncsnpp_release_program")
+
     # ---- forward ---------------------------------------------------------------------------
     def forward(self, x, time_cond=None):
         """x: complex64 [B, input_channels/2, F, T] (x, y[, y_denoised]); time_cond: float32 [B]."""
@@ -297,8 +305,9 @@ class NCSNpp(nn.Module):
         B, F, T = x0.shape
         dev = x0.device
         code = L.dt(self.compute_dtype)
-        h = self._get_handle(code, dev)
-        ws = self._get_workspace(h, B, F, T, code, dev)
+        with self._lock:
+            h = self._get_handle(code, dev)
+            ws = self._get_workspace(h, B, F, T, code, dev)
         out = torch.empty((B, 1, F, T), dtype=torch.complex64, device=dev)
         parts = (C.c_void_p * len(ins))()
         for j, t_in in enumerate(ins):

@@ -887,6 +887,7 @@ static int launch_splitk(const storm_conv_args& a, const int S, hipStream_t st) 
     prm.kslices = S; prm.split_nct = n_ct;
     const int tiles_per_xcd = cdiv(ntiles, 8);
     const long long vblocks = 8LL * tiles_per_xcd * n_ct * S;
+    STORM_CHECK(vblocks > 0 && vblocks < (1LL << 31) && ntiles < (1LL << 31), "storm_conv: split-K grid %lld out of range", vblocks);
     const long long resident = (device_cus() + 7) / 8 * 8;
     const long long grid = vblocks < resident ? vblocks : resident;
     hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(THREADS), Cfg::LDS_BYTES, st, prm, n_ct * S, tiles_per_xcd, (int)ntiles,

@@ -712,6 +712,16 @@ extern "C" int storm_ncsnpp_program(storm_ncsnpp* h, int B, int F, int T, const 
     return STORM_OK;
 }
 
+// Unpin a program handed out by storm_ncsnpp_program (the op list may be freed from now on - by an eviction, a fusion change or the
+// handle's destruction, whichever comes first): a profiler sweeping many shapes calls this when it is done with one.
+extern "C" int storm_ncsnpp_release_program(storm_ncsnpp* h, const storm_op* ops) {
+    STORM_CHECK(h != nullptr && ops != nullptr, "storm_ncsnpp_release_program: null argument");
+    std::lock_guard<std::mutex> lk(h->mu);
+    for (auto it = h->exported.begin(); it != h->exported.end(); ++it)
+        if ((*it)->ops.data() == ops) { h->exported.erase(it); return STORM_OK; }
+    STORM_CHECK(false, "storm_ncsnpp_release_program: not an op list of this handle");
+}
+
 extern "C" const void* storm_ncsnpp_arena(storm_ncsnpp* h) { return h ? h->arena : nullptr; }
 
 // ---- one evaluation: eager launches, or HIP-graph replay ---------------------------------------------------------------------

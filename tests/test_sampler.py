@@ -123,8 +123,8 @@ def test_ode_per_row_control_equals_the_reference_per_utterance_runs(dev, golden
     assert coupled.nfev_rows == [nc] * 3 and not torch.equal(xc.cpu(), x.cpu())
 
 
-def f13_noises(g):
-    """the 61 recorded draws of fixture F13, regenerated from their seed (oracle/make_golden.py::gen_f13; SHA-256 checked)"""
+def full_sampler_noises(g):
+    """the 61 recorded draws of fixtures F13 / F14, regenerated from their seed (oracle/make_golden.py::_full_sampler_fixture; SHA-256 checked)"""
     import hashlib
     gen = torch.Generator().manual_seed(int(g["seeds"][1]))
     shape = tuple(int(v) for v in g["noise_shape"])
@@ -133,84 +133,66 @@ def f13_noises(g):
     return zs
 
 
-def test_f13_fixture_inputs_regenerate(golden):
-    """F13 (the reference's full-width, 60-evaluation ScoreModel.enhance) stores seeds instead of 16 MB of noise: the draws and the
-    27.8 M weights regenerate bit for bit here (hashes), so the GPU test below feeds the engine what the reference consumed."""
+FULL_SAMPLER_FIXTURES = {"f13_full_sampler": 16000, "f14_full_sampler_4s": 64000}     # name -> samples of the utterance
+
+
+@pytest.mark.parametrize("name", list(FULL_SAMPLER_FIXTURES))
+def test_full_sampler_fixture_inputs_regenerate(golden, name):
+    """F13 / F14 (the reference's full-width, 60-evaluation ScoreModel.enhance on a 1-s / on the bench's 4-s utterance) store seeds
+    instead of 16 / 63 MB of noise: the draws and the 27.8 M weights regenerate bit for bit here (hashes), so the GPU tests below
+    feed the engine what the reference consumed."""
     import hashlib
-    g = golden["f13_full_sampler"]
-    assert len(f13_noises(g)) == 61 and int(g["nfe"]) == 60
+    g = golden[name]
+    n = FULL_SAMPLER_FIXTURES[name]
+    assert len(full_sampler_noises(g)) == 61 and int(g["nfe"]) == 60
     sd = NR.seeded_state_dict(NR.NCSNppConfig(input_channels=4), seed=int(g["seeds"][0]))
     h = hashlib.sha256()
     for k in sorted(sd):
         h.update(k.encode())
         h.update(sd[k].detach().contiguous().numpy().tobytes())
     assert h.hexdigest() == str(g["sdhash"])
-    wav = torch.randn(1, 16000, generator=torch.Generator().manual_seed(int(g["seeds"][2]))) * 0.1
-    assert torch.equal(wav, T(g["wav_in"]))
+    wav = torch.randn(1, n, generator=torch.Generator().manual_seed(int(g["seeds"][2]))) * 0.1
+    assert torch.equal(wav, T(g["wav_in"])) and tuple(g["out"].shape)[-1] == n
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("prec,tol_wav,tol_spec", [("fp32", 1e-3, 1e-3), ("bf16", 5e-2, 5e-2), ("fp16", 2e-2, 2e-2)])
-def test_full_width_60_evaluation_sampler_vs_reference_golden(golden, prec, tol_wav, tol_spec):
-    """The product of the path against the REFERENCE at full width and full sampler length (fixture F13): ScoreModel.enhance of the
-    seeded 27.8 M `ncsnpp` on a 1-s utterance, N = 30 reverse steps + 1 ald corrector step each = 60 score evaluations
-    (model.py:273-310, sampling/__init__.py:54-66), under the noise the reference consumed - at batch 16 (the same row 16 times, so
-    the production kernel selection of the bench batch is active and every row must reproduce the reference), in the parity
-    precision and in the two 16-bit operand precisions: what 60 chained evaluations of a 1e-2 network error amount to, measured
-    against the reference instead of against the engine's own fp32 run."""
+@pytest.mark.parametrize("name,prec,B,tol_wav,tol_spec", [
+    ("f13_full_sampler", "fp32", 16, 1e-3, 1e-3), ("f13_full_sampler", "bf16", 16, 5e-2, 5e-2), ("f13_full_sampler", "fp16", 16, 2e-2, 2e-2),
+    ("f14_full_sampler_4s", "bf16", 16, 5e-2, 5e-2), ("f14_full_sampler_4s", "fp16", 16, 2e-2, 2e-2), ("f14_full_sampler_4s", "fp32", 2, 1e-3, 1e-3),
+    ("f14_full_sampler_4s", "bf16", 1, 5e-2, 5e-2)])
+def test_full_width_60_evaluation_sampler_vs_reference_golden(golden, name, prec, B, tol_wav, tol_spec):
+    """The product of the path against the REFERENCE at full width and full sampler length: ScoreModel.enhance of the seeded 27.8 M
+    `ncsnpp`, N = 30 reverse steps + 1 ald corrector step each = 60 score evaluations (model.py:273-310, sampling/__init__.py:54-66),
+    under the noise the reference consumed.  F13: a 1-s utterance; **F14: the bench's own utterance length (4 s = 64 000 samples ->
+    512 frames), i.e. BASELINE.json configs[1] as bench.py times it - batch 16 in bf16** (the same row 16 times, so the production
+    kernel selection of the bench batch is active and every row must reproduce the reference), fp16, the parity precision, and ONE
+    utterance per call (the reference's own operating point, with its other kernel selection).  What 60 chained evaluations of a 1e-2
+    network error amount to, measured against the reference instead of against the engine's own fp32 run."""
     from tests.backend import setup_backend
     from storm_amd.model import ScoreModel
     dev = setup_backend("hip")
-    g = golden["f13_full_sampler"]
+    g = golden[name]
+    n = FULL_SAMPLER_FIXTURES[name]
     m = ScoreModel(backbone="ncsnpp", sde="ouve", theta=1.5, sigma_min=0.05, sigma_max=0.5, spec_factor=0.15, spec_abs_exponent=0.5)
     m.dnn.load_state_dict(NR.seeded_state_dict(NR.NCSNppConfig(input_channels=4), seed=int(g["seeds"][0])))
     m._error_loading_ema = True
     m = m.eval().to(dev)
     m.set_precision(prec)
-    B = 16
-    zs = [z.to(dev).expand(B, -1, -1, -1).contiguous() for z in f13_noises(g)]
+    zs = [z.to(dev) for z in full_sampler_noises(g)]
     it = iter(zs)
     wav = T(g["wav_in"]).to(dev).expand(B, -1).contiguous()
     Y, peak, T_orig = m._prepare(wav)                         # (enhance_batch, opened up to read the sampler's final state as well)
     sampler = m.get_pc_sampler("reverse_diffusion", "ald", Y, N=int(g["N"]), corrector_steps=1, snr=0.5, intermediate=False,
-                               langevin_per_row=True, noise_fn=lambda: next(it))
+                               langevin_per_row=True, noise_fn=lambda: next(it).expand(B, -1, -1, -1).contiguous())
     sample, nfe = sampler()
     x = m.data_module.spec_to_wav(sample, T_orig, peak)
-    assert nfe == int(g["nfe"]) == 60 and x.shape == (B, 16000)
+    assert nfe == int(g["nfe"]) == 60 and x.shape == (B, n)
     e_spec = [rel_l2(sample[b].reshape(-1).cpu(), T(g["final_spec"]).reshape(-1)) for b in range(B)]
     e_wav = [rel_l2(x[b].float().cpu(), g["out"]) for b in range(B)]
-    print(f"F13 60-evaluation enhance, {prec}, batch {B}: wav rel-L2 vs reference {max(e_wav):.3e} (final spectrogram {max(e_spec):.3e})")
+    print(f"{name[:3].upper()} 60-evaluation enhance of a {n // 16000}-s utterance, {prec}, batch {B}: wav rel-L2 vs reference {max(e_wav):.3e} "
+          f"(final spectrogram {max(e_spec):.3e})")
     assert max(e_wav) < tol_wav and max(e_spec) < tol_spec
     assert all(torch.equal(x[b], x[0]) for b in range(1, B))          # identical rows in, identical rows out (no batch coupling in ald)
-
-
-@pytest.mark.gpu
-def test_bf16_sampler_drift_over_a_full_run():
-    """BASELINE.json configs[1] numerics: the FULL 30-step PC run (reverse_diffusion + 1 ald step = 60 score evaluations of
-    the 27.8 M network, 4-s utterances) in the bench precision (bf16 MFMA operands and activations) against the fp32 engine
-    (itself 1e-6 from the oracle) under the SAME noise (in-kernel Philox stream of the same seed): the error a score
-    evaluation makes (1e-2) is amplified by 1/t in the network head and re-enters 59 times.  wav rel-L2 <= 5e-2."""
-    import bench
-    from tests.backend import setup_backend
-    from storm_amd.model import ScoreModel
-    dev = setup_backend("hip")
-    model = ScoreModel(backbone="ncsnpp", sde="ouve", theta=1.5, sigma_min=0.05, sigma_max=0.5, spec_factor=0.15,
-                       spec_abs_exponent=0.5)
-    bench.randomize(model, seed=0)
-    model._error_loading_ema = True
-    model.eval()
-    model = model.to(dev)
-    wav = (0.1 * torch.randn(2, 64000, generator=torch.Generator().manual_seed(3))).to(dev)
-    outs = {}
-    for prec in ("fp32", "bf16"):
-        model.set_precision(prec)
-        x, nfe = model.enhance_batch(wav, predictor="reverse_diffusion", corrector="ald", N=30, corrector_steps=1, snr=0.5,
-                                     seed=7, return_nfe=True)
-        assert nfe == 60
-        outs[prec] = x.float().cpu()
-    err = rel_l2(outs["bf16"], outs["fp32"])
-    print(f"60-NFE PC run, bf16 vs fp32 engine under identical noise: wav rel-L2 {err:.3e}")
-    assert err < 5e-2
 
 
 def test_langevin_step_size_modes(dev, monkeypatch):
