@@ -384,7 +384,7 @@ void storm_ncsnpp_destroy(storm_ncsnpp* h);
 int storm_ncsnpp_set_fusion(storm_ncsnpp* h, int fuse_stats, int fuse_apply, int fused_attention);
 /* HIP-graph replay of this handle's evaluations (the reference's own operating point is ONE utterance per
  * call, enhancement.py:66-72, where an evaluation is ~120 short launches): mode 0 = eager launches, 1 = replay, -1 (default) = the
- * library's rule (replay for small batches).  The first call per (shape, workspace address) runs eagerly, the second records the runs
+ * library's rule (today: eager - measured on MI355X the launch loop keeps the queue full at every batch size, profiles/r05a_*).  The first call per (shape, workspace address) runs eagerly, the second records the runs
  * of ops that touch only the workspace and the weights, later calls are one hipGraphLaunch per run + the three ops that read the
  * caller's tensors (input packing, time embedding, output head).  A replayed evaluation executes exactly the eager kernels with the
  * eager arguments: results are bit-identical.  A workspace passed to a graph-mode call must stay allocated while the handle lives

@@ -158,7 +158,7 @@ class NCSNpp(nn.Module):
         self._handles = {}                # dtype code -> (engine handle, arena tensor, params version, device)
         self._workspaces = {}             # (device, dtype, stream) -> ONE grow-only scratch tensor (the workspace holds no state between calls)
         self._lock = threading.RLock()    # handle / scratch bookkeeping (host threads driving different streams share the module)
-        self._graph_mode = -1             # storm_ncsnpp_set_graph: -1 = the library's rule (replay for small batches), 0 eager, 1 replay
+        self._graph_mode = -1             # storm_ncsnpp_set_graph: -1 = the library's rule (eager: measured, profiles/r05a_*), 0 eager, 1 replay
         self._param_version = 0
         self.register_load_state_dict_post_hook(lambda m, keys: m.invalidate())
 
@@ -178,7 +178,7 @@ class NCSNpp(nn.Module):
 
     def set_graph(self, mode):
         """HIP-graph replay of the score evaluations (include/storm_hip.h: storm_ncsnpp_set_graph): "auto" / -1 = the library's rule
-        (small batches), 0 / False = eager launches, 1 / True = replay.  Results are bit-identical either way."""
+        (eager launches: the queue never drains on MI355X, profiles/r05a_*), 0 / False = eager launches, 1 / True = replay.  Results are bit-identical either way."""
         self._graph_mode = -1 if mode in ("auto", -1, None) else int(bool(mode))
         for h, _, _, _ in self._handles.values():
             L.check(L.lib().storm_ncsnpp_set_graph(h, self._graph_mode), "storm_ncsnpp_set_graph")

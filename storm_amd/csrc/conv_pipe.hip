@@ -843,20 +843,29 @@ void splitk_combine_kernel(const float* __restrict__ slabs, const int S, const l
     }
 }
 
-// K slices for a layer, 0 = no split.  The rule looks at ONE image only - its 128-cout tiles (pixel tiles x cout tiles <= 8: images up
-// to 16 x 64 / 32 x 32 pixels at 256 couts) - never at the batch size: a split changes the fp32 summation order, and an utterance must
-// come out the same alone, in a batch, or on another rank (test_batch_independence_and_determinism).  At configs[3]'s 8 utterances per
-// GPU that is <= 64 workgroups unsplit; at 128 ... 256 workgroups (the 32 x 64 level at batch 16) the split measured slower.  4 slices,
-// 2 when there are fewer than four 64-channel chunks: 8 measured behind 4 wherever both apply (profiles/r04f_probe_splitk_s.txt;
-// unsplit -> 4 slices): 256 -> 256 @ 8 x 16 x 64 39.2 -> 37.9 us, 512 -> 256 67.9 -> 43.8; @ 8 x 8 x 32 36.7 -> 25.1 and 63.7 -> 32.2;
-// @ 8 x 4 x 16 32.2 -> 25.3 and 55.3 -> 26.5.
+// K slices for a layer, 0 = no split.  Two clauses:
+//  (1) the IMAGE rule looks at one image only - its 128-cout tiles (pixel tiles x cout tiles <= 8: images up to 16 x 64 / 32 x 32 pixels at
+//      256 couts) - never at the batch size.  At configs[3]'s 8 utterances per GPU that is <= 64 workgroups unsplit; at 128 ... 256
+//      workgroups (the 32 x 64 level at batch 16) the split measured slower.  4 slices, 2 when there are fewer than four 64-channel chunks:
+//      8 measured behind 4 wherever both apply (profiles/r04f_probe_splitk_s.txt; unsplit -> 4 slices): 256 -> 256 @ 8 x 16 x 64 39.2 -> 37.9 us,
+//      512 -> 256 67.9 -> 43.8; @ 8 x 8 x 32 36.7 -> 25.1 and 63.7 -> 32.2; @ 8 x 4 x 16 32.2 -> 25.3 and 55.3 -> 26.5.
+//  (2) the SMALL-CALL rule (round 5; STORM_SPLITK_SMALL=0 switches it off) looks at the call: at most 64 unsplit workgroups in the WHOLE
+//      launch.  One utterance per call is the reference's own operating point (enhancement.py:66-72) and a ragged stream's tail batches hold
+//      one to three rows: there the 32 x 64 level of NCSN++ is 16 workgroups per utterance and its twelve launches were 19 % of a batch-1
+//      evaluation at 52 - 57 TFLOP/s (profiles/r05a_ops_b1.json), the 64 x 128 level (64 workgroups) 17 %.
+// A split changes the fp32 summation order of K (slices summed in slice order: bit-reproducible, no atomics), so: under clause (1) alone an
+// utterance comes out the same bits alone, in any batch and on any rank (test_batch_independence_and_determinism); clause (2) is - like
+// the 256- / 128-cout tile and conv_pipe128 selections of choose_variant - a throughput decision on the launch, and across ITS threshold
+// (a one-utterance call against the same utterance in a batch of sixteen) a row agrees to the rounding of its 16-bit activations, not
+// bit for bit; run-to-run and rank-to-rank results of the same call stay bit-identical.
 int conv_splitk_slices(const storm_conv_args& a) {
     if (!conv_pipe_supports(a) || a.outC <= 128 || a.out_f32) return 0;
     const int n9 = cdiv(a.seg[0].Ca, KC) + (a.seg[0].Cb ? cdiv(a.seg[0].Cb, KC) : 0);
     const int forced = switches().splitk;                    // (A/B hook)
     if (forced == 1) return 0;
     if (forced >= 2) return forced <= n9 ? forced : 0;
-    if ((long long)cdiv(a.W, TILE_W) * cdiv(a.H, TILE_H) * cdiv(a.outC, 128) > 8) return 0;
+    const long long per_image = (long long)cdiv(a.W, TILE_W) * cdiv(a.H, TILE_H) * cdiv(a.outC, 128);
+    if (per_image > 8 && (switches().splitk_small == 0 || per_image * a.B > 64)) return 0;
     return n9 >= 4 ? 4 : n9 >= 2 ? 2 : 0;
 }
 long long conv_splitk_bytes(const storm_conv_args& a, int slices) {

@@ -739,10 +739,13 @@ static int run_range(const Program& p, int a, int b, void* const* bufs, int dtyp
     return STORM_OK;
 }
 
-// The library's rule when nobody chose (storm_ncsnpp_set_graph(h, -1)): replay where an evaluation is a chain of SHORT launches - the
-// one-to-four-utterance calls of the reference's own operating point (enhancement.py:66-72 is a batch-1 loop) and the ragged stream's
-// tail batches.  At the bench batch the launches are long and the stream is gap-free either way.
-static int graph_wanted(const Program& p) { return (long long)p.B * p.F * p.T <= 4LL * 256 * 640 ? 1 : 0; }
+// The library's rule when nobody chose (storm_ncsnpp_set_graph(h, -1)): eager launches.  MEASURED (round 5, profiles/r05a_*): at ONE utterance
+// per call - the reference's own operating point (enhancement.py:66-72), where an evaluation is 117 launches of 5 - 160 us - the kernels
+// of an evaluation are busy 3325 us of its 3331 us wall: the C launch loop (0.5 ms of host time per evaluation) already runs ahead of
+// the GPU and the queue never drains, so replay moves nothing (batch 1 / 2 / 4 / 16: 3.332 vs 3.328, 4.52 vs 4.54, 6.70 vs 6.70,
+// 21.16 vs 21.11 ms per evaluation; ragged stream 5.53 vs 5.47 utt/s).  What a one-utterance call lacks is work per launch, not
+// launches per second (conv_splitk_slices' small-call rule).  Replay stays available for hosts whose launch thread is slower.
+static int graph_wanted(const Program&) { return 0; }
 
 // maximal runs (>= 4 ops) of ops that reference nothing but the workspace and the weight arena: their kernel arguments depend on
 // (program, workspace address) only, so one instantiated graph serves every later call with that workspace

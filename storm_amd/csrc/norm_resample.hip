@@ -552,6 +552,19 @@ static int gn_stats_t(const void* xa, int Ca, const void* xb, int Cb, int B, int
     return STORM_OK;
 }
 
+// Rows per strip of the two resampling kernels: 16 where that already gives every CU four workgroups (the bench batch: thousands), halved
+// down to 4 for small calls.  One utterance per call (the reference's own operating point, enhancement.py:66-72) at 16 rows is 128
+// workgroups for the level-0 down-sampling launch - one wave per SIMD on half the chip, a launch that lasts as long as ONE strip's chain
+// of row loads (41 us for 33 MB, profiles/r05a_b1_eager_rocprofv3_kernel_stats.csv); short strips re-read 3 halo rows per strip (4 rows:
+// 1.4 x the reads) and finish sooner.  A strip boundary does not change an output's arithmetic (each output row is the same four-tap
+// combination of the same filtered rows), so the choice is invisible in the results (test_groupnorm_fir_fused, STORM_GN_ROWS sweep).
+static int strip_rows(int rows_total, long long wgs_per_strip, int dflt) {
+    if (switches().gn_rows > 0) return switches().gn_rows;
+    int r = dflt;
+    while (r > 4 && wgs_per_strip * cdiv(rows_total, r) < 4LL * device_cus()) r >>= 1;
+    return r;
+}
+
 template <typename T, int R>
 static int gn_apply_t(const void* xa, int Ca, const void* xb, int Cb, int B, int H, int W, int G,
                       const double* stats, const float* gamma, const float* beta, float eps, int silu,
@@ -562,7 +575,7 @@ static int gn_apply_t(const void* xa, int Ca, const void* xb, int Cb, int B, int
     const int NSr = switches().gn_wide == 0 ? 8 : (slots % 32 == 0 ? 32 : slots % 16 == 0 ? 16 : 8);
     if (R == 2) {
         const int OH = H / 2, OW = W / 2;
-        const int ncg = cdiv(Ca + Cb, NSr * Elem<T>::PER16), nstrips = cdiv(OH, switches().gn_rows > 0 ? switches().gn_rows : DN_ROWS);
+        const int ncg = cdiv(Ca + Cb, NSr * Elem<T>::PER16), nstrips = cdiv(OH, strip_rows(OH, (long long)cdiv(OW, 256 / NSr) * ncg * B, DN_ROWS));
         const long long gy = (long long)ncg * nstrips * B;
         STORM_CHECK(OH > 0 && OW > 0 && gy < 65536, "storm_gn_apply: down-sampling grid %lld out of range", gy);
 #define STORM_GN_DOWN(SILU_, NS_) hipLaunchKernelGGL((gn_apply_down_kernel<T, SILU_, NS_>), dim3(cdiv(OW, 256 / NS_), (unsigned)gy), dim3(256), 0, st, \
@@ -574,7 +587,7 @@ static int gn_apply_t(const void* xa, int Ca, const void* xb, int Cb, int B, int
         return STORM_OK;
     }
     if (R == 1) {
-        const int ncg = cdiv(Ca + Cb, NSr * Elem<T>::PER16), nstrips = cdiv(H, switches().gn_rows > 0 ? switches().gn_rows : UP_ROWS);
+        const int ncg = cdiv(Ca + Cb, NSr * Elem<T>::PER16), nstrips = cdiv(H, strip_rows(H, (long long)cdiv(W, 256 / NSr) * ncg * B, UP_ROWS));
         const long long gy = (long long)ncg * nstrips * B;
         STORM_CHECK(gy < 65536, "storm_gn_apply: up-sampling grid %lld out of range", gy);
 #define STORM_GN_UP(SILU_, NS_) hipLaunchKernelGGL((gn_apply_up_kernel<T, SILU_, NS_>), dim3(cdiv(W, 256 / NS_), (unsigned)gy), dim3(256), 0, st, \

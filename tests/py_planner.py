@@ -333,7 +333,7 @@ class Program:
 
     def splitk_bytes(self, segs, H, W, outC, out_f32):
         """conv_pipe.hip: conv_splitk_slices / conv_splitk_bytes restated - a 16-bit 3x3 layer with > 128 output channels and at most
-        8 128-cout tiles PER IMAGE splits its nine-tap chunks (64 channels each) into 4 (or 2) slices, one fp32 slab [B][H][W][outC]
+        8 128-cout tiles PER IMAGE - or at most 64 in the whole launch (small calls) - splits its nine-tap chunks (64 channels each) into 4 (or 2) slices, one fp32 slab [B][H][W][outC]
         per slice."""
         if self.esize != 2 or out_f32 or outC <= 128 or segs[0]["taps"] != 9:
             return 0
@@ -362,7 +362,8 @@ class Program:
         a0 = segs[0]["a"]
         Ca0 = a0.C if isinstance(a0, Act) else a0[2]
         Cb0 = segs[0]["b"].C if segs[0].get("b") is not None else 0
-        if (-(-W // 32)) * (-(-H // 8)) * (-(-outC // 128)) > 8:      # per image, never the batch size: results must not depend on it
+        per_image = (-(-W // 32)) * (-(-H // 8)) * (-(-outC // 128))
+        if per_image > 8 and per_image * self.B > 64:                 # the image rule (batch-invariant) or the small-call rule (<= 64 workgroups)
             return 0
         n9 = -(-Ca0 // 64) + (-(-Cb0 // 64) if Cb0 else 0)
         S = 4 if n9 >= 4 else 2 if n9 >= 2 else 0

@@ -306,6 +306,33 @@ PIPE128_CASES = {
 }
 
 
+def test_split_k_small_call_rule(dev, switch):
+    """conv_splitk_slices, clause (2) (round 5): a 3x3 layer with > 128 output channels splits its K loop when the WHOLE launch has at most
+    64 unsplit workgroups - one utterance per call at the 32 x 64 (16 workgroups) and 64 x 128 (64) levels of NCSN++, the reference's own
+    operating point (enhancement.py:66-72) - and not at the bench batch, where the same layers fill the chip; STORM_SPLITK_SMALL=0 leaves
+    the per-image rule alone (rows then do not depend on the batch they ride in).  Result == the unsplit tile to fp32 summation order."""
+    from storm_amd import ops
+    dtype = torch.bfloat16
+    g = torch.Generator().manual_seed(5)
+    w = ops.pack_conv_weight((torch.randn(256, 256, 3, 3, generator=g) * 0.03).to(dev), dtype)
+    name = lambda B, H, W: ops.conv_kernel_name([ops.Seg(torch.zeros(B, H, W, 256, dtype=dtype, device=dev), w, 9)], 256)
+    split, half, full = "storm::conv_pipe_splitk_kernel", "storm::conv_pipe_kernel<storm::bf16_t, 128, 8", "storm::conv_pipe_kernel<storm::bf16_t, 256, 8"
+    assert name(1, 32, 64).startswith(split) and name(4, 32, 64).startswith(split) and name(1, 64, 128).startswith(split)
+    assert name(5, 32, 64).startswith(half) and name(16, 32, 64).startswith(half) and name(2, 64, 128).startswith(half)
+    assert name(1, 128, 256).startswith(half) and name(1, 256, 512).startswith(full)
+    assert name(16, 8, 32).startswith(split)                       # (the image rule: 2 tiles per image, whatever the batch)
+    switch("STORM_SPLITK_SMALL", 0)
+    assert name(1, 32, 64).startswith(half) and name(1, 64, 128).startswith(half) and name(16, 8, 32).startswith(split)
+    switch("STORM_SPLITK_SMALL", 1)
+    x = torch.randn(1, 256, 32, 64, generator=g)
+    seg = [ops.Seg(nhwc(x).to(dtype).to(dev), w, 9)]
+    y, part = ops.conv(seg, 256, gn_partials=True)
+    switch("STORM_SPLITK_SMALL", 0)
+    y0, part0 = ops.conv(seg, 256, gn_partials=True)
+    assert rel_l2(y.float().cpu(), y0.float().cpu()) < 3e-3 and not torch.equal(part, torch.zeros_like(part))
+    assert torch.allclose(part.cpu(), part0.cpu(), rtol=2e-2, atol=2e-2 * float(part0.abs().max()))
+
+
 @pytest.mark.parametrize("case", ["natural", "natural@8", "deep_k", "deep_k@8", "natural:f16", "one_slice_pair", "three_chunks", "tiny_images"])
 def test_conv_split_k(dev, case, switch):
     """Split-K for 3x3 layers whose 128-cout tiles would leave most CUs idle (conv_pipe.hip: conv_pipe_splitk_kernel + splitk_combine_kernel;
@@ -548,6 +575,10 @@ def test_groupnorm_fir_fused(dev, dtype, resample, shape, switch):
     switch("STORM_GN_WIDE", 0)
     act8, raw8 = ops.gn_apply(xa, st, gam.to(dev), bet.to(dev), resample=resample)
     assert torch.equal(act, act8) and torch.equal(raw, raw8)
+    for rows in (4, 8, 16):          # rows per strip (strip_rows picks 4 ... 16 by the size of the call): the same bits whatever the strips
+        switch("STORM_GN_ROWS", rows)
+        actr, rawr = ops.gn_apply(xa, st, gam.to(dev), bet.to(dev), resample=resample)
+        assert torch.equal(act, actr) and torch.equal(raw, rawr)
 
 
 def test_fir_golden(dev, golden):
