@@ -64,9 +64,6 @@ def parse():
     p.add_argument("--include-h2d", action="store_true", help="(accepted for old command lines: the from-host pass is now the default)")
     p.add_argument("--graph", default="auto", choices=["auto", "on", "off"],
                    help="HIP-graph replay of the score evaluations (storm_ncsnpp_set_graph): auto = the library's rule (small batches)")
-    p.add_argument("--streams", type=int, default=1, metavar="K",
-                   help="--stream only: micro-batches in flight at once, each on its own HIP stream with its own host thread "
-                        "(storm_amd.distributed.run_concurrent)")
     p.add_argument("--selftest-cpu", action="store_true",
                    help="(tests) run the launch / sharding / timing skeleton with a stand-in step on CPU ranks (gloo)")
     return p.parse_args()
@@ -257,12 +254,13 @@ def main():
     def step(i):
         if not args.stream:
             return model.enhance_batch(wav, seed=1000 * rank + i, return_nfe=True, **skw)
-        def one(kb):
-            k, (yb, bl) = kb
-            o, n_ = model.enhance_batch(yb, seed=1000 * rank + 100 * i + k, return_nfe=True, lengths=bl, **skw)
-            return o, n_ * yb.shape[0]
-        res = D.run_concurrent(one, list(enumerate(batches)), args.streams, dev)
-        return res[-1][0], sum(r[1] for r in res) / args.stream     # mean score evaluations per utterance
+        # (one micro-batch at a time, one stream: kernels of concurrent streams corrupt each other on this platform,
+        #  profiles/r05_concurrent_streams_corruption.txt)
+        nfes, out = [], None
+        for k, (yb, bl) in enumerate(batches):
+            out, n_ = model.enhance_batch(yb, seed=1000 * rank + 100 * i + k, return_nfe=True, lengths=bl, **skw)
+            nfes.append(n_ * yb.shape[0])
+        return out, sum(nfes) / args.stream                 # mean score evaluations per utterance
 
     elapsed, per_rank, (out, nfe) = D.timed_steps(step, args.steps, args.warmup, sync=torch.cuda.synchronize, single_rank_group=args.dist_world1)
     assert torch.isfinite(out).all(), "non-finite output"
@@ -287,8 +285,7 @@ def main():
         "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True,
         "scaling": "weak", "vs_baseline": None, "dtype": args.precision, "data": "synthetic",
         "config": {"workload": (f"configs[4]-style: {args.backbone} stream of {args.stream} utterances of 2-10 s@16 kHz per GPU in "
-                                f"{len(batches)} ragged micro-batches (<= {args.batch}, bucketed by padded frame count"
-                                f"{f'; {args.streams} in flight on {args.streams} HIP streams' if args.streams > 1 else ''}), " if args.stream else
+                                f"{len(batches)} ragged micro-batches (<= {args.batch}, bucketed by padded frame count), " if args.stream else
                                 f"{cfg_name}: {args.backbone} batch={args.batch}x{args.seconds:g} s@16 kHz per GPU, ") +
                                (f"{args.N}-step PC sampler (reverse_diffusion + {args.corrector} x{args.corrector_steps}), " if args.sampler == "pc"
                                 else "probability-flow ODE sampler (RK45, rtol = atol = 1e-5), ") +

@@ -48,7 +48,6 @@ def main():
     p.add_argument("--precision", choices=("fp32", "bf16", "fp16"), default="fp32")
     p.add_argument("--batch", type=int, default=16)
     p.add_argument("--seed", type=int, default=None, help="Philox seed of the sampler noise (default: drawn from torch's RNG, as the reference)")
-    p.add_argument("--streams", type=int, default=1, help="micro-batches in flight at once on this GPU (own HIP stream + host thread each)")
     p.add_argument("--dist-world1", action="store_true", help="with ONE rank: form the RCCL process group anyway (dry run of the sharded path on one GPU)")
     args = p.parse_args()
 
@@ -91,7 +90,8 @@ def main():
             outs = [x_hat[k, :lens[k]] for k in range(len(ids))]
         return ids, outs
 
-    for ids, outs in D.run_concurrent(run, D.bucket_by_frames([lengths[i] for i in mine], args.batch), args.streams):
+    for batch in D.bucket_by_frames([lengths[i] for i in mine], args.batch):
+        ids, outs = run(batch)
         for i, x in zip(ids, outs):
             write_wav(os.path.join(args.enhanced_dir, os.path.basename(files[i])), x.float().reshape(-1), 16000)
     D.finish()

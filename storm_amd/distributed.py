@@ -152,69 +152,6 @@ def bucket_by_frames(lengths, max_batch, hop=128, multiple=64):
     return batches
 
 
-_SIDE_STREAMS = {}                 # (device index, k) -> torch.cuda.Stream: created once (the score network keeps one scratch per stream)
-
-
-def _walk_tensors(obj):
-    if isinstance(obj, torch.Tensor):
-        yield obj
-    elif isinstance(obj, (list, tuple)):
-        for o in obj:
-            yield from _walk_tensors(o)
-    elif isinstance(obj, dict):
-        for o in obj.values():
-            yield from _walk_tensors(o)
-
-
-def run_concurrent(fn, items, n_streams, device=None):
-    """results[k] = fn(items[k]) with up to `n_streams` items in flight on the GPU at once: one host thread + one HIP stream per lane,
-    items handed out in order.  For INDEPENDENT micro-batches of a ragged stream (BASELINE.json configs[4]): a two- or three-row batch
-    leaves most CUs idle in the low-resolution half of the network and - with the ODE sampler - the GPU idles through every step
-    controller's host read; a second and third sampler fill both.  Every lane runs the unchanged sampler on its own stream (own scratch,
-    own recorded graphs), so an item's result does not depend on what ran beside it.  On return the results are complete and safe to
-    use on the caller's stream.  n_streams <= 1 (or a CPU device) is the plain loop."""
-    items = list(items)
-    dev = torch.device(device) if device is not None else (torch.device("cuda", torch.cuda.current_device()) if torch.cuda.is_available() else None)
-    if n_streams <= 1 or len(items) <= 1 or dev is None or dev.type != "cuda":
-        return [fn(it) for it in items]
-    import threading
-    idx = dev.index if dev.index is not None else torch.cuda.current_device()
-    lanes = min(n_streams, len(items))
-    streams = [_SIDE_STREAMS.setdefault((idx, k), torch.cuda.Stream(device=idx)) for k in range(lanes)]
-    main = torch.cuda.current_stream(idx)
-    ready = torch.cuda.Event()
-    ready.record(main)
-    results, errors = [None] * len(items), []
-    lock, nxt = threading.Lock(), iter(range(len(items)))
-
-    def lane(s):
-        try:
-            torch.cuda.set_device(idx)
-            s.wait_event(ready)                             # whatever the caller enqueued (the inputs' H2D copies) comes first
-            with torch.cuda.stream(s), torch.no_grad():
-                while not errors:
-                    with lock:
-                        k = next(nxt, None)
-                    if k is None:
-                        break
-                    results[k] = fn(items[k])
-            s.synchronize()
-        except BaseException as e:                          # noqa: BLE001 - re-raised on the calling thread
-            errors.append(e)
-
-    threads = [threading.Thread(target=lane, args=(s,), daemon=True) for s in streams]
-    for t in threads:
-        t.start()
-    for t in threads:
-        t.join()
-    if errors:
-        raise errors[0]
-    for t in _walk_tensors(results):                        # allocated on a side stream, consumed on the caller's
-        if t.is_cuda:
-            t.record_stream(main)
-    return results
-
-
 def gather_objects(obj, rank, world):
     """All ranks' python objects on rank 0 (None elsewhere)."""
     if world == 1:

@@ -289,54 +289,6 @@ def test_ragged_micro_batch_equals_per_utterance_runs(dev):
         m.enhance_batch(torch.zeros(2, 9000).to(dev), lengths=[9000, 4000])     # 71 vs 32 frames: not one bucket
 
 
-def test_run_concurrent_is_the_plain_loop_without_a_gpu():
-    """storm_amd.distributed.run_concurrent on a host without a GPU (or with one lane): fn over the items, in order"""
-    from storm_amd import distributed as D
-    seen = []
-    assert D.run_concurrent(lambda v: (seen.append(v), v * v)[1], [3, 1, 2], 3, device="cpu") == [9, 1, 4] and seen == [3, 1, 2]
-    assert D.run_concurrent(lambda v: -v, [5], 4) == [-5]
-
-
-@pytest.mark.gpu
-@pytest.mark.parametrize("sampler", ["pc", "ode"])
-def test_concurrent_micro_batches_equal_the_sequential_stream(sampler):
-    """BASELINE.json configs[4] scheduling: the micro-batches of a ragged stream are independent, so three of them are kept in flight
-    on three HIP streams (own host thread, own scratch, own recorded graphs: storm_amd.distributed.run_concurrent).  Every utterance
-    must come out bit for bit as in the sequential stream - PC sampler (seeded in-kernel Philox noise per micro-batch) and the ODE
-    sampler (one RK45 step controller per row, host reads every step) - with graph replay on, tail batches of 1 - 3 rows."""
-    from tests.backend import setup_backend
-    from storm_amd import distributed as D
-    from storm_amd.model import ScoreModel
-    dev = setup_backend("hip")
-    m = ScoreModel(backbone="ncsnpp", **{**COMMON, "nf": 16})
-    m.dnn.load_state_dict(NR.seeded_state_dict(NR.NCSNppConfig(nf=16, input_channels=4), seed=5))
-    m.eval(no_ema=True)
-    m = m.to(dev)
-    m.set_precision("fp16")
-    m.dnn.set_graph(1)
-    g = torch.Generator().manual_seed(77)
-    lens = [int(v) for v in torch.randint(6000, 30001, (11,), generator=g)]
-    batches = []
-    for ids in D.bucket_by_frames(lens, 3):
-        bl = [lens[i] for i in ids]
-        yb = torch.zeros(len(ids), max(bl))
-        for k, n_ in enumerate(bl):
-            yb[k, :n_] = 0.1 * torch.randn(n_, generator=g)
-        batches.append((yb.to(dev), None if len(set(bl)) == 1 else bl))
-    assert len(batches) >= 4
-    kw = dict(sampler_type="pc", N=3, corrector="ald", snr=0.5) if sampler == "pc" else dict(sampler_type="ode", N=3, rtol=1e-3, atol=1e-3)
-
-    def one(kb):
-        k, (yb, bl) = kb
-        return m.enhance_batch(yb, seed=100 + k, lengths=bl, **kw)
-    seq = [o.cpu() for o in D.run_concurrent(one, list(enumerate(batches)), 1)]
-    for rep in range(2):
-        par = [o.cpu() for o in D.run_concurrent(one, list(enumerate(batches)), 3)]
-        for a, b in zip(seq, par):
-            assert torch.isfinite(a).all() and torch.equal(a, b)
-    assert m.dnn.graph_launches() > 0
-
-
 @pytest.mark.gpu
 @pytest.mark.parametrize("dtype,tol", [(torch.float32, 2e-3), (torch.float16, 3e-2)])
 def test_configs4_ode_ragged_rows_vs_reference_per_utterance_runs(golden, dtype, tol):
