@@ -71,11 +71,6 @@ template <int BN_, int TH_> struct PCfg {
     static constexpr int PPIECES = (NPIX + 7) / 8;            // 1-KiB DMA pieces (8 rows) of a haloed patch
     static constexpr int PATCH_BYTES = PPIECES * 1024;
     static constexpr int CPIECES = TH * 4;                    // pieces of a compact (one-tap) patch
-    // one-tap chunks (round 5): a chunk's TH x 32 pixels are staged as two HALF images of 32 channels (64 B per pixel), each the operand of
-    // one phase, in a ring of four half slots (two per patch buffer)
-    static constexpr int HALF_BYTES = TH * 32 * 64;            // 16 KiB
-    static constexpr int HPIECES = HALF_BYTES / 1024;          // 1-KiB DMA pieces (16 pixels) of a half image
-    static constexpr int HSLOT = HPIECES / 4;                  // ... per lagging wave
     static constexpr int NLAG = 4;                            // patch-fetching (lagging) waves
     static constexpr int NSLOT = (PPIECES + NLAG - 1) / NLAG; // haloed pieces per lagging wave (one per phase)
     static constexpr int NSLOT1 = CPIECES / NLAG;             // compact pieces per lagging wave
@@ -99,7 +94,6 @@ template <int BN_, int TH_> struct PCfg {
     static_assert(PATCH_BYTES % 256 == 0, "k-group XOR must stay inside the slot field");
     static_assert(NSLOT * NLAG - PPIECES < NLAG, "at most one surplus slot per wave");
     static_assert(CPIECES % NLAG == 0 && NSLOT1 <= NSLOT, "compact pieces fit the same slots");
-    static_assert(2 * HALF_BYTES <= PATCH_BYTES && 2 * HPIECES == CPIECES && NSLOT1 == 2 * HSLOT, "two half slots per patch buffer");
     static_assert(NSLOT - 1 + LAZY <= 16, "the whole patch is transformed two phases before a nine-tap chunk ends");
 };
 
@@ -191,10 +185,7 @@ __device__ __forceinline__ void conv_pipe_body(const PipeParams& a, const int n_
     int pbase[3];
 #pragma unroll
     for (int d = 0; d < 3; ++d) pbase[d] = ((wn * WN) * PW + (lane & 31)) * PIXB + p_swz((lane & 31) + d, lane >> 5);
-    // one-tap half images: this lane's pixel of ni = 0, k-group 0 (k-group 1: ^ 32; pixel row ni: + 2 KiB; half slot: + half_off(q))
-    int hbase = ((wn * WN) * TILE_W + (lane & 31)) * 64 + (((lane >> 5) ^ (((lane & 31) >> 2) & 3)) << 4);
-    auto half_off = [&](int q) { return (q >> 1) * PATCH_BYTES + (q & 1) * Cfg::HALF_BYTES; };
-    int hq = 0, hj = 0;                                     // one-tap section: half slot being read / its index in the section
+    const int cdelta = wn * WN * (PW - TILE_W) * PIXB;      // haloed row index - compact row index of this wave's pixels (uniform)
 
     // ---- role registers ---------------------------------------------------------------------------------------
     // leading waves: R[j] = per-lane source offset of weight piece j of the current run;
@@ -272,30 +263,18 @@ __device__ __forceinline__ void conv_pipe_body(const PipeParams& a, const int n_
         dma16(nx_srd, ok ? mad24(v >> 3, (uint32_t)nx_C2, (v & 7u) * 16u) : OOB, (uint32_t)nx_cbeg2,
               smem + into * PATCH_BYTES + k * 1024, lane);
     };
-    // (lagging) one-tap chunks: piece kk = lw + 4 i (i = 0 .. HSLOT - 1) of HALF image hf of a chunk -> half slot q (0, 1: patch buffer 0;
-    // 2, 3: buffer 1).  Half image: pixel p = 32 row + col at 64 p, its four 16-B slots (8 channels each) XOR-swizzled by (col >> 2) & 3 -
-    // the 16 lanes of a fragment-read group (16 consecutive columns, 64 B apart) then hit 16 distinct bank groups.  A piece = 16 pixels.
-    auto issue_half_piece = [&](const u32x4& srd, int C2, int cbeg2, int cvalid, int hf, int i, int q) {
-        const int kk = lw + Cfg::NLAG * i;
-        const int pq = kk * 16 + (lane >> 2), trow = pq >> 5, n = pq & 31;
-        const int slot = (lane & 3) ^ ((n >> 2) & 3);
+    // (lagging) one compact piece (one-tap chunk: TH x 32 pixels, no halo): piece k = pixel row k >> 2, columns 8 (k & 3) ..
+    auto issue_compact = [&](int k, int into) {
+        const int trow = k >> 2, n = (k & 3) * 8 + (lane >> 3);
+        const int slot = (lane & 7) ^ ((n >> 1) & 7);
         const int gy = ty0 + trow, gx = tx0 + n;
-        const bool ok = gy < imgH && gx < imgW && hf * 32 + slot * 8 < cvalid;
-        dma16(srd, ok ? mad24((uint32_t)(gy * imgW + gx), (uint32_t)C2, (uint32_t)(hf * 64 + slot * 16)) : OOB, (uint32_t)cbeg2,
-              smem + (q >> 1) * PATCH_BYTES + (q & 1) * Cfg::HALF_BYTES + kk * 1024, lane);
-    };
-    // (lagging) half jf of the tile's one-tap section (descriptor n9 + jf / 2; past the last chunk: the terminator, zeros) -> half slot q
-    auto issue_future_half = [&](int jf, int q) {
-        const int i = n9 + (jf >> 1);
-        const ChunkDesc& d = ap->chunk[SPLIT ? (i < nchunks ? c0 + i : nchunks_k) : (i < nchunks_k ? i : nchunks_k)];
-        const u32x4 srd = make_srd(reinterpret_cast<const char*>(d.src + (unsigned long long)b * d.bstride), d.src_bytes);
-        const int C2 = d.C2, cbeg2 = d.cbeg2, cvalid = d.cvalid;
-#pragma unroll
-        for (int k = 0; k < Cfg::HSLOT; ++k) issue_half_piece(srd, C2, cbeg2, cvalid, jf & 1, k, q);
+        const bool ok = gy < imgH && gx < imgW && slot * 8 < nx_cvalid;
+        dma16(nx_srd, ok ? mad24((uint32_t)(gy * imgW + gx), (uint32_t)nx_C2, (uint32_t)slot * 16u) : OOB, (uint32_t)nx_cbeg2,
+              smem + into * PATCH_BYTES + k * 1024, lane);
     };
     auto issue_any = [&](int i, int into) {                 // (lagging) slot i, in the next chunk's layout
         if (nx_ntaps == 9) issue_slot(i, into);
-        else if (i < NSLOT1) issue_half_piece(nx_srd, nx_C2, nx_cbeg2, nx_cvalid, i / Cfg::HSLOT, i % Cfg::HSLOT, into * 2 + i / Cfg::HSLOT);
+        else if (i < NSLOT1) issue_compact(lw + Cfg::NLAG * i, into);
         else issue_table(into);                              // surplus slot (keeps the VMEM count uniform)
     };
     // (lagging) fused GroupNorm-apply (+ SiLU): in place, by the lane that fetched the unit (haloed layout only)
@@ -356,7 +335,7 @@ __device__ __forceinline__ void conv_pipe_body(const PipeParams& a, const int n_
     };
     Frag fa0[WM], fb0[WN], fa1[WM], fb1[WN];
     int tstep = 0;                                          // (profiling) tap-steps stamped so far
-    typedef IC<PW * PIXB> Prow9; typedef IC<TILE_W * 64> Prow1;
+    typedef IC<PW * PIXB> Prow9; typedef IC<TILE_W * PIXB> Prow1;
 
     // ---- one tap-step (two phases) of a chunk with NT taps; TP = tap index ------------------------------------------
     auto tap_step = [&](auto t_, auto nt_) {
@@ -367,6 +346,7 @@ __device__ __forceinline__ void conv_pipe_body(const PipeParams& a, const int n_
         constexpr int POFFN = NT == 9 ? (((TP + 1) / 3) * PW + DXN) * PIXB : 0;
         typedef IC<POFF> Poff; typedef IC<POFFN> PoffN;
         typedef std::conditional_t<NT == 9, Prow9, Prow1> Prow;
+        const int pb = NT == 9 ? pbase[DX] : pbase[0] - cdelta;
         const int into = par ^ 1;
         const int sb = tstep < 30 ? 4 + 16 * tstep : 4096;   // (profiling: the first 30 tap-steps are stamped)
         // the weight stream moves to the next tap (last tap: to the first tap of the next chunk)
@@ -380,15 +360,9 @@ __device__ __forceinline__ void conv_pipe_body(const PipeParams& a, const int n_
             constexpr int h = decltype(h_)::value;
             constexpr int p = 2 * TP + h;                    // phase of the chunk
             constexpr bool pdma = !(ABL & 128);
-            // a one-tap phase reads half slot hq (k-groups 0, 1 of ITS image); a nine-tap phase k-groups 2 h, 2 h + 1 of the haloed patch
-            const int pb = NT == 9 ? pbase[DX] : hbase + half_off(hq);
-            typedef IC<NT == 9 ? 2 * h + 1 : 1> K1;
             // ================= S =================
             stamp(sb + (h ? 7 : 0));
-            if constexpr (NT == 1) {                             // (not pre-read: the half was waited for ONE interval ago - see top)
-                if constexpr (h == 0) read_frags(fa0, fb0, ring_rd, pb, IC<0>{}, IC<0>{}, Prow{});
-                else static_for<WN>([&](auto ni_) { read_b(fb0[decltype(ni_)::value], pb, IC<0>{}, IC<0>{}, Prow{}, ni_); });
-            }
+            if constexpr (NT == 1 && h == 0) read_frags(fa0, fb0, ring_rd, pb, IC<0>{}, Poff{}, Prow{});   // (not pre-read: see top)
             if (grp == 0) {
                 w_issue(h);
                 stamp(sb + (h ? 12 : 1));
@@ -402,16 +376,12 @@ __device__ __forceinline__ void conv_pipe_body(const PipeParams& a, const int n_
                     vm_wait<(p < NSLOT ? p : NSLOT - 1) - i>();
                     if (nx_gn) commit_slot(i, into);
                 }
-            } else if constexpr (pdma) {
-                // one-tap phase hj: half hj + 3 -> the slot half hj - 1 left one interval ago (both groups are past its C); the first
-                // phase issues halves 2 AND 3 (the buffer the last nine-tap chunk has just left; halves 0, 1 came in under that chunk).
-                // Then: everything but the two newest halves has landed, i.e. half hj + 1 - read from the next interval on.  A half has
-                // two phases between its issue and its wait (the whole-chunk fetch of rounds 2 - 4 had one, and fetched in bursts of
-                // 32 KiB per workgroup: idx 103 of profiles/r04f_ops.json lost 3.1 us per one-tap chunk to it).
-                if (hj == 0) { issue_future_half(2, (hq + 2) & 3); issue_future_half(3, (hq + 3) & 3); }
-                else issue_future_half(hj + 3, (hq + 3) & 3);
+            } else if constexpr (pdma) {                         // one-tap chunk: the whole compact patch of the next chunk
+                if constexpr (h == 0) {
+#pragma unroll
+                    for (int i = 0; i < NSLOT1; ++i) issue_compact(lw + Cfg::NLAG * i, into);
+                } else vm_wait<0>();
                 stamp(sb + (h ? 12 : 1));
-                vm_wait<2 * Cfg::HSLOT>();
             }
             stamp(sb + (h ? 8 : 2));
             raw_barrier();
@@ -432,11 +402,11 @@ __device__ __forceinline__ void conv_pipe_body(const PipeParams& a, const int n_
                 };
                 auto next_b = [&](auto ni_) {
                     constexpr int ni = decltype(ni_)::value;
-                    if constexpr (NT == 1) { (void)ni; }             // (a one-tap phase reads its pixel fragments at the start of its own S)
-                    else if constexpr (h == 0) read_b(fb0[ni], pb, IC<2>{}, Poff{}, Prow{}, ni_);
+                    if constexpr (h == 0) read_b(fb0[ni], pb, IC<2>{}, Poff{}, Prow{}, ni_);
                     else if constexpr (TP < NT - 1) read_b(fb0[ni], pbase[DXN], IC<0>{}, PoffN{}, Prow{}, ni_);
                     else if constexpr (NT == 9) { if (nx_ntaps == 9) read_b(fb0[ni], pbase[0] + (par ? -PATCH_BYTES : PATCH_BYTES), IC<0>{}, IC<0>{}, Prow9{}, ni_); }
                 };
+                typedef IC<2 * h + 1> K1;
 #define STORM_SB() __builtin_amdgcn_sched_barrier(0)
                 if constexpr (WM * WN == 4) {
                 // <128, 8>: four MFMAs per k-group (fa[i / 2], fb[i % 2]); the same rule - one or two reads per MFMA gap, a fragment
@@ -478,14 +448,13 @@ __device__ __forceinline__ void conv_pipe_body(const PipeParams& a, const int n_
             } else {
             mma_part(fa0, fb0, 0, 2);                            // the matrix pipe starts at once (operands were pre-read)
             __builtin_amdgcn_sched_barrier(0);
-            read_frags(fa1, fb1, ring_rd, pb, K1{}, Poff{}, Prow{});
+            read_frags(fa1, fb1, ring_rd, pb, IC<2 * h + 1>{}, Poff{}, Prow{});
             __builtin_amdgcn_sched_barrier(0);
             mma_part(fa0, fb0, 2, WM * WN);
             __builtin_amdgcn_sched_barrier(0);
             {   // first k-group of the NEXT phase into the registers the MFMAs above have consumed
                 const int rn = (ring_rd + WPHASE) & (RINGB - 1);
-                if constexpr (NT == 1) { if constexpr (h == 0) static_for<WM>([&](auto mi_) { read_a(fa0[decltype(mi_)::value], rn, IC<2>{}, mi_); }); }
-                else if constexpr (h == 0) read_frags(fa0, fb0, rn, pb, IC<2>{}, Poff{}, Prow{});
+                if constexpr (h == 0) read_frags(fa0, fb0, rn, pb, IC<2>{}, Poff{}, Prow{});
                 else if constexpr (TP < NT - 1) read_frags(fa0, fb0, rn, pbase[DXN], IC<0>{}, PoffN{}, Prow{});
                 else if constexpr (NT == 9) {                    // next chunk: the other buffer (a one-tap chunk reads in its own S)
                     if (nx_ntaps == 9) read_frags(fa0, fb0, rn, pbase[0] + (par ? -PATCH_BYTES : PATCH_BYTES), IC<0>{}, IC<0>{}, Prow9{});
@@ -499,7 +468,6 @@ __device__ __forceinline__ void conv_pipe_body(const PipeParams& a, const int n_
             __builtin_amdgcn_sched_barrier(0);
             prio(0);
             ring_next();
-            if constexpr (NT == 1) { hq = (hq + 1) & 3; ++hj; }
         });
         stamp(sb + 11);
         if (TRACE) ++tstep;
@@ -563,8 +531,6 @@ __device__ __forceinline__ void conv_pipe_body(const PipeParams& a, const int n_
             static_for<9>([&](auto t) { tap_step(t, IC<9>{}); });
             chunk_change(ci + 1);
         }
-        hq = par * 2; hj = 0;                               // halves 0, 1 of the one-tap section wait in the buffer the last nine-tap chunk filled
-        launder(hbase);
         for (; ci < nchunks; ++ci) {
             tap_step(IC<0>{}, IC<1>{});
             chunk_change(ci + 1);

@@ -64,7 +64,7 @@ def test_conv_persistent_tile_loop(dev, dtype, k, switch):
 
 @pytest.mark.parametrize("variant", [3, 7, 9])
 @pytest.mark.parametrize("case", ["plain", "block_tail", "gn_fused", "ragged", "deep_k", "skip", "plain@8", "block_tail@8", "gn_fused@8",
-                                  "skip@8", "plain:f16", "gn_fused:f16"])
+                                  "skip@8", "deep_k@8", "plain:f16", "gn_fused:f16", "deep_k:f16"])
 def test_conv_pipelined_kernels(dev, variant, case, switch):
     """conv_pipe.hip (chunk-unrolled LDS-DMA pipeline, 256-cout tile; variant 9: its 128-cout tile for layers with few pixel
     tiles) on shapes the default dispatch would give to conv_igemm.hip: plain 3x3, fused 1x1 shortcut over a concat, fused GroupNorm-apply operand, ragged sizes, many
