@@ -30,6 +30,11 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 METRIC = "enhanced utterances/sec @ 30 PC steps, NCSN++ 27.8M, 4 s@16 kHz"
+# What the matrix pipes sustain at the socket's 1400 W cap on RANDOM bf16 operands when every 8 MFMAs re-read their six fragments from LDS,
+# which every convolution must (tools/ubench/mfma_rate.hip, profiles/r02_ubench.txt / r03_ubench.txt: 1.55 - 1.57 PF; registers only: 1.82 PF;
+# the 2.5 PF datasheet figure needs quiet operands and no operand traffic).  `roofline.power_bound` divides by THIS: the honest second denominator.
+POWER_BOUND_TFLOPS = {"bf16": 1550.0, "fp16": 1440.0, "fp32": None}     # (fp16: the same streams run 7 % slower, profiles/r04_power_probe.txt)
+POWER_CAP_W = 1400.0
 HBM_PEAK_GBS = 8000.0            # HBM3E specification (MI355X_MICROARCH.md); measured float4 copy: 6290
 BF16_MFMA_PEAK_TFLOPS = 2500.0      # MI355X_MICROARCH.md: dense bf16 MFMA peak
 F32_MFMA_PEAK_TFLOPS = 157.3
@@ -174,6 +179,49 @@ def profile_ops(net, Y, nfe_count):
     return rows
 
 
+class PowerSampler:
+    """Socket power / shader clock beside the timed steps (rocm-smi, one sample per ~0.1 s in a host thread; nothing when rocm-smi is
+    missing): the convolutions of this workload run AT the 1400 W cap (profiles/r04_power_probe.txt), so throughput per watt is the
+    quantity a kernel change can move."""
+
+    def __init__(self):
+        import shutil
+        import threading
+        self.samples, self.stop = [], False
+        self.thread = threading.Thread(target=self._run, daemon=True) if shutil.which("rocm-smi") else None
+
+    def _run(self):
+        import re
+        import subprocess
+        while not self.stop:
+            try:
+                out = subprocess.run(["rocm-smi", "--showpower", "--showclocks"], capture_output=True, text=True, timeout=5).stdout
+                w = re.search(r"Power \(W\):\s*([\d.]+)", out)
+                c = re.search(r"sclk clock level:.*?\((\d+)Mhz\)", out)
+                if w:
+                    self.samples.append((float(w.group(1)), int(c.group(1)) if c else -1))
+            except Exception:  # noqa: BLE001
+                pass
+            time.sleep(0.05)
+
+    def __enter__(self):
+        if self.thread:
+            self.thread.start()
+        return self
+
+    def __exit__(self, *a):
+        self.stop = True
+        if self.thread:
+            self.thread.join(timeout=10)
+
+    def summary(self):
+        hot = sorted(s for s in self.samples if s[0] > 0.6 * POWER_CAP_W)      # (samples taken while the GPU was loaded)
+        if not hot:
+            return None
+        return {"median_w": hot[len(hot) // 2][0], "max_w": hot[-1][0], "median_sclk_mhz": sorted(h[1] for h in hot)[len(hot) // 2],
+                "samples": len(hot), "cap_w": POWER_CAP_W}
+
+
 def selftest_cpu(args, rank, world):
     """Launch / sharding / timing skeleton on CPU ranks (gloo) with a stand-in step: what tests/test_distributed.py runs."""
     import torch.distributed as dist
@@ -262,7 +310,9 @@ def main():
             nfes.append(n_ * yb.shape[0])
         return out, sum(nfes) / args.stream                 # mean score evaluations per utterance
 
-    elapsed, per_rank, (out, nfe) = D.timed_steps(step, args.steps, args.warmup, sync=torch.cuda.synchronize, single_rank_group=args.dist_world1)
+    with PowerSampler() as power:
+        elapsed, per_rank, (out, nfe) = D.timed_steps(step, args.steps, args.warmup, sync=torch.cuda.synchronize, single_rank_group=args.dist_world1)
+    power = power.summary() if rank == 0 else None
     assert torch.isfinite(out).all(), "non-finite output"
     value = units * world * args.steps / elapsed
     h2d = None
@@ -340,9 +390,15 @@ def main():
             traffic = tj.get(kname.replace("storm::", "").replace(" ", ""), {}).get("hbm_bytes_per_launch")
             tsrc = "profiles/conv_traffic.json: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes, FETCH_SIZE x2 per the " \
                    "gfx950 correction) over this bench command, average per launch of this kernel; not re-measured in this run"
-        by_kernel = {k: {"launches_per_nfe": len(v), "ms_per_nfe": round(sum(r["ms"] for r in v), 3),
-                         "tflops": round(sum(r["flops"] for r in v) / (sum(r["ms"] for r in v) * 1e-3) / 1e12, 1)}
-                     for k, v in groups.items()}
+        # socket power of each kernel family running sustained (tools/power_probe.py, profiles/r04_power_probe.txt: one kernel back to back for 4 s)
+        probe_w = {"conv_pipe_kernel": 1397.0, "conv_pipe128_kernel": 1328.0, "conv_igemm_kernel": 1371.0, "conv_pipe_splitk_kernel": None}
+        by_kernel = {}
+        for k, v in groups.items():
+            tf = sum(r["flops"] for r in v) / (sum(r["ms"] for r in v) * 1e-3) / 1e12
+            w = next((pw for nm, pw in probe_w.items() if nm in k), None)
+            by_kernel[k] = {"launches_per_nfe": len(v), "ms_per_nfe": round(sum(r["ms"] for r in v), 3), "tflops": round(tf, 1),
+                            "probe_w": w, "tflops_per_kw": None if not w else round(tf / (w / 1e3), 1),
+                            "pj_per_flop": None if not w else round(w / tf, 3)}
         result["roofline"] = {
             "bound": "mfma", "kernel": kname,
             "achieved": ach, "peak": peak, "unit": "TFLOP/s", "frac": ach / peak, "traffic": traffic, "traffic_source": tsrc,
@@ -356,6 +412,14 @@ def main():
                                                     "tflops": round(sum(r["flops"] for r in v) / (sum(r["ms"] for r in v) * 1e-3) / 1e12, 1)}
                                        for (h, w), v in sorted({(r["H"], r["W"]): [q for q in big if (q["H"], q["W"]) == (r["H"], r["W"])] for r in big}.items(),
                                                                reverse=True)},
+            # the second denominator: what the part sustains at its 1400 W cap for this operand mix (POWER_BOUND_TFLOPS above)
+            "power_bound": None if POWER_BOUND_TFLOPS[args.precision] is None else {
+                "tflops_at_cap": POWER_BOUND_TFLOPS[args.precision], "cap_w": POWER_CAP_W, "frac": ach / POWER_BOUND_TFLOPS[args.precision],
+                "source": "tools/ubench/mfma_rate.hip on random operands with the convolutions' 6 LDS fragment reads per 8 MFMAs, sustained at the "
+                          "socket cap (profiles/r02_ubench.txt, r03_ubench.txt); the kernels of this evaluation run at 1328 - 1400 W "
+                          "(profiles/r04_power_probe.txt)"},
+            "power": power,
+            "evaluation_tflops_per_kw": None if not power else round(sum(r.get("flops", 0) for r in rows) / (total_ms * 1e-3) / 1e12 / (power["median_w"] / 1e3), 1),
             "all_3x3_tflops": sum(r["flops"] for r in all3) / (sum(r["ms"] for r in all3) * 1e-3) / 1e12,
             "all_conv_tflops": sum(r["flops"] for r in all_conv) / (sum(r["ms"] for r in all_conv) * 1e-3) / 1e12,
             "method": f"HIP events per op on the launch stream (storm_program_run_timed) over {args.profile_nfe} score "

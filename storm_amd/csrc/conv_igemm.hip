@@ -32,6 +32,7 @@
 #include "common.h"
 #include "conv_index.h"
 #include "conv_params.h"
+#include "conv_dispatch_table.h"
 
 namespace storm {
 using namespace cidx;
@@ -690,6 +691,21 @@ static int splitk_slices_of(const storm_conv_args& a) {
     return S;
 }
 
+// The measured exceptions to the ladder below (conv_dispatch_table.h, regenerated by tools/tune_dispatch.py): -1 = no entry
+static int table_variant(const storm_conv_args& a) {
+    if (a.dtype == STORM_F32 || a.seg[0].ntaps != 9 || a.nseg > 2 || switches().conv_table == 0) return -1;
+    const int k9 = a.seg[0].Ca + a.seg[0].Cb, k1 = a.nseg == 2 ? a.seg[1].Ca + a.seg[1].Cb : 0;
+    if (a.nseg == 2 && a.seg[1].ntaps != 1) return -1;
+    const int tiles_img = cdiv(a.W, TILE_W) * cdiv(a.H, TILE_H);
+    for (const DispatchEntry& e : kDispatchTable)
+        if (e.variant >= 0 && e.k9 == k9 && e.k1 == k1 && e.outC == a.outC && e.tiles_img == tiles_img && a.B >= e.images_lo && a.B <= e.images_hi) {
+            const bool ok = e.variant == 0 || e.variant == 2 || e.variant == 7 || ((e.variant == 3 || e.variant == 9) && conv_pipe_supports(a)) ||
+                            (e.variant == 4 && conv_pipe128_supports(a));
+            return ok ? e.variant : -1;
+        }
+    return -1;
+}
+
 static int choose_variant(const storm_conv_args& a, bool any9) {
     const int forced = switches().conv_variant;                      // (test / A-B hook, storm_set_switch)
     if (forced >= 0 && forced != 10) return forced;
@@ -700,25 +716,39 @@ static int choose_variant(const storm_conv_args& a, bool any9) {
     if (forced == 10) return conv_pipe_supports(a) ? 9 : 0;        // (forced split without scratch / with one chunk: the unsplit tile)
     if (conv_thin_supports(a)) return 6;
     if (conv_narrow_supports(a)) return 8;
+    if (any9 && a.outC > 32) { const int tv = table_variant(a); if (tv >= 0) return tv; }
     const long long px_tiles = (long long)a.B * cdiv((long long)a.H * a.W, TILE_H * TILE_W);
-    if (a.outC > 128 && px_tiles >= 512) return any9 && conv_pipe_supports(a) ? 3 : 2;
-    // fewer than 512 pixel tiles (the 32 x 64 level of NCSN++ at batch 16; 32 x 128 ... 4 x 16 of ncsnpplarge at batch 8): the launch time is the
-    // serial chain of phases per workgroup, not throughput.  conv_pipe with 128-cout tiles (<128, 8>: twice the workgroups of its
-    // 256-cout tile, half the MFMAs per phase and wave) against the 256-cout tile / the generic 64-cout tiles on all CUs, same box
-    // (profiles/r04_probe_small_half.txt): 256 -> 256 @ 16 x 32 x 64: 48.6 vs 66.7 / 72.1 us, 512 -> 256: 84.0 vs 109 / 133;
-    // 8 x 16 x 64: 38.2 vs 52.7 / 43.7; 8 x 8 x 32: 36.1 vs 51.0 / 41.1; 8 x 4 x 16: 31.8 vs 46.9 / 37.7
-    if (a.outC > 128 && any9 && conv_pipe_supports(a)) return 9;
-    // conv_pipe128: measured against this file's two-workgroup kernel on MI355X, each kernel sustained in its own process, alternating
-    // (profiles/r04_duo_fair_ab.txt, profiles/r04_half_fair_ab.txt: two boxes).  The three structures stay within 5 % of each other
-    // (the part runs these layers at its power cap); conv_pipe128 is ahead on both boxes where its per-tile fixed cost is
-    // amortised - 4 of its tiles per CU (128 x 256 x 16: +0 ... +20 %) and, at 16 tiles per CU (256 x 512 x 16), the layers with >= 256
-    // input channels (384 -> 128: +2.6 / +4.6 %, 256 -> 128: +0.7 / +3.2 %) - and behind or level on 128 -> 128 there (-3 / 0 %), with or
-    // without the fused 1x1 shortcut.  (A stem-like layer with fewer than 32 input channels is HBM-bound either way.)
     const int cin9 = a.seg[0].Ca + a.seg[0].Cb;
-    if (a.outC > 32 && a.outC <= 128 && any9 && px_tiles >= 1024 && (px_tiles <= 4096 || cin9 >= 256) && cin9 >= 32 &&
-        switches().conv_pipe128 != 0 && conv_pipe128_supports(a)) return 4;    // (A/B switch: 0 = conv_igemm for these layers)
-    // so few pixel tiles that 128-cout tiles do not give every CU its two workgroups (the 32 x 64 level of NCSN++ at 4 s: 128
-    // pixel tiles x 2 cout tiles): 64-cout tiles double the workgroups (measured +5 % on 256 -> 256 and 512 -> 256 @ 32 x 64 x 16)
+    const int cus = device_cus();
+    if (a.outC > 128 && !(any9 && conv_pipe_supports(a)) && px_tiles >= 512) return 2;       // (1x1 / NIN / GEMMs, the fp32 parity path)
+    if (a.outC > 128 && any9 && conv_pipe_supports(a)) {
+        // conv_pipe's 256-cout tile (3) or its 128-cout tile (9: twice the workgroups, each with the same chain of phases but 8 MFMAs per phase
+        // and wave instead of 16).  A launch lasts rounds x (phases x time per phase + ~12 us fixed): 0.6 us per phase for the 256-cout tile,
+        // 0.36 us for the 128-cout one (profiles/r04_probe_small_half.txt), rounds = workgroups / CUs rounded up (one workgroup per CU).  Up to
+        // 128 pixel tiles the half tile wins (one round either way: 256 -> 256 @ 16 x 32 x 64 48.6 vs 66.7 us); from 129 on its second round
+        // costs more than the 256-cout tile's idle CUs.  Rounds 1 - 4 sent everything below 512 pixel tiles to the half tile: measured wrong
+        // by the tuner in round 5 wherever a call is not the bench batch (profiles/r05_tune_dispatch.log: two utterances @ 128 x 256
+        // 0.075 -> 0.069 ms plain, 0.098 -> 0.080 with a shortcut; ncsnpplarge 8 x 32 x 128 ties; three 10-s rows @ 64 x 320 0.093 -> 0.075).
+        const int n_ph = 2 * (9 * (cdiv(a.seg[0].Ca, 64) + (a.seg[0].Cb ? cdiv(a.seg[0].Cb, 64) : 0)) +
+                              (a.nseg == 2 ? cdiv(a.seg[1].Ca, 64) + (a.seg[1].Cb ? cdiv(a.seg[1].Cb, 64) : 0) : 0));
+        const double t3 = (double)cdiv(px_tiles * cdiv(a.outC, 256), (long long)cus) * (0.60 * n_ph + 12.0);
+        const double t9 = (double)cdiv(px_tiles * cdiv(a.outC, 128), (long long)cus) * (0.36 * n_ph + 12.0);
+        return t9 < t3 ? 9 : 3;
+    }
+    // <= 128 output channels.  Measured against each other on MI355X, each kernel sustained, alternating (profiles/r04_duo_fair_ab.txt,
+    // profiles/r04_half_fair_ab.txt, and the tuner's table profiles/r05_tune_dispatch.log): the structures stay within 5 % of each other
+    // wherever the chip is full (the part runs these layers at its power cap), so the rules are few:
+    //  * up to 256 pixel tiles (one or two utterances at 128 x 256): conv_pipe's 128-cout tile - one workgroup per CU, the pipelined loop -
+    //    beats the 64-cout generic tiles the ladder used there (128 -> 128: 0.024 -> 0.022 ms at one utterance, 0.032 -> 0.027 at two);
+    //  * conv_pipe128 (16 x 32 pixel tiles, triple-buffered patches) where its per-tile fixed cost is amortised: >= 256 input channels from
+    //    512 pixel tiles on (384 -> 128: -5 ... -8 % at every batch size; 256 -> 128: -3 ... -6 %), 128 input channels between 512 and 4096
+    //    pixel tiles (a tie with the generic tile within +-3 %: kept where rounds 2 - 4 measured it ahead);
+    //  * the generic 128-cout tile (two workgroups per CU hide each other's epilogue) everywhere else; its 64-cout form for few-tile
+    //    layers that conv_pipe does not cover (fp32 has its own path).
+    if (a.outC > 32 && any9 && cin9 >= 32) {
+        if (px_tiles <= 256 && conv_pipe_supports(a)) return 9;
+        if (switches().conv_pipe128 != 0 && conv_pipe128_supports(a) && px_tiles >= 512 && (cin9 >= 256 || px_tiles <= 4096)) return 4;
+    }
     if (any9 && a.outC >= 128 && px_tiles * cdiv(a.outC, 128) <= 256) return 7;
     return 0;
 }

@@ -16,7 +16,7 @@ SOURCES = ["abi", "conv_igemm", "conv_pipe", "conv_pipe128", "conv_duo", "conv_t
 
 def build(force=False):
     srcs = [os.path.join(CSRC, s + ".hip") for s in SOURCES] + [os.path.join(HERE, "simrt.cpp")]
-    deps = srcs + [os.path.join(CSRC, "common.h"), os.path.join(CSRC, "conv_index.h"), os.path.join(CSRC, "conv_params.h"), os.path.join(CSRC, "conv_pipe_common.h"), os.path.join(CSRC, "conv_epilogue.h"), os.path.join(CSRC, "hw.h"),
+    deps = srcs + [os.path.join(CSRC, "common.h"), os.path.join(CSRC, "conv_index.h"), os.path.join(CSRC, "conv_params.h"), os.path.join(CSRC, "conv_pipe_common.h"), os.path.join(CSRC, "conv_epilogue.h"), os.path.join(CSRC, "conv_dispatch_table.h"), os.path.join(CSRC, "hw.h"),
                    os.path.join(HERE, "hip_host_shim.h"), os.path.join(ROOT, "include", "storm_hip.h")]
     if not force and os.path.exists(OUT) and all(os.path.getmtime(OUT) >= os.path.getmtime(d) for d in deps):
         return OUT
