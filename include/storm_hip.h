@@ -145,6 +145,14 @@ int storm_attention_supported(int C, int dtype);
 int storm_attention(const void* q, const void* k, const void* vT, const float* bias, void* out, int B, int L, int C, int ldv,
                     long long q_bstride, long long k_bstride, long long vT_bstride, long long out_bstride, float scale,
                     int dtype, storm_stream_t s);
+/* The same with caller scratch: a call whose query blocks leave most CUs idle (one to four utterances) splits the KEY loop into 2 - 8
+ * ranges on as many workgroups and merges them in a second launch (fixed order, no atomics).  storm_attention_scratch_bytes = the scratch
+ * that call wants (0: it runs unsplit; fp32 never splits); scratch NULL or too small = unsplit.  The merged result differs from the
+ * unsplit one by fp32 rounding of the merge (layerspp.py:82-86 computes one softmax over all keys; so does the merge, exactly, in fp32). */
+long long storm_attention_scratch_bytes(int B, int L, int C, int dtype);
+int storm_attention_ws(const void* q, const void* k, const void* vT, const float* bias, void* out, int B, int L, int C, int ldv,
+                       long long q_bstride, long long k_bstride, long long vT_bstride, long long out_bstride, float scale, int dtype,
+                       void* scratch, long long scratch_bytes, storm_stream_t s);
 
 /* ------------------------------------------------------------------------------------------
  * GroupNorm(min(C/4,32) groups, eps) [+ SiLU] [+ FIR x2 up / down of BOTH the activated and

@@ -1,14 +1,14 @@
 #!/bin/bash
-# One GPU-box visit: smoke, the -m gpu suite, the default bench line (roofline + roofline_hbm + cpu_baseline), rocprofv3
+# One GPU-box visit (round 5 form): smoke, the -m gpu suite, the default bench line (roofline + roofline_hbm + cpu_baseline), rocprofv3
 # kernel stats of the same bench command (socket power / clock sampled beside the bench line), HBM-traffic PMC passes (-> conv_traffic.json), SQ counters; the other configs' lines.
 TAG=${1:-r04a}
 mkdir -p gpurun_out
 export TMPDIR=/tmp
 python -c "import __graft_entry__ as g; g.build(); g.smoke()" > gpurun_out/smoke_$TAG.log 2>&1; echo "smoke rc=$?" >> gpurun_out/smoke_$TAG.log; tail -2 gpurun_out/smoke_$TAG.log
-timeout 1500 python -m pytest tests -m gpu -q --tb=short > gpurun_out/pytest_gpu_$TAG.log 2>&1; tail -3 gpurun_out/pytest_gpu_$TAG.log
+STORM_PARITY_JSON=gpurun_out/parity_$TAG.json timeout 2400 python -m pytest tests -m gpu -q --tb=short > gpurun_out/pytest_gpu_$TAG.log 2>&1; tail -3 gpurun_out/pytest_gpu_$TAG.log
 grep -h "rel-L2\|nfev\|vs reference" gpurun_out/pytest_gpu_$TAG.log | head -20
 python tools/power_trace.py gpurun_out/power_$TAG.csv & PT=$!
-timeout 900 python bench.py --include-h2d --ops-json gpurun_out/ops_$TAG.json > gpurun_out/bench_$TAG.json 2> gpurun_out/bench_$TAG.err; head -c 400 gpurun_out/bench_$TAG.json; echo
+timeout 900 python bench.py --ops-json gpurun_out/ops_$TAG.json > gpurun_out/bench_$TAG.json 2> gpurun_out/bench_$TAG.err; head -c 400 gpurun_out/bench_$TAG.json; echo
 kill $PT; sleep 0.3; python tools/power_trace.py --summary gpurun_out/power_$TAG.csv | tee gpurun_out/power_summary_$TAG.txt
 if [ "$2" != "short" ]; then
 timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_$TAG -o trace -- python bench.py --steps 1 --warmup 0 --no-cpu-baseline > gpurun_out/prof_bench_$TAG.json 2> gpurun_out/prof_$TAG.err
@@ -26,3 +26,7 @@ run fp16 --precision fp16 --steps 1 --warmup 1 --no-cpu-baseline
 run cfg3 --backbone ncsnpplarge --seconds 8 --N 50 --batch 8 --steps 1 --warmup 1 --no-cpu-baseline
 run cfg4 --stream 32 --sampler ode --precision fp16 --batch 16 --steps 1 --warmup 0 --no-cpu-baseline
 run cfg4pc --stream 32 --precision fp16 --batch 16 --steps 1 --warmup 0 --no-cpu-baseline
+# the small-call regime (the reference's own operating point is ONE utterance per call): latency / RTF lines with their per-op tables
+run b1 --batch 1 --steps 5 --warmup 2 --no-cpu-baseline --ops-json gpurun_out/ops_${TAG}_b1.json
+run b2 --batch 2 --steps 4 --warmup 2 --no-cpu-baseline --ops-json gpurun_out/ops_${TAG}_b2.json
+run b4 --batch 4 --steps 3 --warmup 1 --no-cpu-baseline --ops-json gpurun_out/ops_${TAG}_b4.json

@@ -27,11 +27,16 @@ constexpr int ATTN_THREADS = attn::THREADS;
 
 __device__ __forceinline__ uint4 ldg16(const void* p) { return *reinterpret_cast<const uint4*>(p); }
 
-template <typename T, int CT>
+// SPLIT (round 5): blockIdx.z walks `nsplit` contiguous ranges of the key tiles; a workgroup leaves its UNNORMALISED accumulator (fp32) and
+// its running (maximum, sum) per query in the caller's scratch, attention_combine_kernel below merges the ranges.  For calls whose query
+// blocks do not fill the chip - one utterance is 16 workgroups, each a serial chain of 64 key tiles (154 us of a 2.8-ms evaluation) -
+// the chain is what a launch lasts: splitting it 8 ways is 8 x the workgroups and an eighth of the chain.
+template <typename T, int CT, bool SPLIT>
 __global__ __launch_bounds__(ATTN_THREADS)
 void attention_kernel(const T* __restrict__ q, const T* __restrict__ k, const T* __restrict__ vT,
                       const float* __restrict__ bias, T* __restrict__ out, int L, int ldv, long long q_bs,
-                      long long k_bs, long long v_bs, long long o_bs, float scale_log2e) {
+                      long long k_bs, long long v_bs, long long o_bs, float scale_log2e,
+                      float* __restrict__ part_o, float* __restrict__ part_ml, int nsplit) {
     constexpr int C = 32 * CT, KG = C / 16;            // channels; 16-channel k-groups of the score product
     constexpr int KROW = C * 2, KSLOTS = KROW / 16;    // K tile row: bytes, 16-B slots
     constexpr int KTILE = BK * KROW, VTILE = C * 64;   // bytes per buffer
@@ -106,12 +111,14 @@ void attention_kernel(const T* __restrict__ q, const T* __restrict__ k, const T*
         }
     };
 
-    const int ntiles = (L + BK - 1) / BK;
-    load_tile(0);
+    const int ntiles_all = (L + BK - 1) / BK;
+    const int n_lo = SPLIT ? (int)blockIdx.z * ntiles_all / nsplit : 0;
+    const int ntiles = SPLIT ? ((int)blockIdx.z + 1) * ntiles_all / nsplit : ntiles_all;      // (one past this range's last tile)
+    load_tile(n_lo * BK);
     store_tile(0);
     __syncthreads();
-    for (int n = 0; n < ntiles; ++n) {
-        const int buf = n & 1, j0 = n * BK;
+    for (int n = n_lo; n < ntiles; ++n) {
+        const int buf = (n - n_lo) & 1, j0 = n * BK;
         if (n + 1 < ntiles) load_tile(j0 + BK);                      // in flight under this tile's MFMAs
         // ---- S^T = K Q^T (32 keys x 32 queries per wave) ------------------------------------------------------------
         f32x16 s;
@@ -174,8 +181,21 @@ void attention_kernel(const T* __restrict__ q, const T* __restrict__ k, const T*
         __syncthreads();
     }
 
-    // ---- epilogue: h = O / l + b_v (rows of P sum to one, so the NIN_2 bias passes through), 16-bit, 8-byte stores ----------
     const int qrow = q0 + wave * 32 + j;
+    if (SPLIT) {                                     // this key range's partial result: O (unnormalised), running maximum (log2 domain), sum
+        if (qrow < L) {
+            const long long prow = ((long long)blockIdx.z * gridDim.y + b) * L + qrow;
+            float* po = part_o + prow * C;
+#pragma unroll
+            for (int t = 0; t < CT; ++t)
+#pragma unroll
+                for (int g = 0; g < 4; ++g)
+                    *reinterpret_cast<float4*>(po + 32 * t + 8 * g + 4 * h) = make_float4(o[t][4 * g], o[t][4 * g + 1], o[t][4 * g + 2], o[t][4 * g + 3]);
+            if (h == 0) *reinterpret_cast<float2*>(part_ml + prow * 2) = make_float2(m_run, l_run);     // (both lane halves hold the same pair)
+        }
+        return;
+    }
+    // ---- epilogue: h = O / l + b_v (rows of P sum to one, so the NIN_2 bias passes through), 16-bit, 8-byte stores ----------
     if (qrow < L) {
         const float inv = 1.0f / l_run;
         T* orow = out + (long long)b * o_bs + (long long)qrow * C;
@@ -191,6 +211,56 @@ void attention_kernel(const T* __restrict__ q, const T* __restrict__ k, const T*
             }
     }
 }
+
+// Merge of the key ranges: out = sum_s O_s 2^(m_s - m) / sum_s l_s 2^(m_s - m) + bias, m = max_s m_s; ranges in index order (fixed: bit-reproducible).
+// One thread per (query, four channels).
+template <typename T>
+__global__ __launch_bounds__(256)
+void attention_combine_kernel(const float* __restrict__ part_o, const float* __restrict__ part_ml, const float* __restrict__ bias,
+                              T* __restrict__ out, int S, int B, int L, int C, long long o_bs) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    const int c4 = C / 4;
+    const long long row = i / c4;
+    if (row >= (long long)B * L) return;
+    const int c = (int)(i - row * c4) * 4;
+    const long long rows = (long long)B * L;
+    float m = -INFINITY;
+    for (int sp = 0; sp < S; ++sp) m = fmaxf(m, part_ml[(sp * rows + row) * 2]);
+    float l = 0.f, a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+    for (int sp = 0; sp < S; ++sp) {
+        const float2 ml = *reinterpret_cast<const float2*>(part_ml + (sp * rows + row) * 2);
+        const float w = hw_exp2(ml.x - m);
+        const float4 v = *reinterpret_cast<const float4*>(part_o + (sp * rows + row) * C + c);
+        l = fmaf(ml.y, w, l);
+        a0 = fmaf(v.x, w, a0); a1 = fmaf(v.y, w, a1); a2 = fmaf(v.z, w, a2); a3 = fmaf(v.w, w, a3);
+    }
+    const float inv = 1.0f / l;
+    const int b = (int)(row / L);
+    const long long qrow = row - (long long)b * L;
+    float v[4] = {a0 * inv, a1 * inv, a2 * inv, a3 * inv};
+    if (bias) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] += bias[c + e];
+    }
+    *reinterpret_cast<uint2*>(out + (long long)b * o_bs + qrow * C + c) = make_uint2(pack2(v[0], v[1], (T*)nullptr), pack2(v[2], v[3], (T*)nullptr));
+}
+
+// Key ranges for a call (1 = none): only where the query blocks leave most CUs idle (fewer than 128 workgroups), doubling while the split
+// launch still fits the chip and a range keeps at least four key tiles; never for the fp32 parity path.  Like conv_splitk_slices' small-call
+// rule a decision on the CALL: across its threshold a row agrees to the rounding of its 16-bit output, not bit for bit.
+int attn_splits(int B, int L, int dtype) {
+    if (dtype == STORM_F32) return 1;
+    const int ntiles = cdiv(L, BK);
+    const int forced = switches().attn_split;                // (tests / A-B: 1 = never, 2 / 4 / 8 = that many where the tiles allow)
+    if (forced == 1) return 1;
+    if (forced >= 2) return forced <= ntiles ? forced : 1;
+    const long long wgs = (long long)cdiv(L, BQ) * B;
+    if (wgs >= 128) return 1;
+    int S = 1;
+    while (S < 8 && wgs * S * 2 <= 256 && ntiles / (S * 2) >= 4) S *= 2;
+    return S;
+}
+long long attn_scratch_bytes(int B, int L, int C, int S) { return S < 2 ? 0 : (long long)S * B * L * (C + 2) * 4; }
 
 // ---- fp32 (parity path): the same online-softmax structure on v_mfma_f32_32x32x2_f32 (exact fp32 products, fp32 sums).
 // Key tiles of 32 keys, K [32][C] and V^T [C][32] fp32 in LDS (2 x 32 KB at C = 256, double buffered = 128 KB), Q fragments of the
@@ -306,7 +376,7 @@ void attention_f32_kernel(const float* __restrict__ q, const float* __restrict__
 
 template <typename T, int CT>
 static int attn_launch(const void* q, const void* k, const void* vT, const float* bias, void* out, int B, int L, int ldv,
-                  long long q_bs, long long k_bs, long long v_bs, long long o_bs, float scale, hipStream_t st) {
+                  long long q_bs, long long k_bs, long long v_bs, long long o_bs, float scale, void* scratch, long long scratch_bytes, hipStream_t st) {
     constexpr int C = 32 * CT;
     constexpr bool F32 = sizeof(T) == 4;
     constexpr int lds = F32 ? 2 * (BK * (C * 4 + 16)) + 2 * (C * (BK * 4 + 16)) : 2 * (BK * C * 2) + 2 * (C * 64);
@@ -320,13 +390,27 @@ static int attn_launch(const void* q, const void* k, const void* vT, const float
         hipLaunchKernelGGL(kern, dim3(cdiv(L, BQ), B), dim3(ATTN_THREADS), lds, st, (const float*)q, (const float*)k, (const float*)vT,
                            bias, (float*)out, L, ldv, q_bs, k_bs, v_bs, o_bs, scale * 1.44269504088896341f);
     } else {
-        auto kern = attention_kernel<T, CT>;
+        auto kern = attention_kernel<T, CT, false>;
+        auto kern_s = attention_kernel<T, CT, true>;
         if (!attr_set) {
             STORM_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+            STORM_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern_s), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
             attr_set = true;
         }
-        hipLaunchKernelGGL(kern, dim3(cdiv(L, BQ), B), dim3(ATTN_THREADS), lds, st, (const T*)q, (const T*)k, (const T*)vT,
-                           bias, (T*)out, L, ldv, q_bs, k_bs, v_bs, o_bs, scale * 1.44269504088896341f);
+        const int S = scratch != nullptr ? attn_splits(B, L, sizeof(T) == 4 ? STORM_F32 : STORM_BF16) : 1;
+        if (S >= 2 && scratch_bytes >= attn_scratch_bytes(B, L, C, S)) {
+            float* const part_o = static_cast<float*>(scratch);
+            float* const part_ml = part_o + (long long)S * B * L * C;
+            hipLaunchKernelGGL(kern_s, dim3(cdiv(L, BQ), B, S), dim3(ATTN_THREADS), lds, st, (const T*)q, (const T*)k, (const T*)vT,
+                               bias, (T*)out, L, ldv, q_bs, k_bs, v_bs, o_bs, scale * 1.44269504088896341f, part_o, part_ml, S);
+            STORM_LAUNCH_CHECK();
+            const long long nthreads = (long long)B * L * (C / 4);
+            hipLaunchKernelGGL(attention_combine_kernel<T>, dim3((unsigned)cdiv(nthreads, 256LL)), dim3(256), 0, st, part_o, part_ml, bias, (T*)out,
+                               S, B, L, C, o_bs);
+        } else {
+            hipLaunchKernelGGL(kern, dim3(cdiv(L, BQ), B), dim3(ATTN_THREADS), lds, st, (const T*)q, (const T*)k, (const T*)vT,
+                               bias, (T*)out, L, ldv, q_bs, k_bs, v_bs, o_bs, scale * 1.44269504088896341f, (float*)nullptr, (float*)nullptr, 1);
+        }
     }
     STORM_LAUNCH_CHECK();
     return STORM_OK;
@@ -334,12 +418,13 @@ static int attn_launch(const void* q, const void* k, const void* vT, const float
 
 template <typename T>
 static int attn_dispatch(int C, const void* q, const void* k, const void* vT, const float* bias, void* out, int B, int L, int ldv,
-                         long long q_bs, long long k_bs, long long v_bs, long long o_bs, float scale, hipStream_t st) {
+                         long long q_bs, long long k_bs, long long v_bs, long long o_bs, float scale, void* scratch, long long scratch_bytes,
+                         hipStream_t st) {
     switch (C) {
-        case 32: return attn_launch<T, 1>(q, k, vT, bias, out, B, L, ldv, q_bs, k_bs, v_bs, o_bs, scale, st);
-        case 64: return attn_launch<T, 2>(q, k, vT, bias, out, B, L, ldv, q_bs, k_bs, v_bs, o_bs, scale, st);
-        case 128: return attn_launch<T, 4>(q, k, vT, bias, out, B, L, ldv, q_bs, k_bs, v_bs, o_bs, scale, st);
-        default: return attn_launch<T, 8>(q, k, vT, bias, out, B, L, ldv, q_bs, k_bs, v_bs, o_bs, scale, st);
+        case 32: return attn_launch<T, 1>(q, k, vT, bias, out, B, L, ldv, q_bs, k_bs, v_bs, o_bs, scale, scratch, scratch_bytes, st);
+        case 64: return attn_launch<T, 2>(q, k, vT, bias, out, B, L, ldv, q_bs, k_bs, v_bs, o_bs, scale, scratch, scratch_bytes, st);
+        case 128: return attn_launch<T, 4>(q, k, vT, bias, out, B, L, ldv, q_bs, k_bs, v_bs, o_bs, scale, scratch, scratch_bytes, st);
+        default: return attn_launch<T, 8>(q, k, vT, bias, out, B, L, ldv, q_bs, k_bs, v_bs, o_bs, scale, scratch, scratch_bytes, st);
     }
 }
 
@@ -349,9 +434,15 @@ extern "C" int storm_attention_supported(int C, int dtype) {
     return (dtype == STORM_BF16 || dtype == STORM_F16 || dtype == STORM_F32) && (C == 32 || C == 64 || C == 128 || C == 256);
 }
 
-extern "C" int storm_attention(const void* q, const void* k, const void* vT, const float* bias, void* out, int B, int L, int C,
-                               int ldv, long long q_bstride, long long k_bstride, long long vT_bstride, long long out_bstride,
-                               float scale, int dtype, storm_stream_t s) {
+// scratch for the key-range split of a call (0 = this call runs unsplit): fp32 [S][B][L][C] partial outputs + [S][B][L][2] (maximum, sum)
+extern "C" long long storm_attention_scratch_bytes(int B, int L, int C, int dtype) {
+    if (B <= 0 || L <= 0 || !storm_attention_supported(C, dtype)) return 0;
+    return storm::attn_scratch_bytes(B, L, C, storm::attn_splits(B, L, dtype));
+}
+
+extern "C" int storm_attention_ws(const void* q, const void* k, const void* vT, const float* bias, void* out, int B, int L, int C,
+                                  int ldv, long long q_bstride, long long k_bstride, long long vT_bstride, long long out_bstride,
+                                  float scale, int dtype, void* scratch, long long scratch_bytes, storm_stream_t s) {
     using namespace storm;
     STORM_CHECK(q && k && vT && out && B > 0 && L > 0, "storm_attention: bad arguments");
     STORM_CHECK(ldv >= L && ldv % 8 == 0, "storm_attention: ldv=%d (L=%d)", ldv, L);
@@ -360,7 +451,13 @@ extern "C" int storm_attention(const void* q, const void* k, const void* vT, con
         return STORM_ERR_UNSUPPORTED;
     }
     hipStream_t st = (hipStream_t)s;
-    if (dtype == STORM_F32) return attn_dispatch<float>(C, q, k, vT, bias, out, B, L, ldv, q_bstride, k_bstride, vT_bstride, out_bstride, scale, st);
-    if (dtype == STORM_F16) return attn_dispatch<half_t>(C, q, k, vT, bias, out, B, L, ldv, q_bstride, k_bstride, vT_bstride, out_bstride, scale, st);
-    return attn_dispatch<bf16_t>(C, q, k, vT, bias, out, B, L, ldv, q_bstride, k_bstride, vT_bstride, out_bstride, scale, st);
+    if (dtype == STORM_F32) return attn_dispatch<float>(C, q, k, vT, bias, out, B, L, ldv, q_bstride, k_bstride, vT_bstride, out_bstride, scale, nullptr, 0, st);
+    if (dtype == STORM_F16) return attn_dispatch<half_t>(C, q, k, vT, bias, out, B, L, ldv, q_bstride, k_bstride, vT_bstride, out_bstride, scale, scratch, scratch_bytes, st);
+    return attn_dispatch<bf16_t>(C, q, k, vT, bias, out, B, L, ldv, q_bstride, k_bstride, vT_bstride, out_bstride, scale, scratch, scratch_bytes, st);
+}
+
+extern "C" int storm_attention(const void* q, const void* k, const void* vT, const float* bias, void* out, int B, int L, int C,
+                               int ldv, long long q_bstride, long long k_bstride, long long vT_bstride, long long out_bstride,
+                               float scale, int dtype, storm_stream_t s) {
+    return storm_attention_ws(q, k, vT, bias, out, B, L, C, ldv, q_bstride, k_bstride, vT_bstride, out_bstride, scale, dtype, nullptr, 0, s);
 }

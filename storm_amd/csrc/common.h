@@ -36,6 +36,7 @@ struct Switches {
     int gn_nt = 5;              // STORM_GN_NT: non-temporal output stores - bit 0 gn_apply_up, bit 1 gn_apply_down (no gain: off), bit 2 conv_thin (A/B: profiles/r04_gnexp.txt)
     int gn_wide = 1;            // STORM_GN_WIDE: 0 = the GroupNorm + FIR kernels with 8 slots (128 B) of a pixel per workgroup (A/B)
     int splitk = 0;             // STORM_SPLITK: 0 = the dispatcher's K slices for few-tile 3x3 layers, 1 = never split, 2 / 4 / 8 = that many (A/B)
+    int attn_split = 0;         // STORM_ATTN_SPLIT: 0 = attn_splits' rule (key ranges for calls that leave most CUs idle), 1 = never, 2 / 4 / 8 = that many (tests, A/B)
     int conv_table = 1;         // STORM_CONV_TABLE: 0 = ignore the measured dispatch table (conv_dispatch_table.h), the rule ladder alone decides (the tuner's baseline)
     int splitk_small = 1;       // STORM_SPLITK_SMALL: 0 = split K by the per-image rule only (bit-identical rows across batch sizes), 1 = also for launches of <= 64 workgroups (conv_splitk_slices)
     int graph = -1;             // STORM_GRAPH: HIP-graph replay of storm_ncsnpp_forward - -1 = the handle's mode (storm_ncsnpp_set_graph), 0 = never, 1 = always (A/B)

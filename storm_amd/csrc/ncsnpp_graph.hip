@@ -401,6 +401,8 @@ struct Program {
             storm_op& a = op(STORM_OP_ATTENTION);
             ws(a, 0, q.off); ws(a, 1, kk.off); ws(a, 2, vT.off); par(a, 3, k + "NIN_2.b"); ws(a, 4, o.off);
             a.i[0] = B; a.i[1] = Lp; a.i[2] = Cc; a.i[3] = Lp8; a.f[0] = scale;
+            const long long nb = storm_attention_scratch_bytes(B, Lp, Cc, dtype);       // key-range split of small calls: scratch live for this op only
+            if (nb > 0) { const long long off = arena.alloc(nb); ws(ops.back(), 5, off); ops.back().i[4] = nb; arena.release(off); }
             flops += 4LL * B * Lp * Lp * Cc;
             free_act(q); free_act(kk); free_act(vT);
         } else {

@@ -105,9 +105,9 @@ static int run_ops(const storm_op* ops, int n_ops, void* const* bufs, int n_bufs
                 rc = storm_softmax_rows((const float*)p[0], p[1], (long long)i[0], (int)i[1], (int)i[2], dtype, s);
                 break;
             case STORM_OP_ATTENTION:
-                rc = storm_attention(p[0], p[1], p[2], (const float*)p[3], p[4], (int)i[0], (int)i[1], (int)i[2], (int)i[3],
-                                     (long long)i[1] * i[2], (long long)i[1] * i[2], (long long)i[2] * i[3], (long long)i[1] * i[2],
-                                     op.f[0], dtype, s);
+                rc = storm_attention_ws(p[0], p[1], p[2], (const float*)p[3], p[4], (int)i[0], (int)i[1], (int)i[2], (int)i[3],
+                                        (long long)i[1] * i[2], (long long)i[1] * i[2], (long long)i[2] * i[3], (long long)i[1] * i[2],
+                                        op.f[0], dtype, p[5], (long long)i[4], s);
                 break;
             case STORM_OP_OUTPUT_HEAD:
                 rc = storm_output_head(p[0], (const float*)p[1], (const float*)p[2], (const float*)p[3], (int)i[0],

@@ -145,8 +145,10 @@ def attention(q, k, vT, bias, scale):
     """q, k [B, L, C], vT [B, C, ldv] (bf16) -> softmax(scale q k^T) v + bias, [B, L, C] (storm_attention)."""
     B, Lq, Cc = q.shape
     out = torch.empty_like(q)
-    L.check(L.lib().storm_attention(L.ptr(q), L.ptr(k), L.ptr(vT), L.ptr(bias), L.ptr(out), B, Lq, Cc, vT.shape[-1], Lq * Cc, Lq * Cc,
-                                    Cc * vT.shape[-1], Lq * Cc, float(scale), L.dt(q), L.stream()), "storm_attention")
+    need = L.lib().storm_attention_scratch_bytes(B, Lq, Cc, L.dt(q))        # small calls: scratch for the split of the key loop
+    ws = torch.empty((need,), dtype=torch.uint8, device=q.device) if need > 0 else None
+    L.check(L.lib().storm_attention_ws(L.ptr(q), L.ptr(k), L.ptr(vT), L.ptr(bias), L.ptr(out), B, Lq, Cc, vT.shape[-1], Lq * Cc, Lq * Cc,
+                                       Cc * vT.shape[-1], Lq * Cc, float(scale), L.dt(q), L.ptr(ws), need, L.stream()), "storm_attention")
     return out
 
 

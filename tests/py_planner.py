@@ -422,6 +422,20 @@ class Program:
             self.free(xr)
         return out
 
+    def attn_scratch_bytes(self, Lp, Cc):
+        """attention.hip: attn_splits / attn_scratch_bytes restated - a 16-bit call with fewer than 128 query blocks (128 queries each)
+        splits its key tiles (32 keys) into 2 / 4 / 8 ranges while the split launch fits 256 workgroups and a range keeps >= 4 tiles;
+        scratch = fp32 partial outputs [S][B][L][C] + (maximum, sum) [S][B][L][2]"""
+        if self.esize != 2:
+            return 0
+        ntiles, wgs = -(-Lp // 32), -(-Lp // 128) * self.B
+        if wgs >= 128:
+            return 0
+        S = 1
+        while S < 8 and wgs * S * 2 <= 256 and ntiles // (S * 2) >= 4:
+            S *= 2
+        return S * self.B * Lp * (Cc + 2) * 4 if S >= 2 else 0
+
     def attnblock(self, idx, p, x: Act):
         """AttnBlockpp.forward (layerspp.py:75-91): GN -> q,k,v (NIN) -> softmax(q k^T / sqrt C) v -> NIN_3 -> skip."""
         k = f"all_modules.{idx}."
@@ -443,6 +457,12 @@ class Program:
             self._ws(op, 0, q); self._ws(op, 1, kk); self._ws(op, 2, vT); self._par(op, 3, k + "NIN_2.b"); self._ws(op, 4, o)
             op.i[0], op.i[1], op.i[2], op.i[3] = self.B, Lp, Cc, Lp8
             op.f[0] = float(int(Cc) ** (-0.5))
+            nb = self.attn_scratch_bytes(Lp, Cc)        # key-range split of small calls: scratch live for this op only
+            if nb > 0:
+                off = self.arena.alloc(nb)
+                self._ws(op, 5, off)
+                op.i[4] = nb
+                self.arena.release(off)
             self.flops += 4 * self.B * Lp * Lp * Cc
             self.free(q); self.free(kk); self.free(vT)
         else:

@@ -820,6 +820,43 @@ def test_fused_attention(dev, C, Lq, dt, tol):
     assert rel_l2(out, ref) < tol
 
 
+@pytest.mark.parametrize("dt,tol", [(torch.bfloat16, 8e-3), (torch.float16, 1.5e-3)])
+@pytest.mark.parametrize("C,Lq,S", [(32, 300, 2), (64, 260, 8), (256, 200, 4), (256, 70, 2)])
+def test_fused_attention_key_split(dev, C, Lq, S, dt, tol, switch):
+    """attention.hip, round 5: a call whose query blocks leave most CUs idle (one utterance: 16 workgroups, each a chain of 64 key tiles)
+    splits the KEY loop into S ranges on S x the workgroups (partial accumulator + running maximum / sum per range in caller scratch) and
+    merges them in a second launch - the softmax of layerspp.py:82-86 over all keys, exactly.  Forced here at small L (ragged last
+    tiles, uneven ranges, more ranges than whole tiles allow -> unsplit): == the reference formula, == the unsplit kernel to the
+    rounding of the 16-bit output, bit-reproducible; and the rule's own choice for one / two / sixteen utterances at L = 2048."""
+    from storm_amd import ops
+    from storm_amd import _lib as L
+    g = torch.Generator().manual_seed(60 + C)
+    B = 2
+    q, k, v = (torch.randn(B, Lq, C, generator=g) for _ in range(3))
+    q = q * 1.5
+    bias = 0.1 * torch.randn(C, generator=g)
+    ldv = ops.round_up(Lq, 8)
+    vT = torch.zeros(B, C, ldv)
+    vT[:, :, :Lq] = v.transpose(1, 2)
+    rd = lambda t: t.to(dt)
+    args = (rd(q).to(dev), rd(k).to(dev), rd(vT).to(dev), bias.to(dev), C ** -0.5)
+    switch("STORM_ATTN_SPLIT", 1)
+    whole = ops.attention(*args).float().cpu()
+    switch("STORM_ATTN_SPLIT", S)
+    ntiles = -(-Lq // 32)
+    assert (L.lib().storm_attention_scratch_bytes(B, Lq, C, L.dt(dt)) > 0) == (S <= ntiles)
+    out = ops.attention(*args)
+    assert torch.equal(out, ops.attention(*args))
+    out = out.float().cpu()
+    w = torch.softmax(torch.einsum("bic,bjc->bij", rd(q).double(), rd(k).double()) * C ** -0.5, -1)
+    ref = (torch.einsum("bij,bjc->bic", w, rd(v).double()) + bias).float()
+    assert rel_l2(out, ref) < tol and rel_l2(out, whole) < tol
+    switch("STORM_ATTN_SPLIT", 0)
+    nb = lambda b: L.lib().storm_attention_scratch_bytes(b, 2048, 256, L.dt(dt))
+    assert nb(1) == 8 * 1 * 2048 * 258 * 4 and nb(2) == 8 * 2 * 2048 * 258 * 4 and nb(4) == 4 * 4 * 2048 * 258 * 4 and nb(8) == 0 and nb(16) == 0
+    assert L.lib().storm_attention_scratch_bytes(1, 2048, 256, L.F32) == 0
+
+
 @pytest.mark.gpu
 def test_attention_block_L2048_vs_reference_golden(golden):
     """AttnBlockpp at the bench shape (256 channels, 32 x 64 = 2048 positions; layerspp.py:60-91) against the REFERENCE's
