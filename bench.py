@@ -184,11 +184,11 @@ class PowerSampler:
     missing): the convolutions of this workload run AT the 1400 W cap (profiles/r04_power_probe.txt), so throughput per watt is the
     quantity a kernel change can move."""
 
-    def __init__(self):
+    def __init__(self, enabled=True):
         import shutil
         import threading
         self.samples, self.stop = [], False
-        self.thread = threading.Thread(target=self._run, daemon=True) if shutil.which("rocm-smi") else None
+        self.thread = threading.Thread(target=self._run, daemon=True) if enabled and shutil.which("rocm-smi") else None
 
     def _run(self):
         import re
@@ -202,7 +202,7 @@ class PowerSampler:
                     self.samples.append((float(w.group(1)), int(c.group(1)) if c else -1))
             except Exception:  # noqa: BLE001
                 pass
-            time.sleep(0.05)
+            time.sleep(0.2)
 
     def __enter__(self):
         if self.thread:
@@ -310,7 +310,7 @@ def main():
             nfes.append(n_ * yb.shape[0])
         return out, sum(nfes) / args.stream                 # mean score evaluations per utterance
 
-    with PowerSampler() as power:
+    with PowerSampler(enabled=rank == 0) as power:                # (rocm-smi's first GPU = rank 0's device)
         elapsed, per_rank, (out, nfe) = D.timed_steps(step, args.steps, args.warmup, sync=torch.cuda.synchronize, single_rank_group=args.dist_world1)
     power = power.summary() if rank == 0 else None
     assert torch.isfinite(out).all(), "non-finite output"

@@ -321,19 +321,19 @@ def gen_f12(ref):
     np.savez_compressed(os.path.join(OUT, "f12_ode_rows.npz"), **f12)
 
 
-def _full_sampler_fixture(ref, tag, fname, nsamples, seeds, what):
-    """ScoreModel.enhance (model.py:273-310) of the seeded 27.8 M `ncsnpp` on ONE utterance of `nsamples` samples: N = 30 reverse steps,
-    `reverse_diffusion` + `ald` x 1 = 60 score evaluations inside pc_sampler (sampling/__init__.py:54-66), with RECORDED noise (61 draws,
+def _full_sampler_fixture(ref, tag, fname, nsamples, seeds, what, backbone="ncsnpp", N=30):
+    """ScoreModel.enhance (model.py:273-310) of the seeded 27.8 M `ncsnpp` (or `backbone`) on ONE utterance of `nsamples` samples: N = 30 (or N) reverse steps,
+    `reverse_diffusion` + `ald` x 1 = 2 N score evaluations inside pc_sampler (sampling/__init__.py:54-66), with RECORDED noise (61 draws,
     regenerated on both sides from a seed; their SHA-256 is stored).  Stores the reference's wav and the sampler's final spectrogram (the
     tensor enhance hands to to_audio), and checks the oracle restatement against both on the way."""
-    print(f"{tag} full-width 60-evaluation enhance, {what}")
+    print(f"{tag} full-width {2 * N}-evaluation enhance, {what}")
     torch.set_num_threads(16)
     M, DM = ref["model"], ref["data_module"].SpecsDataModule
-    N, steps = 30, 1
+    steps = 1
     seed_w, seed_n, seed_wav = seeds
-    cfg = NR.NCSNppConfig(input_channels=4)
+    cfg = NR.NCSNppConfig(**NR.NAMED_CONFIGS[backbone], input_channels=4)
     sd = NR.seeded_state_dict(cfg, seed=seed_w)
-    m = M.ScoreModel(backbone="ncsnpp", sde="ouve", data_module_cls=DM, theta=1.5, sigma_min=0.05, sigma_max=0.5,
+    m = M.ScoreModel(backbone=backbone, sde="ouve", data_module_cls=DM, theta=1.5, sigma_min=0.05, sigma_max=0.5,
                      spec_factor=0.15, spec_abs_exponent=0.5)
     m.dnn.load_state_dict(sd)
     m.eval(no_ema=True)
@@ -365,7 +365,7 @@ def _full_sampler_fixture(ref, tag, fname, nsamples, seeds, what):
                                  lambda x, t, y: -NR.ncsnpp_forward(sd, cfg, torch.cat([x, y], 1), t),
                                  Y, lambda: next(it), corrector_steps=steps, snr=0.5)
     xh_or = FR.spec_to_wav(samp, nfac, T0)
-    check(f"{tag} enhance wav (60 evaluations, 27.8 M)", xh_or, xh_ref, 1e-4)
+    check(f"{tag} enhance wav ({2 * N} evaluations, {backbone})", xh_or, xh_ref, 1e-4)
     fs = final["spec"].reshape(samp.shape) if "spec" in final else None
     if fs is not None:
         check(f"{tag} final sampler state", samp, fs, 1e-4)
@@ -387,6 +387,14 @@ def gen_f14(ref):
     _full_sampler_fixture(ref, "F14", "f14_full_sampler_4s.npz", 64000, (12, 1414, 1402), "4-s utterance = the bench length (about 40 minutes)")
 
 
+def gen_f15(ref):
+    """F15: BASELINE.json configs[3]'s SAMPLER on its network - `ncsnpplarge` (65.6 M, ncsnpp.py:460-470), N = 50 reverse steps + 1 `ald` corrector step
+    each = 100 score evaluations (the configuration's "50-step PC + 1 corrector"), on a 2-s utterance (32 000 samples -> 251 -> 256 frames: the 8-s
+    length of configs[3] would cost the CPU reference four hours; the forward at that length is pinned by F11).  About 25 minutes on 8 cores."""
+    _full_sampler_fixture(ref, "F15", "f15_large_sampler.npz", 32000, (13, 1515, 1503), "ncsnpplarge, 2-s utterance, 100 evaluations (about 25 minutes)",
+                          backbone="ncsnpplarge", N=50)
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
     if "--only-f9" in sys.argv:
@@ -398,7 +406,7 @@ def main():
     if "--only-f8" in sys.argv:
         gen_f8(import_reference())
         return
-    for flag, fn in (("--only-f10", gen_f10), ("--only-f11", gen_f11), ("--only-f12", gen_f12), ("--only-f13", gen_f13), ("--only-f14", gen_f14)):
+    for flag, fn in (("--only-f10", gen_f10), ("--only-f11", gen_f11), ("--only-f12", gen_f12), ("--only-f13", gen_f13), ("--only-f14", gen_f14), ("--only-f15", gen_f15)):
         if flag in sys.argv:
             fn(import_reference())
             return
@@ -649,6 +657,7 @@ def main():
     gen_f12(ref)
     gen_f13(ref)
     gen_f14(ref)
+    gen_f15(ref)
     for fn in sorted(os.listdir(OUT)):
         print(f"  {fn}: {os.path.getsize(os.path.join(OUT, fn))/1024:.0f} KiB")
     print("golden fixtures written to", OUT)

@@ -133,7 +133,8 @@ def full_sampler_noises(g):
     return zs
 
 
-FULL_SAMPLER_FIXTURES = {"f13_full_sampler": 16000, "f14_full_sampler_4s": 64000}     # name -> samples of the utterance
+# name -> (samples of the utterance, backbone): F13 / F14 the 27.8 M network at 1 s / the bench's 4 s; F15 configs[3]'s network and sampler (50 + 50 evaluations) at 2 s
+FULL_SAMPLER_FIXTURES = {"f13_full_sampler": (16000, "ncsnpp"), "f14_full_sampler_4s": (64000, "ncsnpp"), "f15_large_sampler": (32000, "ncsnpplarge")}
 
 
 @pytest.mark.parametrize("name", list(FULL_SAMPLER_FIXTURES))
@@ -143,9 +144,9 @@ def test_full_sampler_fixture_inputs_regenerate(golden, name):
     feed the engine what the reference consumed."""
     import hashlib
     g = golden[name]
-    n = FULL_SAMPLER_FIXTURES[name]
-    assert len(full_sampler_noises(g)) == 61 and int(g["nfe"]) == 60
-    sd = NR.seeded_state_dict(NR.NCSNppConfig(input_channels=4), seed=int(g["seeds"][0]))
+    n, backbone = FULL_SAMPLER_FIXTURES[name]
+    assert len(full_sampler_noises(g)) == 1 + int(g["nfe"]) and int(g["nfe"]) == 2 * int(g["N"]) == (100 if backbone == "ncsnpplarge" else 60)
+    sd = NR.seeded_state_dict(NR.NCSNppConfig(**NR.NAMED_CONFIGS[backbone], input_channels=4), seed=int(g["seeds"][0]))
     h = hashlib.sha256()
     for k in sorted(sd):
         h.update(k.encode())
@@ -159,22 +160,25 @@ def test_full_sampler_fixture_inputs_regenerate(golden, name):
 @pytest.mark.parametrize("name,prec,B,tol_wav,tol_spec", [
     ("f13_full_sampler", "fp32", 16, 1e-3, 1e-3), ("f13_full_sampler", "bf16", 16, 5e-2, 5e-2), ("f13_full_sampler", "fp16", 16, 2e-2, 2e-2),
     ("f14_full_sampler_4s", "bf16", 16, 5e-2, 5e-2), ("f14_full_sampler_4s", "fp16", 16, 2e-2, 2e-2), ("f14_full_sampler_4s", "fp32", 2, 1e-3, 1e-3),
-    ("f14_full_sampler_4s", "bf16", 1, 5e-2, 5e-2)])
+    ("f14_full_sampler_4s", "bf16", 1, 5e-2, 5e-2),
+    ("f15_large_sampler", "bf16", 8, 5e-2, 5e-2), ("f15_large_sampler", "fp16", 8, 2e-2, 2e-2), ("f15_large_sampler", "fp32", 2, 1e-3, 1e-3)])
 def test_full_width_60_evaluation_sampler_vs_reference_golden(golden, name, prec, B, tol_wav, tol_spec):
     """The product of the path against the REFERENCE at full width and full sampler length: ScoreModel.enhance of the seeded 27.8 M
     `ncsnpp`, N = 30 reverse steps + 1 ald corrector step each = 60 score evaluations (model.py:273-310, sampling/__init__.py:54-66),
     under the noise the reference consumed.  F13: a 1-s utterance; **F14: the bench's own utterance length (4 s = 64 000 samples ->
     512 frames), i.e. BASELINE.json configs[1] as bench.py times it - batch 16 in bf16** (the same row 16 times, so the production
     kernel selection of the bench batch is active and every row must reproduce the reference), fp16, the parity precision, and ONE
-    utterance per call (the reference's own operating point, with its other kernel selection).  What 60 chained evaluations of a 1e-2
-    network error amount to, measured against the reference instead of against the engine's own fp32 run."""
+    utterance per call (the reference's own operating point, with its other kernel selection).  **F15: BASELINE.json configs[3]'s network and
+    sampler - `ncsnpplarge` (65.6 M, ncsnpp.py:460-470), N = 50 + 1 corrector step each = 100 evaluations - on a 2-s utterance, 8 per GPU as
+    configs[3] shards them** (its split-K levels included).  What 60 / 100 chained evaluations of a 1e-2 network error amount to, measured
+    against the reference instead of against the engine's own fp32 run."""
     from tests.backend import setup_backend
     from storm_amd.model import ScoreModel
     dev = setup_backend("hip")
     g = golden[name]
-    n = FULL_SAMPLER_FIXTURES[name]
-    m = ScoreModel(backbone="ncsnpp", sde="ouve", theta=1.5, sigma_min=0.05, sigma_max=0.5, spec_factor=0.15, spec_abs_exponent=0.5)
-    m.dnn.load_state_dict(NR.seeded_state_dict(NR.NCSNppConfig(input_channels=4), seed=int(g["seeds"][0])))
+    n, backbone = FULL_SAMPLER_FIXTURES[name]
+    m = ScoreModel(backbone=backbone, sde="ouve", theta=1.5, sigma_min=0.05, sigma_max=0.5, spec_factor=0.15, spec_abs_exponent=0.5)
+    m.dnn.load_state_dict(NR.seeded_state_dict(NR.NCSNppConfig(**NR.NAMED_CONFIGS[backbone], input_channels=4), seed=int(g["seeds"][0])))
     m._error_loading_ema = True
     m = m.eval().to(dev)
     m.set_precision(prec)
@@ -186,10 +190,10 @@ def test_full_width_60_evaluation_sampler_vs_reference_golden(golden, name, prec
                                langevin_per_row=True, noise_fn=lambda: next(it).expand(B, -1, -1, -1).contiguous())
     sample, nfe = sampler()
     x = m.data_module.spec_to_wav(sample, T_orig, peak)
-    assert nfe == int(g["nfe"]) == 60 and x.shape == (B, n)
+    assert nfe == int(g["nfe"]) == 2 * int(g["N"]) and x.shape == (B, n)
     e_spec = [rel_l2(sample[b].reshape(-1).cpu(), T(g["final_spec"]).reshape(-1)) for b in range(B)]
     e_wav = [rel_l2(x[b].float().cpu(), g["out"]) for b in range(B)]
-    print(f"{name[:3].upper()} 60-evaluation enhance of a {n // 16000}-s utterance, {prec}, batch {B}: wav rel-L2 vs reference {max(e_wav):.3e} "
+    print(f"{name[:3].upper()} {nfe}-evaluation enhance ({backbone}) of a {n // 16000}-s utterance, {prec}, batch {B}: wav rel-L2 vs reference {max(e_wav):.3e} "
           f"(final spectrogram {max(e_spec):.3e})")
     assert max(e_wav) < tol_wav and max(e_spec) < tol_spec
     assert all(torch.equal(x[b], x[0]) for b in range(1, B))          # identical rows in, identical rows out (no batch coupling in ald)
