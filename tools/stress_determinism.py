@@ -32,12 +32,34 @@ if large:
                 print("forward repetition", i, "differs")
     print("ncsnpplarge 8 x 256 x 1024: finite:", bool(torch.isfinite(ref.abs()).all()), " RESULT", "FAIL" if bad else "PASS")
     sys.exit(1 if bad else 0)
+small = len(sys.argv) > 2 and sys.argv[2] == "small"     # one / two / four utterances per call: the small-call split-K pairs and the attention key split (round 5)
 m = ScoreModel(backbone="ncsnpp", sde="ouve", theta=1.5, sigma_min=0.05, sigma_max=0.5, spec_factor=0.15, spec_abs_exponent=0.5)
 m.dnn.load_state_dict(NR.seeded_state_dict(NR.NCSNppConfig(), seed=7))
 m._error_loading_ema = True
 m = m.eval().to(dev)
 m.set_precision("bf16")
 g = torch.Generator().manual_seed(0)
+if small:
+    bad = 0
+    with torch.no_grad():
+        for B in (1, 2, 4):
+            x = torch.randn(B, 1, 256, 512, dtype=torch.complex64, generator=g).to(dev)
+            y = torch.randn(B, 1, 256, 512, dtype=torch.complex64, generator=g).to(dev)
+            t = torch.linspace(0.1, 0.9, B).to(dev)
+            ref = m(x, t, y).clone()
+            for i in range(reps):
+                if not torch.equal(m(x, t, y), ref):
+                    bad += 1
+                    print(f"batch {B}: forward repetition {i} differs")
+            wav = (0.1 * torch.randn(B, 64000, generator=g)).to(dev)
+            w0 = m.enhance_batch(wav, N=3, corrector="ald", snr=0.5, seed=11).clone()
+            for i in range(3):
+                if not torch.equal(w0, m.enhance_batch(wav, N=3, corrector="ald", snr=0.5, seed=11)):
+                    bad += 1
+                    print(f"batch {B}: sampler repetition {i} differs")
+            print(f"ncsnpp {B} x 256 x 512: finite {bool(torch.isfinite(ref.abs()).all())}")
+    print("small calls (1 / 2 / 4 utterances): RESULT", "FAIL" if bad else "PASS")
+    sys.exit(1 if bad else 0)
 x = torch.randn(16, 1, 256, 512, dtype=torch.complex64, generator=g).to(dev)
 y = torch.randn(16, 1, 256, 512, dtype=torch.complex64, generator=g).to(dev)
 t = torch.linspace(0.1, 0.9, 16).to(dev)
