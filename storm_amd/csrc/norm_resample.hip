@@ -87,6 +87,16 @@ void gn_finalize_kernel(const float* __restrict__ pa, int Ca, int tiles_a, const
     const int C = Ca + Cb, gs = C / G;
     double s0 = 0.0, s1 = 0.0;
     const int c_lo = g * gs, c_hi = c_lo + gs;
+    // the affine parameters of this group's channels are fetched NOW, beside the partials (round 5: fetched where they are used - behind the
+    // reduction and its barrier - they were one more exposed round trip at the end of each of the 45 launches of an evaluation)
+    float gam[4], bet[4];                                    // (gs <= 1024 channels per group: four per thread at most)
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+        const int k = tid + 256 * u;
+        const bool live = ss != nullptr && k < gs;
+        gam[u] = live ? gamma[c_lo + k] : 0.f;
+        bet[u] = live ? beta[c_lo + k] : 0.f;
+    }
     for (int part = 0; part < 2; ++part) {
         const float* p = part == 0 ? pa : pb;
         const int Cs = part == 0 ? Ca : Cb, nt = part == 0 ? tiles_a : tiles_b, off = part == 0 ? 0 : Ca;
@@ -122,12 +132,16 @@ void gn_finalize_kernel(const float* __restrict__ pa, int Ca, int tiles_a, const
         double var = s1 / n - m * m;
         if (var < 0.0) var = 0.0;
         const float rstd = (float)(1.0 / sqrt(var + (double)eps));
-        for (int k = tid; k < gs; k += 256) {
-            const int c = g * gs + k;
-            const float sc = rstd * gamma[c];
-            float* const o = ss + ((long long)b * C + (c & ~7)) * 2 + (c & 7);     // [C/8][2][8]: 8 scales, then 8 shifts
-            o[0] = sc;
-            o[8] = beta[c] - (float)m * sc;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int k = tid + 256 * u;
+            if (k < gs) {
+                const int c = g * gs + k;
+                const float sc = rstd * gam[u];
+                float* const o = ss + ((long long)b * C + (c & ~7)) * 2 + (c & 7);     // [C/8][2][8]: 8 scales, then 8 shifts
+                o[0] = sc;
+                o[8] = bet[u] - (float)m * sc;
+            }
         }
     }
 }

@@ -86,6 +86,17 @@ inline void any_fn(const void* const* in, char (*out)[64], int nlanes, long long
     for (int l = 0; l < nlanes; ++l) memcpy(out[l], &any, sizeof(any));
 }
 }  // namespace simrt
+namespace simrt {
+template <typename V> inline void shfl_idx_fn(const void* const* in, char (*out)[64], int nlanes, long long src) {
+    for (int l = 0; l < nlanes; ++l) memcpy(out[l], in[(int)src < nlanes ? (int)src : l], sizeof(V));
+}
+}  // namespace simrt
+template <typename V> inline V __shfl(V v, int src, int width = 64) {       // (uniform source lane)
+    (void)width;
+    V r;
+    simrt::wave_collective(&v, &r, sizeof(V), &simrt::shfl_idx_fn<V>, src);
+    return r;
+}
 template <typename V> inline V __shfl_xor(V v, int mask, int width = 64) {
     (void)width;
     V r;
