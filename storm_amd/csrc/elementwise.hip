@@ -32,13 +32,14 @@ __global__ void pack_input_kernel(PackPtrs in, int n_in, T* __restrict__ out, lo
 // One wave per output row of a Linear: the row is read as 16-byte pieces (coalesced), the input vector sits in LDS, the dot
 // product is one wave reduction.  Grid (B, TEMB_SPLIT): every workgroup computes the first layer (cheap) and its share of the
 // second one.  (The first version gave every THREAD a row and walked it sequentially, uncoalesced: 67 us for 6 MFLOP.)
-constexpr int TEMB_SPLIT = 4, TEMB_ROWS = 8, TEMB_THREADS = 1024;
+constexpr int TEMB_SPLIT = 4, TEMB_ROWS = 8, TEMB_ROWS1 = 8, TEMB_THREADS = 1024;       // (32 rows of the first layer in ONE pass measured no faster: 43.7 vs 41.2 us - the passes are not where this launch's time goes)
 // TEMB_ROWS rows at once: all their loads are issued before the first reduction (one memory round trip per 8 rows, not per row)
 // The bias of a row is fetched WITH its weights (lane r holds row r's): round 5 found the first form - lane 0 loading bias[n] inside `emit`, behind
 // each row's reduction - a chain of eight exposed round trips per pass (47 us per launch at every batch size, rocprofv3; ~20 us of it bias latency).
-template <typename F>
+template <int ROWS, typename F>
 __device__ __forceinline__ void rows_dot(const float* __restrict__ W, const float* __restrict__ bias, const float* __restrict__ x, int K, int n0, int n_end,
                                          int nstep, int lane, F&& emit) {
+    constexpr int TEMB_ROWS = ROWS;                  // rows per pass: all their loads are in flight together (one memory round trip per pass)
     for (int n = n0; n < n_end; n += nstep * TEMB_ROWS) {
         float acc[TEMB_ROWS];
         const int brow = n + (lane & (TEMB_ROWS - 1)) * nstep;
@@ -78,10 +79,10 @@ void time_embedding_kernel(const float* __restrict__ t, const float* __restrict_
     }
     __syncthreads();
     const int E = 2 * nf, Hd = 4 * nf;
-    rows_dot(W1, b1, emb, E, wave, Hd, nw, lane, [&](int n, float v) { h1[n] = silu_f(v); });
+    rows_dot<TEMB_ROWS1>(W1, b1, emb, E, wave, Hd, nw, lane, [&](int n, float v) { h1[n] = silu_f(v); });
     __syncthreads();
     const int per = (Hd + gridDim.y - 1) / gridDim.y, n0 = blockIdx.y * per, n1 = min(Hd, n0 + per);
-    rows_dot(W2, b2, h1, Hd, n0 + wave, n1, nw, lane, [&](int n, float v) { out[(long long)b * Hd + n] = silu_f(v); });   // blocks consume SiLU(temb)
+    rows_dot<TEMB_ROWS>(W2, b2, h1, Hd, n0 + wave, n1, nw, lane, [&](int n, float v) { out[(long long)b * Hd + n] = silu_f(v); });   // blocks consume SiLU(temb)
 }
 
 // ---- dense: out[b][n] = W[n][:] . x[b][:] + bias[n]; one wave per output row n ------------
