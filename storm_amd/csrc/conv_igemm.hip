@@ -731,23 +731,40 @@ static int choose_variant(const storm_conv_args& a, bool any9) {
         // 0.075 -> 0.069 ms plain, 0.098 -> 0.080 with a shortcut; ncsnpplarge 8 x 32 x 128 ties; three 10-s rows @ 64 x 320 0.093 -> 0.075).
         const int n_ph = 2 * (9 * (cdiv(a.seg[0].Ca, 64) + (a.seg[0].Cb ? cdiv(a.seg[0].Cb, 64) : 0)) +
                               (a.nseg == 2 ? cdiv(a.seg[1].Ca, 64) + (a.seg[1].Cb ? cdiv(a.seg[1].Cb, 64) : 0) : 0));
-        const double t3 = (double)cdiv(px_tiles * cdiv(a.outC, 256), (long long)cus) * (0.60 * n_ph + 12.0);
-        const double t9 = (double)cdiv(px_tiles * cdiv(a.outC, 128), (long long)cus) * (0.36 * n_ph + 12.0);
+        // (a persistent workgroup's second, third ... tile hides its prologue under the previous epilogue: ~4 us per round + ~8 us once)
+        const long long r3 = cdiv(px_tiles * cdiv(a.outC, 256), (long long)cus), r9 = cdiv(px_tiles * cdiv(a.outC, 128), (long long)cus);
+        const double t3 = (double)r3 * (0.60 * n_ph + 4.0) + 8.0;
+        const double t9 = (double)r9 * (0.36 * n_ph + 4.0) + 8.0;
         return t9 < t3 ? 9 : 3;
     }
-    // <= 128 output channels.  Measured against each other on MI355X, each kernel sustained, alternating (profiles/r04_duo_fair_ab.txt,
-    // profiles/r04_half_fair_ab.txt, and the tuner's table profiles/r05_tune_dispatch.log): the structures stay within 5 % of each other
-    // wherever the chip is full (the part runs these layers at its power cap), so the rules are few:
-    //  * up to 256 pixel tiles (one or two utterances at 128 x 256): conv_pipe's 128-cout tile - one workgroup per CU, the pipelined loop -
-    //    beats the 64-cout generic tiles the ladder used there (128 -> 128: 0.024 -> 0.022 ms at one utterance, 0.032 -> 0.027 at two);
-    //  * conv_pipe128 (16 x 32 pixel tiles, triple-buffered patches) where its per-tile fixed cost is amortised: >= 256 input channels from
-    //    512 pixel tiles on (384 -> 128: -5 ... -8 % at every batch size; 256 -> 128: -3 ... -6 %), 128 input channels between 512 and 4096
-    //    pixel tiles (a tie with the generic tile within +-3 %: kept where rounds 2 - 4 measured it ahead);
-    //  * the generic 128-cout tile (two workgroups per CU hide each other's epilogue) everywhere else; its 64-cout form for few-tile
-    //    layers that conv_pipe does not cover (fp32 has its own path).
+    // <= 128 output channels.  Three structures - the generic tile (0: this file, two workgroups per CU hide each other's epilogue), conv_pipe128
+    // (4: 16 x 32 pixel tiles, triple-buffered 32-channel chunks) and conv_pipe's 128-cout tile (9) - measured against each other on MI355X, each kernel
+    // sustained, alternating (profiles/r04_duo_fair_ab.txt, r04_half_fair_ab.txt, r05_tune_dispatch*.log): within 5 % of each other wherever the chip
+    // is full (the part runs these layers at its power cap; conv_pipe128 3 - 8 % ahead from 256 input channels on, the 128-cout tile of
+    // conv_pipe 8 % behind) - so between them the ROUNDS decide.  (The 64-cout generic tile, 7, remains for few-tile layers conv_pipe does not cover.)
+    //  Round 5, second tuner pass over the ragged stream's shapes (profiles/r05_tune_dispatch_stream_shapes_before.log: 60 exceptions of 4 - 20 %,
+    //  none at the bench batch): what decides between the three is how a layer's tiles QUANTISE into rounds of workgroups -
+    //    generic tile (0): 8 x 32 pixels, two workgroups per CU, dispatched by the hardware: full rounds of 2 x CUs tiles cost one unit each;
+    //      a remainder of at most CUs tiles runs one workgroup per CU, ~0.68 of a unit (a lone workgroup has the CU to itself);
+    //    conv_pipe128 (4): 16 x 32 pixels, one persistent workgroup per CU: ceil(tiles / CUs) units (0.95 of a unit once K reaches 9 x 128 + 256 - 256 input
+    //      channels, or 128 with a 256-channel shortcut: its triple-buffered 32-channel chunks amortise over a longer K);
+    //    conv_pipe's 128-cout tile (9): 8 x 32 pixels, one persistent workgroup per CU: ceil(tiles / CUs) x 0.545 units.
+    //  E.g. one 9-s utterance at 256 x 1152 (1152 / 576 tiles): 2.68 | 3.0 | 2.73 units - measured 0.69 | 0.83 | 0.72 ms.
     if (a.outC > 32 && any9 && cin9 >= 32) {
-        if (px_tiles <= 256 && conv_pipe_supports(a)) return 9;
-        if (switches().conv_pipe128 != 0 && conv_pipe128_supports(a) && px_tiles >= 512 && (cin9 >= 256 || px_tiles <= 4096)) return 4;
+        const long long n0 = px_tiles, n4 = (long long)a.B * cdiv(a.H, 16) * cdiv(a.W, TILE_W);
+        const long long rem = n0 % (2LL * cus);
+        double best = (double)(n0 / (2LL * cus)) + (rem == 0 ? 0.0 : rem <= cus ? 0.68 : 1.0);
+        int pick = 0;
+        if (switches().conv_pipe128 != 0 && conv_pipe128_supports(a)) {
+            const int k1 = a.nseg == 2 ? a.seg[1].Ca + a.seg[1].Cb : 0;                  // (a fused 1x1 shortcut lengthens K like input channels do)
+            const double t4 = (double)cdiv(n4, (long long)cus) * (9 * cin9 + k1 >= 9 * 128 + 256 ? 0.95 : 1.0);
+            if (t4 < best * 0.995) { best = t4; pick = 4; }
+        }
+        if (conv_pipe_supports(a)) {
+            const double t9 = (double)cdiv(n0, (long long)cus) * 0.545;
+            if (t9 < best * 0.995) { best = t9; pick = 9; }
+        }
+        if (pick != 0) return pick;
     }
     if (any9 && a.outC >= 128 && px_tiles * cdiv(a.outC, 128) <= 256) return 7;
     return 0;
