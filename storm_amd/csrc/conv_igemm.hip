@@ -758,7 +758,8 @@ static int choose_variant(const storm_conv_args& a, bool any9) {
         if (switches().conv_pipe128 != 0 && conv_pipe128_supports(a)) {
             const int k1 = a.nseg == 2 ? a.seg[1].Ca + a.seg[1].Cb : 0;                  // (a fused 1x1 shortcut lengthens K like input channels do)
             const double t4 = (double)cdiv(n4, (long long)cus) * (9 * cin9 + k1 >= 9 * 128 + 256 ? 0.95 : 1.0);
-            if (t4 < best * 0.995) { best = t4; pick = 4; }
+            // (a tie goes to conv_pipe128 up to 4096 pixel tiles - 0 ... 4 % ahead there in rounds 2 - 4 and in the tuner's passes - and to the generic tile above)
+            if (t4 < best * 0.995 || (t4 <= best * 1.005 && n0 <= 4096)) { best = t4; pick = 4; }
         }
         if (conv_pipe_supports(a)) {
             const double t9 = (double)cdiv(n0, (long long)cus) * 0.545;
