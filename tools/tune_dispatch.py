@@ -39,6 +39,8 @@ def main():
     p = argparse.ArgumentParser()
     p.add_argument("--reps", type=int, default=24)
     p.add_argument("--margin", type=float, default=0.03)
+    p.add_argument("--keep", type=float, default=0.05, help="only exceptions of at least this gain go into the table (3 - 5 % ties between the two "
+                   "<= 128-cout structures flip from box to box and from pass to pass)")
     p.add_argument("--write", action="store_true", help="write storm_amd/csrc/conv_dispatch_table.h")
     p.add_argument("--configs", default="ncsnpp:16:512,ncsnpp:8:512,ncsnpp:4:512,ncsnpp:2:512,ncsnpp:1:512,ncsnpplarge:8:1024,ncsnpp:3:1280,ncsnpp:2:768")
     p.add_argument("--json", default="", help="also dump the measurements here")
@@ -144,7 +146,10 @@ def main():
                 picks[Bq] = (best, 1 - (b1 + b2) / (base1 + base2))
         # merge neighbouring batch sizes with the same pick into ranges (only measured batch sizes: no extrapolation across an unmeasured ladder decision)
         for Bq, (v, gain) in sorted(picks.items()):
-            entries.append((key, Bq, Bq, v, gain))
+            if gain >= args.keep:
+                entries.append((key, Bq, Bq, v, gain))
+            else:
+                print(f"  (below --keep: K9={key[0]} K1={key[1]} outC={key[2]} tiles/img={key[3]} B={Bq}: variant {v}, -{100 * gain:.1f} %)")
     print("\nexceptions to the ladder (margin %.0f %% in both halves of the repetitions):" % (100 * args.margin))
     for (k9, k1, outC, tiles), lo, hi, v, gain in entries:
         print(f"  K9={k9} K1={k1} outC={outC} tiles/img={tiles} B={lo}..{hi}: variant {v} ({NAMES.get(v, v)}), -{100 * gain:.1f} % time")
