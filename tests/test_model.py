@@ -317,6 +317,8 @@ def test_configs4_ode_ragged_rows_vs_reference_per_utterance_runs(golden, dtype,
     out, nfe = m.enhance_batch(y.to(dev), sampler_type="ode", lengths=lens, noise_fn=lambda: z, return_nfe=True)
     out, rows = out.cpu(), list(m.last_nfev_rows)
     want_nfe = [int(g[f"ode_nfe{i}"]) for i in range(3)]
+    errs = [rel_l2(out[k, :lens[k]], g[f"ode_out{k}"]) for k in range(3)]
+    print(f"configs[4] ODE rows {dtype}: nfev per row {rows} vs reference {want_nfe}; wav rel-L2 vs reference " + " ".join(f"{e:.3e}" for e in errs))
     assert nfe == max(rows) and all(abs(a - b) <= 0.15 * b for a, b in zip(rows, want_nfe)), (rows, want_nfe)
     for k in range(3):
         assert rel_l2(out[k, :lens[k]], g[f"ode_out{k}"]) < tol, (k, rel_l2(out[k, :lens[k]], g[f"ode_out{k}"]))
