@@ -48,6 +48,8 @@ def main():
     p.add_argument("--precision", choices=("fp32", "bf16", "fp16"), default="fp32")
     p.add_argument("--batch", type=int, default=16)
     p.add_argument("--seed", type=int, default=None, help="Philox seed of the sampler noise (default: drawn from torch's RNG, as the reference)")
+    p.add_argument("--batch-invariant", action="store_true", help="every utterance's result independent - bit for bit - of what it is batched with "
+                   "(storm_amd.set_batch_invariant: launch decisions per image; costs the batch-aware kernel selections)")
     p.add_argument("--dist-world1", action="store_true", help="with ONE rank: form the RCCL process group anyway (dry run of the sharded path on one GPU)")
     args = p.parse_args()
 
@@ -64,6 +66,9 @@ def main():
     model.eval(no_ema=False)
     model.cuda()
     model.set_precision(args.precision)
+    if args.batch_invariant:
+        import storm_amd
+        storm_amd.set_batch_invariant(True)
 
     files = sorted(glob.glob(os.path.join(args.test_dir, "*.wav")))
     wavs, lengths = [], []

@@ -48,7 +48,10 @@ long long storm_abi_struct_bytes(int which);   /* 0: storm_conv_args, 1: storm_o
  * persistent tile walks, ...) are a table filled once from the environment variables of the same names when the library is
  * first used; these two calls read / change an entry afterwards (names: STORM_CONV_VARIANT, STORM_CONV_PIPE128,
  * STORM_CONV_CUS; profiling build also STORM_CONV_PERSIST / _DMA / _ABLATE / _TRACE_PTR).  Production code
- * never calls them and a launch never reads the environment. */
+ * never calls them and a launch never reads the environment - with ONE exception that is a serving mode, not a test hook:
+ * STORM_BATCH_INVARIANT = 1 takes every launch decision that changes a summation order (conv tile by rounds of workgroups,
+ * small-call K split, key ranges of the attention) for one image whatever the call holds, so that a row's result does not
+ * depend - bit for bit - on what it is batched with (storm_amd.set_batch_invariant). */
 int storm_set_switch(const char* name, long long value);
 long long storm_get_switch(const char* name);
 /* device name / CU count of the current device, for logs; host out-buffers */

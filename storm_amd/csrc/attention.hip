@@ -254,6 +254,7 @@ int attn_splits(int B, int L, int dtype) {
     const int forced = switches().attn_split;                // (tests / A-B: 1 = never, 2 / 4 / 8 = that many where the tiles allow)
     if (forced == 1) return 1;
     if (forced >= 2) return forced <= ntiles ? forced : 1;
+    if (switches().batch_invariant != 0) return 1;             // (the rule below is a decision on the call: not in the per-image mode)
     const long long wgs = (long long)cdiv(L, BQ) * B;
     if (wgs >= 128) return 1;
     int S = 1;

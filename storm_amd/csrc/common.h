@@ -39,6 +39,9 @@ struct Switches {
     int attn_split = 0;         // STORM_ATTN_SPLIT: 0 = attn_splits' rule (key ranges for calls that leave most CUs idle), 1 = never, 2 / 4 / 8 = that many (tests, A/B)
     int conv_table = 1;         // STORM_CONV_TABLE: 0 = ignore the measured dispatch table (conv_dispatch_table.h), the rule ladder alone decides (the tuner's baseline)
     int splitk_small = 1;       // STORM_SPLITK_SMALL: 0 = split K by the per-image rule only (bit-identical rows across batch sizes), 1 = also for launches of <= 64 workgroups (conv_splitk_slices)
+    int batch_invariant = 0;    // STORM_BATCH_INVARIANT: 1 = every launch decision that changes a summation order is taken per IMAGE (as for a one-image call): the kernel
+                                //   ladder of choose_variant without the batch-ranged table, no small-call K split, no key-range split of the attention - an utterance then
+                                //   comes out the same bits alone and in any batch (serving with dynamic batching; costs the batch-aware selections)
     int graph = -1;             // STORM_GRAPH: HIP-graph replay of storm_ncsnpp_forward - -1 = the handle's mode (storm_ncsnpp_set_graph), 0 = never, 1 = always (A/B)
     unsigned long long conv_trace_ptr = 0;   // STORM_CONV_TRACE_PTR (profiling build): device buffer of tools/conv_trace.py
 };

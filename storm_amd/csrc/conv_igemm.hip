@@ -716,8 +716,13 @@ static int choose_variant(const storm_conv_args& a, bool any9) {
     if (forced == 10) return conv_pipe_supports(a) ? 9 : 0;        // (forced split without scratch / with one chunk: the unsplit tile)
     if (conv_thin_supports(a)) return 6;
     if (conv_narrow_supports(a)) return 8;
-    if (any9 && a.outC > 32) { const int tv = table_variant(a); if (tv >= 0) return tv; }
-    const long long px_tiles = (long long)a.B * cdiv((long long)a.H * a.W, TILE_H * TILE_W);
+    // STORM_BATCH_INVARIANT: the ladder below is a throughput decision on the LAUNCH (rounds of workgroups), and the structures it chooses between sum K - and the
+    // fused GroupNorm partials (conv_epilogue.h:write_stats: 2 wave rows x 4 pixel rows against 4 x 2) - in different orders: with the switch the decision is
+    // taken for ONE image whatever the batch, and the batch-ranged table stays out, so a row's bits do not depend on what it is batched with.
+    const bool per_image = switches().batch_invariant != 0;
+    const int Bq = per_image ? 1 : a.B;
+    if (any9 && a.outC > 32 && !per_image) { const int tv = table_variant(a); if (tv >= 0) return tv; }
+    const long long px_tiles = (long long)Bq * cdiv((long long)a.H * a.W, TILE_H * TILE_W);
     const int cin9 = a.seg[0].Ca + a.seg[0].Cb;
     const int cus = device_cus();
     if (a.outC > 128 && !(any9 && conv_pipe_supports(a)) && px_tiles >= 512) return 2;       // (1x1 / NIN / GEMMs, the fp32 parity path)
@@ -751,7 +756,7 @@ static int choose_variant(const storm_conv_args& a, bool any9) {
     //    conv_pipe's 128-cout tile (9): 8 x 32 pixels, one persistent workgroup per CU: ceil(tiles / CUs) x 0.545 units.
     //  E.g. one 9-s utterance at 256 x 1152 (1152 / 576 tiles): 2.68 | 3.0 | 2.73 units - measured 0.69 | 0.83 | 0.72 ms.
     if (a.outC > 32 && any9 && cin9 >= 32) {
-        const long long n0 = px_tiles, n4 = (long long)a.B * cdiv(a.H, 16) * cdiv(a.W, TILE_W);
+        const long long n0 = px_tiles, n4 = (long long)Bq * cdiv(a.H, 16) * cdiv(a.W, TILE_W);
         const long long rem = n0 % (2LL * cus);
         double best = (double)(n0 / (2LL * cus)) + (rem == 0 ? 0.0 : rem <= cus ? 0.68 : 1.0);
         int pick = 0;

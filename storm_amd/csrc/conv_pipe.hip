@@ -865,7 +865,7 @@ int conv_splitk_slices(const storm_conv_args& a) {
     if (forced == 1) return 0;
     if (forced >= 2) return forced <= n9 ? forced : 0;
     const long long per_image = (long long)cdiv(a.W, TILE_W) * cdiv(a.H, TILE_H) * cdiv(a.outC, 128);
-    if (per_image > 8 && (switches().splitk_small == 0 || per_image * a.B > 64)) return 0;
+    if (per_image > 8 && (switches().splitk_small == 0 || switches().batch_invariant != 0 || per_image * a.B > 64)) return 0;
     return n9 >= 4 ? 4 : n9 >= 2 ? 2 : 0;
 }
 long long conv_splitk_bytes(const storm_conv_args& a, int slices) {

@@ -539,8 +539,9 @@ struct storm_ncsnpp {
     bool fuse_stats = true, fuse_apply = true, fused_attention = true;
     // planned programs by (B, F, T): a ragged stream produces one per bucket and tail batch size, so the cache is bounded
     // (least recently used out) and guarded - a handle may be shared by host threads driving different streams
-    std::map<std::tuple<int, int, int>, std::shared_ptr<Program>> programs;
-    std::map<std::tuple<int, int, int>, unsigned long long> last_use;
+    // (the fourth key: STORM_BATCH_INVARIANT - the planner sizes the split-K / attention scratch by the rules that switch changes)
+    std::map<std::tuple<int, int, int, int>, std::shared_ptr<Program>> programs;
+    std::map<std::tuple<int, int, int, int>, unsigned long long> last_use;
     unsigned long long tick = 0;
     // programs whose op list has been handed out through storm_ncsnpp_program (profilers hold the raw pointer): pinned for the life of
     // the handle, whatever the cache evicts or storm_ncsnpp_set_fusion drops
@@ -672,7 +673,7 @@ extern "C" long long storm_ncsnpp_graph_launches(storm_ncsnpp* h) { return h ? h
 static int get_program(storm_ncsnpp* h, int B, int F, int T, std::shared_ptr<Program>* out) {
     STORM_CHECK(h != nullptr && B > 0 && F > 0 && T > 0, "storm_ncsnpp: bad shape B=%d F=%d T=%d", B, F, T);
     std::lock_guard<std::mutex> lk(h->mu);
-    auto key = std::make_tuple(B, F, T);
+    auto key = std::make_tuple(B, F, T, storm::switches().batch_invariant != 0 ? 1 : 0);
     auto it = h->programs.find(key);
     if (it == h->programs.end()) {
         std::shared_ptr<Program> p(new Program(h->cfg, h->layout, B, F, T));

@@ -557,7 +557,7 @@ template <typename T>
 static int gn_stats_t(const void* xa, int Ca, const void* xb, int Cb, int B, int HW, int G, double* stats,
                       hipStream_t st) {
     const GnGeom g = gn_geom(Ca + Cb);
-    const int per_thread = pixels_per_thread((long long)B * HW, g.PL, 256);
+    const int per_thread = pixels_per_thread((long long)(switches().batch_invariant ? 1 : B) * HW, g.PL, 256);   // (a thread's fp32 partial spans `per_thread` pixels)
     int ppb = g.PL * per_thread;
     const int nblk = cdiv(HW, ppb);
     hipLaunchKernelGGL((gn_stats_kernel<T>), dim3(nblk, B), dim3(g.NT), 0, st, (const T*)xa, Ca, (const T*)xb, Cb,

@@ -131,7 +131,7 @@ def test_enhancement_cli(tmp_path):
            if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
     r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1",
                         "--master-port", "29578", os.path.join(root, "enhancement.py"), "--test_dir", noisy, "--enhanced_dir", out,
-                        "--ckpt", path, "--mode", "score-only", "--N", "2", "--corrector", "ald", "--seed", "123", "--dist-world1"],
+                        "--ckpt", path, "--mode", "score-only", "--N", "2", "--corrector", "ald", "--seed", "123", "--dist-world1", "--batch-invariant"],
                        env=env, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stderr[-2000:]
     got = []

@@ -333,6 +333,38 @@ def test_split_k_small_call_rule(dev, switch):
     assert torch.allclose(part.cpu(), part0.cpu(), rtol=2e-2, atol=2e-2 * float(part0.abs().max()))
 
 
+def test_batch_invariant_mode_decides_per_image(dev, switch):
+    """STORM_BATCH_INVARIANT=1 (the 256- / 128-cout tile choice looked at B x tiles, and the two tiles sum the fused GroupNorm
+    partials in different orders): every launch decision that changes a summation order - choose_variant's ladder, the batch-ranged table,
+    the small-call K split, the attention's key ranges - is then taken for ONE image whatever the batch.  Here: the kernel a layer gets is
+    the same for every batch size at every level of NCSN++ (4-s and 10-s utterances), for both cout classes, with and without a fused
+    shortcut, while the default rules do differ across those batch sizes; the network-level bit-equality is tests/test_net.py's."""
+    from storm_amd import ops, _lib as L
+    dtype = torch.bfloat16
+    g = torch.Generator().manual_seed(5)
+    packed = {}
+
+    def name(B, H, W, cin, cout, sc):
+        for key, shape in (((cout, cin, 3), (cout, cin, 3, 3)), ((cout, sc, 1), (cout, sc, 1, 1))):
+            if key[1] and key not in packed:
+                packed[key] = ops.pack_conv_weight((torch.randn(*shape, generator=g) * 0.03).to(dev), dtype)
+        segs = [ops.Seg(torch.zeros(B, H, W, cin, dtype=dtype, device=dev), packed[(cout, cin, 3)], 9)]
+        if sc:
+            segs.append(ops.Seg(torch.zeros(B, H, W, sc, dtype=dtype, device=dev), packed[(cout, sc, 1)], 1))
+        return ops.conv_kernel_name(segs, cout)
+    layers = [(H, W, cin, cout, sc) for (H, W) in ((256, 512), (128, 256), (64, 128), (32, 64), (16, 32), (64, 320))
+              for (cin, cout, sc) in ((256, 256, 0), (128, 128, 0), (256, 128, 256), (128, 256, 128))]
+    batches = (1, 2, 3, 4, 8, 16)
+    differs = sum(len({name(B, *l) for B in batches}) > 1 for l in layers)
+    assert differs >= 4                                     # the default rules ARE decisions on the launch
+    switch("STORM_BATCH_INVARIANT", 1)
+    for l in layers:
+        assert len({name(B, *l) for B in batches}) == 1, l
+    assert L.lib().storm_attention_scratch_bytes(1, 2048, 256, L.BF16) == 0      # (no key-range split: one utterance would get one by default)
+    switch("STORM_BATCH_INVARIANT", 0)
+    assert L.lib().storm_attention_scratch_bytes(1, 2048, 256, L.BF16) > 0
+
+
 @pytest.mark.parametrize("case", ["natural", "natural@8", "deep_k", "deep_k@8", "natural:f16", "one_slice_pair", "three_chunks", "tiny_images"])
 def test_conv_split_k(dev, case, switch):
     """Split-K for 3x3 layers whose 128-cout tiles would leave most CUs idle (conv_pipe.hip: conv_pipe_splitk_kernel + splitk_combine_kernel;
