@@ -296,8 +296,8 @@ def test_configs4_ode_ragged_rows_vs_reference_per_utterance_runs(golden, dtype,
     ONE micro-batch, against what the REFERENCE returned for each utterance enhanced on its own (fixture F12:
     ScoreModel.enhance(y, sampler_type="ode"), model.py:224-244, 273-310; 8000 / 7300 / 6600 samples = 63 / 58 / 52 frames in
     the 64-frame bucket; 536 / 578 / 566 score evaluations).  Per-row step control: every row's wav within `tol` of the
-    reference's and its evaluation count within 15 % (the error estimate rides on the network's rounding noise, so the
-    exact step sequence is precision dependent); and row b equals our own single-utterance run bit for bit."""
+    reference's and its evaluation count within 5 % (fp32) / 10 % (fp16) (the error estimate rides on the network's rounding
+    noise, so the exact step sequence is precision dependent); and row b equals our own single-utterance run bit for bit."""
     from tests.backend import setup_backend
     from storm_amd.model import ScoreModel
     dev = setup_backend("hip")
@@ -319,7 +319,9 @@ def test_configs4_ode_ragged_rows_vs_reference_per_utterance_runs(golden, dtype,
     want_nfe = [int(g[f"ode_nfe{i}"]) for i in range(3)]
     errs = [rel_l2(out[k, :lens[k]], g[f"ode_out{k}"]) for k in range(3)]
     print(f"configs[4] ODE rows {dtype}: nfev per row {rows} vs reference {want_nfe}; wav rel-L2 vs reference " + " ".join(f"{e:.3e}" for e in errs))
-    assert nfe == max(rows) and all(abs(a - b) <= 0.15 * b for a, b in zip(rows, want_nfe)), (rows, want_nfe)
+    # (measured, profiles/r05m_parity.json: fp32 536 / 560 / 578 - the first row to the evaluation, the others within 3.2 % -, fp16 578 / 566 / 554: within 7.9 %)
+    slack = 0.05 if dtype == torch.float32 else 0.10
+    assert nfe == max(rows) and all(abs(a - b) <= slack * b for a, b in zip(rows, want_nfe)), (rows, want_nfe)
     for k in range(3):
         assert rel_l2(out[k, :lens[k]], g[f"ode_out{k}"]) < tol, (k, rel_l2(out[k, :lens[k]], g[f"ode_out{k}"]))
         assert float(out[k, lens[k]:].abs().max() if lens[k] < max(lens) else 0.0) == 0.0
