@@ -32,6 +32,32 @@ if large:
                 print("forward repetition", i, "differs")
     print("ncsnpplarge 8 x 256 x 1024: finite:", bool(torch.isfinite(ref.abs()).all()), " RESULT", "FAIL" if bad else "PASS")
     sys.exit(1 if bad else 0)
+if len(sys.argv) > 2 and sys.argv[2] == "invariant":     # the batch-invariant mode at the bench shape: every row alone / in 2s / 4s / 8s == the row in the batch of 16
+    import storm_amd
+    m = ScoreModel(backbone="ncsnpp", sde="ouve", theta=1.5, sigma_min=0.05, sigma_max=0.5, spec_factor=0.15, spec_abs_exponent=0.5)
+    m.dnn.load_state_dict(NR.seeded_state_dict(NR.NCSNppConfig(), seed=7))
+    m._error_loading_ema = True
+    m = m.eval().to(dev)
+    bad = n = 0
+    storm_amd.set_batch_invariant(True)
+    with torch.no_grad():
+        for prec in ("bf16", "fp16"):
+            m.set_precision(prec)
+            for seed in range(reps):
+                g = torch.Generator().manual_seed(100 + seed)
+                x = torch.randn(16, 1, 256, 512, dtype=torch.complex64, generator=g).to(dev)
+                y = torch.randn(16, 1, 256, 512, dtype=torch.complex64, generator=g).to(dev)
+                t = (0.03 + 0.97 * torch.rand(16, generator=g)).to(dev)
+                ref = m(x, t, y).clone()
+                for k in (1, 2, 4, 8):
+                    for b0 in range(0, 16, k):
+                        n += 1
+                        if not torch.equal(m(x[b0:b0 + k], t[b0:b0 + k], y[b0:b0 + k]), ref[b0:b0 + k]):
+                            bad += 1
+                            print(prec, "seed", seed, "rows", b0, "...", b0 + k - 1, "differ from the batch of 16")
+    storm_amd.set_batch_invariant(False)
+    print(f"batch-invariant mode, 16 x 256 x 512, bf16 + fp16, {reps} inputs each: {n} sub-batch evaluations (1 / 2 / 4 / 8 rows) against the batch of 16:", bad, "differ.  RESULT", "FAIL" if bad else "PASS")
+    sys.exit(1 if bad else 0)
 small = len(sys.argv) > 2 and sys.argv[2] == "small"     # one / two / four utterances per call: the small-call split-K pairs and the attention key split (round 5)
 m = ScoreModel(backbone="ncsnpp", sde="ouve", theta=1.5, sigma_min=0.05, sigma_max=0.5, spec_factor=0.15, spec_abs_exponent=0.5)
 m.dnn.load_state_dict(NR.seeded_state_dict(NR.NCSNppConfig(), seed=7))
