@@ -36,6 +36,14 @@ def main():
     if len(evals) < 2:
         print(json.dumps({"error": "fewer than two evaluations after the skip"}))
         return
+    if "--timeline" in sys.argv:                           # one evaluation as a table: start offset, duration, gap before (us), kernel
+        ev = evals[len(evals) // 2]
+        t0, prev = ev[0][0], ev[0][0]
+        out = sys.argv[sys.argv.index("--timeline") + 1]
+        with open(out, "w") as f:
+            for s, e, n in ev:
+                f.write(f"{(s - t0) / 1e3:9.1f} {(e - s) / 1e3:8.1f} {max(0, s - prev) / 1e3:6.1f}  {n.replace('storm::', '').replace('void ', '')[:90]}\n")
+                prev = e
     busy = [sum(e - s for s, e, _ in ev) for ev in evals]
     span = [evals[k][-1][1] - evals[k - 1][-1][1] for k in range(1, len(evals))]     # head end -> next head end (sampler update kernels included)
     inner = [ev[-1][1] - ev[0][0] for ev in evals]                                     # first kernel start -> head end
