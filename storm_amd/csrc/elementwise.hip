@@ -33,6 +33,8 @@ __global__ void pack_input_kernel(PackPtrs in, int n_in, T* __restrict__ out, lo
 // product is one wave reduction.  Grid (B, TEMB_SPLIT): every workgroup computes the first layer (cheap) and its share of the
 // second one.  (The first version gave every THREAD a row and walked it sequentially, uncoalesced: 67 us for 6 MFLOP.)
 constexpr int TEMB_SPLIT = 4, TEMB_ROWS = 8, TEMB_ROWS1 = 8, TEMB_THREADS = 1024;       // (32 rows of the first layer in ONE pass measured no faster: 43.7 vs 41.2 us - the passes are not where this launch's time goes)
+// (nor the two double-precision calls per projection: sine and cosine on separate threads 23.6 -> 23.3 us.  Alone and repeated the launch takes 23 us, inside an evaluation 41: there its 1.5 MB of fp32
+//  weights come from HBM every time - the evaluation in between moved hundreds of MB through the L2 - and each dependent round trip is that much longer)
 // TEMB_ROWS rows at once: all their loads are issued before the first reduction (one memory round trip per 8 rows, not per row)
 // The bias of a row is fetched WITH its weights (lane r holds row r's): round 5 found the first form - lane 0 loading bias[n] inside `emit`, behind
 // each row's reduction - a chain of eight exposed round trips per pass (47 us per launch at every batch size, rocprofv3; ~20 us of it bias latency).
