@@ -19,7 +19,7 @@ struct SwitchName { const char* name; int Switches::*field; };
 const SwitchName kSwitches[] = {
     {"STORM_CONV_VARIANT", &Switches::conv_variant}, {"STORM_CONV_PIPE128", &Switches::conv_pipe128}, 
     {"STORM_CONV_CUS", &Switches::conv_cus}, {"STORM_CONV_PERSIST", &Switches::conv_persist},
-    {"STORM_CONV_DMA", &Switches::conv_dma}, {"STORM_CONV_ABLATE", &Switches::conv_ablate}, {"STORM_SPLITK", &Switches::splitk}, {"STORM_GN_WIDE", &Switches::gn_wide}, {"STORM_GN_ROWS", &Switches::gn_rows}, {"STORM_GN_NT", &Switches::gn_nt}, {"STORM_GRAPH", &Switches::graph}, {"STORM_SPLITK_SMALL", &Switches::splitk_small}, {"STORM_CONV_TABLE", &Switches::conv_table}, {"STORM_ATTN_SPLIT", &Switches::attn_split}, {"STORM_BATCH_INVARIANT", &Switches::batch_invariant},
+    {"STORM_CONV_DMA", &Switches::conv_dma}, {"STORM_CONV_ABLATE", &Switches::conv_ablate}, {"STORM_SPLITK", &Switches::splitk}, {"STORM_GN_WIDE", &Switches::gn_wide}, {"STORM_GN_DOWN_SHARE", &Switches::gn_down_share}, {"STORM_GN_ROWS", &Switches::gn_rows}, {"STORM_GN_NT", &Switches::gn_nt}, {"STORM_GRAPH", &Switches::graph}, {"STORM_SPLITK_SMALL", &Switches::splitk_small}, {"STORM_CONV_TABLE", &Switches::conv_table}, {"STORM_ATTN_SPLIT", &Switches::attn_split}, {"STORM_BATCH_INVARIANT", &Switches::batch_invariant},
 };
 }  // namespace
 

@@ -34,6 +34,7 @@ struct Switches {
     int conv_ablate = 0;        // STORM_CONV_ABLATE (profiling build): work-skipping instantiations
     int gn_rows = 0;            // STORM_GN_ROWS (experiment): rows per strip of the GroupNorm + FIR kernels (0 = 16)
     int gn_nt = 5;              // STORM_GN_NT: non-temporal output stores - bit 0 gn_apply_up, bit 1 gn_apply_down (no gain: off), bit 2 conv_thin (A/B: profiles/r04_gnexp.txt)
+    int gn_down_share = 0;      // STORM_GN_DOWN_SHARE: gn_apply_down with the activation shared between neighbouring threads through LDS - 0 = the launcher's rule (full launches), 1 = never, 2 = always (A/B, tests)
     int gn_wide = 1;            // STORM_GN_WIDE: 0 = the GroupNorm + FIR kernels with 8 slots (128 B) of a pixel per workgroup (A/B)
     int splitk = 0;             // STORM_SPLITK: 0 = the dispatcher's K slices for few-tile 3x3 layers, 1 = never split, 2 / 4 / 8 = that many (A/B)
     int attn_split = 0;         // STORM_ATTN_SPLIT: 0 = attn_splits' rule (key ranges for calls that leave most CUs idle), 1 = never, 2 / 4 / 8 = that many (tests, A/B)

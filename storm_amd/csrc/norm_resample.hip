@@ -381,6 +381,209 @@ void gn_apply_down_kernel(const T* __restrict__ xa, int Ca, const T* __restrict_
     }
 }
 
+// Round 5: the down-sampling kernel with the ACTIVATION shared between neighbouring threads.  Timed without its SiLU the kernel above runs at the
+// memory time (169 of 280 us at the bench batch's level-0 launch, tools/debug/probe_gn_silu.py): it is bound by the activation - two quarter-rate
+// transcendentals per element - and evaluates it TWICE per input pixel, because the four taps of neighbouring output columns overlap by two.  Here a
+// thread still loads its four taps (the raw tensor's filter needs them) but normalises + activates only the two centre columns it owns (2 ox,
+// 2 ox + 1), hands them to its neighbours through LDS and takes its outer taps from theirs; the first / last column of a workgroup activates its
+// outer tap itself (one masked pass in the two edge waves).  5 activation passes per output row and wave on average instead of 8; one barrier per
+// output row (double-buffered exchange); every activated value is computed by the same arithmetic from the same inputs whoever computes it, and
+// each output keeps its own tap order: the same bits (test_groupnorm_fir_fused).  Wider register windows instead (two output columns per thread)
+// paid the saved instructions back in occupancy: tools/experiments/gn_down_two_columns.patch.
+template <typename T, bool SILU, int NS>
+__global__ __launch_bounds__(256)
+void gn_apply_down_share_kernel(const T* __restrict__ xa, int Ca, const T* __restrict__ xb, int Cb,
+                                int H, int W, int G, const double* __restrict__ stats,
+                                const float* __restrict__ gamma, const float* __restrict__ beta, float eps,
+                                T* __restrict__ out_act, T* __restrict__ out_raw, int ncg, int nstrips, int nt_stores) {
+    constexpr int PER16 = Elem<T>::PER16;
+    constexpr int CG = NS * PER16;                  // channels per workgroup
+    constexpr int DN_COLS = 256 / NS;               // output columns per workgroup
+    constexpr int LC = 2 * DN_COLS + 2;             // local input columns 0 .. LC - 1 = taps 2 col + j (0 and LC - 1: the edge threads' own)
+    __shared__ float gtab[2 * CG];
+    __shared__ uint4 xact[2][2][LC][NS];            // [exchange buffer][row of the pair][local input column][slot]: activated, in T
+    const int C = Ca + Cb, tid = threadIdx.x;
+    const int slot = tid % NS, col = tid / NS;
+    const int OH = H / 2, OW = W / 2;
+    int t = blockIdx.y;                             // (channel group, strip, batch item)
+    const int cg = t % ncg; t /= ncg;
+    const int strip = t % nstrips, b = t / nstrips;
+    const int gs = C / G;
+    if (tid < CG) {                                 // (scale, shift) of this workgroup's channels: y = x * sc + sh
+        const int cc = cg * CG + tid;
+        float sc = 0.f, sh = 0.f;
+        if (cc < C) {
+            const double n = (double)gs * H * W;
+            const int g = cc / gs;
+            const double m = stats[((long long)b * G + g) * 2] / n;
+            double var = stats[((long long)b * G + g) * 2 + 1] / n - m * m;
+            if (var < 0.0) var = 0.0;
+            const float pm = (float)m;
+            sc = (float)(1.0 / sqrt(var + (double)eps)) * gamma[cc];
+            sh = beta[cc] - pm * sc;
+        }
+        gtab[2 * tid] = sc; gtab[2 * tid + 1] = sh;
+    }
+    __syncthreads();
+    const int c = cg * CG + slot * PER16;
+    const int ox = blockIdx.x * DN_COLS + col;
+    const bool chan = c < C;                        // (a slot past a ragged last channel group loads nothing - but every thread takes part in the barriers)
+    const bool live = chan && ox < OW;              // (a column past the image may still own input columns a live neighbour filters)
+    float pa[PER16], pb[PER16];
+#pragma unroll
+    for (int e = 0; e < PER16; ++e) { pa[e] = gtab[2 * (slot * PER16 + e)]; pb[e] = gtab[2 * (slot * PER16 + e) + 1]; }
+    const int cl = chan ? c : 0;
+    const T* const src = (cl < Ca) ? xa + cl : xb + (cl - Ca);
+    const int cs = (cl < Ca) ? Ca : Cb;             // channel stride of the source this slot lives in
+    const long long ibase = (long long)b * H * W;
+    const long long obase = (long long)b * OH * OW;
+    const int ix0 = 2 * ox - 1;
+    bool x_in[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) x_in[j] = chan && ix0 + j >= 0 && ix0 + j < W;
+    const bool first = col == 0, last = col == DN_COLS - 1;
+
+    auto activate = [&](const uint4 qv, bool ok) -> uint4 {          // GroupNorm affine (+ SiLU) of one 16-byte slot, rounded to T
+        uint4 r = make_uint4(0u, 0u, 0u, 0u);
+        if (!ok) return r;
+        alignas(16) T raw[PER16];
+        *reinterpret_cast<uint4*>(raw) = qv;
+        if constexpr (sizeof(T) == 2) {
+            uint32_t aw[4];
+#pragma unroll
+            for (int e = 0; e < PER16; e += 2) {
+                f32x2 y = __builtin_elementwise_fma(f32x2{to_f32(raw[e]), to_f32(raw[e + 1])}, f32x2{pa[e], pa[e + 1]}, f32x2{pb[e], pb[e + 1]});
+                if (SILU) y = silu2(y);
+                aw[e / 2] = pack2(y.x, y.y, (T*)nullptr);
+            }
+            r = make_uint4(aw[0], aw[1], aw[2], aw[3]);
+        } else {
+            alignas(16) T ya[PER16];
+#pragma unroll
+            for (int e = 0; e < PER16; ++e) {
+                float y = fmaf(to_f32(raw[e]), pa[e], pb[e]);
+                if (SILU) y = silu_f(y);
+                from_f32(ya[e], y);                 // (the activated tensor is rounded to T before it is filtered)
+            }
+            r = *reinterpret_cast<const uint4*>(ya);
+        }
+        return r;
+    };
+    // raw taps of input row iy (zeros outside the image)
+    auto load_row = [&](int iy, uint4 (&q)[4]) {
+        const bool rowok = iy >= 0 && iy < H;
+        const T* const row = src + (ibase + (long long)(rowok ? iy : 0) * W) * cs;
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+            q[j] = rowok && x_in[j] ? *reinterpret_cast<const uint4*>(row + (long long)(ix0 + j) * cs) : make_uint4(0u, 0u, 0u, 0u);
+    };
+    // own activations of a row: the centre taps (to LDS for the neighbours) and, in the first / last column, the outer tap
+    auto own_acts = [&](int iy, const uint4 (&q)[4], uint4 (&a)[4], int buf, int r) {
+        const bool rowok = iy >= 0 && iy < H;       // (uniform in the workgroup)
+        a[0] = a[1] = a[2] = a[3] = make_uint4(0u, 0u, 0u, 0u);
+        if (!rowok) return;
+        a[1] = activate(q[1], x_in[1]);
+        a[2] = activate(q[2], x_in[2]);
+        xact[buf][r][2 * col + 1][slot] = a[1];
+        xact[buf][r][2 * col + 2][slot] = a[2];
+        if (first || last) {
+            const uint4 e = activate(first ? q[0] : q[3], first ? x_in[0] : x_in[3]);
+            if (first) a[0] = e; else a[3] = e;
+            if (first && last) a[3] = activate(q[3], x_in[3]);       // (one column per workgroup: never with NS <= 32, kept for completeness)
+        }
+    };
+    // the neighbours' activations of the outer taps (after the barrier)
+    auto nb_acts = [&](int iy, uint4 (&a)[4], int buf, int r) {
+        if (iy < 0 || iy >= H) return;
+        if (!first) a[0] = xact[buf][r][2 * col][slot];
+        if (!last) a[3] = xact[buf][r][2 * col + 3][slot];
+    };
+    // horizontal filter of one row: activated (hA) and raw (hR), taps in the order 0 .. 3
+    auto hfilter = [&](const uint4 (&a)[4], const uint4 (&q)[4], float (&hA)[PER16], float (&hR)[PER16]) {
+#pragma unroll
+        for (int e = 0; e < PER16; ++e) { hA[e] = 0.f; hR[e] = 0.f; }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const float wgt = (j == 0 || j == 3) ? 0.125f : 0.375f;
+            if constexpr (sizeof(T) == 2) {
+                uint32_t wl = tap_weight_bits(wgt, (T*)nullptr), wh = wl << 16;
+                keep_rw(wl); keep_rw(wh);            // (packed 16-bit operands of v_dot2c must come from registers)
+                const uint32_t aw[4] = {a[j].x, a[j].y, a[j].z, a[j].w}, rw[4] = {q[j].x, q[j].y, q[j].z, q[j].w};
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    hA[2 * i] = dot2_acc(aw[i], wl, hA[2 * i], (T*)nullptr); hA[2 * i + 1] = dot2_acc(aw[i], wh, hA[2 * i + 1], (T*)nullptr);
+                    hR[2 * i] = dot2_acc(rw[i], wl, hR[2 * i], (T*)nullptr); hR[2 * i + 1] = dot2_acc(rw[i], wh, hR[2 * i + 1], (T*)nullptr);
+                }
+            } else {
+                alignas(16) T ya[PER16];
+                alignas(16) T xr[PER16];
+                *reinterpret_cast<uint4*>(ya) = a[j];
+                *reinterpret_cast<uint4*>(xr) = q[j];
+#pragma unroll
+                for (int e = 0; e < PER16; ++e) { hA[e] = fmaf(wgt, to_f32(ya[e]), hA[e]); hR[e] = fmaf(wgt, to_f32(xr[e]), hR[e]); }
+            }
+        }
+    };
+    const int dn_rows = (OH + nstrips - 1) / nstrips;
+    const int oy0 = strip * dn_rows, oy1 = min(OH, oy0 + dn_rows);
+    float cA[PER16], cR[PER16];                     // carry: k0 h[2 oy - 1] + k1 h[2 oy]
+    int buf = 1;
+    {
+        uint4 q0[4], q1[4], a0[4], a1[4];
+        load_row(2 * oy0 - 1, q0);
+        load_row(2 * oy0, q1);
+        own_acts(2 * oy0 - 1, q0, a0, buf, 0);
+        own_acts(2 * oy0, q1, a1, buf, 1);
+        __syncthreads();
+        nb_acts(2 * oy0 - 1, a0, buf, 0);
+        nb_acts(2 * oy0, a1, buf, 1);
+        float h0A[PER16], h0R[PER16], h1A[PER16], h1R[PER16];
+        hfilter(a0, q0, h0A, h0R);
+        hfilter(a1, q1, h1A, h1R);
+#pragma unroll
+        for (int e = 0; e < PER16; ++e) { cA[e] = fmaf(0.375f, h1A[e], 0.125f * h0A[e]); cR[e] = fmaf(0.375f, h1R[e], 0.125f * h0R[e]); }
+    }
+    for (int oy = oy0; oy < oy1; ++oy) {
+        buf ^= 1;
+        uint4 q2[4], q3[4], a2[4], a3[4];
+        load_row(2 * oy + 1, q2);
+        load_row(2 * oy + 2, q3);
+        own_acts(2 * oy + 1, q2, a2, buf, 0);
+        own_acts(2 * oy + 2, q3, a3, buf, 1);
+        __syncthreads();
+        nb_acts(2 * oy + 1, a2, buf, 0);
+        nb_acts(2 * oy + 2, a3, buf, 1);
+        float h2A[PER16], h2R[PER16], h3A[PER16], h3R[PER16];
+        hfilter(a2, q2, h2A, h2R);
+        hfilter(a3, q3, h3A, h3R);
+        float va[PER16], vr[PER16];
+#pragma unroll
+        for (int e = 0; e < PER16; ++e) {
+            va[e] = fmaf(0.125f, h3A[e], fmaf(0.375f, h2A[e], cA[e]));
+            vr[e] = fmaf(0.125f, h3R[e], fmaf(0.375f, h2R[e], cR[e]));
+            cA[e] = fmaf(0.375f, h3A[e], 0.125f * h2A[e]);
+            cR[e] = fmaf(0.375f, h3R[e], 0.125f * h2R[e]);
+        }
+        if (!live) continue;
+        const long long o = (obase + (long long)oy * OW + ox) * C + c;
+        if constexpr (sizeof(T) == 2) {
+            const uint4 qa = make_uint4(pack2(va[0], va[1], (T*)nullptr), pack2(va[2], va[3], (T*)nullptr),
+                                        pack2(va[4], va[5], (T*)nullptr), pack2(va[6], va[7], (T*)nullptr));
+            const uint4 qr = make_uint4(pack2(vr[0], vr[1], (T*)nullptr), pack2(vr[2], vr[3], (T*)nullptr),
+                                        pack2(vr[4], vr[5], (T*)nullptr), pack2(vr[6], vr[7], (T*)nullptr));
+            if (nt_stores) { store16_nt(out_act + o, qa); if (out_raw) store16_nt(out_raw + o, qr); }
+            else { *reinterpret_cast<uint4*>(out_act + o) = qa; if (out_raw) *reinterpret_cast<uint4*>(out_raw + o) = qr; }
+        } else {
+            alignas(16) T oa[PER16];
+            alignas(16) T orr[PER16];
+#pragma unroll
+            for (int e = 0; e < PER16; ++e) { from_f32(oa[e], va[e]); from_f32(orr[e], vr[e]); }
+            *reinterpret_cast<uint4*>(out_act + o) = *reinterpret_cast<const uint4*>(oa);
+            if (out_raw) *reinterpret_cast<uint4*>(out_raw + o) = *reinterpret_cast<const uint4*>(orr);
+        }
+    }
+}
+
 // The same for x2 UP: out[2i] = 3/4 x[i] + 1/4 x[i - 1], out[2i + 1] = 3/4 x[i] + 1/4 x[i + 1] per axis (k = [1,3,3,1], gain 2 per
 // axis, zero boundary).  A thread owns one 16-byte channel slot of one INPUT column and walks down a strip of input rows: per
 // input row three loads (left, centre, right), each normalised + activated once, give the two horizontally up-sampled columns
@@ -592,11 +795,17 @@ static int gn_apply_t(const void* xa, int Ca, const void* xb, int Cb, int B, int
         const int ncg = cdiv(Ca + Cb, NSr * Elem<T>::PER16), nstrips = cdiv(OH, strip_rows(OH, (long long)cdiv(OW, 256 / NSr) * ncg * B, DN_ROWS));
         const long long gy = (long long)ncg * nstrips * B;
         STORM_CHECK(OH > 0 && OW > 0 && gy < 65536, "storm_gn_apply: down-sampling grid %lld out of range", gy);
-#define STORM_GN_DOWN(SILU_, NS_) hipLaunchKernelGGL((gn_apply_down_kernel<T, SILU_, NS_>), dim3(cdiv(OW, 256 / NS_), (unsigned)gy), dim3(256), 0, st, \
+        // the activation shared through LDS (gn_apply_down_share_kernel) for full launches; the barrier-free kernel for small calls (a chain of
+        // latencies, not of instructions).  STORM_GN_DOWN_SHARE: 0 = this rule, 1 = never, 2 = always (A/B, tests)
+        const int shsw = switches().gn_down_share;
+        const bool share = shsw == 2 || (shsw == 0 && (long long)cdiv(OW, 256 / NSr) * gy >= 4LL * device_cus());
+#define STORM_GN_DOWN1(KERN_, SILU_, NS_) hipLaunchKernelGGL((KERN_<T, SILU_, NS_>), dim3(cdiv(OW, 256 / NS_), (unsigned)gy), dim3(256), 0, st, \
                            (const T*)xa, Ca, (const T*)xb, Cb, H, W, G, stats, gamma, beta, eps, (T*)out_act, (T*)out_raw, ncg, nstrips, (switches().gn_nt >> 1) & 1)
+#define STORM_GN_DOWN(SILU_, NS_) do { if (share) STORM_GN_DOWN1(gn_apply_down_share_kernel, SILU_, NS_); else STORM_GN_DOWN1(gn_apply_down_kernel, SILU_, NS_); } while (0)
         if (silu) { if (NSr == 32) STORM_GN_DOWN(true, 32); else if (NSr == 16) STORM_GN_DOWN(true, 16); else STORM_GN_DOWN(true, 8); }
         else { if (NSr == 32) STORM_GN_DOWN(false, 32); else if (NSr == 16) STORM_GN_DOWN(false, 16); else STORM_GN_DOWN(false, 8); }
 #undef STORM_GN_DOWN
+#undef STORM_GN_DOWN1
         STORM_LAUNCH_CHECK();
         return STORM_OK;
     }

@@ -611,6 +611,18 @@ def test_groupnorm_fir_fused(dev, dtype, resample, shape, switch):
         switch("STORM_GN_ROWS", rows)
         actr, rawr = ops.gn_apply(xa, st, gam.to(dev), bet.to(dev), resample=resample)
         assert torch.equal(act, actr) and torch.equal(raw, rawr)
+    switch("STORM_GN_ROWS", 0)
+    if resample == 2:                # the down-sampling kernel with the activation shared between neighbouring threads through LDS (full launches) and
+        for share in (1, 2):         # the barrier-free one (small calls): the same bits, whatever the strips
+            switch("STORM_GN_DOWN_SHARE", share)
+            for rows in (0, 4):
+                switch("STORM_GN_ROWS", rows)
+                acts, raws = ops.gn_apply(xa, st, gam.to(dev), bet.to(dev), resample=resample)
+                assert torch.equal(act, acts) and torch.equal(raw, raws), (share, rows)
+            switch("STORM_GN_WIDE", 1)
+            acts, raws = ops.gn_apply(xa, st, gam.to(dev), bet.to(dev), resample=resample)
+            assert torch.equal(act, acts) and torch.equal(raw, raws), (share, "wide")
+            switch("STORM_GN_WIDE", 0)
 
 
 def test_fir_golden(dev, golden):
