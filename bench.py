@@ -163,11 +163,8 @@ def profile_ops(net, Y, nfe_count):
             esz, Cc = (4 if code == 0 else 2), Ca + Cb
             n_in = Bq * H * W * Cc
             n_out = n_in if rs == 0 else (2 * 4 * n_in if rs == 1 else 2 * n_in // 4)     # up / down: two output tensors
-            slots = Cc // (16 // esz)                       # norm_resample.hip: 16-byte slots of a pixel per workgroup (32 / 16 / 8)
-            ns = 32 if slots % 32 == 0 else (16 if slots % 16 == 0 else 8)
             row.update(algorithmic_bytes=(n_in + n_out) * esz, H=H, W=W, C=Cc, resample=rs,
-                       kernel=f"storm::gn_apply_kernel<{tname}, 0>" if rs == 0 else
-                       f"storm::gn_apply_{'up' if rs == 1 else 'down'}_kernel<{tname}, {'true' if int(op.i[6]) else 'false'}, {ns}>")
+                       kernel=L.lib().storm_gn_apply_kernel_name(Cc, Bq, H, W, int(op.i[6]), rs, code).decode())   # (what the launcher picks)
         elif op.code in (7, 8):                             # FIR x2 of the 8-channel pyramids
             Bq, H, W, Cc = [int(op.i[j]) for j in range(4)]
             esz = 4 if code == 0 else 2

@@ -183,6 +183,9 @@ int storm_gn_apply(const void* xa, int Ca, const void* xb, int Cb, int B, int H,
                    int groups, const double* stats, const float* gamma, const float* beta,
                    float eps, int silu, int resample, void* out_act, void* out_raw,
                    int dtype, storm_stream_t s);
+/* name (as rocprofv3 prints it, without the argument list) of the kernel storm_gn_apply launches for these arguments (C = Ca + Cb):
+ * lets a profiler / bench.py's per-op table name what the launcher really picked; static storage */
+const char* storm_gn_apply_kernel_name(int C, int B, int H, int W, int silu, int resample, int dtype);
 
 /* FIR resampling with taps [1,3,3,1] (zero boundary), optional "+ add" on the output.
  * Replaces upsample_2d / downsample_2d -> upfirdn2d (up_or_down_sampling.py:195-257,

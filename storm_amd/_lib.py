@@ -74,6 +74,7 @@ _SIGNATURES = {
     "storm_conv_tiles": ([C.POINTER(ConvArgs)], C.c_int),
     "storm_conv_splitk_bytes": ([C.POINTER(ConvArgs)], C.c_longlong),
     "storm_conv_kernel_name": ([C.POINTER(ConvArgs)], C.c_char_p),
+    "storm_gn_apply_kernel_name": ([_i, _i, _i, _i, _i, _i, _i], C.c_char_p),
     "storm_gn_finalize": ([_vp, _i, _i, _vp, _i, _i, _i, _i, _vp, _vp], C.c_int),
     "storm_gn_finalize_ss": ([_vp, _i, _i, _vp, _i, _i, _i, _i, _ll, _vp, _vp, _f, _vp, _vp, _vp], C.c_int),
     "storm_gn_stats": ([_vp, _i, _vp, _i, _i, _i, _i, _vp, _i, _vp], C.c_int),

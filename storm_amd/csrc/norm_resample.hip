@@ -7,6 +7,7 @@
 // reduced per thread in fp32 over <=256 pixels, then in fp64 across threads / workgroups
 // (one fp64 atomicAdd per (batch, group) per workgroup).  The resampling variants fuse
 // GN-apply + SiLU + FIR of BOTH the activated and the raw tensor (BigGAN block) in one pass.
+#include <cstdio>
 #include <cstdlib>
 #include "common.h"
 
@@ -782,6 +783,22 @@ static int strip_rows(int rows_total, long long wgs_per_strip, int dflt) {
     return r;
 }
 
+// The launch of the down-sampling kernel: channel groups, strips, and which of the two kernels.  The activation shared through LDS
+// (gn_apply_down_share_kernel) for full launches - at least four workgroups per CU; the barrier-free kernel for small calls (a chain of
+// latencies, not of instructions: measured slower there, profiles/r05_probe_gn_down_share.txt).  STORM_GN_DOWN_SHARE: 0 = this rule, 1 = never,
+// 2 = always (A/B, tests)
+struct DownPlan { int ncg, nstrips; long long gy; bool share; };
+static DownPlan down_plan(int C, int B, int H, int W, int per16, int NSr) {
+    const int OH = H / 2, OW = W / 2;
+    DownPlan d;
+    d.ncg = cdiv(C, NSr * per16);
+    d.nstrips = cdiv(OH, strip_rows(OH, (long long)cdiv(OW, 256 / NSr) * d.ncg * B, DN_ROWS));
+    d.gy = (long long)d.ncg * d.nstrips * B;
+    const int shsw = switches().gn_down_share;
+    d.share = shsw == 2 || (shsw == 0 && (long long)cdiv(OW, 256 / NSr) * d.gy >= 4LL * device_cus());
+    return d;
+}
+
 template <typename T, int R>
 static int gn_apply_t(const void* xa, int Ca, const void* xb, int Cb, int B, int H, int W, int G,
                       const double* stats, const float* gamma, const float* beta, float eps, int silu,
@@ -792,13 +809,11 @@ static int gn_apply_t(const void* xa, int Ca, const void* xb, int Cb, int B, int
     const int NSr = switches().gn_wide == 0 ? 8 : (slots % 32 == 0 ? 32 : slots % 16 == 0 ? 16 : 8);
     if (R == 2) {
         const int OH = H / 2, OW = W / 2;
-        const int ncg = cdiv(Ca + Cb, NSr * Elem<T>::PER16), nstrips = cdiv(OH, strip_rows(OH, (long long)cdiv(OW, 256 / NSr) * ncg * B, DN_ROWS));
-        const long long gy = (long long)ncg * nstrips * B;
+        const DownPlan dp = down_plan(Ca + Cb, B, H, W, Elem<T>::PER16, NSr);
+        const int ncg = dp.ncg, nstrips = dp.nstrips;
+        const long long gy = dp.gy;
         STORM_CHECK(OH > 0 && OW > 0 && gy < 65536, "storm_gn_apply: down-sampling grid %lld out of range", gy);
-        // the activation shared through LDS (gn_apply_down_share_kernel) for full launches; the barrier-free kernel for small calls (a chain of
-        // latencies, not of instructions).  STORM_GN_DOWN_SHARE: 0 = this rule, 1 = never, 2 = always (A/B, tests)
-        const int shsw = switches().gn_down_share;
-        const bool share = shsw == 2 || (shsw == 0 && (long long)cdiv(OW, 256 / NSr) * gy >= 4LL * device_cus());
+        const bool share = dp.share;
 #define STORM_GN_DOWN1(KERN_, SILU_, NS_) hipLaunchKernelGGL((KERN_<T, SILU_, NS_>), dim3(cdiv(OW, 256 / NS_), (unsigned)gy), dim3(256), 0, st, \
                            (const T*)xa, Ca, (const T*)xb, Cb, H, W, G, stats, gamma, beta, eps, (T*)out_act, (T*)out_raw, ncg, nstrips, (switches().gn_nt >> 1) & 1)
 #define STORM_GN_DOWN(SILU_, NS_) do { if (share) STORM_GN_DOWN1(gn_apply_down_share_kernel, SILU_, NS_); else STORM_GN_DOWN1(gn_apply_down_kernel, SILU_, NS_); } while (0)
@@ -910,6 +925,19 @@ extern "C" int storm_gn_apply(const void* xa, int Ca, const void* xb, int Cb, in
     if (dtype == STORM_F32) { STORM_GN_DISPATCH(float) }
 #undef STORM_GN_DISPATCH
     STORM_CHECK(false, "storm_gn_apply: dtype %d", dtype);
+}
+
+// name (as rocprofv3 prints it, without the argument list) of the kernel storm_gn_apply launches for these arguments; static storage
+extern "C" const char* storm_gn_apply_kernel_name(int C, int B, int H, int W, int silu, int resample, int dtype) {
+    static thread_local char name[160];
+    const char* const tn = dtype == STORM_F32 ? "float" : dtype == STORM_F16 ? "storm::half_t" : "storm::bf16_t";
+    const int per16 = dtype == STORM_F32 ? 4 : 8;
+    if (resample == 0) { snprintf(name, sizeof(name), "storm::gn_apply_kernel<%s, 0>", tn); return name; }
+    const int slots = C / per16;
+    const int NSr = switches().gn_wide == 0 ? 8 : (slots % 32 == 0 ? 32 : slots % 16 == 0 ? 16 : 8);
+    const bool share = resample == 2 && down_plan(C, B, H, W, per16, NSr).share;
+    snprintf(name, sizeof(name), "storm::gn_apply_%s_kernel<%s, %s, %d>", resample == 1 ? "up" : share ? "down_share" : "down", tn, silu ? "true" : "false", NSr);
+    return name;
 }
 
 extern "C" int storm_fir_up2(const void* x, const void* add, void* out, int B, int H, int W, int C, int dtype,
