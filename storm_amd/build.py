@@ -44,6 +44,16 @@ def build(force=False, verbose=False, profiling=False):
     cc = hipcc()
     bdir = os.path.join(CSRC, "build_prof" if profiling else "build")
     os.makedirs(bdir, exist_ok=True)
+    # one builder at a time (test workers / ranks that find the library stale at the same moment): the others wait, then find it fresh
+    import fcntl
+    with open(os.path.join(bdir, ".lock"), "w") as lk:
+        fcntl.flock(lk, fcntl.LOCK_EX)
+        if not profiling and not force and up_to_date():
+            return OUT
+        return _build_locked(cc, bdir, out, force, verbose, profiling)
+
+
+def _build_locked(cc, bdir, out, force, verbose, profiling):
     # (STORM_EXTRA_DEFS: extra -D switches of one-off experiments, profiling build only)
     flags = FLAGS + (["-DSTORM_PROFILING", "-DSTORM_WITH_DUO"] + os.environ.get("STORM_EXTRA_DEFS", "").split() if profiling else [])
     hdr_time = max(os.path.getmtime(h) for h in HEADERS + [os.path.abspath(__file__)])
@@ -66,10 +76,11 @@ def build(force=False, verbose=False, profiling=False):
         objs = list(ex.map(compile_one, PROF_SOURCES if profiling else SOURCES))
     with open(stamp, "w") as f:
         f.write(" ".join(flags))
-    r = subprocess.run([cc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", out] + objs,
+    r = subprocess.run([cc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", out + ".tmp"] + objs,
                        stdout=subprocess.PIPE, stderr=subprocess.STDOUT)
     if r.returncode != 0:
         raise RuntimeError(f"link failed:\n{r.stdout.decode()}")
+    os.replace(out + ".tmp", out)                          # (atomic: never a half-written library under the product's name)
     return out
 
 

@@ -14,6 +14,28 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 
 
+# ---- the CPU suite on several workers by default -------------------------------------------------------------------------------
+# `python -m pytest tests -q -m "not gpu"` is ~270 tests, most of them kernels and whole sampler runs on the host simulator: half an hour
+# on one core, a quarter of that on four.  When the run is the CPU suite (-m "not gpu"), pytest-xdist is installed, nobody chose -n and the
+# host has the cores, four workers are started (STORM_TEST_WORKERS = N overrides, 0 / 1 = serial).  Never for -m gpu: tests of one GPU run
+# one after the other (kernels of concurrent queues are not safe on this platform: profiles/r05_concurrent_streams_corruption.txt).
+@pytest.hookimpl(tryfirst=True)
+def pytest_cmdline_main(config):
+    if hasattr(config, "workerinput") or not config.pluginmanager.hasplugin("xdist"):
+        return None
+    opt = config.option
+    if getattr(opt, "numprocesses", None) is not None or getattr(opt, "markexpr", "") != "not gpu":
+        return None
+    if getattr(opt, "usepdb", False) or getattr(opt, "collectonly", False):
+        return None
+    want = os.environ.get("STORM_TEST_WORKERS", "")
+    n = int(want) if want.isdigit() else min(4, (os.cpu_count() or 1) // 2)
+    if n >= 2:
+        opt.numprocesses = n
+        opt.dist = "load"
+    return None
+
+
 @pytest.fixture(scope="session")
 def golden():
     import numpy as np

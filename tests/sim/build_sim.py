@@ -18,8 +18,21 @@ def build(force=False):
     srcs = [os.path.join(CSRC, s + ".hip") for s in SOURCES] + [os.path.join(HERE, "simrt.cpp")]
     deps = srcs + [os.path.join(CSRC, "common.h"), os.path.join(CSRC, "conv_index.h"), os.path.join(CSRC, "conv_params.h"), os.path.join(CSRC, "conv_pipe_common.h"), os.path.join(CSRC, "conv_epilogue.h"), os.path.join(CSRC, "conv_dispatch_table.h"), os.path.join(CSRC, "hw.h"),
                    os.path.join(HERE, "hip_host_shim.h"), os.path.join(ROOT, "include", "storm_hip.h")]
-    if not force and os.path.exists(OUT) and all(os.path.getmtime(OUT) >= os.path.getmtime(d) for d in deps):
+    fresh = lambda: os.path.exists(OUT) and all(os.path.getmtime(OUT) >= os.path.getmtime(d) for d in deps)  # noqa: E731
+    if not force and fresh():
         return OUT
+    # one builder at a time (the CPU suite runs on several pytest-xdist workers, each of which lands here on its first launch): the others
+    # wait for the lock and then find the library fresh
+    import fcntl
+    os.makedirs(os.path.join(HERE, "build"), exist_ok=True)
+    with open(os.path.join(HERE, "build", ".lock"), "w") as lk:
+        fcntl.flock(lk, fcntl.LOCK_EX)
+        if not force and fresh():
+            return OUT
+        return _build_locked(srcs)
+
+
+def _build_locked(srcs):
     objs = []
     bdir = os.path.join(HERE, "build")
     os.makedirs(bdir, exist_ok=True)
@@ -35,7 +48,8 @@ def build(force=False):
         if p.returncode != 0:
             sys.stderr.write(out.decode())
             raise RuntimeError(f"sim build failed for {s}")
-    subprocess.check_call([CXX, "-shared", "-fPIC", "-o", OUT] + objs + ["-lpthread"])
+    subprocess.check_call([CXX, "-shared", "-fPIC", "-o", OUT + ".tmp"] + objs + ["-lpthread"])
+    os.replace(OUT + ".tmp", OUT)                           # (atomic: a process that already mapped the old library keeps its copy)
     return OUT
 
 
