@@ -836,7 +836,8 @@ def test_conv_wait_placement_under_late_dma_landing():
     if os.environ.get("STORM_SIM_DMA") == "late":
         pytest.skip("already inside the late-landing run")
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    env = dict(os.environ, STORM_SIM_DMA="late", PYTHONPATH=root)
+    # (the inner run is this suite's longest item: two workers of its own - tests/conftest.py - beside the outer run's)
+    env = dict(os.environ, STORM_SIM_DMA="late", PYTHONPATH=root, STORM_TEST_WORKERS="2")
     r = subprocess.run([sys.executable, "-m", "pytest", os.path.join(root, "tests", "test_ops.py"), "-q", "-x", "-m", "not gpu",
                         "-k", "conv and not late_dma", "-p", "no:cacheprovider"], env=env, capture_output=True, text=True, timeout=1500)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-1000:]
