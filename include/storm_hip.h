@@ -194,6 +194,18 @@ int storm_fir_up2(const void* x, const void* add, void* out, int B, int H, int W
                   int dtype, storm_stream_t s);
 int storm_fir_down2(const void* x, void* out, int B, int H, int W, int C,
                     int dtype, storm_stream_t s);
+/* The reference's one native-op ABI with its own argument list:
+ *   upfirdn2d(input[N,H,W,1], kernel[kh,kw], up_x, up_y, down_x, down_y, pad_x0, pad_x1, pad_y0, pad_y1) -> [N,outH,outW,1]
+ * (op/upfirdn2d.cpp:12-22 -> upfirdn2d_op, op/upfirdn2d_kernel.cu:209-369; the CPU form is upfirdn2d_native, op/upfirdn2d.py:159-200).
+ * input / out: N contiguous planes (the reference reshapes [B,C,H,W] to [B*C,H,W,1]: minor = 1) of `dtype`; kernel: fp32 device taps
+ * (the reference always builds it as fp32, up_or_down_sampling.py:223,256); any up / down factors, pads (negative = crop) and kernel
+ * size.  out must hold N * outH * outW elements with outH / outW = storm_upfirdn2d_out_size(...) (the caller allocates: at::empty in
+ * upfirdn2d_kernel.cu:242-243).  Errors as everywhere: negative code + storm_last_error (TORCH_CHECK in the reference). */
+int storm_upfirdn2d(const void* input, const float* kernel, void* out, int N, int H, int W, int kh, int kw,
+                    int up_x, int up_y, int down_x, int down_y, int pad_x0, int pad_x1, int pad_y0, int pad_y1,
+                    int dtype, storm_stream_t s);
+/* (in * up + pad0 + pad1 - ktaps) / down + 1 (upfirdn2d_kernel.cu:226-227); host arithmetic, no device work */
+long long storm_upfirdn2d_out_size(int in, int up, int down, int pad0, int pad1, int ktaps);
 
 /* Row softmax of fp32 scores [rows][ld] (first L columns valid) -> probabilities (activation
  * dtype, same row stride, padding columns written as 0).

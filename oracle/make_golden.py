@@ -395,6 +395,144 @@ def gen_f15(ref):
                           backbone="ncsnpplarge", N=50)
 
 
+F16_LENGTHS = (156000, 158000, 160000)                    # 1219 / 1235 / 1251 frames: all in the 1280-frame bucket (util/other.py:102-109)
+F16_SEEDS = dict(weights=16, x=1616, wav=1600, noise=1610, state=1620, ode_z=1630)
+F16_ODE_TOL = 0.03
+
+
+def gen_f16(ref):
+    """F16: BASELINE.json configs[4] at its REAL shape - the seeded 27.8 M `ncsnpp` on 10-s rows (160 000 samples -> 1251 -> 1280
+    frames; 256 x 1280 conv levels, L = 5120 attention: layerspp.py:82-86).  (a) NCSNpp.forward of ONE [1,2,256,1280] input
+    (ncsnpp.py:281-450); (b) ScoreModel.enhance (model.py:273-310) with N = 3 reverse steps + 1 ald step each = 6 evaluations, wav -> wav,
+    on THREE utterances of 156 000 / 158 000 / 160 000 samples, one by one as the reference runs them (they share the 1280-frame bucket),
+    under recorded noise (regenerated from seeds on both sides); (c) one probability-flow right-hand side rsde.sde(x, t, y)[0]
+    (sampling/__init__.py:104-106, sdes.py:123-145) at that shape; (d) ScoreModel.enhance(sampler_type="ode") of the 160 000-sample
+    utterance with rtol = atol = F16_ODE_TOL (the solver's own loop at the real shape; the configured 1e-5 would cost the CPU reference
+    ~500 evaluations of 20 s).  About an hour on 8 cores."""
+    print("F16 configs[4] at its real shape: 27.8 M ncsnpp on 256 x 1280 (about an hour)")
+    torch.set_num_threads(8)
+    import time
+    M, DM = ref["model"], ref["data_module"].SpecsDataModule
+    S = F16_SEEDS
+    cfg = NR.NCSNppConfig(**NR.NAMED_CONFIGS["ncsnpp"], input_channels=4)
+    sd = NR.seeded_state_dict(cfg, seed=S["weights"])
+    m = M.ScoreModel(backbone="ncsnpp", sde="ouve", data_module_cls=DM, theta=1.5, sigma_min=0.05, sigma_max=0.5,
+                     spec_factor=0.15, spec_abs_exponent=0.5)
+    m.dnn.load_state_dict(sd)
+    m.eval(no_ema=True)
+    f16 = dict(sdhash=np.array(sd_hash(sd)), lengths=np.array(F16_LENGTHS), t=np.array([0.37], dtype=np.float32),
+               seeds=np.array([S[k] for k in ("weights", "x", "wav", "noise", "state", "ode_z")]), ode_tol=np.array(F16_ODE_TOL))
+    # (a) one forward
+    xin = seeded_input((1, 2, 256, 1280), S["x"], 0.5)
+    tt = torch.tensor([0.37])
+    t0 = time.time()
+    with torch.no_grad():
+        y_ref = m.dnn(xin, tt)
+        y_or = NR.ncsnpp_forward(sd, cfg, xin, tt)
+    check("ncsnpp4 forward @ 256x1280", y_or, y_ref, 5e-5)
+    print(f"  (a) two forwards {time.time() - t0:.0f} s")
+    f16.update(fwd_y=c2np(y_ref), fwd_xhash=np.array(tensor_hash(xin)))
+    # (b) three 6-evaluation enhance runs, one utterance per call
+    N, steps = 3, 1
+    orig = torch.randn_like
+    nhashes = []
+    for i, n in enumerate(F16_LENGTHS):
+        t0 = time.time()
+        ywav = torch.randn(1, n, generator=torch.Generator().manual_seed(S["wav"] + i)) * 0.1
+        gn = torch.Generator().manual_seed(S["noise"] + i)
+        noises = [SR.complex_randn((1, 1, 256, 1280), gn) for _ in range(1 + N * (steps + 1))]
+        nhashes.append(hashlib.sha256(b"".join(c2np(z).tobytes() for z in noises)).hexdigest())
+        it = iter(noises)
+        final = {}
+        to_audio_orig = m.to_audio
+
+        def to_audio_spy(spec, length=None):
+            final["spec"] = spec.detach().clone()
+            return to_audio_orig(spec, length)
+        torch.randn_like = lambda x, *a, **k: next(it).to(x.dtype)
+        m.to_audio = to_audio_spy
+        try:
+            with torch.no_grad():
+                xh_ref = m.enhance(ywav.clone(), N=N, corrector="ald", corrector_steps=steps, snr=0.5)
+        finally:
+            torch.randn_like = orig
+            m.to_audio = to_audio_orig
+        f16[f"pc_out{i}"] = xh_ref.numpy()
+        f16[f"pc_wavhash{i}"] = np.array(tensor_hash(ywav))
+        if i == 0:                                         # the shortest row: the most padded frames behind its content
+            f16["pc_final_spec0"] = c2np(final["spec"].reshape(1, 1, 256, 1280))
+            Y, nfac, T0 = FR.wav_to_spec(ywav)
+            it = iter(noises)
+            with torch.no_grad():
+                samp, nfe = SR.pc_sample(SR.OUVE(1.5, 0.05, 0.5, N=N), lambda x, t, y: -NR.ncsnpp_forward(sd, cfg, torch.cat([x, y], 1), t),
+                                         Y, lambda: next(it), corrector_steps=steps, snr=0.5)
+            check("F16 enhance wav (6 evaluations, 156 000 samples)", FR.spec_to_wav(samp, nfac, T0), xh_ref, 1e-4)
+            check("F16 final sampler state", samp, final["spec"].reshape(samp.shape), 1e-4)
+        print(f"  (b) utterance {i} ({n} samples) {time.time() - t0:.0f} s")
+    f16["pc_noise_hashes"] = np.array(nhashes)
+    f16.update(pc_N=np.array(N), pc_nfe=np.array(N * (steps + 1)))
+    # (c) one probability-flow right-hand side at that shape
+    ywav = torch.randn(1, F16_LENGTHS[2], generator=torch.Generator().manual_seed(S["wav"] + 2)) * 0.1
+    Y, nfac, T0 = FR.wav_to_spec(ywav)
+    xs = Y + seeded_input((1, 1, 256, 1280), S["state"], 0.2)
+    tv = torch.tensor([0.5])
+    sde = m.sde.copy()
+    sde.N = 30
+    with torch.no_grad():
+        drift = sde.reverse(m, probability_flow=True).sde(xs, tv, Y)[0]
+        s_or = -NR.ncsnpp_forward(sd, cfg, torch.cat([xs, Y], 1), tv)
+        osde = SR.OUVE(1.5, 0.05, 0.5, N=30)
+        f_or, g_or = osde.sde(xs, tv, Y)
+        drift_or = f_or - 0.5 * g_or[:, None, None, None] ** 2 * s_or
+    check("F16 probability-flow drift @ 256x1280", drift_or, drift, 5e-5)
+    f16.update(pf_drift=c2np(drift), pf_t=np.array([0.5], dtype=np.float32), pf_xhash=np.array(tensor_hash(xs)))
+    # (d) the ODE sampler's own loop at the real shape, loose tolerance
+    t0 = time.time()
+    zi = SR.complex_randn((1, 1, 256, 1280), torch.Generator().manual_seed(S["ode_z"]))
+    torch.randn_like = lambda x, *a, **k: zi.to(x.dtype)
+    try:
+        with torch.no_grad():
+            xh, nfe, _ = m.enhance(ywav.clone(), sampler_type="ode", timeit=True, device="cpu", rtol=F16_ODE_TOL, atol=F16_ODE_TOL)
+    finally:
+        torch.randn_like = orig
+    nfe = int(nfe[0]) if isinstance(nfe, (list, tuple)) else int(nfe)
+    print(f"  (d) enhance(ode, tol {F16_ODE_TOL}) nfev {nfe}, {time.time() - t0:.0f} s")
+    f16.update(ode_out=xh.numpy(), ode_nfe=np.array(nfe), ode_zhash=np.array(tensor_hash(zi)))
+    np.savez_compressed(os.path.join(OUT, "f16_cfg4_shape.npz"), **f16)
+
+
+UPFIRDN_CASES = {
+    # name: (N, H, W, kh, kw, up_x, up_y, down_x, down_y, pad_x0, pad_x1, pad_y0, pad_y1)
+    "up2": (3, 6, 9, 4, 4, 2, 2, 1, 1, 2, 1, 2, 1),           # upsample_2d(k=[1,3,3,1], factor 2): pads (2, 1) (up_or_down_sampling.py:219-224)
+    "down2": (3, 6, 10, 4, 4, 1, 1, 2, 2, 1, 1, 1, 1),        # downsample_2d: pads (1, 1) (up_or_down_sampling.py:252-257)
+    "mixed": (2, 5, 7, 3, 5, 3, 1, 2, 1, -1, 2, 0, 3),        # factors / pads that differ per axis, a cropping (negative) pad, a 3 x 5 kernel
+    "updown": (2, 4, 4, 2, 3, 2, 3, 3, 2, 1, 0, 2, 2),
+}
+
+
+def gen_f17(ref):
+    """F17: the reference's one native-op seam, upfirdn2d(input, kernel, up_x, up_y, down_x, down_y, pad_x0, pad_x1, pad_y0, pad_y1)
+    (op/upfirdn2d.cpp:12-22), through its CPU form upfirdn2d_native (op/upfirdn2d.py:159-200) on four parameter sets: the two the
+    network uses and two that no layer uses (storm_upfirdn2d accepts the full argument list)."""
+    print("F17 upfirdn2d_native, four parameter sets")
+    import importlib
+    U = importlib.import_module("sgmse.backbones.ncsnpp_utils.op.upfirdn2d")
+    g = torch.Generator().manual_seed(1717)
+    f17 = {}
+    for name, (N, H, W, kh, kw, ux, uy, dx, dy, px0, px1, py0, py1) in UPFIRDN_CASES.items():
+        x = torch.randn(N, 1, H, W, generator=g)
+        k = torch.randn(kh, kw, generator=g)
+        if name in ("up2", "down2"):
+            k1 = torch.tensor([1., 3., 3., 1.])
+            k = torch.outer(k1, k1)
+            k = k / k.sum() * (4 if name == "up2" else 1)
+        y = U.upfirdn2d_native(x, k, ux, uy, dx, dy, px0, px1, py0, py1)[:, 0]
+        check(f"upfirdn2d {name}", NR.upfirdn2d(x[:, 0], k, ux, uy, dx, dy, px0, px1, py0, py1), y, 1e-6)
+        f17.update({f"{name}_x": x[:, 0].numpy(), f"{name}_k": k.numpy(), f"{name}_y": y.numpy(),
+                    f"{name}_args": np.array([ux, uy, dx, dy, px0, px1, py0, py1])})
+    np.savez_compressed(os.path.join(OUT, "f17_upfirdn2d.npz"), **f17)
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
     if "--only-f9" in sys.argv:
@@ -406,7 +544,7 @@ def main():
     if "--only-f8" in sys.argv:
         gen_f8(import_reference())
         return
-    for flag, fn in (("--only-f10", gen_f10), ("--only-f11", gen_f11), ("--only-f12", gen_f12), ("--only-f13", gen_f13), ("--only-f14", gen_f14), ("--only-f15", gen_f15)):
+    for flag, fn in (("--only-f10", gen_f10), ("--only-f11", gen_f11), ("--only-f12", gen_f12), ("--only-f13", gen_f13), ("--only-f14", gen_f14), ("--only-f15", gen_f15), ("--only-f16", gen_f16), ("--only-f17", gen_f17)):
         if flag in sys.argv:
             fn(import_reference())
             return

@@ -102,6 +102,33 @@ def fir_down2(x):
     return down_axis(down_axis(x, 2), 3)
 
 
+def upfirdn2d(x, k, up_x=1, up_y=1, down_x=1, down_y=1, pad_x0=0, pad_x1=0, pad_y0=0, pad_y1=0):
+    """The reference's native op for ANY parameter set (op/upfirdn2d.cpp:12-22; CPU form upfirdn2d_native, op/upfirdn2d.py:159-200;
+    CUDA form op/upfirdn2d_kernel.cu:107-369), restated as a gather: x [N, H, W] planes, k [kh, kw] ->
+        out[n, oy, ox] = sum_{ky,kx} k[kh-1-ky, kw-1-kx] * U[n, oy*down_y + ky - pad_y0, ox*down_x + kx - pad_x0]
+    with U the zero-stuffed image (U[up_y*i, up_x*j] = x[i, j], zero elsewhere and outside), i.e. a true convolution (the reference
+    flips the kernel for F.conv2d) of the padded / cropped zero-stuffed image followed by decimation;
+    out_h = (H*up_y + pad_y0 + pad_y1 - kh) // down_y + 1 (likewise out_w)."""
+    x, k = torch.as_tensor(x), torch.as_tensor(k)
+    N, H, W = x.shape
+    kh, kw = k.shape
+    OH = (H * up_y + pad_y0 + pad_y1 - kh) // down_y + 1
+    OW = (W * up_x + pad_x0 + pad_x1 - kw) // down_x + 1
+    U = torch.zeros(N, H * up_y, W * up_x, dtype=x.dtype)
+    U[:, ::up_y, ::up_x] = x
+    out = torch.zeros(N, max(OH, 0), max(OW, 0), dtype=x.dtype)
+    oy, ox = torch.arange(max(OH, 0)), torch.arange(max(OW, 0))
+    for ky in range(kh):
+        uy = oy * down_y + ky - pad_y0
+        my = (uy >= 0) & (uy < H * up_y)
+        for kx in range(kw):
+            ux = ox * down_x + kx - pad_x0
+            mx = (ux >= 0) & (ux < W * up_x)
+            g = U[:, uy.clamp(0, H * up_y - 1)][:, :, ux.clamp(0, W * up_x - 1)]
+            out += k[kh - 1 - ky, kw - 1 - kx] * g * (my[:, None] & mx[None, :]).to(x.dtype)
+    return out
+
+
 def nin(x, W, b):
     """layers.NIN (layers.py:548-557): y = x . W + b over the channel axis, W [Cin, Cout]."""
     return torch.einsum("bchw,cd->bdhw", x, W) + b[None, :, None, None]

@@ -81,6 +81,8 @@ _SIGNATURES = {
     "storm_gn_apply": ([_vp, _i, _vp, _i, _i, _i, _i, _i, _vp, _vp, _vp, _f, _i, _i, _vp, _vp, _i, _vp], C.c_int),
     "storm_fir_up2": ([_vp, _vp, _vp, _i, _i, _i, _i, _i, _vp], C.c_int),
     "storm_fir_down2": ([_vp, _vp, _i, _i, _i, _i, _i, _vp], C.c_int),
+    "storm_upfirdn2d": ([_vp, _vp, _vp] + [_i] * 14 + [_vp], C.c_int),
+    "storm_upfirdn2d_out_size": ([_i] * 6, C.c_longlong),
     "storm_attention_supported": ([_i, _i], C.c_int),
     "storm_attention": ([_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _ll, _ll, _ll, _ll, _f, _i, _vp], C.c_int),
     "storm_attention_scratch_bytes": ([_i, _i, _i, _i], C.c_longlong),

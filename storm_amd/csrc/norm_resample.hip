@@ -858,6 +858,41 @@ static int fir_t(const void* x, const void* add, void* out, int B, int H, int W,
     return STORM_OK;
 }
 
+// The reference's ONE native op with its own argument list (op/upfirdn2d.cpp:12-22, op/upfirdn2d_kernel.cu:107-369): N planes [H][W]
+// (the reference reshapes [B,C,H,W] to [B*C,H,W,1]), zero-stuffing by (up_x, up_y), padding / cropping by the four pads, a true convolution
+// with kernel[kh][kw] (upfirdn2d_native flips it, op/upfirdn2d.py:183-184) and decimation by (down_x, down_y).  One thread per output
+// element gathers its taps (zero-stuffed positions are skipped, not multiplied); fp32 accumulation in tap order.  The network never
+// calls this - its FIR steps are fused into gn_apply_up / gn_apply_down / fir_kernel on NHWC tensors - it is the drop-in for the seam.
+template <typename T>
+__global__ void upfirdn2d_planes_kernel(const T* __restrict__ x, const float* __restrict__ k, T* __restrict__ out, int H, int W, int OH, int OW,
+                                        int kh, int kw, int up_x, int up_y, int down_x, int down_y, int pad_x0, int pad_y0) {
+    const long long plane = blockIdx.y;
+    const int p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= OH * OW) return;
+    const int oy = p / OW, ox = p - oy * OW;
+    const T* xp = x + plane * H * W;
+    float acc = 0.0f;
+    for (int ky = 0; ky < kh; ++ky) {
+        const int uy = oy * down_y + ky - pad_y0;          // row of the zero-stuffed image
+        if (uy < 0 || uy % up_y != 0 || uy / up_y >= H) continue;
+        for (int kx = 0; kx < kw; ++kx) {
+            const int ux = ox * down_x + kx - pad_x0;
+            if (ux < 0 || ux % up_x != 0 || ux / up_x >= W) continue;
+            acc += to_f32(xp[(long long)(uy / up_y) * W + ux / up_x]) * k[(kh - 1 - ky) * kw + (kw - 1 - kx)];
+        }
+    }
+    from_f32(out[plane * OH * OW + p], acc);
+}
+
+template <typename T>
+static int upfirdn2d_t(const void* x, const float* k, void* out, int N, int H, int W, int OH, int OW, int kh, int kw, int up_x, int up_y,
+                       int down_x, int down_y, int pad_x0, int pad_y0, hipStream_t st) {
+    hipLaunchKernelGGL((upfirdn2d_planes_kernel<T>), dim3(cdiv((long long)OH * OW, 256), N), dim3(256), 0, st, (const T*)x, k, (T*)out, H, W, OH, OW,
+                       kh, kw, up_x, up_y, down_x, down_y, pad_x0, pad_y0);
+    STORM_LAUNCH_CHECK();
+    return STORM_OK;
+}
+
 }  // namespace storm
 
 using namespace storm;
@@ -958,4 +993,25 @@ extern "C" int storm_fir_down2(const void* x, void* out, int B, int H, int W, in
     if (dtype == STORM_F16) return fir_t<half_t, 2>(x, nullptr, out, B, H, W, C, st);
     if (dtype == STORM_F32) return fir_t<float, 2>(x, nullptr, out, B, H, W, C, st);
     STORM_CHECK(false, "storm_fir_down2: dtype %d", dtype);
+}
+
+extern "C" int storm_upfirdn2d(const void* input, const float* kernel, void* out, int N, int H, int W, int kh, int kw, int up_x, int up_y,
+                               int down_x, int down_y, int pad_x0, int pad_x1, int pad_y0, int pad_y1, int dtype, storm_stream_t s) {
+    STORM_CHECK(input && kernel && out && N > 0 && H > 0 && W > 0 && kh > 0 && kw > 0, "storm_upfirdn2d: bad arguments (N=%d H=%d W=%d kernel %dx%d)", N, H, W, kh, kw);
+    STORM_CHECK(up_x > 0 && up_y > 0 && down_x > 0 && down_y > 0, "storm_upfirdn2d: up / down factors must be positive");
+    STORM_CHECK(N < 65536, "storm_upfirdn2d: %d planes exceed the launch grid (split the call)", N);
+    const long long OH = storm_upfirdn2d_out_size(H, up_y, down_y, pad_y0, pad_y1, kh), OW = storm_upfirdn2d_out_size(W, up_x, down_x, pad_x0, pad_x1, kw);
+    STORM_CHECK(OH > 0 && OW > 0 && OH * OW < (1LL << 31), "storm_upfirdn2d: empty or oversized output %lld x %lld", OH, OW);
+    hipStream_t st = (hipStream_t)s;
+    if (dtype == STORM_BF16) return upfirdn2d_t<bf16_t>(input, kernel, out, N, H, W, (int)OH, (int)OW, kh, kw, up_x, up_y, down_x, down_y, pad_x0, pad_y0, st);
+    if (dtype == STORM_F16) return upfirdn2d_t<half_t>(input, kernel, out, N, H, W, (int)OH, (int)OW, kh, kw, up_x, up_y, down_x, down_y, pad_x0, pad_y0, st);
+    if (dtype == STORM_F32) return upfirdn2d_t<float>(input, kernel, out, N, H, W, (int)OH, (int)OW, kh, kw, up_x, up_y, down_x, down_y, pad_x0, pad_y0, st);
+    set_error("storm_upfirdn2d: dtype %d", dtype);
+    return STORM_ERR_UNSUPPORTED;
+}
+
+extern "C" long long storm_upfirdn2d_out_size(int in, int up, int down, int pad0, int pad1, int ktaps) {
+    if (up <= 0 || down <= 0 || ktaps <= 0) return -1;
+    const long long span = (long long)in * up + pad0 + pad1 - ktaps;       // upfirdn2d_kernel.cu:226-227 / op/upfirdn2d.py:197-198
+    return span < 0 ? 0 : span / down + 1;
 }

@@ -194,6 +194,23 @@ def fir_down2(x):
     return out
 
 
+def upfirdn2d(input, kernel, up_x=1, up_y=1, down_x=1, down_y=1, pad_x0=0, pad_x1=0, pad_y0=0, pad_y1=0):
+    """The reference's native op with its own argument list (op/upfirdn2d.cpp:12-22): input [N, H, W, 1] contiguous (planes),
+    kernel [kh, kw] -> [N, outH, outW, 1]; any factors / pads.  One call of storm_upfirdn2d on torch's current stream."""
+    if input.dim() != 4 or input.shape[-1] != 1 or not input.is_contiguous():
+        raise ValueError("upfirdn2d: input must be a contiguous [N, H, W, 1] tensor (op/upfirdn2d.cpp:9)")
+    N, H, W, _ = input.shape
+    kh, kw = kernel.shape
+    lib = L.lib()
+    OH = lib.storm_upfirdn2d_out_size(H, up_y, down_y, pad_y0, pad_y1, kh)
+    OW = lib.storm_upfirdn2d_out_size(W, up_x, down_x, pad_x0, pad_x1, kw)
+    out = _alloc((N, max(OH, 0), max(OW, 0), 1), input.dtype, input)
+    k32 = kernel.to(device=input.device, dtype=torch.float32).contiguous()
+    L.check(lib.storm_upfirdn2d(L.ptr(input), L.ptr(k32), L.ptr(out), N, H, W, kh, kw, up_x, up_y, down_x, down_y,
+                                pad_x0, pad_x1, pad_y0, pad_y1, L.dt(input), L.stream()), "storm_upfirdn2d")
+    return out
+
+
 def softmax_rows(scores, dtype, valid=None):
     """softmax over the first `valid` columns of each row (the rest is row padding, written as 0)."""
     ld = scores.shape[-1]

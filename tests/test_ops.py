@@ -639,6 +639,26 @@ def test_fir_golden(dev, golden):
     assert rel_l2(nchw(up2)[:, :5], torch.from_numpy(g["fir_up"]) + add[:, :5]) < 1e-6
 
 
+@pytest.mark.parametrize("name", ["up2", "down2", "mixed", "updown"])
+def test_upfirdn2d_reference_argument_list(dev, golden, name):
+    """storm_upfirdn2d = the reference's one native-op ABI with its own argument list (op/upfirdn2d.cpp:12-22: input [N,H,W,1], kernel
+    [kh,kw], up_x, up_y, down_x, down_y, pad_x0, pad_x1, pad_y0, pad_y1) against what upfirdn2d_native returned (fixture F17): the
+    two parameter sets of the network and two that no layer uses; 16-bit planes against the fp32 result within their rounding."""
+    from storm_amd import ops
+    g = golden["f17_upfirdn2d"]
+    x, k, args = torch.from_numpy(g[f"{name}_x"]), torch.from_numpy(g[f"{name}_k"]), [int(v) for v in g[f"{name}_args"]]
+    want = torch.from_numpy(g[f"{name}_y"])
+    y = ops.upfirdn2d(x[..., None].contiguous().to(dev), k.to(dev), *args).cpu()
+    assert y.shape == want.shape + (1,) and rel_l2(y[..., 0], want) < 1e-6
+    for dt in (torch.bfloat16, torch.float16):
+        y16 = ops.upfirdn2d(x[..., None].contiguous().to(dt).to(dev), k.to(dev), *args).float().cpu()
+        assert rel_l2(y16[..., 0], want) < 8e-3
+    with pytest.raises(Exception):
+        ops.upfirdn2d(x[..., None].contiguous().to(dev), k.to(dev), 0, 1, 1, 1, 0, 0, 0, 0)        # up_x = 0
+    with pytest.raises(ValueError):
+        ops.upfirdn2d(x.to(dev), k.to(dev))                                                        # not [N, H, W, 1]
+
+
 @pytest.mark.parametrize("dtype", DTYPES)
 def test_softmax_rows(dev, dtype):
     from storm_amd import ops
