@@ -2,6 +2,7 @@
 the checkpoint reader / EMA swap, and batched == per-utterance."""
 import math
 import os
+import sys
 
 import pytest
 import torch
@@ -88,6 +89,150 @@ def test_checkpoint_reader_and_ema(dev, tmp_path):
     with torch.no_grad():
         want = -NR.ncsnpp_forward(ema, cfg, torch.cat([x.cpu(), x.cpu()], 1), t.cpu())
     assert rel_l2(m(x, t, x).cpu(), want) < 1e-4
+
+
+def _fake_lightning_modules(monkeypatch):
+    """What the pickle stream of a real pytorch-lightning 1.8.3 checkpoint of the reference names (requirements.txt:9): the hyper-parameter
+    container pytorch_lightning.utilities.parsing.AttributeDict and, inside it, the CLASS sgmse.data_module.SpecsDataModule
+    (model.py:60 save_hyperparameters stores data_module_cls).  Fabricated here so that torch.save writes those global names."""
+    import types
+
+    class AttributeDict(dict):
+        def __getattr__(self, k):                             # (pytorch_lightning/utilities/parsing.py: a missing key is an AttributeError)
+            try:
+                return self[k]
+            except KeyError as e:
+                raise AttributeError(k) from e
+
+        def __setattr__(self, k, v):
+            self[k] = v
+
+    class SpecsDataModule:                                    # (pickled by reference: only its qualified name reaches the file)
+        pass
+
+    class ModelCheckpoint:                                    # a callback object some checkpoints carry: must unpickle to something inert
+        def __init__(self):
+            self.best_model_score = torch.tensor(1.5)
+    AttributeDict.__module__, AttributeDict.__qualname__ = "pytorch_lightning.utilities.parsing", "AttributeDict"
+    SpecsDataModule.__module__, SpecsDataModule.__qualname__ = "sgmse.data_module", "SpecsDataModule"
+    ModelCheckpoint.__module__, ModelCheckpoint.__qualname__ = "pytorch_lightning.callbacks.model_checkpoint", "ModelCheckpoint"
+    mods = {"pytorch_lightning": types.ModuleType("pytorch_lightning"), "pytorch_lightning.utilities": types.ModuleType("pytorch_lightning.utilities"),
+            "pytorch_lightning.utilities.parsing": types.ModuleType("pytorch_lightning.utilities.parsing"),
+            "pytorch_lightning.callbacks": types.ModuleType("pytorch_lightning.callbacks"),
+            "pytorch_lightning.callbacks.model_checkpoint": types.ModuleType("pytorch_lightning.callbacks.model_checkpoint"),
+            "sgmse": types.ModuleType("sgmse"), "sgmse.data_module": types.ModuleType("sgmse.data_module")}
+    mods["pytorch_lightning.utilities.parsing"].AttributeDict = AttributeDict
+    mods["pytorch_lightning.callbacks.model_checkpoint"].ModelCheckpoint = ModelCheckpoint
+    mods["sgmse.data_module"].SpecsDataModule = SpecsDataModule
+    for k, v in mods.items():
+        monkeypatch.setitem(sys.modules, k, v)
+    return AttributeDict, SpecsDataModule, ModelCheckpoint, list(mods)
+
+
+def _lightning_extras(ModelCheckpoint):
+    return {"epoch": 3, "global_step": 1234, "pytorch-lightning_version": "1.8.3", "hparams_name": "kwargs",
+            "callbacks": {"ModelCheckpoint{'monitor': 'pesq'}": {"best_model_score": torch.tensor(2.1), "obj": ModelCheckpoint()}},
+            "optimizer_states": [{"state": {0: {"step": torch.tensor(5.0), "exp_avg": torch.zeros(3)}}, "param_groups": [{"lr": 1e-4}]}],
+            "lr_schedulers": [], "loops": {"fit_loop": {"state_dict": {}}}}
+
+
+def test_checkpoint_as_lightning_writes_it_score_model(monkeypatch, tmp_path):
+    """The hard part of the Lightning-free reader (enhancement.py:49-61, model.py:86-111): a file whose pickle stream names
+    pytorch_lightning's AttributeDict (hyper_parameters), the class sgmse.data_module.SpecsDataModule inside it and a callback object,
+    loaded in a process where neither package exists.  EMA state as torch-ema 0.3 writes it (requirements.txt:15)."""
+    from storm_amd.data_module import SpecsDataModule as OurDM
+    from storm_amd.model import ScoreModel
+    AD, DM, MC, names = _fake_lightning_modules(monkeypatch)
+    cfg = NR.NCSNppConfig(nf=8, input_channels=4)
+    live, ema = NR.seeded_state_dict(cfg, seed=1), NR.seeded_state_dict(cfg, seed=2)
+    ref = ScoreModel(backbone="ncsnpp", **dict(COMMON))
+    ref.dnn.load_state_dict(ema)
+    shadow = [p.detach().clone() for p in ref.parameters()]           # torch-ema 0.3: every parameter, in parameters() order
+    hp = AD(backbone="ncsnpp", data_module_cls=DM, lr=1e-4, ema_decay=0.999, t_eps=0.03, num_eval_files=10, loss_type="mse",
+            base_dir="/data/wsj0", batch_size=8, num_workers=4, gpus=4, **COMMON)
+    ckpt = {"state_dict": {"dnn." + k: v for k, v in live.items()}, "hyper_parameters": hp,
+            "ema": {"decay": 0.999, "num_updates": 10, "shadow_params": shadow, "collected_params": None}, **_lightning_extras(MC)}
+    path = os.path.join(tmp_path, "score.ckpt")
+    torch.save(ckpt, path)
+    for n in names:
+        monkeypatch.delitem(sys.modules, n)
+    assert "pytorch_lightning" not in sys.modules and "sgmse" not in sys.modules
+    with pytest.raises(Exception):                                      # the plain unpickler cannot resolve those names here
+        torch.load(path, weights_only=False)
+    m = ScoreModel.load_from_checkpoint(path, base_dir="", batch_size=1, num_workers=0, kwargs=dict(gpu=False))
+    assert isinstance(m.data_module, OurDM) and m.t_eps == 0.03 and m.sde.theta == COMMON["theta"]
+    assert all(torch.equal(m.dnn.state_dict()[k], live[k]) for k in live)
+    m.eval(no_ema=False)
+    assert all(torch.equal(m.dnn.state_dict()[k], ema[k]) for k in ema)
+    m.train(True)
+    assert all(torch.equal(m.dnn.state_dict()[k], live[k]) for k in live)
+    # no 'ema' entry: warning, live weights stay (model.py:88-93)
+    del ckpt["ema"]
+    AD2, DM2, MC2, names2 = _fake_lightning_modules(monkeypatch)
+    ckpt["hyper_parameters"] = AD2(ckpt["hyper_parameters"], data_module_cls=DM2)
+    ckpt["callbacks"] = {}
+    torch.save(ckpt, path)
+    for n in names2:
+        monkeypatch.delitem(sys.modules, n)
+    with pytest.warns(UserWarning, match="EMA"):
+        m2 = ScoreModel.load_from_checkpoint(path, base_dir="", batch_size=1, num_workers=0, kwargs=dict(gpu=False))
+    m2.eval(no_ema=False)
+    assert all(torch.equal(m2.dnn.state_dict()[k], live[k]) for k in live)
+
+
+def test_checkpoint_as_lightning_writes_it_storm(dev, monkeypatch, tmp_path):
+    """A StoRM checkpoint (model.py:496-531): keys score_net.* / denoiser_net.*, ONE EMA over both nets' parameters in parameters()
+    order (denoiser first, model.py:416-424), here as an older torch-ema wrote it - shadow tensors for the TRAINABLE parameters only
+    (the two Gaussian-Fourier W are requires_grad = False, layerspp.py:37), so _EMA._match's second branch runs.  The loaded model's
+    enhance() must run on the EMA weights of BOTH nets."""
+    from storm_amd.model import StochasticRegenerationModel
+    AD, DM, MC, names = _fake_lightning_modules(monkeypatch)
+    cfg_d, cfg_s = NR.NCSNppConfig(nf=8, input_channels=2, discriminative=True), NR.NCSNppConfig(nf=8, input_channels=6)
+    live_d, live_s = NR.seeded_state_dict(cfg_d, seed=3), NR.seeded_state_dict(cfg_s, seed=4)
+    ema_d, ema_s = NR.seeded_state_dict(cfg_d, seed=5), NR.seeded_state_dict(cfg_s, seed=6)
+    for k in live_d:                                                   # frozen parameters are not averaged: the EMA run keeps the live W
+        if k.endswith("all_modules.0.W"):
+            ema_d[k] = live_d[k]
+    for k in live_s:
+        if k.endswith("all_modules.0.W"):
+            ema_s[k] = live_s[k]
+    hpd = dict(backbone_denoiser="ncsnpp", backbone_score="ncsnpp", condition="both", mode="regen-joint-training", **COMMON)
+    ref = StochasticRegenerationModel(**dict(hpd))
+    ref.denoiser_net.load_state_dict(ema_d)
+    ref.score_net.load_state_dict(ema_s)
+    params = list(ref.parameters())
+    frozen = [p for p in params if not p.requires_grad]
+    assert len(frozen) == 2, "expected the two Gaussian-Fourier projections to be frozen parameters (layerspp.py:37)"
+    shadow = [p.detach().clone() for p in params if p.requires_grad]
+    sd = {**{"denoiser_net." + k: v for k, v in live_d.items()}, **{"score_net." + k: v for k, v in live_s.items()}}
+    ckpt = {"state_dict": sd, "hyper_parameters": AD(data_module_cls=DM, loss_type_denoiser="mse", loss_type_score="mse", **hpd),
+            "ema": {"decay": 0.999, "num_updates": 77, "shadow_params": shadow, "collected_params": None}, **_lightning_extras(MC)}
+    path = os.path.join(tmp_path, "storm.ckpt")
+    torch.save(ckpt, path)
+    for n in names:
+        monkeypatch.delitem(sys.modules, n)
+    m = StochasticRegenerationModel.load_from_checkpoint(path, base_dir="", batch_size=1, num_workers=0, kwargs=dict(gpu=False))
+    assert m.condition == "both"
+    assert all(torch.equal(m.score_net.state_dict()[k], live_s[k]) for k in live_s)
+    m.eval(no_ema=False)
+    assert all(torch.equal(m.denoiser_net.state_dict()[k], ema_d[k]) for k in ema_d)
+    assert all(torch.equal(m.score_net.state_dict()[k], ema_s[k]) for k in ema_s)
+    m = m.to(dev)
+    g = torch.Generator().manual_seed(8)
+    wav = 0.1 * torch.randn(1, 4000, generator=g)
+    N = 2
+    Y, nfac, T0 = FR.wav_to_spec(wav)
+    noises = [SR.complex_randn(Y.shape, g) for _ in range(1 + N)]
+    it = iter([z.to(dev) for z in noises])
+    got = m.enhance(wav.to(dev), N=N, corrector="none", snr=0.5, noise_fn=lambda: next(it))
+    with torch.no_grad():                                              # the oracle on the EMA weights (model.py:720-780)
+        Yd = NR.ncsnpp_forward(ema_d, cfg_d, Y, None)
+        it = iter(noises)
+        samp, _ = SR.pc_sample(SR.OUVE(1.5, 0.05, 0.5, N=N), lambda x, t, y: -NR.ncsnpp_forward(ema_s, cfg_s, torch.cat([x, Y, Yd], 1), t),
+                               Yd, lambda: next(it), corrector="none", snr=0.5)
+    assert rel_l2(got, FR.spec_to_wav(samp, nfac, T0)) < 1e-3
+    m.train(True)
+    assert all(torch.equal(m.score_net.state_dict()[k].cpu(), live_s[k]) for k in live_s)
 
 
 def test_no_cpu_fallback():
