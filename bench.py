@@ -68,7 +68,13 @@ def parse():
                         "which is reported as `from_host` beside `value`, never as it")
     p.add_argument("--include-h2d", action="store_true", help="(accepted for old command lines: the from-host pass is now the default)")
     p.add_argument("--graph", default="auto", choices=["auto", "on", "off"],
-                   help="HIP-graph replay of the score evaluations (storm_ncsnpp_set_graph): auto = the library's rule (small batches)")
+                   help="HIP-graph replay of the score evaluations (storm_ncsnpp_set_graph): auto = the library's rule (today: eager at every batch size, profiles/r05a_*)")
+    p.add_argument("--no-other-configs", action="store_true",
+                   help="skip the `other_configs` object: BASELINE.json configs[3], a configs[4]-style ragged stream (PC and a shortened ODE leg) and "
+                        "one utterance per call, each timed AFTER the headline region on rank 0 of a one-GPU run (never inside it, never part of `value`)")
+    p.add_argument("--power", action="store_true",
+                   help="sample socket power / clock with rocm-smi DURING the timed steps (perturbs rank 0: off by default; the default samples an "
+                        "untimed repetition of the same step instead)")
     p.add_argument("--selftest-cpu", action="store_true",
                    help="(tests) run the launch / sharding / timing skeleton with a stand-in step on CPU ranks (gloo)")
     return p.parse_args()
@@ -174,6 +180,90 @@ def profile_ops(net, Y, nfe_count):
         rows.append(row)
     net.release_program(ops)                               # (the rows above hold plain numbers: the op list may go)
     return rows
+
+
+def ragged_stream(n, batch, seed, gen, dev):
+    """configs[4]'s input: n synthetic utterances of 2-10 s (seeded lengths), micro-batched by padded frame count (<= batch rows per
+    launch, rows keep their own lengths), resident in HBM.  Returns [(wav [b, Lmax], lengths or None)], lengths of all utterances."""
+    from storm_amd import distributed as D
+    lens = [int(v) for v in torch.randint(32000, 160001, (n,), generator=torch.Generator().manual_seed(seed))]
+    batches = []
+    for ids in D.bucket_by_frames(lens, batch):
+        bl = [lens[i] for i in ids]
+        yb = torch.zeros(len(ids), max(bl))
+        for k, n_ in enumerate(bl):
+            yb[k, :n_] = 0.1 * torch.randn(n_, generator=gen)
+        batches.append((yb.to(dev), None if len(set(bl)) == 1 else bl))
+    return batches, lens
+
+
+def other_configs(model, dev, sync):
+    """The configurations of BASELINE.json that are not the headline, each timed on its own AFTER the headline region (rank 0, one GPU):
+    same engine, same wav -> wav step, synthetic inputs resident in HBM, one untimed pass first (plans / workspaces of the new shapes).
+    Every entry carries its own workload, dtype, steps and ms_per_step; none of them enters `value`."""
+    from storm_amd import distributed as D
+    from storm_amd.model import ScoreModel
+    out = {}
+
+    def run(step, steps, warm_step=None):
+        (warm_step or step)(0)                              # untimed: planning, workspace allocation, first-touch
+        el, _, res = D.timed_steps(step, steps, 0, sync=sync)
+        return el, res
+
+    # ---- one utterance per call (the reference's own operating point, enhancement.py:66-72): latency and real-time factor
+    g = torch.Generator().manual_seed(4321)
+    wav1 = (0.1 * torch.randn(1, 64000, generator=g)).to(dev)
+    model.set_precision("bf16")
+    el, (_, nfe) = run(lambda i: model.enhance_batch(wav1, seed=7000 + i, return_nfe=True, N=30, corrector="ald", corrector_steps=1, snr=0.5), 3)
+    out["one_utterance_per_call"] = {"workload": "configs[0]'s shape on the GPU: ncsnpp, ONE 4-s utterance per call, 30-step PC (reverse_diffusion + ald x1), bf16, wav->wav",
+                                     "value": 3 / el, "unit": "utterances/s", "steps": 3, "ms_per_step": 1e3 * el / 3, "dtype": "bf16",
+                                     "nfe_per_utterance": nfe, "rtf": el / 3 / 4.0}
+    # ---- configs[4]-style: ragged stream, fp16, PC sampler and a shortened ODE leg
+    model.set_precision("fp16")
+    batches, lens = ragged_stream(32, 16, 77, g, dev)
+
+    def stream_step(kw, sel):
+        def step(i):
+            nfes, o = [], None
+            for k, (yb, bl) in enumerate(sel):
+                o, n_ = model.enhance_batch(yb, seed=9000 + 100 * i + k, return_nfe=True, lengths=bl, **kw)
+                nfes.append(n_ * yb.shape[0])
+            return o, sum(nfes) / sum(b[0].shape[0] for b in sel)
+        return step
+    pc = dict(sampler_type="pc", predictor="reverse_diffusion", corrector="ald", N=30, corrector_steps=1, snr=0.5)
+    el, (_, nfe) = run(stream_step(pc, batches), 1, warm_step=stream_step(dict(pc, N=1), batches))
+    audio_s = sum(lens) / 16000.0
+    out["configs4_stream_pc"] = {"workload": f"configs[4]-style on one GPU: ncsnpp, stream of 32 utterances of 2-10 s ({audio_s:.0f} s of audio) in {len(batches)} ragged "
+                                             "micro-batches (<= 16 rows, bucketed by padded frame count), 30-step PC (reverse_diffusion + ald x1), fp16, wav->wav",
+                                 "value": 32 / el, "unit": "utterances/s", "steps": 1, "ms_per_step": 1e3 * el, "dtype": "fp16", "nfe_per_utterance": nfe,
+                                 "micro_batches": len(batches), "rtf_per_audio_second": el / audio_s}
+    # the ODE leg on the micro-batches that hold the first 8 utterances' worth of rows (shapes planned by the PC pass above)
+    sel, n_sel = [], 0
+    for b in sorted(batches, key=lambda b: -b[0].shape[0]):
+        if n_sel >= 8:
+            break
+        sel.append(b)
+        n_sel += b[0].shape[0]
+    el, (_, nfe) = D.timed_steps(stream_step(dict(sampler_type="ode", N=30), sel), 1, 0, sync=sync)[::2]
+    out["configs4_stream_ode"] = {"workload": f"configs[4] as configured, shortened: ncsnpp, {n_sel} utterances of 2-10 s in {len(sel)} ragged micro-batches of the same stream, "
+                                              "probability-flow ODE sampler (RK45, rtol = atol = 1e-5, one step controller per row), fp16, wav->wav",
+                                  "value": n_sel / el, "unit": "utterances/s", "steps": 1, "ms_per_step": 1e3 * el, "dtype": "fp16",
+                                  "nfe_per_utterance": nfe, "micro_batches": len(sel)}
+    model.set_precision("bf16")
+    # ---- configs[3]: ncsnpplarge (65.6 M), 8 utterances of 8 s per GPU, 50-step PC + 1 corrector step = 100 evaluations
+    large = ScoreModel(backbone="ncsnpplarge", sde="ouve", theta=1.5, sigma_min=0.05, sigma_max=0.5, spec_factor=0.15, spec_abs_exponent=0.5)
+    randomize(large, seed=1)
+    large._error_loading_ema = True
+    large = large.eval().to(dev)
+    large.set_precision("bf16")
+    wav8 = (0.1 * torch.randn(8, 128000, generator=g)).to(dev)
+    kw3 = dict(predictor="reverse_diffusion", corrector="ald", corrector_steps=1, snr=0.5, return_nfe=True)
+    el, (_, nfe) = run(lambda i: large.enhance_batch(wav8, seed=8000 + i, N=50, **kw3), 1, warm_step=lambda i: large.enhance_batch(wav8, seed=1, N=1, **kw3))
+    out["configs3"] = {"workload": "configs[3] per GPU: ncsnpplarge (65.6 M) batch=8x8 s@16 kHz, 50-step PC + 1 corrector (reverse_diffusion + ald x1 = 100 evaluations), bf16, wav->wav",
+                       "value": 8 / el, "unit": "utterances/s", "steps": 1, "ms_per_step": 1e3 * el, "dtype": "bf16", "nfe_per_utterance": nfe,
+                       "evaluation_tflops": 8 * 2131.0e9 * nfe / el / 1e12, "mfma_frac": 8 * 2131.0e9 * nfe / el / 1e12 / BF16_MFMA_PEAK_TFLOPS}
+    del large
+    return out
 
 
 class PowerSampler:
@@ -286,14 +376,7 @@ def main():
                snr=0.5) if args.sampler == "pc" else dict(sampler_type="ode", N=args.N)
     units = args.batch
     if args.stream:                                         # configs[4]: ragged micro-batches (2-10 s), resident in HBM
-        lens = [int(v) for v in torch.randint(32000, 160001, (args.stream,), generator=torch.Generator().manual_seed(77 + rank))]
-        batches = []
-        for ids in D.bucket_by_frames(lens, args.batch):
-            bl = [lens[i] for i in ids]
-            yb = torch.zeros(len(ids), max(bl))
-            for k, n_ in enumerate(bl):
-                yb[k, :n_] = 0.1 * torch.randn(n_, generator=g)
-            batches.append((yb.to(dev), None if len(set(bl)) == 1 else bl))
+        batches, _ = ragged_stream(args.stream, args.batch, 77 + rank, g, dev)
         units = args.stream
 
     def step(i):
@@ -307,7 +390,10 @@ def main():
             nfes.append(n_ * yb.shape[0])
         return out, sum(nfes) / args.stream                 # mean score evaluations per utterance
 
-    with PowerSampler(enabled=rank == 0) as power:                # (rocm-smi's first GPU = rank 0's device)
+    # socket power: by default NOT sampled inside the timed region (the sampler spawns rocm-smi every 0.2 s on rank 0's host cores and
+    # would perturb that rank only); one more repetition of the same step is sampled after it, on a one-rank run, where rocm-smi's
+    # first GPU is this rank's device.  --power samples the timed steps themselves.
+    with PowerSampler(enabled=args.power and rank == 0 and world == 1) as power:
         elapsed, per_rank, (out, nfe) = D.timed_steps(step, args.steps, args.warmup, sync=torch.cuda.synchronize, single_rank_group=args.dist_world1)
     power = power.summary() if rank == 0 else None
     assert torch.isfinite(out).all(), "non-finite output"
@@ -361,6 +447,14 @@ def main():
         dist.destroy_process_group()
         dist = None
 
+    if rank == 0 and world == 1 and not args.power and not args.no_roofline and not args.stream:
+        with PowerSampler(enabled=True) as ps:               # untimed repetitions of the same step, sampled
+            for i in range(2):
+                step(args.warmup + args.steps + i)
+            torch.cuda.synchronize()
+        power = ps.summary()
+        if power is not None:
+            power["sampled"] = "two untimed repetitions of the step after the timed region"
     if rank == 0 and not args.no_roofline and not args.stream:
         Y, _, _ = model._prepare(wav)
         rows = profile_ops(model.dnn, Y, args.profile_nfe)
@@ -459,6 +553,12 @@ def main():
         if args.ops_json:
             with open(args.ops_json, "w") as f:
                 json.dump(rows, f, indent=0)
+
+    if rank == 0 and world == 1 and not args.no_other_configs and not args.stream and cfg_name == "configs[1]":
+        t0 = time.perf_counter()
+        result["other_configs"] = other_configs(model, dev, torch.cuda.synchronize)
+        result["other_configs"]["seconds_spent"] = round(time.perf_counter() - t0, 1)
+        model.set_precision(args.precision)
 
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         dt, times, cores = cpu_baseline(args.backbone, args.seconds)
