@@ -5,8 +5,8 @@ mkdir -p gpurun_out
 export TMPDIR=/tmp
 python -c "import __graft_entry__ as g; g.build(); g.smoke()" > gpurun_out/smoke_$TAG.log 2>&1; echo "smoke rc=$?" >> gpurun_out/smoke_$TAG.log; tail -2 gpurun_out/smoke_$TAG.log
 STORM_PARITY_JSON=gpurun_out/parity_$TAG.json timeout 900 python -m pytest tests -m gpu -q --tb=short -k "upfirdn or lightning or checkpoint" > gpurun_out/pytest_gpu_$TAG.log 2>&1; tail -3 gpurun_out/pytest_gpu_$TAG.log
-/usr/bin/time -v timeout 900 python bench.py --steps 20 --warmup 5 > gpurun_out/bench_$TAG.json 2> gpurun_out/bench_$TAG.err; head -c 300 gpurun_out/bench_$TAG.json; echo
-grep -E "Elapsed|Maximum resident" gpurun_out/bench_$TAG.err
+SECONDS=0; timeout 900 python bench.py --steps 20 --warmup 5 > gpurun_out/bench_$TAG.json 2> gpurun_out/bench_$TAG.err; head -c 300 gpurun_out/bench_$TAG.json; echo
+echo "bench wall ${SECONDS}s"
 python - <<'PY'
 import json
 r = json.load(open("gpurun_out/bench_r06a.json"))

@@ -57,25 +57,32 @@ def _build_locked(cc, bdir, out, force, verbose, profiling):
     # (STORM_EXTRA_DEFS: extra -D switches of one-off experiments, profiling build only)
     flags = FLAGS + (["-DSTORM_PROFILING", "-DSTORM_WITH_DUO"] + os.environ.get("STORM_EXTRA_DEFS", "").split() if profiling else [])
     hdr_time = max(os.path.getmtime(h) for h in HEADERS + [os.path.abspath(__file__)])
-    stamp = os.path.join(bdir, ".flags")
-    same_flags = os.path.exists(stamp) and open(stamp).read() == " ".join(flags)
+    # every object is keyed on a hash of its flags (an object built with other -D switches can never be linked by mistake, whatever
+    # failed or was interrupted in between) and appears under its name only when its compile succeeded (tmp file + atomic replace)
+    import hashlib
+    tag = hashlib.sha256(" ".join(flags).encode()).hexdigest()[:10]
 
     def compile_one(s):
-        src, obj = os.path.join(CSRC, s + ".hip"), os.path.join(bdir, s + ".o")
-        if same_flags and not force and os.path.exists(obj) and os.path.getmtime(obj) >= max(hdr_time, os.path.getmtime(src)):
+        src, obj = os.path.join(CSRC, s + ".hip"), os.path.join(bdir, f"{s}.{tag}.o")
+        if not force and os.path.exists(obj) and os.path.getmtime(obj) >= max(hdr_time, os.path.getmtime(src)):
             return obj                                     # this object is current: only edited sources recompile
-        cmd = [cc] + flags + ["-c", src, "-o", obj]
+        tmp = f"{obj}.{os.getpid()}.tmp"
+        cmd = [cc] + flags + ["-c", src, "-o", tmp]
         r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)
         if r.returncode != 0:
+            if os.path.exists(tmp):
+                os.remove(tmp)
             raise RuntimeError(f"hipcc failed on {s}.hip:\n{r.stdout.decode()}")
+        os.replace(tmp, obj)
         if verbose and r.stdout:
             sys.stderr.write(r.stdout.decode())
         return obj
 
     with ThreadPoolExecutor(max_workers=4) as ex:
         objs = list(ex.map(compile_one, PROF_SOURCES if profiling else SOURCES))
-    with open(stamp, "w") as f:
-        f.write(" ".join(flags))
+    for f in os.listdir(bdir):                             # objects of other flag sets / older layouts: not ours to link, not worth keeping
+        if f.endswith(".o") and f".{tag}.o" not in f:
+            os.remove(os.path.join(bdir, f))
     r = subprocess.run([cc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", out + ".tmp"] + objs,
                        stdout=subprocess.PIPE, stderr=subprocess.STDOUT)
     if r.returncode != 0:

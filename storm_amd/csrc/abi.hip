@@ -1,4 +1,5 @@
 // Error channel, version and device info of libstorm_hip.
+#include <atomic>
 #include <cstdarg>
 #include <cstdio>
 #include <cstdlib>
@@ -14,6 +15,7 @@ void set_error(const char* fmt, ...) {
     va_end(ap);
 }
 
+void bump_switch_epoch();
 namespace {
 struct SwitchName { const char* name; int Switches::*field; };
 const SwitchName kSwitches[] = {
@@ -34,6 +36,10 @@ Switches& switches() {
     return sw;
 }
 
+static std::atomic<unsigned long long> g_switch_epoch{0};
+unsigned long long switch_epoch() { return g_switch_epoch.load(std::memory_order_relaxed); }
+void bump_switch_epoch() { g_switch_epoch.fetch_add(1, std::memory_order_relaxed); }
+
 int device_cus() {
     const int forced = switches().conv_cus;
     if (forced > 0) return forced;
@@ -52,7 +58,7 @@ extern "C" int storm_set_switch(const char* name, long long value) {
     STORM_CHECK(name != nullptr, "storm_set_switch: null name");
     if (strcmp(name, "STORM_CONV_TRACE_PTR") == 0) { storm::switches().conv_trace_ptr = (unsigned long long)value; return STORM_OK; }
     for (const storm::SwitchName& n : storm::kSwitches)
-        if (strcmp(name, n.name) == 0) { storm::switches().*(n.field) = (int)value; return STORM_OK; }
+        if (strcmp(name, n.name) == 0) { storm::switches().*(n.field) = (int)value; storm::bump_switch_epoch(); return STORM_OK; }
     STORM_CHECK(false, "storm_set_switch: unknown switch %s", name);
 }
 extern "C" long long storm_get_switch(const char* name) {

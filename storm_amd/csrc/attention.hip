@@ -256,9 +256,10 @@ int attn_splits(int B, int L, int dtype) {
     if (forced >= 2) return forced <= ntiles ? forced : 1;
     if (switches().batch_invariant != 0) return 1;             // (the rule below is a decision on the call: not in the per-image mode)
     const long long wgs = (long long)cdiv(L, BQ) * B;
-    if (wgs >= 128) return 1;
+    const int cus = device_cus();                              // (256 on MI355X; honours STORM_CONV_CUS like the convolutions' ladder)
+    if (wgs >= cus / 2) return 1;
     int S = 1;
-    while (S < 8 && wgs * S * 2 <= 256 && ntiles / (S * 2) >= 4) S *= 2;
+    while (S < 8 && wgs * S * 2 <= cus && ntiles / (S * 2) >= 4) S *= 2;
     return S;
 }
 long long attn_scratch_bytes(int B, int L, int C, int S) { return S < 2 ? 0 : (long long)S * B * L * (C + 2) * 4; }

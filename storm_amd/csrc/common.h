@@ -47,6 +47,9 @@ struct Switches {
     unsigned long long conv_trace_ptr = 0;   // STORM_CONV_TRACE_PTR (profiling build): device buffer of tools/conv_trace.py
 };
 Switches& switches();
+// bumped by every storm_set_switch: recorded HIP graphs bake in the kernel selection of the moment (conv variant, split-K, attention split,
+// GroupNorm launch geometry ...), so a graph set recorded under another epoch is dropped and re-recorded (ncsnpp_graph.hip::forward_replay)
+unsigned long long switch_epoch();
 int device_cus();               // CU count of the current device (cached), or switches().conv_cus
 #define STORM_CHECK(cond, ...) do { if (!(cond)) { storm::set_error(__VA_ARGS__); return STORM_ERR_INVALID; } } while (0)
 #define STORM_HIP(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) { \

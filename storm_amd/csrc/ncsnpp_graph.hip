@@ -231,6 +231,7 @@ struct Program {
     struct GraphSeg { int first, last; hipGraphExec_t exec; };
     struct GraphSet {
         int state = 0; std::vector<GraphSeg> segs; unsigned long long used = 0;
+        unsigned long long epoch = switch_epoch();              // the launchers' switch table as it stood when this set was created
         ~GraphSet() { for (auto& sg : segs) if (sg.exec) (void)hipGraphExecDestroy(sg.exec); }
     };
     std::map<void*, std::shared_ptr<GraphSet>> graphs;
@@ -772,6 +773,10 @@ static int forward_replay(storm_ncsnpp* h, Program& p, void* const* bufs, int ne
     {
         std::lock_guard<std::mutex> lk(h->mu);
         auto it = p.graphs.find(bufs[BUF_WS]);
+        if (it != p.graphs.end() && it->second->epoch != switch_epoch()) {      // a switch changed since: the recorded kernel selection is stale
+            p.graphs.erase(it);
+            it = p.graphs.end();
+        }
         if (it == p.graphs.end()) {
             if (p.graphs.size() >= storm_ncsnpp::MAX_GRAPH_WS) {
                 auto old = p.graphs.begin();

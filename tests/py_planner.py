@@ -429,10 +429,11 @@ class Program:
         if self.esize != 2:
             return 0
         ntiles, wgs = -(-Lp // 32), -(-Lp // 128) * self.B
-        if wgs >= 128:
+        cus = getattr(self, "cus", 256)                    # device_cus(): 256 on MI355X and in the simulator
+        if wgs >= cus // 2:
             return 0
         S = 1
-        while S < 8 and wgs * S * 2 <= 256 and ntiles // (S * 2) >= 4:
+        while S < 8 and wgs * S * 2 <= cus and ntiles // (S * 2) >= 4:
             S *= 2
         return S * self.B * Lp * (Cc + 2) * 4 if S >= 2 else 0
 

@@ -235,6 +235,122 @@ def test_checkpoint_as_lightning_writes_it_storm(dev, monkeypatch, tmp_path):
     assert all(torch.equal(m.score_net.state_dict()[k].cpu(), live_s[k]) for k in live_s)
 
 
+# ---- fixture F16: BASELINE.json configs[4] at its REAL shape (27.8 M ncsnpp, 10-s rows -> 256 x 1280, L = 5120 attention) -------------------
+def _f16_inputs(g):
+    """Everything fixture F16 stores as a seed, regenerated and checked against its SHA-256 (oracle/make_golden.py::gen_f16): the 27.8 M
+    weights, the forward's input, the three wavs (156 000 / 158 000 / 160 000 samples), their 7 noise draws each, the ODE prior draw."""
+    import hashlib
+    from oracle.make_golden import sd_hash, seeded_input, tensor_hash
+    s_w, s_x, s_wav, s_noise, s_state, s_z = [int(v) for v in g["seeds"]]
+    lens = [int(v) for v in g["lengths"]]
+    cfg = NR.NCSNppConfig(**NR.NAMED_CONFIGS["ncsnpp"], input_channels=4)
+    sd = NR.seeded_state_dict(cfg, seed=s_w)
+    assert sd_hash(sd) == str(g["sdhash"])
+    xin = seeded_input((1, 2, 256, 1280), s_x, 0.5)
+    assert tensor_hash(xin) == str(g["fwd_xhash"])
+    wavs, noises = [], []
+    for i, n in enumerate(lens):
+        w = torch.randn(1, n, generator=torch.Generator().manual_seed(s_wav + i)) * 0.1
+        assert tensor_hash(w) == str(g[f"pc_wavhash{i}"])
+        gn = torch.Generator().manual_seed(s_noise + i)
+        zs = [SR.complex_randn((1, 1, 256, 1280), gn) for _ in range(1 + 2 * int(g["pc_N"]))]
+        assert hashlib.sha256(b"".join(z.numpy().tobytes() for z in zs)).hexdigest() == str(g["pc_noise_hashes"][i])
+        wavs.append(w)
+        noises.append(zs)
+    zode = SR.complex_randn((1, 1, 256, 1280), torch.Generator().manual_seed(s_z))
+    assert tensor_hash(zode) == str(g["ode_zhash"])
+    Y2, nfac, T0 = FR.wav_to_spec(wavs[2])
+    xs = Y2 + seeded_input((1, 1, 256, 1280), s_state, 0.2)
+    assert tensor_hash(xs) == str(g["pf_xhash"])
+    return dict(cfg=cfg, sd=sd, xin=xin, wavs=wavs, noises=noises, zode=zode, lens=lens, pf_x=xs, pf_y=Y2)
+
+
+def test_f16_fixture_inputs_regenerate(golden):
+    """F16 stores seeds, not 100 MB of weights and noise: they regenerate bit for bit here (hashes), so the GPU test below feeds the engine
+    exactly what the reference consumed; all three rows share the 1280-frame bucket (util/other.py:102-109)."""
+    g = golden["f16_cfg4_shape"]
+    inp = _f16_inputs(g)
+    assert [-(-(1 + n // 128) // 64) * 64 for n in inp["lens"]] == [1280, 1280, 1280]
+    assert int(g["pc_nfe"]) == 6 and int(g["ode_nfe"]) == 32 and g["fwd_y"].shape == (1, 1, 256, 1280)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("prec,tol_fwd,tol_wav", [("fp32", 1e-4, 1e-4), ("bf16", 3e-2, 3e-2), ("fp16", 3e-2, 3e-2)])
+def test_configs4_real_shape_vs_reference_golden(golden, switch, prec, tol_fwd, tol_wav):
+    """BASELINE.json configs[4] at its real shape against the REFERENCE (fixture F16): the 27.8 M `ncsnpp` on 10-s rows - 256 x 1280 conv
+    levels, L = 5120 attention (layerspp.py:82-86), the kernels that regime selects (conv_pipe128 at 2.25 rounds, 256 x 1280 strips of the
+    resampling kernels).  (a) NCSNpp.forward of one [1,2,256,1280] input (ncsnpp.py:281-450); (b) a RAGGED THREE-ROW micro-batch in the
+    1280-frame bucket (156 000 / 158 000 / 160 000 samples) through ScoreModel.enhance's path, N = 3 + 1 ald step each = 6 evaluations
+    (model.py:273-310, sampling/__init__.py:54-66), every row against the reference's own run of that utterance, row 0 also at the sampler's
+    final state, and a row against its batch-1 run (fp32: <= 1e-5; 16-bit: bit-equal in the batch-invariant mode); (c) one probability-flow
+    right-hand side (sampling/__init__.py:104-106, sdes.py:123-145) through rsde.sde and through the fused drift kernel; (d) the ODE sampler's
+    own loop at that shape (rtol = atol = 0.03: 32 evaluations in the reference), wav -> wav, with the reference's evaluation count."""
+    from tests.backend import setup_backend
+    from storm_amd import ops
+    from storm_amd.model import ScoreModel
+    dev = setup_backend("hip")
+    g = golden["f16_cfg4_shape"]
+    inp = _f16_inputs(g)
+    m = ScoreModel(backbone="ncsnpp", sde="ouve", theta=1.5, sigma_min=0.05, sigma_max=0.5, spec_factor=0.15, spec_abs_exponent=0.5)
+    m.dnn.load_state_dict(inp["sd"])
+    m._error_loading_ema = True
+    m = m.eval().to(dev)
+    m.set_precision(prec)
+    m.dnn.negate_output = False
+    # (a) the forward
+    t = T(g["t"]).to(dev)
+    e_fwd = rel_l2(m.dnn(inp["xin"].to(dev), t).cpu(), g["fwd_y"])
+    m.dnn.negate_output = True
+    # (b) ragged three-row micro-batch, 6 evaluations
+    lens, N = inp["lens"], int(g["pc_N"])
+    y = torch.zeros(3, max(lens))
+    for k, w in enumerate(inp["wavs"]):
+        y[k, :lens[k]] = w[0]
+    draws = [torch.cat([inp["noises"][b][j] for b in range(3)], 0).to(dev) for j in range(1 + 2 * N)]
+    it = iter(draws)
+    Y, peak, T_orig = m._prepare(y.to(dev), lens)
+    sampler = m.get_pc_sampler("reverse_diffusion", "ald", Y, N=N, corrector_steps=1, snr=0.5, intermediate=False, noise_fn=lambda: next(it))
+    sample, nfe = sampler()
+    out = m.data_module.spec_to_wav(sample, T_orig, peak, lengths=lens).cpu()
+    assert nfe == int(g["pc_nfe"]) and Y.shape == (3, 1, 256, 1280)
+    e_rows = [rel_l2(out[k, :lens[k]], g[f"pc_out{k}"]) for k in range(3)]
+    e_spec = rel_l2(sample[0].cpu().reshape(-1), T(g["pc_final_spec0"]).reshape(-1))
+    assert all(float(out[k, lens[k]:].abs().max()) == 0.0 for k in range(2))
+    # a row against its own batch-1 run
+    k = 1
+    itk = iter([d[k:k + 1] for d in draws])
+    alone = m.enhance_batch(inp["wavs"][k].to(dev), N=N, corrector="ald", corrector_steps=1, snr=0.5, noise_fn=lambda: next(itk)).cpu()
+    e_alone = rel_l2(out[k, :lens[k]], alone[0])
+    if prec != "fp32":                                        # the serving mode: the same bits alone and in the ragged batch
+        switch("STORM_BATCH_INVARIANT", 1)
+        iti, itk = iter(draws), iter([d[k:k + 1] for d in draws])
+        inv = m.enhance_batch(y.to(dev), N=N, corrector="ald", corrector_steps=1, snr=0.5, lengths=lens, noise_fn=lambda: next(iti)).cpu()
+        inv1 = m.enhance_batch(inp["wavs"][k].to(dev), N=N, corrector="ald", corrector_steps=1, snr=0.5, noise_fn=lambda: next(itk)).cpu()
+        assert torch.equal(inv[k, :lens[k]], inv1[0]), "batch-invariant mode: row differs from its batch-1 run"
+        assert rel_l2(inv[k, :lens[k]], g[f"pc_out{k}"]) < tol_wav
+        switch("STORM_BATCH_INVARIANT", 0)
+    # (c) one probability-flow right-hand side
+    xs, Yc, tv = inp["pf_x"].to(dev), inp["pf_y"].to(dev), T(g["pf_t"]).to(dev)
+    with torch.no_grad():
+        drift = m.sde.reverse(m, probability_flow=True).sde(xs, tv, Yc)[0]
+        score = m(xs, tv, Yc)
+        drift_fused = ops.ouve_pf_drift_g(m.sde, xs.contiguous(), Yc.contiguous(), score.contiguous(), m.sde.diffusion(tv.cpu()))
+    e_pf, e_pff = rel_l2(drift.cpu(), g["pf_drift"]), rel_l2(drift_fused.cpu(), g["pf_drift"])
+    # (d) the ODE sampler's own loop at this shape
+    tol_ode = float(g["ode_tol"])
+    zode = inp["zode"].to(dev)
+    xo, nfe_o = m.enhance_batch(inp["wavs"][2].to(dev), sampler_type="ode", rtol=tol_ode, atol=tol_ode, noise_fn=lambda: zode, return_nfe=True)
+    e_ode = rel_l2(xo.cpu()[0], g["ode_out"])
+    print(f"F16 configs[4] real shape (27.8 M ncsnpp @ 256 x 1280, ragged rows 156k / 158k / 160k) {prec}: forward rel-L2 vs reference {e_fwd:.3e}; "
+          f"6-evaluation enhance per row " + " ".join(f"{e:.3e}" for e in e_rows) + f" (final spectrogram row 0 {e_spec:.3e}); row vs its batch-1 run {e_alone:.3e}; "
+          f"probability-flow drift {e_pf:.3e} (fused kernel {e_pff:.3e}); ODE enhance {e_ode:.3e} with nfev {nfe_o} (reference {int(g['ode_nfe'])})")
+    assert e_fwd < tol_fwd and max(e_rows) < tol_wav and e_spec < tol_wav
+    assert e_alone < (1e-5 if prec == "fp32" else tol_wav)
+    assert e_pf < tol_fwd and e_pff < tol_fwd
+    assert e_ode < (1e-3 if prec == "fp32" else tol_wav)
+    assert nfe_o == int(g["ode_nfe"]) if prec == "fp32" else abs(nfe_o - int(g["ode_nfe"])) <= 6
+
+
 def test_no_cpu_fallback():
     """the product path refuses CPU tensors when the real library is bound"""
     from storm_amd import _lib
