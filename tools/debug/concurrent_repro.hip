@@ -22,6 +22,8 @@
 
 constexpr int NFFT = 510, NBIN = 256;
 
+// ACC = double: the product's structure (LDS operands, fp64 accumulation); ACC = float: the same loop without any fp64 instruction
+template <typename ACC>
 __global__ void dft_victim(const float* __restrict__ frames, const float2* __restrict__ tw, float2* __restrict__ out) {
     __shared__ float xs[NFFT];
     __shared__ float2 tws[NFFT];
@@ -29,12 +31,28 @@ __global__ void dft_victim(const float* __restrict__ frames, const float2* __res
     for (int k = threadIdx.x; k < NFFT; k += blockDim.x) { xs[k] = x[k]; tws[k] = tw[k]; }
     __syncthreads();
     for (int f = threadIdx.x; f < NBIN; f += blockDim.x) {
-        double re = 0.0, im = 0.0;
+        ACC re = 0, im = 0;
         int idx = 0;
         for (int k = 0; k < NFFT; ++k) {
             const float2 w = tws[idx];
-            re += (double)(xs[k] * w.x);
-            im -= (double)(xs[k] * w.y);
+            re += (ACC)(xs[k] * w.x);
+            im -= (ACC)(xs[k] * w.y);
+            idx += f; if (idx >= NFFT) idx -= NFFT;
+        }
+        out[(size_t)blockIdx.x * NBIN + f] = make_float2((float)re, (float)im);
+    }
+}
+// the same arithmetic with the operands in REGISTERS / global memory only (no LDS instruction in the kernel): every thread streams its
+// frame and the twiddles through the caches
+__global__ void dft_victim_nolds(const float* __restrict__ frames, const float2* __restrict__ tw, float2* __restrict__ out) {
+    const float* x = frames + (size_t)blockIdx.x * NFFT;
+    for (int f = threadIdx.x; f < NBIN; f += blockDim.x) {
+        double re = 0.0, im = 0.0;
+        int idx = 0;
+        for (int k = 0; k < NFFT; ++k) {
+            const float2 w = tw[idx];
+            re += (double)(x[k] * w.x);
+            im -= (double)(x[k] * w.y);
             idx += f; if (idx >= NFFT) idx -= NFFT;
         }
         out[(size_t)blockIdx.x * NBIN + f] = make_float2((float)re, (float)im);
@@ -70,6 +88,7 @@ __global__ void __launch_bounds__(256) mfma_aggressor(float* __restrict__ sink, 
 
 // the same with the operand traffic of a convolution: every MFMA's B fragment is re-read from a 64-KiB LDS image (ds_read_b128), the image
 // rewritten between rounds - MFMA + LDS reads + LDS writes + barriers on the aggressor's side, like conv_igemm / a GEMM main loop
+template <bool MFMA, bool REWRITE>
 __global__ void __launch_bounds__(256) mfma_lds_aggressor(float* __restrict__ sink, int iters, uint32_t seed) {
     __shared__ uint4 img[4096];                              // 64 KiB
     f32x16 acc[4];
@@ -82,7 +101,7 @@ __global__ void __launch_bounds__(256) mfma_lds_aggressor(float* __restrict__ si
 #pragma unroll
     for (int j = 0; j < 4; ++j) { s = s * 1664525u + 1013904223u; a.u[j] = (s & 0x007f007fu) | 0x3f003f00u; }
     for (int it = 0; it < iters; ++it) {
-        if ((it & 63) == 0) {
+        if ((it & 63) == 0 && (REWRITE || it == 0)) {
             __syncthreads();
             for (int k = threadIdx.x; k < 4096; k += 256) { s = s * 1664525u + 1013904223u; img[k] = make_uint4((s & 0x007f007fu) | 0x3f003f00u, (s >> 3 & 0x007f007fu) | 0x3f003f00u, (s >> 5 & 0x007f007fu) | 0x3f003f00u, (s >> 7 & 0x007f007fu) | 0x3f003f00u); }
             __syncthreads();
@@ -90,7 +109,8 @@ __global__ void __launch_bounds__(256) mfma_lds_aggressor(float* __restrict__ si
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             b.q = img[(threadIdx.x + 67 * (4 * it + i)) & 4095];
-            acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.v, b.v, acc[i], 0, 0, 0);
+            if (MFMA) acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.v, b.v, acc[i], 0, 0, 0);
+            else { acc[i][0] += __uint_as_float(b.u[0]); acc[i][1] += __uint_as_float(b.u[1]); acc[i][2] += __uint_as_float(b.u[2]); acc[i][3] += __uint_as_float(b.u[3]); }
         }
     }
     float t = 0.f;
@@ -111,6 +131,72 @@ __global__ void __launch_bounds__(256) valu_aggressor(float* __restrict__ sink, 
 }
 
 static double now() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
+
+// ---- part 2: is it the LDS itself?  A victim that only fills its LDS with a pattern, waits and re-checks it (no arithmetic), beside
+// aggressors that only WRITE their own LDS allocation (no MFMA), for several allocation sizes.  Two workgroups of two different
+// kernels must never see each other's LDS whatever their sizes: any mismatch here is an LDS allocation overlap on the CU.
+__global__ void __launch_bounds__(256) lds_pattern_victim(unsigned* __restrict__ bad, unsigned* __restrict__ first, int words, int spins) {
+    extern __shared__ unsigned vlds[];
+    const unsigned tag = 0xA5000000u | ((blockIdx.x & 0xfff) << 12);
+    for (int i = threadIdx.x; i < words; i += blockDim.x) vlds[i] = tag | (i & 0xfff);
+    __syncthreads();
+    const unsigned long long t0 = __builtin_amdgcn_s_memtime();
+    while (__builtin_amdgcn_s_memtime() - t0 < (unsigned long long)spins) {}
+    __syncthreads();
+    for (int i = threadIdx.x; i < words; i += blockDim.x) {
+        const unsigned v = vlds[i];
+        if (v != (tag | (i & 0xfff))) { if (atomicAdd(bad, 1u) == 0) { first[0] = (unsigned)i; first[1] = v; first[2] = blockIdx.x; first[3] = tag | (i & 0xfff); } }
+    }
+}
+__global__ void __launch_bounds__(256) lds_writer_aggressor(float* __restrict__ sink, int words, int rounds) {
+    extern __shared__ unsigned alds[];
+    unsigned acc = 0;
+    for (int r = 0; r < rounds; ++r) {
+        for (int i = threadIdx.x; i < words; i += blockDim.x) alds[i] = 0x3f803f80u + (unsigned)r;     // (1.0 bf16 pairs: what an operand tile looks like)
+        __syncthreads();
+        for (int i = threadIdx.x; i < words; i += blockDim.x) acc += alds[(i * 33 + r) % words];
+        __syncthreads();
+    }
+    if (acc == 0x12345678u) sink[0] = (float)acc;
+}
+
+static int part2(hipStream_t sv, hipStream_t sa, float* dsink, int cus, double seconds) {
+    unsigned *dbad, *dfirst;
+    CK(hipMalloc(&dbad, 4)); CK(hipMalloc(&dfirst, 16));
+    CK(hipFuncSetAttribute(reinterpret_cast<const void*>(lds_writer_aggressor), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    CK(hipFuncSetAttribute(reinterpret_cast<const void*>(lds_pattern_victim), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    hipEvent_t ev;
+    CK(hipEventCreate(&ev));
+    int any = 0;
+    const int vict_kb[] = {6, 24};
+    const int agg_kb[] = {0, 16, 32, 48, 64, 80, 96, 128, 152};
+    for (int vk : vict_kb) for (int ak : agg_kb) {
+        if (vk + ak > 160) continue;
+        CK(hipMemset(dbad, 0, 4));
+        long launches = 0, agg = 0;
+        int inflight = 0;
+        const double t0 = now();
+        while (now() - t0 < seconds) {
+            if (ak > 0 && (inflight == 0 || hipEventQuery(ev) == hipSuccess)) {
+                for (int q = 0; q < 4; ++q) { hipLaunchKernelGGL(lds_writer_aggressor, dim3(cus * 2), dim3(256), ak * 1024, sa, dsink, ak * 256, 300); ++agg; }
+                CK(hipEventRecord(ev, sa));
+                inflight = 1;
+            }
+            hipLaunchKernelGGL(lds_pattern_victim, dim3(cus * 4), dim3(256), vk * 1024, sv, dbad, dfirst, vk * 256, 20000);
+            CK(hipStreamSynchronize(sv));
+            ++launches;
+        }
+        CK(hipStreamSynchronize(sa));
+        unsigned bad = 0, first[4] = {0, 0, 0, 0};
+        CK(hipMemcpy(&bad, dbad, 4, hipMemcpyDeviceToHost)); CK(hipMemcpy(first, dfirst, 16, hipMemcpyDeviceToHost));
+        printf("LDS pattern victim (%3d KiB) beside LDS writer (%3d KiB dynamic LDS): %6ld launches, %9u corrupted words", vk, ak, launches, bad);
+        if (bad) printf("  first: word %u of workgroup %u holds %08x, expected %08x", first[0], first[2], first[1], first[3]);
+        printf("\n");
+        any += bad != 0;
+    }
+    return any;
+}
+
 
 int main(int argc, char** argv) {
     const double seconds = argc > 1 ? atof(argv[1]) : 4.0;
@@ -133,50 +219,64 @@ int main(int argc, char** argv) {
     CK(hipEventCreate(&ev));
     const size_t nout = (size_t)nframes * NBIN * 2;
     std::vector<float> gold(nout), got(nout);
-    // solo golden + solo reproducibility
-    hipLaunchKernelGGL(dft_victim, dim3(nframes), dim3(256), 0, sv, dframes, dtw, dout);
-    CK(hipStreamSynchronize(sv));
-    CK(hipMemcpy(gold.data(), dout, nout * 4, hipMemcpyDeviceToHost));
-
-    struct Pair { const char* name; int kind; };             // kind: 0 none, 1 valu, 2 mfma 4 acc, 3 mfma 14 acc, 4 mfma + LDS
-    const Pair pairs[] = {{"solo (no aggressor)", 0}, {"VALU fp32 FMA loop", 1}, {"MFMA bf16 32x32x16, 4 accumulators (shares SIMDs)", 2},
-                          {"MFMA bf16 32x32x16, 14 accumulators (256 VGPRs)", 3}, {"MFMA + 64 KiB LDS image (reads, rewrites, barriers)", 4}};
+    struct Victim { const char* name; int kind; };
+    const Victim victims[] = {{"DFT out of LDS, fp64 accumulation", 0}, {"DFT out of LDS, fp32 accumulation", 1}, {"DFT from global memory (no LDS), fp64 accumulation", 2}};
+    struct Pair { const char* name; int kind; };
+    const Pair pairs[] = {{"solo (no aggressor)", 0}, {"VALU fp32 FMA loop", 1}, {"MFMA bf16 32x32x16, 4 accumulators (128 VGPRs: shares SIMDs)", 2},
+                          {"MFMA bf16 32x32x16, 14 accumulators (448 VGPRs)", 3}, {"MFMA fed from a 64 KiB LDS image (reads, rewrites, barriers)", 4},
+                          {"MFMA fed from a 64 KiB LDS image (reads only)", 5}, {"LDS image reads + rewrites feeding VALU adds (no MFMA)", 6}};
+    auto launch_victim = [&](int kind) {
+        if (kind == 0) hipLaunchKernelGGL(dft_victim<double>, dim3(nframes), dim3(256), 0, sv, dframes, dtw, dout);
+        if (kind == 1) hipLaunchKernelGGL(dft_victim<float>, dim3(nframes), dim3(256), 0, sv, dframes, dtw, dout);
+        if (kind == 2) hipLaunchKernelGGL(dft_victim_nolds, dim3(nframes), dim3(256), 0, sv, dframes, dtw, dout);
+    };
     int total_bad = 0;
-    for (const Pair& p : pairs) {
-        long launches = 0, bad = 0, agg = 0;
-        size_t first_idx = 0; float first_got = 0, first_want = 0;
-        const double t0 = now();
-        int inflight = 0;
-        while (now() - t0 < seconds) {
-            // keep the aggressor's queue fed: a few launches ahead, each ~1-2 ms
-            if (p.kind != 0) {
-                if (hipEventQuery(ev) == hipSuccess || inflight == 0) {
+    for (const Victim& v : victims) {
+        launch_victim(v.kind);                               // solo golden of this victim
+        CK(hipStreamSynchronize(sv));
+        CK(hipMemcpy(gold.data(), dout, nout * 4, hipMemcpyDeviceToHost));
+        printf("victim: %s\n", v.name);
+        for (const Pair& p : pairs) {
+            long launches = 0, bad = 0, agg = 0, bad_elems = 0;
+            size_t first_idx = 0; float first_got = 0, first_want = 0;
+            const double t0 = now();
+            int inflight = 0;
+            while (now() - t0 < seconds) {
+                if (p.kind != 0 && (inflight == 0 || hipEventQuery(ev) == hipSuccess)) {     // keep the aggressor's queue fed, a few launches ahead
                     for (int q = 0; q < 4; ++q) {
-                        if (p.kind == 1) hipLaunchKernelGGL(valu_aggressor, dim3(prop.multiProcessorCount * 4), dim3(256), 0, sa, dsink, 20000);
-                        if (p.kind == 2) hipLaunchKernelGGL((mfma_aggressor<4>), dim3(prop.multiProcessorCount * 4), dim3(256), 0, sa, dsink, 20000, (uint32_t)agg);
-                        if (p.kind == 4) hipLaunchKernelGGL(mfma_lds_aggressor, dim3(prop.multiProcessorCount * 2), dim3(256), 0, sa, dsink, 20000, (uint32_t)agg);
-                        if (p.kind == 3) hipLaunchKernelGGL((mfma_aggressor<14>), dim3(prop.multiProcessorCount * 2), dim3(256), 0, sa, dsink, 6000, (uint32_t)agg);
+                        const int cus = prop.multiProcessorCount;
+                        if (p.kind == 1) hipLaunchKernelGGL(valu_aggressor, dim3(cus * 4), dim3(256), 0, sa, dsink, 20000);
+                        if (p.kind == 2) hipLaunchKernelGGL((mfma_aggressor<4>), dim3(cus * 4), dim3(256), 0, sa, dsink, 20000, (uint32_t)agg);
+                        if (p.kind == 3) hipLaunchKernelGGL((mfma_aggressor<14>), dim3(cus * 2), dim3(256), 0, sa, dsink, 6000, (uint32_t)agg);
+                        if (p.kind == 4) hipLaunchKernelGGL((mfma_lds_aggressor<true, true>), dim3(cus * 2), dim3(256), 0, sa, dsink, 20000, (uint32_t)agg);
+                        if (p.kind == 5) hipLaunchKernelGGL((mfma_lds_aggressor<true, false>), dim3(cus * 2), dim3(256), 0, sa, dsink, 20000, (uint32_t)agg);
+                        if (p.kind == 6) hipLaunchKernelGGL((mfma_lds_aggressor<false, true>), dim3(cus * 2), dim3(256), 0, sa, dsink, 20000, (uint32_t)agg);
                         ++agg;
                     }
                     CK(hipEventRecord(ev, sa));
                     inflight = 1;
                 }
+                launch_victim(v.kind);
+                CK(hipMemcpyAsync(got.data(), dout, nout * 4, hipMemcpyDeviceToHost, sv));
+                CK(hipStreamSynchronize(sv));
+                ++launches;
+                if (memcmp(got.data(), gold.data(), nout * 4) != 0) {
+                    long n = 0;
+                    for (size_t i = 0; i < nout; ++i) if (memcmp(&got[i], &gold[i], 4) != 0) { if (n == 0 && bad == 0) { first_idx = i; first_got = got[i]; first_want = gold[i]; } ++n; }
+                    bad_elems += n;
+                    ++bad;
+                }
             }
-            hipLaunchKernelGGL(dft_victim, dim3(nframes), dim3(256), 0, sv, dframes, dtw, dout);
-            CK(hipMemcpyAsync(got.data(), dout, nout * 4, hipMemcpyDeviceToHost, sv));
-            CK(hipStreamSynchronize(sv));
-            ++launches;
-            if (memcmp(got.data(), gold.data(), nout * 4) != 0) {
-                if (bad == 0) for (size_t i = 0; i < nout; ++i) if (memcmp(&got[i], &gold[i], 4) != 0) { first_idx = i; first_got = got[i]; first_want = gold[i]; break; }
-                ++bad;
-            }
+            CK(hipStreamSynchronize(sa));
+            printf("  beside %-62s : %6ld launches, %6ld corrupted (aggressor launches %ld)", p.name, launches, bad, agg);
+            if (bad) printf("  %.1f wrong values per corrupted launch of %zu; first: frame %zu bin %zu %s got %.9g want %.9g", (double)bad_elems / bad, nout,
+                            first_idx / (2 * NBIN), (first_idx / 2) % NBIN, first_idx & 1 ? "im" : "re", first_got, first_want);
+            printf("\n");
+            total_bad += bad != 0;
         }
-        CK(hipStreamSynchronize(sa));
-        printf("victim DFT beside %-52s : %6ld launches, %6ld corrupted (aggressor launches %ld)", p.name, launches, bad, agg);
-        if (bad) printf("  first: element %zu (frame %zu, bin %zu, %s) got %.9g want %.9g", first_idx, first_idx / (2 * NBIN), (first_idx / 2) % NBIN, first_idx & 1 ? "im" : "re", first_got, first_want);
-        printf("\n");
-        total_bad += bad != 0;
     }
-    printf("%s\n", total_bad ? "RESULT: concurrent queues corrupt the DFT victim on this box" : "RESULT: no corruption observed");
+    printf("%s\n", total_bad ? "RESULT part 1: concurrent queues corrupt the DFT victim on this box" : "RESULT part 1: no corruption observed");
+    const int p2 = part2(sv, sa, dsink, prop.multiProcessorCount, seconds / 3);
+    printf("%s\n", p2 ? "RESULT part 2: workgroups of two kernels on different queues see each other's LDS (allocation overlap)" : "RESULT part 2: LDS allocations stay disjoint");
     return 0;
 }
