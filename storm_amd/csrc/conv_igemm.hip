@@ -367,7 +367,7 @@ __device__ __forceinline__ void conv_tile(const ConvParams& a, const int vblock,
             if (pf_now) patch_issue(nxt, 0, Cfg::PU);
             stamp(4 + 4 * step);
             __syncthreads();                       // patch + wbuf[step&1] visible; ring slots of step-1 free
-            if (Cfg::DMA && has_next) {            // next tile straight into the other ring slot: lands under the MFMAs
+            if (Cfg::DMA && has_next && !(ABL & 16)) {            // next tile straight into the other ring slot: lands under the MFMAs
                 if (more_taps) w_dma(cur, tp + 1, (step + 1) & 1);
                 else w_dma(nxt, 0, (step + 1) & 1);
             }
@@ -745,7 +745,7 @@ static int choose_variant(const storm_conv_args& a, bool any9) {
     // <= 128 output channels.  Three structures - the generic tile (0: this file, two workgroups per CU hide each other's epilogue), conv_pipe128
     // (4: 16 x 32 pixel tiles, triple-buffered 32-channel chunks) and conv_pipe's 128-cout tile (9) - measured against each other on MI355X, each kernel
     // sustained, alternating (profiles/r04_duo_fair_ab.txt, r04_half_fair_ab.txt, r05_tune_dispatch*.log): within 5 % of each other wherever the chip
-    // is full (the part runs these layers at its power cap; conv_pipe128 3 - 8 % ahead from 256 input channels on, the 128-cout tile of
+    // is full (the part runs these layers at its power cap, LAB_NOTES 2.3; conv_pipe128 3 - 8 % ahead from 256 input channels on, the 128-cout tile of
     // conv_pipe 8 % behind) - so between them the ROUNDS decide.  (The 64-cout generic tile, 7, remains for few-tile layers conv_pipe does not cover.)
     //  Round 5, second tuner pass over the ragged stream's shapes (profiles/r05_tune_dispatch_stream_shapes_before.log: 60 exceptions of 4 - 20 %,
     //  none at the bench batch): what decides between the three is how a layer's tiles QUANTISE into rounds of workgroups -
@@ -789,12 +789,15 @@ static int dispatch_conv(const storm_conv_args& a, hipStream_t st) {
     const int abl = switches().conv_ablate;
     if (any9 && !small && abl && variant < 3) {
         const bool v2 = variant == 2;
+        // (the generic 128-cout tile as production runs it: weights by LDS-DMA.  1 no MFMA, 2 no fragment reads, 4 patch staged for the first
+        //  chunk only (no patch path / fused GroupNorm transform), 8 no epilogue, 16 no weight DMA after the first tile, 64 wave stamps)
         switch (abl) {
-            case 1: return v2 ? launch_conv<T, 9, 2, 4, 2, true, false, 1>(a, st) : launch_conv<T, 9, 2, 2, 2, false, false, 1>(a, st);
-            case 2: return v2 ? launch_conv<T, 9, 2, 4, 2, true, false, 2>(a, st) : launch_conv<T, 9, 2, 2, 2, false, false, 2>(a, st);
-            case 4: return v2 ? launch_conv<T, 9, 2, 4, 2, true, false, 4>(a, st) : launch_conv<T, 9, 2, 2, 2, false, false, 4>(a, st);
-            case 8: return v2 ? launch_conv<T, 9, 2, 4, 2, true, false, 8>(a, st) : launch_conv<T, 9, 2, 2, 2, false, false, 8>(a, st);
-            case 16: return v2 ? launch_conv<T, 9, 2, 4, 2, true, false, 16>(a, st) : launch_conv<T, 9, 2, 2, 2, false, false, 16>(a, st);
+            case 1: return v2 ? launch_conv<T, 9, 2, 4, 2, true, false, 1>(a, st) : launch_conv<T, 9, 2, 2, 2, false, true, 1>(a, st);
+            case 2: return v2 ? launch_conv<T, 9, 2, 4, 2, true, false, 2>(a, st) : launch_conv<T, 9, 2, 2, 2, false, true, 2>(a, st);
+            case 4: return v2 ? launch_conv<T, 9, 2, 4, 2, true, false, 4>(a, st) : launch_conv<T, 9, 2, 2, 2, false, true, 4>(a, st);
+            case 8: return v2 ? launch_conv<T, 9, 2, 4, 2, true, false, 8>(a, st) : launch_conv<T, 9, 2, 2, 2, false, true, 8>(a, st);
+            case 16: return v2 ? launch_conv<T, 9, 2, 4, 2, true, false, 16>(a, st) : launch_conv<T, 9, 2, 2, 2, false, true, 16>(a, st);
+            case 20: return launch_conv<T, 9, 2, 2, 2, false, true, 20>(a, st);
             case 32: return v2 ? launch_conv<T, 9, 2, 4, 2, true, false, 32>(a, st) : launch_conv<T, 9, 2, 2, 2, false, false, 32>(a, st);
             case 64: return v2 ? launch_conv<T, 9, 2, 4, 2, true, false, 64>(a, st)
                              : (switches().conv_dma ? launch_conv<T, 9, 2, 2, 2, false, true, 64>(a, st) : launch_conv<T, 9, 2, 2, 2, false, false, 64>(a, st));
@@ -808,7 +811,7 @@ static int dispatch_conv(const storm_conv_args& a, hipStream_t st) {
         if (variant == 9 && conv_pipe_supports(a)) return launch_conv_pipe_half(a, st);
         if (variant == 10) return launch_conv_pipe_splitk(a, splitk_slices_of(a), st);
         if (variant == 4 && conv_pipe128_supports(a)) return launch_conv_pipe128(a, st);
-#if defined(STORM_WITH_DUO)                                          // conv_duo.hip: profiling library and the test simulator only (a tie)
+#if defined(STORM_WITH_DUO)                                          // conv_duo.hip: profiling library and the test simulator only (LAB_NOTES 2.3: a tie)
         if (variant == 5 && conv_duo_supports(a)) return launch_conv_duo(a, st);
 #endif
         if (variant == 2) return launch_conv<T, 9, 2, 4, 2, true>(a, st);

@@ -75,12 +75,16 @@ STORM_HD int p_swz(int px, int slot) { return (slot ^ ((px >> 2) & 3)) << 4; }
 }  // namespace pipe128
 using namespace pipe128;
 
-// TRACE: profiling-only instantiation (libstorm_hip_prof.so, STORM_CONV_ABLATE=64): per-tile wave stamps for tools/pipe128_trace.py
-template <typename T, bool TRACE = false>
+// ABL: profiling-only instantiations (libstorm_hip_prof.so, STORM_CONV_ABLATE; the product library holds ABL = 0 only).  64: per-tile wave
+// stamps for tools/pipe128_trace.py; the work-skipping ones use conv_pipe's codes (profiles/r06_power_ablations_128cout.txt): 8 no weight
+// DMA, 16 no fragment reads (operands stay what the registers hold), 128 no patch DMA / table / fused GroupNorm transform, 136 no DMA of
+// either kind, 1024 no epilogue (accumulators kept alive, nothing staged, stored or reduced).  Results of those are garbage by design.
+template <typename T, int ABL = 0>
 __global__ __launch_bounds__(pipe128::THREADS, 2)
 void conv_pipe128_kernel(const PipeParams a, const int n_ct, const int tiles_per_xcd,
                          const int ntiles, const int tiles_x, const int tiles_per_img, const int total_vblocks) {
     typedef typename Mma<T>::Frag Frag;
+    constexpr bool TRACE = (ABL & 64) != 0;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     // parameter block through the kernarg segment pointer, re-laundered per tile (see conv_pipe.hip)
     PipeArgPtr ap = pipe_args(a);
@@ -179,6 +183,7 @@ void conv_pipe128_kernel(const PipeParams a, const int n_ct, const int tiles_per
     };
     int ring_rd = 0;                                        // byte offset of the ring slot of the phase being read
     auto w_issue = [&]() {                                  // (leading) the stream's tap -> the slot two phases ahead
+        if (ABL & 8) return;
         char* dst = smem + OFF_RING + (ring_rd ^ (2 * WPHASE)) + lw * (NWD * 1024);
 #pragma unroll
         for (int j = 0; j < NWD; ++j) dma16(w_srd, R[j], (uint32_t)w_soff, dst + j * 1024, lane);
@@ -189,8 +194,9 @@ void conv_pipe128_kernel(const PipeParams a, const int n_ct, const int tiles_per
     int rd_buf = 0, cm_buf = 1, is_buf = 2;
     // (lagging) the (scale, shift) table of the chunk being issued; every lagging wave fetches its own copy (identical
     // bytes), so that its own vmcnt orders it before its transforms
-    auto issue_table = [&](int into) { dma16(pd_ss_srd, (uint32_t)lane * 16u, 0u, smem + OFF_SS + into * 1024, lane); };
+    auto issue_table = [&](int into) { if (ABL & 128) return; dma16(pd_ss_srd, (uint32_t)lane * 16u, 0u, smem + OFF_SS + into * 1024, lane); };
     auto issue_slot = [&](int i, int into) {                // haloed piece lw + 4 i
+        if (ABL & 128) return;
         const int k = lw + NLAG * i;
         if (k >= PPIECES) { issue_table(into); return; }     // surplus slot: identical table bytes again (keeps the VMEM count uniform)
         const uint32_t v = patch_entry(i);
@@ -200,6 +206,7 @@ void conv_pipe128_kernel(const PipeParams a, const int n_ct, const int tiles_per
     };
     // one compact piece (one-tap chunk: TH x 32 pixels, no halo): piece k = pixel row k >> 1, columns 16 (k & 1) ..
     auto issue_compact = [&](int k, int into) {
+        if (ABL & 128) return;
         const int trow = k >> 1, n = (k & 1) * PXP + (lane >> 2);
         const int slot = (lane & 3) ^ ((n >> 2) & 3);
         const int gy = ty0 + trow, gx = tx0 + n;
@@ -217,6 +224,7 @@ void conv_pipe128_kernel(const PipeParams a, const int n_ct, const int tiles_per
     // time - 2.68 M against 1.88 M cycles per launch - whoever runs it: sharing it slot-wise or half-slot-wise with the leading
     // waves, or dropping s_setprio, moved the launch time by < 2 %.  So it stays where it is simplest.)
     auto commit_slot = [&](int i, int into) {
+        if (ABL & 128) return;
         const int k = lw + NLAG * i;
         if (k < PPIECES) {
             const uint32_t v = patch_entry(i);
@@ -232,6 +240,13 @@ void conv_pipe128_kernel(const PipeParams a, const int n_ct, const int tiles_per
     // ---- fragment reads / MFMAs --------------------------------------------------------------------------------
     auto read_frags = [&](Frag (&fa)[WM], Frag (&fb)[WN], int ring, int pb, auto kg_, auto poff_, auto prow_) {
         constexpr int kg = decltype(kg_)::value, POFF = decltype(poff_)::value, PROW = decltype(prow_)::value;
+        if (ABL & 16) {
+#pragma unroll
+            for (int mi = 0; mi < WM; ++mi) keep_rw(fa[mi]);
+#pragma unroll
+            for (int ni = 0; ni < WN; ++ni) keep_rw(fb[ni]);
+            return;
+        }
         const char* wb = smem + ring + (kg ? aoff1 : aoff);
 #pragma unroll
         for (int mi = 0; mi < WM; ++mi) fa[mi] = *reinterpret_cast<const Frag*>(wb + mi * 32 * WROW);
@@ -241,10 +256,12 @@ void conv_pipe128_kernel(const PipeParams a, const int n_ct, const int tiles_per
     };
     auto read_a = [&](Frag& f, int ring, auto kg_, auto mi_) {
         constexpr int kg = decltype(kg_)::value, mi = decltype(mi_)::value;
+        if (ABL & 16) { keep_rw(f); return; }
         f = *reinterpret_cast<const Frag*>(smem + ring + (kg ? aoff1 : aoff) + mi * 32 * WROW);
     };
     auto read_b = [&](Frag& f, int pb, auto kg_, auto poff_, auto prow_, auto ni_) {
         constexpr int kg = decltype(kg_)::value, POFF = decltype(poff_)::value, PROW = decltype(prow_)::value, ni = decltype(ni_)::value;
+        if (ABL & 16) { keep_rw(f); return; }
         f = *reinterpret_cast<const Frag*>(smem + (pb ^ (kg << 5)) + POFF + ni * PROW);
     };
     auto mma_part = [&](const Frag (&fa)[WM], const Frag (&fb)[WN], int lo, int hi) {
@@ -335,11 +352,15 @@ void conv_pipe128_kernel(const PipeParams a, const int n_ct, const int tiles_per
         w_soff = w2_wsoff;
         if (grp == 0) {
             char* dst = smem + OFF_RING + lw * (NWD * 1024);
+            if (!(ABL & 8)) {
 #pragma unroll
-            for (int j = 0; j < NWD; ++j) dma16(w_srd, R[j], (uint32_t)w_soff, dst + j * 1024, lane);
+                for (int j = 0; j < NWD; ++j) dma16(w_srd, R[j], (uint32_t)w_soff, dst + j * 1024, lane);
+            }
             w_soff += w_tapbytes;                                // (the first chunk has nine taps)
+            if (!(ABL & 8)) {
 #pragma unroll
-            for (int j = 0; j < NWD; ++j) dma16(w_srd, R[j], (uint32_t)w_soff, dst + WPHASE + j * 1024, lane);
+                for (int j = 0; j < NWD; ++j) dma16(w_srd, R[j], (uint32_t)w_soff, dst + WPHASE + j * 1024, lane);
+            }
         } else {
             issue_table(0);
 #pragma unroll
@@ -430,11 +451,18 @@ void conv_pipe128_kernel(const PipeParams a, const int n_ct, const int tiles_per
         // and rows 8-15 (wn = 2, 3).
         const epi::TileAt et = {e_tile, e_b, e_ty0, e_tx0, e_cout0};
         float gsum[8], gsq[8];
+        if (ABL & 1024) {                                    // (profiling) no epilogue: the accumulators stay alive, nothing is staged or stored
+#pragma unroll
+            for (int mi = 0; mi < WM; ++mi)
+#pragma unroll
+                for (int ni = 0; ni < WN; ++ni) keep(acc[mi][ni]);
+        } else {
         epi::store_tile<T, WM, WN>(acc, smem + PATCH_BYTES + wave * WSTAGE, ap, et, wm, wn, lane, imgH, imgW, BN, TH, gsum, gsq);
         stamp();                                            // 4: epilogue stores issued
         if (ap->gn_part != nullptr)
             epi::write_stats<WM, WN, WAVES_N, BN, TH>(gsum, gsq, reinterpret_cast<float*>(smem + OFF_RING + 2 * WPHASE), ap, et, wm, wn, lane, tid,
                                                       imgH, tiles_x, tiles_per_img);
+        }
         stamp();                                            // 5: statistics written
         if (!has_next) break;
         __syncthreads();                                    // the statistics scratch / staging of this tile is free again
@@ -450,9 +478,10 @@ bool conv_pipe128_supports(const storm_conv_args& a) {
     return build_pipe_params(a, p, pipe128::KC);
 }
 
-template <typename T, bool TRACE = false>
+template <typename T, int ABL = 0>
 static int launch_pipe128(const storm_conv_args& a, hipStream_t st) {
-    auto kern = conv_pipe128_kernel<T, TRACE>;
+    constexpr bool TRACE = (ABL & 64) != 0;
+    auto kern = conv_pipe128_kernel<T, ABL>;
     static bool attr_set = false;                       // per instantiation; benign race (idempotent)
     if (!attr_set) {
         STORM_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, pipe128::LDS_BYTES));
@@ -478,13 +507,21 @@ static int launch_pipe128(const storm_conv_args& a, hipStream_t st) {
 
 int launch_conv_pipe128(const storm_conv_args& a, hipStream_t st) {
 #if defined(STORM_PROFILING)
-    if (switches().conv_ablate == 64 && a.dtype == STORM_BF16) return launch_pipe128<bf16_t, true>(a, st);
+    if (a.dtype == STORM_BF16) switch (switches().conv_ablate) {
+        case 64: return launch_pipe128<bf16_t, 64>(a, st);
+        case 8: return launch_pipe128<bf16_t, 8>(a, st);
+        case 16: return launch_pipe128<bf16_t, 16>(a, st);
+        case 128: return launch_pipe128<bf16_t, 128>(a, st);
+        case 136: return launch_pipe128<bf16_t, 136>(a, st);
+        case 1024: return launch_pipe128<bf16_t, 1024>(a, st);
+        default: break;
+    }
 #endif
     return a.dtype == STORM_F16 ? launch_pipe128<half_t>(a, st) : launch_pipe128<bf16_t>(a, st);
 }
 
 const char* conv_pipe128_kernel_name(int dtype) {
-    return dtype == STORM_F16 ? "storm::conv_pipe128_kernel<storm::half_t, false>" : "storm::conv_pipe128_kernel<storm::bf16_t, false>";
+    return dtype == STORM_F16 ? "storm::conv_pipe128_kernel<storm::half_t, 0>" : "storm::conv_pipe128_kernel<storm::bf16_t, 0>";
 }
 
 }  // namespace storm

@@ -19,7 +19,6 @@ from .backbones import BackboneRegistry
 from .checkpoint import load_checkpoint_file
 from .data_module import SpecsDataModule
 from .sdes import SDERegistry
-from .util.other import pad_spec
 
 _PRECISIONS = {"fp32": torch.float32, "float32": torch.float32, "bf16": torch.bfloat16, "bfloat16": torch.bfloat16,
                "fp16": torch.float16, "float16": torch.float16, "half": torch.float16}

@@ -500,7 +500,7 @@ def test_conv_pipelined_128cout_kernel(dev, case, variant, switch):
         switch("STORM_CONV_CUS", cus)
     kname = ops.conv_kernel_name(segs, Co, bias=bias.to(dev), tbias=tbd[:, 8:], skip=skip, scale=0.5)
     if variant == 5 and not kname.startswith("storm::conv_duo_kernel"):
-        pytest.skip("conv_duo.hip is not in the product library (DESIGN 2.3): profiling library and the simulator only")
+        pytest.skip("conv_duo.hip is not in the product library (LAB_NOTES 2.3): profiling library and the simulator only")
     assert kname.startswith({4: "storm::conv_pipe128_kernel", 5: "storm::conv_duo_kernel"}[variant])
     y, part = ops.conv(segs, Co, bias=bias.to(dev), tbias=tbd[:, 8:], skip=skip, scale=0.5, gn_partials=True)
     yc = nchw(y.float().cpu())

@@ -7,7 +7,7 @@ conv_igemm.hip:choose_variant as storm_amd/csrc/conv_dispatch_table.h.
     gpurun -- 'python tools/tune_dispatch.py --write > gpurun_out/tune_dispatch.log'      then rebuild (python -m storm_amd.build)
 
 How: for every configuration (network, batch, frames) the C planner's op list is run op by op through storm_program_run on a
-workspace filled with N(0, 1) values in the operand type (zeros would clock 20 % higher: DESIGN 2.1), each 3x3 convolution with > 32
+workspace filled with N(0, 1) values in the operand type (zeros would clock 20 % higher: LAB_NOTES 2.1), each 3x3 convolution with > 32
 output channels under STORM_CONV_VARIANT = candidate, the candidates of a layer interleaved round-robin, `--reps` timed launches each
 after a sustained warm-up of the whole candidate set.  Split-K layers are skipped (conv_splitk_slices decides them; the planner sizes
 their scratch).  A candidate replaces the ladder's choice when it is faster by more than `--margin` (default 3 %) in BOTH halves of
