@@ -78,7 +78,7 @@ using namespace pipe128;
 // ABL: profiling-only instantiations (libstorm_hip_prof.so, STORM_CONV_ABLATE; the product library holds ABL = 0 only).  64: per-tile wave
 // stamps for tools/pipe128_trace.py; the work-skipping ones use conv_pipe's codes (profiles/r06_power_ablations_128cout.txt): 8 no weight
 // DMA, 16 no fragment reads (operands stay what the registers hold), 128 no patch DMA / table / fused GroupNorm transform, 136 no DMA of
-// either kind, 1024 no epilogue (accumulators kept alive, nothing staged, stored or reduced).  Results of those are garbage by design.
+// either kind, 256 patch DMA from one hot 1-KiB region (same instructions and LDS writes, no memory-system traffic), 1024 no epilogue (accumulators kept alive, nothing staged, stored or reduced).  Results of those are garbage by design.
 template <typename T, int ABL = 0>
 __global__ __launch_bounds__(pipe128::THREADS, 2)
 void conv_pipe128_kernel(const PipeParams a, const int n_ct, const int tiles_per_xcd,
@@ -201,6 +201,10 @@ void conv_pipe128_kernel(const PipeParams a, const int n_ct, const int tiles_per
         if (k >= PPIECES) { issue_table(into); return; }     // surplus slot: identical table bytes again (keeps the VMEM count uniform)
         const uint32_t v = patch_entry(i);
         const bool ok = (int)v >= 0 && (int)(v & 7u) * 8 < pd_cvalid;
+        if (ABL & 256) {                                    // (profiling) the same DMA instructions and LDS writes from ONE hot 1-KiB region: no HBM / L2-miss traffic
+            dma16(pd_srd, ok ? (uint32_t)lane * 16u : OOB, 0u, smem + into * PATCH_BYTES + k * 1024, lane);
+            return;
+        }
         dma16(pd_srd, ok ? mad24(v >> 3, (uint32_t)pd_C2, (v & 7u) * 16u) : OOB, (uint32_t)pd_cbeg2,
               smem + into * PATCH_BYTES + k * 1024, lane);
     };
@@ -514,6 +518,7 @@ int launch_conv_pipe128(const storm_conv_args& a, hipStream_t st) {
         case 128: return launch_pipe128<bf16_t, 128>(a, st);
         case 136: return launch_pipe128<bf16_t, 136>(a, st);
         case 1024: return launch_pipe128<bf16_t, 1024>(a, st);
+        case 256: return launch_pipe128<bf16_t, 256>(a, st);
         default: break;
     }
 #endif
