@@ -60,6 +60,7 @@ def parse():
     p.add_argument("--stream", type=int, default=0, metavar="N",
                    help="configs[4]: a step = N synthetic utterances of 2-10 s (seeded lengths), micro-batched by padded frame count "
                         "(<= --batch per launch, ragged rows) instead of one equal-length batch")
+    p.add_argument("--no-group", action="store_true", help="--stream: one micro-batch after the other instead of grouped score evaluations (A/B)")
     p.add_argument("--dist-world1", action="store_true",
                    help="with ONE rank: initialise the RCCL process group anyway and run the barrier / gather lines through it (dry run of the "
                         "N-rank path on one GPU; the driver launches the real one)")
@@ -222,13 +223,10 @@ def other_configs(model, dev, sync):
     model.set_precision("fp16")
     batches, lens = ragged_stream(32, 16, 77, g, dev)
 
-    def stream_step(kw, sel):
+    def stream_step(kw, sel, grouped=True):
         def step(i):
-            nfes, o = [], None
-            for k, (yb, bl) in enumerate(sel):
-                o, n_ = model.enhance_batch(yb, seed=9000 + 100 * i + k, return_nfe=True, lengths=bl, **kw)
-                nfes.append(n_ * yb.shape[0])
-            return o, sum(nfes) / sum(b[0].shape[0] for b in sel)
+            outs, n_ = model.enhance_stream(sel, grouped=grouped, seed=9000 + 100 * i, return_nfe=True, **kw)
+            return outs[-1], n_
         return step
     pc = dict(sampler_type="pc", predictor="reverse_diffusion", corrector="ald", N=30, corrector_steps=1, snr=0.5)
     el, (_, nfe) = run(stream_step(pc, batches), 1, warm_step=stream_step(dict(pc, N=1), batches))
@@ -236,7 +234,11 @@ def other_configs(model, dev, sync):
     out["configs4_stream_pc"] = {"workload": f"configs[4]-style on one GPU: ncsnpp, stream of 32 utterances of 2-10 s ({audio_s:.0f} s of audio) in {len(batches)} ragged "
                                              "micro-batches (<= 16 rows, bucketed by padded frame count), 30-step PC (reverse_diffusion + ald x1), fp16, wav->wav",
                                  "value": 32 / el, "unit": "utterances/s", "steps": 1, "ms_per_step": 1e3 * el, "dtype": "fp16", "nfe_per_utterance": nfe,
-                                 "micro_batches": len(batches), "rtf_per_audio_second": el / audio_s}
+                                 "micro_batches": len(batches), "rtf_per_audio_second": el / audio_s,
+                                 "grouped": "the micro-batches' samplers in lockstep, one grouped network call per step (storm_ncsnpp_forward_group)",
+                                 "grouped_calls_rows": list(model.last_group_calls or ())}
+    el_seq, _ = D.timed_steps(stream_step(pc, batches, grouped=False), 1, 0, sync=sync)[::2]
+    out["configs4_stream_pc"]["value_one_micro_batch_after_the_other"] = 32 / el_seq
     # the ODE leg on the micro-batches that hold the first 8 utterances' worth of rows (shapes planned by the PC pass above)
     sel, n_sel = [], 0
     for b in sorted(batches, key=lambda b: -b[0].shape[0]):
@@ -248,7 +250,7 @@ def other_configs(model, dev, sync):
     out["configs4_stream_ode"] = {"workload": f"configs[4] as configured, shortened: ncsnpp, {n_sel} utterances of 2-10 s in {len(sel)} ragged micro-batches of the same stream, "
                                               "probability-flow ODE sampler (RK45, rtol = atol = 1e-5, one step controller per row), fp16, wav->wav",
                                   "value": n_sel / el, "unit": "utterances/s", "steps": 1, "ms_per_step": 1e3 * el, "dtype": "fp16",
-                                  "nfe_per_utterance": nfe, "micro_batches": len(sel)}
+                                  "nfe_per_utterance": nfe, "micro_batches": len(sel), "grouped": True}
     model.set_precision("bf16")
     # ---- configs[3]: ncsnpplarge (65.6 M), 8 utterances of 8 s per GPU, 50-step PC + 1 corrector step = 100 evaluations
     large = ScoreModel(backbone="ncsnpplarge", sde="ouve", theta=1.5, sigma_min=0.05, sigma_max=0.5, spec_factor=0.15, spec_abs_exponent=0.5)
@@ -382,13 +384,10 @@ def main():
     def step(i):
         if not args.stream:
             return model.enhance_batch(wav, seed=1000 * rank + i, return_nfe=True, **skw)
-        # (one micro-batch at a time, one stream: kernels of concurrent streams corrupt each other on this platform,
-        #  profiles/r05_concurrent_streams_corruption.txt)
-        nfes, out = [], None
-        for k, (yb, bl) in enumerate(batches):
-            out, n_ = model.enhance_batch(yb, seed=1000 * rank + 100 * i + k, return_nfe=True, lengths=bl, **skw)
-            nfes.append(n_ * yb.shape[0])
-        return out, sum(nfes) / args.stream                 # mean score evaluations per utterance
+        # one stream (kernels of concurrent queues corrupt each other on this platform, profiles/r06_concurrent_repro.txt); the micro-batches
+        # share LAUNCHES instead: ScoreModel.enhance_stream runs their samplers in lockstep around one grouped network call per step
+        outs, n_ = model.enhance_stream(batches, grouped=not args.no_group, seed=1000 * rank + 100 * i, return_nfe=True, **skw)
+        return outs[-1], n_                                 # mean score evaluations per utterance
 
     # socket power: by default NOT sampled inside the timed region (the sampler spawns rocm-smi every 0.2 s on rank 0's host cores and
     # would perturb that rank only); one more repetition of the same step is sampled after it, on a one-rank run, where rocm-smi's
@@ -418,7 +417,7 @@ def main():
         "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True,
         "scaling": "weak", "vs_baseline": None, "dtype": args.precision, "data": "synthetic",
         "config": {"workload": (f"configs[4]-style: {args.backbone} stream of {args.stream} utterances of 2-10 s@16 kHz per GPU in "
-                                f"{len(batches)} ragged micro-batches (<= {args.batch}, bucketed by padded frame count), " if args.stream else
+                                f"{len(batches)} ragged micro-batches (<= {args.batch}, bucketed by padded frame count; " + ("one after the other" if args.no_group else "grouped score evaluations") + "), " if args.stream else
                                 f"{cfg_name}: {args.backbone} batch={args.batch}x{args.seconds:g} s@16 kHz per GPU, ") +
                                (f"{args.N}-step PC sampler (reverse_diffusion + {args.corrector} x{args.corrector_steps}), " if args.sampler == "pc"
                                 else "probability-flow ODE sampler (RK45, rtol = atol = 1e-5), ") +

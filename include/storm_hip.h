@@ -124,6 +124,13 @@ typedef struct storm_conv_args {
 } storm_conv_args;
 
 int storm_conv(const storm_conv_args* a, storm_stream_t s);
+/* The same for P problems that are ONE layer (same weights, channels, taps; own tensors, batch sizes and widths) in ONE launch - the
+ * ragged micro-batches of a stream (BASELINE.json configs[4]).  16-bit 3x3 convolutions of the pipelined kernel only
+ * (STORM_ERR_UNSUPPORTED otherwise: run them one by one).  A pixel tile computes exactly what storm_conv computes for it with the
+ * same tile (bn = 256 or 128 output channels per workgroup; 0 = chosen by the group's tile count); K is never split.  blob: device
+ * scratch >= storm_conv_group_blob_bytes (tables of the launch; this convenience entry fills it with a synchronous copy). */
+long long storm_conv_group_blob_bytes(const storm_conv_args* a, int P);
+int storm_conv_group(const storm_conv_args* a, int P, void* blob, long long blob_bytes, int bn, storm_stream_t s);
 /* scratch bytes with which storm_conv would split K for this call; 0 = it would not (most layers).  No counterpart in the
  * reference: a scheduling aid for ddpm_conv3x3 (layers.py:119-126) on the 16 x 64 ... 4 x 16 pixel levels of ncsnpplarge
  * (ncsnpp.py:460-470), where one launch is otherwise a serial K loop on a few workgroups. */
@@ -427,6 +434,17 @@ long long storm_ncsnpp_workspace_bytes(storm_ncsnpp* h, int B, int F, int T);
  * only; storm_ncsnpp_set_fusion / _destroy must not race with calls. */
 int storm_ncsnpp_forward(storm_ncsnpp* h, const void* const* parts, int n_parts, const float* t, void* out, void* ws,
                          long long ws_bytes, int B, int F, int T, int negate, storm_stream_t s);
+/* GROUPED evaluation - P micro-batches of different (B_p, T_p) of one stream in ONE call (BASELINE.json configs[4]: 2 - 10 s utterances
+ * bucketed by padded frame count are 2 - 3 rows per micro-batch; the reference processes one file per call, enhancement.py:66-72).  All
+ * problems run the same op sequence; op k of every problem shares one launch where a grouped kernel exists (today: the 16-bit 3x3
+ * convolutions with > 128 output channels - one persistent walk over all problems' pixel tiles), and runs problem by problem otherwise.
+ * Every row computes what its own micro-batch's storm_ncsnpp_forward computes in the kernels that serve it (the tile choice and the K split
+ * of few-tile layers follow the GROUP's tile count, so a 16-bit row agrees with its own call to the rounding of its activations; fp32: no
+ * grouped kernel, bit-identical).  parts: P * n_parts pointers, problem-major; t / out: P pointers; ws >= _group_workspace_bytes(same list). */
+long long storm_ncsnpp_group_workspace_bytes(storm_ncsnpp* h, int P, const int* B, const int* T, int F);
+int storm_ncsnpp_forward_group(storm_ncsnpp* h, int P, const int* B, const int* T, int F, const void* const* parts, int n_parts,
+                               const float* const* t, void* const* out, void* ws, long long ws_bytes, int negate, storm_stream_t s);
+long long storm_ncsnpp_group_launches(storm_ncsnpp* h);    /* grouped kernel launches this handle has made (diagnostics: 0 = every op ran problem by problem) */
 /* the planned op list of (B, F, T) (owned by the handle) for storm_program_run_timed / storm_program_kernel_name, the packed
  * arena, and the algorithmic FLOPs of one forward */
 int storm_ncsnpp_program(storm_ncsnpp* h, int B, int F, int T, const storm_op** ops, int* n_ops, long long* flops);

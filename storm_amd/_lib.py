@@ -71,6 +71,8 @@ _SIGNATURES = {
     "storm_pack_conv_weight": ([_vp, _vp, _i, _i, _i, _i, _i, _i, _vp], C.c_int),
     "storm_pack_matrix": ([_vp, _vp, _i, _i, _i, _i, _i, _i, _vp], C.c_int),
     "storm_conv": ([C.POINTER(ConvArgs), _vp], C.c_int),
+    "storm_conv_group_blob_bytes": ([C.POINTER(ConvArgs), _i], C.c_longlong),
+    "storm_conv_group": ([C.POINTER(ConvArgs), _i, _vp, _ll, _i, _vp], C.c_int),
     "storm_conv_tiles": ([C.POINTER(ConvArgs)], C.c_int),
     "storm_conv_splitk_bytes": ([C.POINTER(ConvArgs)], C.c_longlong),
     "storm_conv_kernel_name": ([C.POINTER(ConvArgs)], C.c_char_p),
@@ -121,6 +123,9 @@ _SIGNATURES = {
     "storm_ncsnpp_graph_launches": ([_vp], C.c_longlong),
     "storm_ncsnpp_workspace_bytes": ([_vp, _i, _i, _i], C.c_longlong),
     "storm_ncsnpp_forward": ([_vp, C.POINTER(_vp), _i, _vp, _vp, _vp, _ll, _i, _i, _i, _i, _vp], C.c_int),
+    "storm_ncsnpp_group_workspace_bytes": ([_vp, _i, C.POINTER(C.c_int), C.POINTER(C.c_int), _i], C.c_longlong),
+    "storm_ncsnpp_forward_group": ([_vp, _i, C.POINTER(C.c_int), C.POINTER(C.c_int), _i, C.POINTER(_vp), _i, C.POINTER(_vp), C.POINTER(_vp), _vp, _ll, _i, _vp], C.c_int),
+    "storm_ncsnpp_group_launches": ([_vp], C.c_longlong),
     "storm_ncsnpp_program": ([_vp, _i, _i, _i, C.POINTER(C.POINTER(Op)), C.POINTER(C.c_int), C.POINTER(C.c_longlong)], C.c_int),
     "storm_ncsnpp_release_program": ([_vp, C.POINTER(Op)], C.c_int),
     "storm_ncsnpp_arena": ([_vp], _vp),
@@ -133,8 +138,9 @@ _lib = None
 _sim = False
 
 
-def _bind(path):
-    lib = C.CDLL(path)
+def _bind(path, hold_gil=False):
+    # hold_gil (the test simulator only): its fiber runtime is one global machine - host threads (grouped micro-batches) must enter it one at a time
+    lib = C.PyDLL(path) if hold_gil else C.CDLL(path)
     lib.storm_last_error.restype = C.c_char_p
     lib.storm_last_error.argtypes = []
     for name, (args, res) in _SIGNATURES.items():
@@ -165,7 +171,7 @@ def lib():
 def _load_for_tests(path, sim):
     """TEST HOOK: bind another build of the same C ABI (the host simulation)."""
     global _lib, _sim
-    _lib = _bind(path)
+    _lib = _bind(path, hold_gil=bool(sim))
     _sim = bool(sim)
     return _lib
 

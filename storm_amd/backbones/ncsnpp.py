@@ -188,6 +188,10 @@ class NCSNpp(nn.Module):
         """hipGraphLaunch calls made so far by this module's engine handles (0 = every evaluation ran as eager launches)"""
         return sum(int(L.lib().storm_ncsnpp_graph_launches(h)) for h, _, _, _ in self._handles.values())
 
+    def group_launches(self):
+        """grouped kernel launches made so far by forward_parts_group (0 = every op ran problem by problem)"""
+        return sum(int(L.lib().storm_ncsnpp_group_launches(h)) for h, _, _, _ in self._handles.values())
+
     def invalidate(self):
         """Call after changing parameters in place (e.g. EMA swap): the engine re-packs its weight arena lazily."""
         self._param_version += 1
@@ -301,6 +305,10 @@ class NCSNpp(nn.Module):
     def forward_parts(self, ins, time_cond=None):
         """Same as forward() but takes the complex channels as separate contiguous [B,F,T] tensors
         (avoids materialising torch.cat([x, y], 1) every score evaluation).  One C-ABI call: storm_ncsnpp_forward."""
+        from ..sampling.grouped import grouped_forward_parts
+        routed = grouped_forward_parts(self, ins, time_cond)       # (a micro-batch of a grouped stream: evaluated together with the others)
+        if routed is not None:
+            return routed
         x0 = ins[0]
         B, F, T = x0.shape
         dev = x0.device
@@ -321,9 +329,60 @@ class NCSNpp(nn.Module):
             tc = time_cond.to(device=dev, dtype=torch.float32).contiguous()
             if tc.shape != (B,):
                 raise ValueError(f"time_cond must have shape [{B}]")
-        L.check(L.lib().storm_ncsnpp_forward(h, parts, len(ins), L.ptr(tc), L.ptr(torch.view_as_real(out)), L.ptr(ws), ws.numel(),
-                                             B, F, T, int(self.negate_output), L.stream()), "storm_ncsnpp_forward")
+        with self._lock:       # (the ~120 launches of one evaluation go out together: host threads that share this stream's scratch must not interleave)
+            L.check(L.lib().storm_ncsnpp_forward(h, parts, len(ins), L.ptr(tc), L.ptr(torch.view_as_real(out)), L.ptr(ws), ws.numel(),
+                                                 B, F, T, int(self.negate_output), L.stream()), "storm_ncsnpp_forward")
         return out
+
+
+    def forward_parts_group(self, ins_list, time_conds=None):
+        """P micro-batches of different (B_p, T_p) in ONE C-ABI call (storm_ncsnpp_forward_group): ins_list[p] = the complex channels of
+        problem p as contiguous [B_p, F, T_p] tensors, time_conds[p] = float32 [B_p].  Returns the P outputs [B_p, 1, F, T_p].  The op
+        sequence is the same for every problem; layers with a grouped kernel run all problems' pixel tiles in one launch."""
+        P = len(ins_list)
+        if P == 1:
+            return [self.forward_parts(ins_list[0], None if time_conds is None else time_conds[0])]
+        dev = ins_list[0][0].device
+        F = ins_list[0][0].shape[1]
+        code = L.dt(self.compute_dtype)
+        n_parts = len(ins_list[0])
+        Bs, Ts = (C.c_int * P)(), (C.c_int * P)()
+        parts, tptr, optr = (C.c_void_p * (P * n_parts))(), (C.c_void_p * P)(), (C.c_void_p * P)()
+        outs, keep = [], []
+        for p, ins in enumerate(ins_list):
+            x0 = ins[0]
+            if len(ins) != n_parts or x0.shape[1] != F:
+                raise TypeError("every problem needs the same number of complex channels and frequency bins")
+            Bs[p], Ts[p] = x0.shape[0], x0.shape[2]
+            for j, t_in in enumerate(ins):
+                if t_in.dtype != torch.complex64 or t_in.shape != x0.shape or not t_in.is_contiguous():
+                    raise TypeError("inputs must be contiguous complex64 tensors of identical shape per problem")
+                parts[p * n_parts + j] = L.ptr(torch.view_as_real(t_in))
+            if self.cfg.conditional:
+                if time_conds is None or time_conds[p] is None:
+                    raise ValueError("time_cond is required for a score network")
+                tc = time_conds[p].to(device=dev, dtype=torch.float32).contiguous()
+                if tc.shape != (x0.shape[0],):
+                    raise ValueError(f"time_cond of problem {p} must have shape [{x0.shape[0]}]")
+                keep.append(tc)
+                tptr[p] = L.ptr(tc)
+            out = torch.empty((x0.shape[0], 1, F, x0.shape[2]), dtype=torch.complex64, device=dev)
+            outs.append(out)
+            optr[p] = L.ptr(torch.view_as_real(out))
+        with self._lock:
+            h = self._get_handle(code, dev)
+            n = L.lib().storm_ncsnpp_group_workspace_bytes(h, P, Bs, Ts, F)
+            if n < 0:
+                raise L.StormError(f"storm_ncsnpp_group_workspace_bytes: {L.lib().storm_last_error().decode()}")
+            key = (str(dev), code, L.stream(), "group")
+            ws = self._workspaces.pop(key, None)
+            if ws is None or ws.numel() < n:
+                ws = None
+                ws = torch.empty(n, dtype=torch.uint8, device=dev)
+            self._workspaces[key] = ws
+        L.check(L.lib().storm_ncsnpp_forward_group(h, P, Bs, Ts, F, parts, n_parts, tptr if self.cfg.conditional else None, optr, L.ptr(ws), ws.numel(),
+                                                   int(self.negate_output), L.stream()), "storm_ncsnpp_forward_group")
+        return outs
 
 
 @BackboneRegistry.register("ncsnpplarge")

@@ -221,4 +221,24 @@ __device__ inline double wave_sum_d(double v) {
 
 inline int cdiv(long long a, long long b) { return (int)((a + b - 1) / b); }
 
+// ---- grouped evaluation of P op lists of ONE network on P problems (program.hip; used by storm_ncsnpp_forward_group) -----------------------
+// The ragged micro-batches of a stream run the same op sequence on tensors of different (B, T).  Op k of every problem is launched together
+// where a grouped kernel exists for it (16-bit 3x3 convolutions of the conv_pipe family: one launch over all problems' pixel tiles),
+// one after the other otherwise.  The tables of the grouped launches (absolute device pointers) live in a caller-owned device blob.
+struct GroupOp { int k, outC, bn, kind; long long table_off, tiles_off, ntiles; };   // kind 0: 3x3 convolution (conv_pipe), 1: GroupNorm finalize
+// one problem of a grouped GroupNorm finalize (norm_resample.hip): the arguments of its own storm_gn_finalize(_ss) call
+struct GnFinProblem { const float* pa; const float* pb; double* stats; const float* gamma; const float* beta; float* ss; long long count;
+                      int Ca, tiles_a, Cb, tiles_b; float eps; int pad_; };
+struct GnFinItem { int problem, b; };
+int launch_gn_finalize_group(const GnFinProblem* dev_tab, const void* dev_items, int n_items, int groups, hipStream_t st);
+// bytes of the device blob for these shapes (a bound: every groupable op with all its tiles), 0 = nothing groups
+long long program_group_blob_bytes(const storm_op* const* ops, int n_ops, int P, int dtype);
+// fill the host image of the blob (tables hold pointers resolved against bufs[p]) and the list of grouped ops; returns their count or < 0
+int program_group_build(const storm_op* const* ops, int n_ops, void* const* const* bufs, int n_bufs, int P, int dtype, char* host_blob,
+                        long long blob_bytes, GroupOp* gops, int max_gops);
+// run ops [0, n_ops) of the P problems: grouped ops from the DEVICE copy of the blob, every other op problem by problem; the last op
+// (output head) with `negate`
+int program_run_group(const storm_op* const* ops, int n_ops, void* const* const* bufs, int n_bufs, int P, int dtype, const char* dev_blob,
+                      const GroupOp* gops, int n_gops, int negate, storm_stream_t s);
+
 }  // namespace storm

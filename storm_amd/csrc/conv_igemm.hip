@@ -31,6 +31,7 @@
 #include <cstring>
 #include "common.h"
 #include "conv_index.h"
+#include <vector>
 #include "conv_params.h"
 #include "conv_dispatch_table.h"
 
@@ -874,6 +875,34 @@ extern "C" int storm_conv_tiles(const storm_conv_args* ap) {
 extern "C" long long storm_conv_splitk_bytes(const storm_conv_args* ap) {
     if (ap == nullptr || ap->nseg < 1 || ap->nseg > 2 || ap->B <= 0 || ap->H <= 0 || ap->W <= 0) return 0;
     return storm::conv_splitk_bytes(*ap, storm::splitk_slices_of(*ap));
+}
+
+// One launch for P problems that run the SAME 16-bit 3x3 layer on tensors of their own (storm_hip.h).  blob: device scratch of at least
+// storm_conv_group_blob_bytes(args, P) bytes; the tables are built on the host and copied there (synchronously: a convenience entry for
+// single layers and tests - the whole-network object keeps a pinned image and copies asynchronously).  bn: 256 / 128 couts per workgroup, 0 = by tile count.
+extern "C" long long storm_conv_group_blob_bytes(const storm_conv_args* a, int P) {
+    if (a == nullptr || P < 1) return -1;
+    long long t = 0;
+    for (int g = 0; g < P; ++g) t += (long long)a[g].B * storm::cdiv(a[g].H, 8) * storm::cdiv(a[g].W, 32);
+    return (long long)P * (long long)sizeof(storm::pipe::PipeParams) + 256 + t * (long long)sizeof(storm::pipe::GroupTile);
+}
+extern "C" int storm_conv_group(const storm_conv_args* a, int P, void* blob, long long blob_bytes, int bn, storm_stream_t s) {
+    STORM_CHECK(a != nullptr && P >= 1 && blob != nullptr, "storm_conv_group: bad arguments");
+    const long long need = storm_conv_group_blob_bytes(a, P);
+    STORM_CHECK(blob_bytes >= need, "storm_conv_group: blob %lld < %lld bytes", blob_bytes, need);
+    const long long tab = ((long long)P * (long long)sizeof(storm::pipe::PipeParams) + 255) / 256 * 256;
+    std::vector<char> host((size_t)need);
+    storm::pipe::PipeParams* table = reinterpret_cast<storm::pipe::PipeParams*>(host.data());
+    storm::pipe::GroupTile* tiles = reinterpret_cast<storm::pipe::GroupTile*>(host.data() + tab);
+    const long long nt = storm::conv_pipe_group_prepare(a, P, table, tiles, (need - tab) / (long long)sizeof(storm::pipe::GroupTile));
+    if (nt <= 0) { storm::set_error("storm_conv_group: the problems are not one layer of the pipelined 3x3 kernel (16-bit operands, > 0 nine-tap chunks, same weights)"); return STORM_ERR_UNSUPPORTED; }
+    STORM_HIP(hipMemcpyAsync(blob, host.data(), (size_t)(tab + nt * (long long)sizeof(storm::pipe::GroupTile)), hipMemcpyHostToDevice, (hipStream_t)s));
+#ifndef STORM_HOST_SIM
+    STORM_HIP(hipStreamSynchronize((hipStream_t)s));         // (the host image dies with this call)
+#endif
+    if (bn == 0) bn = nt * storm::cdiv(a[0].outC, 256) >= 512 ? 256 : 128;
+    return storm::launch_conv_pipe_group(reinterpret_cast<const storm::pipe::PipeParams*>(blob), reinterpret_cast<const storm::pipe::GroupTile*>(static_cast<char*>(blob) + tab), nt, a[0].outC, bn,
+                                  a[0].dtype, (hipStream_t)s);
 }
 
 extern "C" int storm_conv(const storm_conv_args* ap, storm_stream_t s) {

@@ -198,6 +198,10 @@ struct PipeParams {
     float* gn_part;
     unsigned long long* trace;        // profiling build (-DSTORM_PROFILING) only
 };
+// Grouped launch (conv_pipe.hip, GROUP instantiation): ONE launch over the pixel tiles of several problems - the same layer (weights, K loop)
+// on activation tensors of different batch sizes / widths in different buffers: the ragged micro-batches of a stream (BASELINE.json configs[4]).
+// A problem = one PipeParams in a device table; a pixel tile = one entry of a device list built on the host.
+struct GroupTile { unsigned int problem, b, yx, tile; };   // yx = ty0 | tx0 << 16; tile = index inside its problem (GroupNorm partials)
 }  // namespace pipe
 
 // defined in conv_pipe.hip: software-pipelined 3x3 kernel (bf16 / fp16 operands), 256 output channels per workgroup
@@ -210,6 +214,11 @@ int launch_conv_pipe_half(const storm_conv_args& a, hipStream_t st);      // 128
 int conv_splitk_slices(const storm_conv_args& a);
 long long conv_splitk_bytes(const storm_conv_args& a, int slices);
 int launch_conv_pipe_splitk(const storm_conv_args& a, int slices, hipStream_t st);
+// grouped launch of P problems that run the SAME layer (conv_pipe_supports each; same weights / channels / taps, own tensors, B, W):
+// conv_pipe_group_prepare fills the host images of the parameter table [P] and the tile list (no device work) and returns the tile
+// count (or -1: not groupable); launch_conv_pipe_group runs them from their DEVICE copies.  bn = 256 or 128 couts per workgroup.
+long long conv_pipe_group_prepare(const storm_conv_args* a, int P, pipe::PipeParams* table, pipe::GroupTile* tiles, long long max_tiles);
+int launch_conv_pipe_group(const pipe::PipeParams* dev_table, const pipe::GroupTile* dev_tiles, long long ntiles, int outC, int bn, int dtype, hipStream_t st);
 const char* conv_pipe_kernel_name(int dtype, bool half_tile);
 // defined in conv_pipe128.hip: the same pipeline for layers with <= 128 output channels (128 couts x 512 pixels per workgroup)
 bool conv_pipe128_supports(const storm_conv_args& a);

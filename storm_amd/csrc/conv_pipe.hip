@@ -111,9 +111,13 @@ using namespace pipe;
 // SPLIT: the workgroup id carries a K slice as well - (pixel tile, cout tile, slice); a workgroup walks only its slice's chunk
 // descriptors (the nine-tap chunks in `kslices` contiguous ranges, the one-tap chunks with the last range) and stores its raw fp32
 // accumulators as slab `slice` of the output (the host points a.out at the slabs: fp32, no bias / skip / statistics).
-template <typename T, int BN, int TH, int ABL, bool SPLIT>
+// GROUP: ONE launch over the pixel tiles of several problems (conv_params.h: GroupTile) - the parameter block of a tile's problem is read
+// from a device table instead of the kernarg segment, its (problem, image, row, column) from a host-built list; everything else - chunk
+// descriptors, phases, epilogue - is the code of the plain instantiation, so a tile's output is the bits its own launch would write.
+template <typename T, int BN, int TH, int ABL, bool SPLIT, bool GROUP = false>
 __device__ __forceinline__ void conv_pipe_body(const PipeParams& a, const int n_ct, const int tiles_per_xcd,
-                                               const int ntiles, const int tiles_x, const int tiles_per_img, const int total_vblocks) {
+                                               const int ntiles, const int tiles_x, const int tiles_per_img, const int total_vblocks,
+                                               const PipeParams* gtab = nullptr, const GroupTile* glist = nullptr) {
     typedef PCfg<BN, TH> Cfg;
     constexpr bool TRACE = (ABL & 64) != 0;
     constexpr int WM = Cfg::WM, WN = Cfg::WN, WAVES_M = Cfg::WAVES_M, WAVES_N = Cfg::WAVES_N, NWD = Cfg::NWD;
@@ -124,7 +128,9 @@ __device__ __forceinline__ void conv_pipe_body(const PipeParams& a, const int n_
     extern __shared__ __attribute__((aligned(16))) char smem[];
     // The parameter block is read through the kernarg segment pointer, re-laundered at every tile and before every epilogue:
     // otherwise every scalar load of the block is hoisted out of the tile loop and the live SGPRs spill.
-    PipeArgPtr ap = pipe_args(a);
+    PipeArgPtr ap = GROUP ? const_table(gtab) : pipe_args(a);
+    const PipeArgPtr gtab4 = GROUP ? const_table(gtab) : PipeArgPtr();
+    const typename KArg<GroupTile>::Ptr glist4 = GROUP ? const_table(glist) : typename KArg<GroupTile>::Ptr();
 #define STORM_RELAUNDER() relaunder(ap)
 
     // Persistent workgroups: at most one per CU, each walking the virtual block ids blockIdx.x, + gridDim.x, ... (gridDim.x
@@ -136,13 +142,21 @@ __device__ __forceinline__ void conv_pipe_body(const PipeParams& a, const int n_
     int tile, b, ty0, tx0, cout0;                           // the tile whose loads are being ISSUED (= computed, until the hand-over)
     int nchunks = pin(ap->nchunks), n9 = pin(ap->nchunks9); // chunks of this workgroup's K loop (SPLIT: of its slice, from descriptor c0 on)
     int c0 = 0, eb_off = 0;
+    int imgH = 0, imgW = 0;                                 // (GROUP: of the problem whose tile is being issued; else set once below)
     auto decode = [&](int v) {
         const BlockMap bm = block_map(v, n_ct, tiles_per_xcd);
+        if constexpr (GROUP) {                              // the tile's problem and place from the host-built list (four scalar loads)
+            const unsigned int gp = glist4[bm.tile].problem, gb = glist4[bm.tile].b, gyx = glist4[bm.tile].yx, gt = glist4[bm.tile].tile;
+            ap = gtab4 + gp;
+            tile = (int)gt; b = (int)gb; ty0 = (int)(gyx & 0xffffu); tx0 = (int)(gyx >> 16);
+            imgH = ap->H; imgW = ap->W;
+        } else {
         tile = bm.tile;
         b = bm.tile / tiles_per_img;
         const int trem = bm.tile - b * tiles_per_img;
         ty0 = (trem / tiles_x) * TH;
         tx0 = (trem % tiles_x) * TILE_W;
+        }
         int ct = bm.ct;
         if constexpr (SPLIT) {
             const int nct = ap->split_nct, S = ap->kslices, n9all = ap->nchunks9;
@@ -156,7 +170,7 @@ __device__ __forceinline__ void conv_pipe_body(const PipeParams& a, const int n_
         cout0 = ct * BN;
     };
     decode(vb);
-    const int imgH = pin(ap->H), imgW = pin(ap->W);         // (two SGPRs for the whole kernel: read in the pipelined loop)
+    if constexpr (!GROUP) { imgH = pin(ap->H); imgW = pin(ap->W); }   // (two SGPRs for the whole kernel: read in the pipelined loop)
 
     const int tid = threadIdx.x;
     int lane = tid & 63;                                    // re-laundered at every chunk (see relaunder())
@@ -543,6 +557,8 @@ __device__ __forceinline__ void conv_pipe_body(const PipeParams& a, const int n_
         raw_barrier();                                      // ... and every wave is done reading: all of LDS is free
         if (first) stamp(501);
         const int e_tile = tile, e_b = b + eb_off, e_ty0 = ty0, e_tx0 = tx0, e_cout0 = cout0;
+        const int e_H = imgH, e_W = imgW;                   // (GROUP: the next tile may belong to another problem)
+        PipeArgPtr ap_e = ap;
         STORM_RELAUNDER();
         int nvb = vb + gridDim.x;
         while (nvb < total_vblocks && block_map(nvb, n_ct, tiles_per_xcd).tile >= ntiles) nvb += gridDim.x;
@@ -578,11 +594,12 @@ __device__ __forceinline__ void conv_pipe_body(const PipeParams& a, const int n_
         char* const stage = smem + (wave < 5 ? PATCH_BYTES + wave * WSTAGE : Cfg::OFF_TAIL + (wave - 5) * WSTAGE);
         const epi::TileAt et = {e_tile, e_b, e_ty0, e_tx0, e_cout0};
         float gsum[8], gsq[8];
-        epi::store_tile<T, WM, WN, (ABL & (2048 | 4096 | 8192))>(acc, stage, ap, et, wm, wn, lane, imgH, imgW, BN, TH, gsum, gsq);
+        if constexpr (GROUP) relaunder(ap_e); else ap_e = ap;
+        epi::store_tile<T, WM, WN, (ABL & (2048 | 4096 | 8192))>(acc, stage, ap_e, et, wm, wn, lane, e_H, e_W, BN, TH, gsum, gsq);
         if (first) stamp(502);
-        if (ap->gn_part != nullptr)
-            epi::write_stats<WM, WN, WAVES_N, BN, TH>(gsum, gsq, reinterpret_cast<float*>(smem + Cfg::OFF_TAIL + 3 * WSTAGE), ap, et, wm, wn, lane, tid,
-                                                      imgH, tiles_x, tiles_per_img);
+        if (ap_e->gn_part != nullptr)
+            epi::write_stats<WM, WN, WAVES_N, BN, TH>(gsum, gsq, reinterpret_cast<float*>(smem + Cfg::OFF_TAIL + 3 * WSTAGE), ap_e, et, wm, wn, lane, tid,
+                                                      e_H, tiles_x, tiles_per_img);
         if (!has_next) break;
         first = false;
         __syncthreads();                                    // the statistics scratch / staging of this tile is free again
@@ -604,6 +621,12 @@ __global__ __launch_bounds__(pipe::THREADS, 2)
 void conv_pipe_splitk_kernel(const PipeParams a, const int n_ct, const int tiles_per_xcd,
                              const int ntiles, const int tiles_x, const int tiles_per_img, const int total_vblocks) {
     conv_pipe_body<T, BN, TH, 0, true>(a, n_ct, tiles_per_xcd, ntiles, tiles_x, tiles_per_img, total_vblocks);
+}
+
+template <typename T, int BN, int TH>
+__global__ __launch_bounds__(pipe::THREADS, 2)
+void conv_pipe_group_kernel(const PipeParams* gtab, const GroupTile* glist, const int n_ct, const int tiles_per_xcd, const int ntiles, const int total_vblocks) {
+    conv_pipe_body<T, BN, TH, 0, false, true>(*gtab, n_ct, tiles_per_xcd, ntiles, 1, 1, total_vblocks, gtab, glist);
 }
 
 // ---- host side ---------------------------------------------------------------------------------------------------
@@ -728,6 +751,61 @@ int launch_conv_pipe_half(const storm_conv_args& a, hipStream_t st) {
     if (switches().conv_ablate == 64) return launch_pipe<bf16_t, 128, 8, 64>(a, st);
 #endif
     return launch_pipe<bf16_t, 128, 8, 0>(a, st);
+}
+
+// ---- grouped launch (ragged micro-batches of one stream: BASELINE.json configs[4]) ---------------------------------------------
+// The micro-batches of a ragged stream run the same network on 1 - 3 rows each: its deep levels are a few pixel tiles per launch, i.e.
+// launches that last as long as one workgroup's chain of phases with most of the chip idle (the small-call regime).  Every op of the
+// path is per image, so P micro-batches can share ONE launch of a layer: the tiles of all problems in one persistent walk, the
+// problem's parameter block looked up per tile.  A tile computes exactly what it computes in its own launch (same chunk order).
+long long conv_pipe_group_prepare(const storm_conv_args* a, int P, PipeParams* table, GroupTile* tiles, long long max_tiles) {
+    if (P < 1) return -1;
+    long long n = 0;
+    for (int g = 0; g < P; ++g) {
+        if (!build_pipe_params(a[g], table[g], KC)) return -1;
+        // one layer: same K loop and weights in every problem (the descriptors differ in tensor addresses and extents only)
+        if (a[g].outC != a[0].outC || a[g].Cout != a[0].Cout || a[g].dtype != a[0].dtype || table[g].nchunks != table[0].nchunks ||
+            table[g].nchunks9 != table[0].nchunks9 || a[g].out_f32 != a[0].out_f32 || a[g].H >= 65536 || a[g].W >= 65536) return -1;
+        for (int r = 0; r < 4; ++r) if (table[g].wrun[r].w != table[0].wrun[r].w) return -1;
+        const int tiles_x = cdiv(a[g].W, TILE_W), tiles_y = cdiv(a[g].H, 8);
+        for (int b = 0; b < a[g].B; ++b)
+            for (int ty = 0; ty < tiles_y; ++ty)
+                for (int tx = 0; tx < tiles_x; ++tx) {
+                    if (n >= max_tiles) return -1;
+                    GroupTile& t = tiles[n++];
+                    t.problem = (unsigned)g; t.b = (unsigned)b;
+                    t.yx = (unsigned)(ty * 8) | ((unsigned)(tx * TILE_W) << 16);
+                    t.tile = (unsigned)((b * tiles_y + ty) * tiles_x + tx);
+                }
+    }
+    return n;
+}
+
+template <typename T, int BN>
+static int launch_group(const PipeParams* dev_table, const GroupTile* dev_tiles, long long ntiles, int outC, hipStream_t st) {
+    typedef PCfg<BN, 8> Cfg;
+    auto kern = conv_pipe_group_kernel<T, BN, 8>;
+    static bool attr_set = false;
+    if (!attr_set) {
+        STORM_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, Cfg::LDS_BYTES));
+        attr_set = true;
+    }
+    const int n_ct = cdiv(outC, BN);
+    const int tiles_per_xcd = cdiv(ntiles, 8);
+    const long long vblocks = 8LL * tiles_per_xcd * n_ct;
+    STORM_CHECK(vblocks > 0 && vblocks < (1LL << 31), "storm_conv (group): grid %lld out of range", vblocks);
+    const long long resident = (device_cus() + 7) / 8 * 8;
+    const long long grid = vblocks < resident ? vblocks : resident;
+    hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(THREADS), Cfg::LDS_BYTES, st, dev_table, dev_tiles, n_ct, tiles_per_xcd, (int)ntiles, (int)vblocks);
+    STORM_LAUNCH_CHECK();
+    return STORM_OK;
+}
+
+int launch_conv_pipe_group(const PipeParams* dev_table, const GroupTile* dev_tiles, long long ntiles, int outC, int bn, int dtype, hipStream_t st) {
+    STORM_CHECK(dev_table && dev_tiles && ntiles > 0 && (bn == 256 || bn == 128), "storm_conv (group): bad arguments");
+    if (dtype == STORM_F16) return bn == 256 ? launch_group<half_t, 256>(dev_table, dev_tiles, ntiles, outC, st) : launch_group<half_t, 128>(dev_table, dev_tiles, ntiles, outC, st);
+    STORM_CHECK(dtype == STORM_BF16, "storm_conv (group): 16-bit operands only");
+    return bn == 256 ? launch_group<bf16_t, 256>(dev_table, dev_tiles, ntiles, outC, st) : launch_group<bf16_t, 128>(dev_table, dev_tiles, ntiles, outC, st);
 }
 
 // ---- split-K (few-tile layers) ---------------------------------------------------------------------------------------------

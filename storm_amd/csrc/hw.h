@@ -65,6 +65,8 @@ __device__ __forceinline__ uint32_t mad24(uint32_t a, uint32_t b, uint32_t c) { 
 template <typename P> struct KArg { typedef const P __attribute__((address_space(4)))* Ptr; };
 template <typename P> __device__ __forceinline__ typename KArg<P>::Ptr kernarg_of(const P&) { return (typename KArg<P>::Ptr)__builtin_amdgcn_kernarg_segment_ptr(); }
 template <typename Q> __device__ __forceinline__ void relaunder(Q& p) { asm volatile("" : "+s"(p)); }     // (re-opaque: its scalar loads stay inside the loop)
+// a read-only table in device memory viewed the same way (grouped launches: one parameter block per problem): scalar loads, no copies
+template <typename P> __device__ __forceinline__ typename KArg<P>::Ptr const_table(const P* p) { return (typename KArg<P>::Ptr)(unsigned long long)p; }
 // a global pointer whose origin the compiler cannot see (keeps the stores global_store instead of flat_store)
 __device__ __forceinline__ char* as_global(unsigned long long u) { asm volatile("" : "+s"(u)); typedef __attribute__((address_space(1))) char G; return (char*)(G*)u; }
 __device__ __forceinline__ unsigned long long hw_memtime() { return __builtin_amdgcn_s_memtime(); }
@@ -134,6 +136,7 @@ __device__ __forceinline__ uint32_t mad24(uint32_t a, uint32_t b, uint32_t c) { 
 template <typename P> struct KArg { typedef const P* Ptr; };
 template <typename P> __device__ __forceinline__ typename KArg<P>::Ptr kernarg_of(const P& a) { return &a; }
 template <typename Q> __device__ __forceinline__ void relaunder(Q&) {}
+template <typename P> __device__ __forceinline__ typename KArg<P>::Ptr const_table(const P* p) { return p; }
 __device__ __forceinline__ char* as_global(unsigned long long u) { return reinterpret_cast<char*>(u); }
 __device__ __forceinline__ unsigned long long hw_memtime() { return 0ull; }
 __device__ __forceinline__ unsigned long long hw_ids() { return 0ull; }

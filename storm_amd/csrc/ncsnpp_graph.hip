@@ -554,6 +554,22 @@ struct storm_ncsnpp {
     unsigned long long gtick = 0;
     std::atomic<long long> graph_launches{0};   // hipGraphLaunch calls so far (storm_ncsnpp_graph_launches: did the replay really run?)
     static constexpr size_t MAX_GRAPH_WS = 4;   // workspaces (addresses) with instantiated graphs per program
+    // grouped evaluation (storm_ncsnpp_forward_group): per list of (B, T) the problems' programs, their workspace offsets and the grouped
+    // launches; the tables of those launches hold absolute pointers, so their device copy is tied to a workspace address and to the caller's
+    // input / output tensors - they are rebuilt and re-uploaded whenever one of those changes
+    struct GroupPlan {
+        std::vector<std::shared_ptr<Program>> progs;
+        std::vector<long long> ws_off;
+        long long blob_bytes = 0, ws_bytes = 0;
+        std::vector<GroupOp> gops;
+        char* host_blob = nullptr;              // PINNED host image of the tables: the per-call upload is a true asynchronous copy
+        std::vector<const void*> built_for;     // ws + every caller pointer the tables were built with
+        unsigned long long epoch = 0, used = 0;
+        ~GroupPlan() { if (host_blob) (void)hipHostFree(host_blob); }
+    };
+    std::map<std::vector<int>, std::shared_ptr<GroupPlan>> groups;
+    static constexpr size_t MAX_GROUPS = 16;
+    std::atomic<long long> group_launches{0};   // grouped kernel launches so far (storm_ncsnpp_group_launches: did the grouping really happen?)
 };
 
 static int to_cfg(const storm_ncsnpp_config* c, Cfg& out) {
@@ -839,3 +855,100 @@ extern "C" int storm_ncsnpp_forward(storm_ncsnpp* h, const void* const* parts, i
     if (mode == 0) return run_range(*p, 0, (int)p->ops.size(), bufs, h->dtype, negate, s);
     return forward_replay(h, *p, bufs, negate, s);
 }
+
+// ---- grouped evaluation: P micro-batches of different (B, T) in ONE call -------------------------------------------------------------------
+// BASELINE.json configs[4]: a stream of 2 - 10 s utterances micro-batched by padded frame count is 2 - 3 rows per launch - the deep levels of
+// such a call are a handful of pixel tiles.  All micro-batches run the same op sequence, so op k of every problem is launched together where
+// a grouped kernel exists (the conv_pipe family: program.hip / conv_pipe.hip), problem by problem otherwise; every row still computes
+// exactly what its own micro-batch's call computes in the kernels that serve it.
+static int get_group(storm_ncsnpp* h, int P, const int* B, const int* T, int F, std::shared_ptr<storm_ncsnpp::GroupPlan>* out) {
+    STORM_CHECK(h != nullptr && P >= 1 && B && T, "storm_ncsnpp_forward_group: bad arguments");
+    std::vector<int> key;
+    key.push_back(F); key.push_back(storm::switches().batch_invariant != 0 ? 1 : 0);
+    for (int g = 0; g < P; ++g) { key.push_back(B[g]); key.push_back(T[g]); }
+    {
+        std::lock_guard<std::mutex> lk(h->mu);
+        auto it = h->groups.find(key);
+        if (it != h->groups.end() && it->second->epoch == switch_epoch()) { it->second->used = ++h->gtick; *out = it->second; return STORM_OK; }
+        if (it != h->groups.end()) h->groups.erase(it);
+    }
+    std::shared_ptr<storm_ncsnpp::GroupPlan> gp(new storm_ncsnpp::GroupPlan());
+    gp->epoch = switch_epoch();
+    for (int g = 0; g < P; ++g) {
+        std::shared_ptr<Program> p;
+        if (int rc = get_program(h, B[g], F, T[g], &p)) return rc;
+        STORM_CHECK(gp->progs.empty() || p->ops.size() == gp->progs[0]->ops.size(), "storm_ncsnpp_forward_group: op lists of different lengths");
+        gp->progs.push_back(p);
+    }
+    std::vector<const storm_op*> ops((size_t)P);
+    for (int g = 0; g < P; ++g) ops[(size_t)g] = gp->progs[(size_t)g]->ops.data();
+    gp->blob_bytes = up(program_group_blob_bytes(ops.data(), (int)gp->progs[0]->ops.size(), P, h->dtype), ALIGN);
+    long long off = gp->blob_bytes;
+    for (int g = 0; g < P; ++g) { gp->ws_off.push_back(off); off += up(gp->progs[(size_t)g]->ws_bytes, ALIGN); }
+    gp->ws_bytes = off;
+    if (gp->blob_bytes > 0) STORM_HIP(hipHostMalloc(reinterpret_cast<void**>(&gp->host_blob), (size_t)gp->blob_bytes));
+    std::lock_guard<std::mutex> lk(h->mu);
+    if (h->groups.size() >= storm_ncsnpp::MAX_GROUPS) {
+        auto old = h->groups.begin();
+        for (auto u = h->groups.begin(); u != h->groups.end(); ++u) if (u->second->used < old->second->used) old = u;
+        h->groups.erase(old);
+    }
+    gp->used = ++h->gtick;
+    h->groups[key] = gp;
+    *out = gp;
+    return STORM_OK;
+}
+
+extern "C" long long storm_ncsnpp_group_workspace_bytes(storm_ncsnpp* h, int P, const int* B, const int* T, int F) {
+    std::shared_ptr<storm_ncsnpp::GroupPlan> gp;
+    if (get_group(h, P, B, T, F, &gp) != STORM_OK) return -1;
+    return gp->ws_bytes;
+}
+
+// parts: P * n_parts device pointers (problem-major) to complex64 [B_p][F][T_p]; t: P pointers to fp32 [B_p] (NULL entries for a
+// discriminative net); out: P pointers to complex64 [B_p][F][T_p]; ws: >= storm_ncsnpp_group_workspace_bytes of the same shape list.
+extern "C" int storm_ncsnpp_forward_group(storm_ncsnpp* h, int P, const int* B, const int* T, int F, const void* const* parts, int n_parts,
+                                          const float* const* t, void* const* out, void* ws, long long ws_bytes, int negate, storm_stream_t s) {
+    std::shared_ptr<storm_ncsnpp::GroupPlan> gp;
+    if (int rc = get_group(h, P, B, T, F, &gp)) return rc;
+    STORM_CHECK(parts && out && ws, "storm_ncsnpp_forward_group: null pointer");
+    STORM_CHECK(n_parts == h->cfg.total() / 2, "storm_ncsnpp_forward_group: %d complex input channels given, the network takes %d", n_parts, h->cfg.total() / 2);
+    STORM_CHECK(ws_bytes >= gp->ws_bytes, "storm_ncsnpp_forward_group: workspace %lld < %lld bytes", ws_bytes, gp->ws_bytes);
+    STORM_CHECK(!h->cfg.conditional() || t != nullptr, "storm_ncsnpp_forward_group: a score network needs t");
+    std::vector<void*> bufs((size_t)P * N_BUFS, nullptr);
+    std::vector<void* const*> bufp((size_t)P);
+    std::vector<const storm_op*> ops((size_t)P);
+    std::vector<const void*> sig;
+    sig.push_back(ws);
+    for (int g = 0; g < P; ++g) {
+        void** b = bufs.data() + (size_t)g * N_BUFS;
+        b[BUF_WS] = static_cast<char*>(ws) + gp->ws_off[(size_t)g]; b[BUF_PARAMS] = h->arena;
+        for (int j = 0; j < n_parts; ++j) {
+            STORM_CHECK(parts[g * n_parts + j] != nullptr, "storm_ncsnpp_forward_group: input %d of problem %d is NULL", j, g);
+            b[BUF_IN0 + j] = const_cast<void*>(parts[g * n_parts + j]);
+            sig.push_back(parts[g * n_parts + j]);
+        }
+        b[BUF_T] = t ? const_cast<float*>(t[g]) : nullptr; b[BUF_OUT] = out[g];
+        sig.push_back(b[BUF_T]); sig.push_back(out[g]);
+        bufp[(size_t)g] = b;
+        ops[(size_t)g] = gp->progs[(size_t)g]->ops.data();
+    }
+    const int n_ops = (int)gp->progs[0]->ops.size();
+    if (gp->blob_bytes > 0) {
+        std::lock_guard<std::mutex> lk(h->mu);               // (one builder; the upload is ordered on the caller's stream before the launches below)
+        if (gp->built_for != sig) {
+            gp->gops.assign((size_t)n_ops, GroupOp());
+            const int n = program_group_build(ops.data(), n_ops, bufp.data(), N_BUFS, P, h->dtype, gp->host_blob, gp->blob_bytes, gp->gops.data(), n_ops);
+            if (n < 0) return n;
+            gp->gops.resize((size_t)n);
+            gp->built_for = sig;
+        }
+        // the tables travel with every call: 14 problems x 32 layers are ~1.5 MB, one asynchronous copy ahead of the evaluation's ~100 launches
+        // (a cached device copy would be wrong as soon as two callers alternate workspaces or tensors on one handle)
+        if (!gp->gops.empty()) STORM_HIP(hipMemcpyAsync(ws, gp->host_blob, (size_t)gp->blob_bytes, hipMemcpyHostToDevice, (hipStream_t)s));
+    }
+    h->group_launches.fetch_add((long long)gp->gops.size(), std::memory_order_relaxed);
+    return program_run_group(ops.data(), n_ops, bufp.data(), N_BUFS, P, h->dtype, static_cast<const char*>(ws), gp->gops.data(), (int)gp->gops.size(), negate, s);
+}
+
+extern "C" long long storm_ncsnpp_group_launches(storm_ncsnpp* h) { return h ? h->group_launches.load(std::memory_order_relaxed) : -1; }

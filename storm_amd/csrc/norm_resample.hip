@@ -76,15 +76,15 @@ __global__ void gn_stats_kernel(const T* __restrict__ xa, int Ca, const T* __res
 }
 
 // Finalise fused statistics: sum the per-tile fp32 partials of a conv epilogue into [B][G][2] fp64.
-__global__ __launch_bounds__(256)
-void gn_finalize_kernel(const float* __restrict__ pa, int Ca, int tiles_a, const float* __restrict__ pb,
-                        int Cb, int tiles_b, int G, double* __restrict__ stats, long long count,
-                        const float* __restrict__ gamma, const float* __restrict__ beta, float eps,
-                        float* __restrict__ ss) {
+__device__ __forceinline__
+void gn_finalize_body(const float* __restrict__ pa, int Ca, int tiles_a, const float* __restrict__ pb,
+                      int Cb, int tiles_b, int G, double* __restrict__ stats, long long count,
+                      const float* __restrict__ gamma, const float* __restrict__ beta, float eps,
+                      float* __restrict__ ss, const int g, const int b) {
     // one workgroup (4 waves) per (group, batch item): the group's gs channels of a tile are contiguous (gs float2), so a
     // thread walks (tile, channel) pairs with the channel fastest; fp64 partial sums, fixed reduction order (deterministic)
     __shared__ double red[2][4];
-    const int g = blockIdx.x, b = blockIdx.y, tid = threadIdx.x;
+    const int tid = threadIdx.x;
     const int C = Ca + Cb, gs = C / G;
     double s0 = 0.0, s1 = 0.0;
     const int c_lo = g * gs, c_hi = c_lo + gs;
@@ -145,6 +145,22 @@ void gn_finalize_kernel(const float* __restrict__ pa, int Ca, int tiles_a, const
             }
         }
     }
+}
+
+__global__ __launch_bounds__(256)
+void gn_finalize_kernel(const float* __restrict__ pa, int Ca, int tiles_a, const float* __restrict__ pb,
+                        int Cb, int tiles_b, int G, double* __restrict__ stats, long long count,
+                        const float* __restrict__ gamma, const float* __restrict__ beta, float eps,
+                        float* __restrict__ ss) {
+    gn_finalize_body(pa, Ca, tiles_a, pb, Cb, tiles_b, G, stats, count, gamma, beta, eps, ss, blockIdx.x, blockIdx.y);
+}
+// The same for the items of SEVERAL problems in one launch (grouped evaluation of a ragged stream's micro-batches, common.h): item =
+// (problem, batch item) from a host-built list, the problem's arguments from a device table.  An item's sums are the sums of its own launch.
+__global__ __launch_bounds__(256)
+void gn_finalize_group_kernel(const GnFinProblem* __restrict__ tab, const GnFinItem* __restrict__ items, int G) {
+    const GnFinItem it = items[blockIdx.y];
+    const GnFinProblem& q = tab[it.problem];
+    gn_finalize_body(q.pa, q.Ca, q.tiles_a, q.pb, q.Cb, q.tiles_b, G, q.stats, q.count, q.gamma, q.beta, q.eps, q.ss, blockIdx.x, it.b);
 }
 
 // FIR taps: down: k = [1,3,3,1]/8 per axis over input 2o-1..2o+2; up: out[2i+a] = 3/4 x[i] + 1/4 x[i -/+ 1].
@@ -924,6 +940,13 @@ extern "C" int storm_gn_finalize(const float* part_a, int Ca, int tiles_a, const
     STORM_CHECK((Cb == 0) == (part_b == nullptr), "storm_gn_finalize: part_b / Cb mismatch");
     hipLaunchKernelGGL(gn_finalize_kernel, dim3(groups, B), dim3(256), 0, (hipStream_t)s, part_a, Ca, tiles_a, part_b, Cb,
                        tiles_b, groups, stats, 0LL, (const float*)nullptr, (const float*)nullptr, 0.f, (float*)nullptr);
+    STORM_LAUNCH_CHECK();
+    return STORM_OK;
+}
+
+int storm::launch_gn_finalize_group(const GnFinProblem* dev_tab, const void* dev_items, int n_items, int groups, hipStream_t st) {
+    STORM_CHECK(dev_tab && dev_items && n_items > 0 && n_items < 65536 && groups > 0, "storm_gn_finalize (group): bad arguments");
+    hipLaunchKernelGGL(gn_finalize_group_kernel, dim3(groups, n_items), dim3(256), 0, st, dev_tab, static_cast<const GnFinItem*>(dev_items), groups);
     STORM_LAUNCH_CHECK();
     return STORM_OK;
 }

@@ -2,7 +2,9 @@
 // C-ABI call, so the ~300 kernel launches of a score evaluation cost no Python dispatch.
 // Field conventions are mirrored by storm_amd/backbones/plan.py (class Op).
 #include <cstring>
+#include <vector>
 #include "common.h"
+#include "conv_params.h"
 
 using namespace storm;
 
@@ -119,6 +121,136 @@ static int run_ops(const storm_op* ops, int n_ops, void* const* bufs, int n_bufs
         if (rc != STORM_OK) return rc;
     }
     if (ev) STORM_HIP(hipEventRecord(ev[n_ops], st));
+    return STORM_OK;
+}
+
+
+// ---- grouped evaluation (common.h) ---------------------------------------------------------------------------------------------------------
+namespace {
+// op k of the P lists groups when it is the same 16-bit 3x3 convolution of the conv_pipe family in every problem
+bool group_candidate(const storm_op* const* ops, int k, int P, int dtype) {
+    if (dtype != STORM_BF16 && dtype != STORM_F16) return false;
+    if (switches().conv_variant >= 0) return false;          // a forced kernel family (tests, A/B) is honoured problem by problem
+    for (int g = 0; g < P; ++g) {
+        const storm_op& o = ops[g][k];
+        if (o.code != STORM_OP_CONV) return false;
+        if ((int)o.i[4] <= 128 || (int)o.i[7] != 0 || (int)o.i[8 + 4] != 9) return false;      // outC, out_f32, taps of segment 0
+        if (o.i[4] != ops[0][k].i[4] || o.i[5] != ops[0][k].i[5] || o.i[0] != ops[0][k].i[0]) return false;
+    }
+    return true;
+}
+long long op_tiles(const storm_op& o) { return (long long)o.i[1] * cdiv(o.i[2], 8) * cdiv(o.i[3], 32); }   // B x 8-row x 32-pixel tiles
+long long align256(long long v) { return (v + 255) / 256 * 256; }
+}  // namespace
+
+// the GroupNorm finalizes (45 per evaluation, ~6 us each whatever the problem's size): same group count in every problem
+static bool fin_candidate(const storm_op* const* ops, int k, int P) {
+    for (int g = 0; g < P; ++g) {
+        const storm_op& o = ops[g][k];
+        if (o.code != STORM_OP_GN_FINALIZE || o.i[5] != ops[0][k].i[5] || o.i[0] + o.i[2] != ops[0][k].i[0] + ops[0][k].i[2]) return false;
+    }
+    return true;
+}
+
+long long storm::program_group_blob_bytes(const storm_op* const* ops, int n_ops, int P, int dtype) {
+    long long n = 0;
+    if (P < 2) return 0;
+    for (int k = 0; k < n_ops; ++k) {
+        if (fin_candidate(ops, k, P)) {
+            long long items = 0;
+            for (int g = 0; g < P; ++g) items += ops[g][k].i[4];
+            n += align256((long long)P * sizeof(GnFinProblem)) + align256(items * 8);
+            continue;
+        }
+        if (!group_candidate(ops, k, P, dtype)) continue;
+        long long t = 0;
+        for (int g = 0; g < P; ++g) t += op_tiles(ops[g][k]);
+        n += align256((long long)P * sizeof(pipe::PipeParams)) + align256(t * (long long)sizeof(pipe::GroupTile));
+    }
+    return n;
+}
+
+int storm::program_group_build(const storm_op* const* ops, int n_ops, void* const* const* bufs, int n_bufs, int P, int dtype, char* host_blob,
+                               long long blob_bytes, GroupOp* gops, int max_gops) {
+    int n = 0;
+    long long off = 0;
+    std::vector<storm_conv_args> args((size_t)P);
+    for (int k = 0; k < n_ops; ++k) {
+        if (fin_candidate(ops, k, P)) {
+            long long items = 0;
+            for (int g = 0; g < P; ++g) items += ops[g][k].i[4];
+            const long long tab = align256((long long)P * sizeof(GnFinProblem)), til = align256(items * 8);
+            STORM_CHECK(off + tab + til <= blob_bytes && n < max_gops && items < 65536, "storm_program_group: table blob too small");
+            GnFinProblem* t = reinterpret_cast<GnFinProblem*>(host_blob + off);
+            int* it = reinterpret_cast<int*>(host_blob + off + tab);
+            long long ni = 0;
+            for (int g = 0; g < P; ++g) {
+                const storm_op& o = ops[g][k];
+                bool ok = true;
+                void* p[STORM_OP_NPTR];
+                for (int j = 0; j < STORM_OP_NPTR; ++j) p[j] = resolve(o.p[j], bufs[g], n_bufs, ok);
+                STORM_CHECK(ok, "storm_program_group: op %d of problem %d references a missing buffer", k, g);
+                GnFinProblem& q = t[g];
+                memset(&q, 0, sizeof(q));
+                q.pa = (const float*)p[0]; q.pb = (const float*)p[1]; q.stats = (double*)p[2]; q.gamma = (const float*)p[3]; q.beta = (const float*)p[4];
+                q.ss = (float*)p[5]; q.count = p[5] != nullptr ? (long long)o.i[6] : 0; q.Ca = (int)o.i[0]; q.tiles_a = (int)o.i[1]; q.Cb = (int)o.i[2];
+                q.tiles_b = (int)o.i[3]; q.eps = p[5] != nullptr ? o.f[0] : 0.f;
+                for (int b = 0; b < (int)o.i[4]; ++b) { it[2 * ni] = g; it[2 * ni + 1] = b; ++ni; }
+            }
+            GroupOp& go = gops[n++];
+            go.k = k; go.kind = 1; go.outC = (int)ops[0][k].i[5]; go.bn = 0; go.table_off = off; go.tiles_off = off + tab; go.ntiles = ni;
+            off += tab + til;
+            continue;
+        }
+        if (!group_candidate(ops, k, P, dtype)) continue;
+        long long t = 0;
+        for (int g = 0; g < P; ++g) {
+            bool ok = true;
+            void* p[STORM_OP_NPTR];
+            for (int j = 0; j < STORM_OP_NPTR; ++j) p[j] = resolve(ops[g][k].p[j], bufs[g], n_bufs, ok);
+            STORM_CHECK(ok, "storm_program_group: op %d of problem %d references a missing buffer", k, g);
+            conv_args_of(ops[g][k], p, dtype, args[(size_t)g]);
+            args[(size_t)g].splitk_ws = nullptr; args[(size_t)g].splitk_ws_bytes = 0;      // (a grouped launch never splits K)
+            t += op_tiles(ops[g][k]);
+        }
+        const long long tab = align256((long long)P * sizeof(pipe::PipeParams)), til = align256(t * (long long)sizeof(pipe::GroupTile));
+        STORM_CHECK(off + tab + til <= blob_bytes && n < max_gops, "storm_program_group: table blob too small");
+        const long long got = conv_pipe_group_prepare(args.data(), P, reinterpret_cast<pipe::PipeParams*>(host_blob + off),
+                                                      reinterpret_cast<pipe::GroupTile*>(host_blob + off + tab), t);
+        if (got != t) continue;                              // outside the pipelined kernel's coverage: runs problem by problem
+        GroupOp& go = gops[n++];
+        go.k = k; go.outC = args[0].outC; go.table_off = off; go.tiles_off = off + tab; go.ntiles = t;
+        go.bn = t * cdiv(args[0].outC, 256) >= 512 ? 256 : 128;   // the ladder's rule for the pipelined kernel's two tiles, on the GROUP's tile count
+        go.kind = 0;
+        off += tab + til;
+    }
+    return n;
+}
+
+int storm::program_run_group(const storm_op* const* ops, int n_ops, void* const* const* bufs, int n_bufs, int P, int dtype, const char* dev_blob,
+                             const GroupOp* gops, int n_gops, int negate, storm_stream_t s) {
+    int gi = 0;
+    for (int k = 0; k < n_ops; ++k) {
+        if (gi < n_gops && gops[gi].k == k) {
+            const GroupOp& go = gops[gi++];
+            if (go.kind == 1) {
+                if (int rc = launch_gn_finalize_group(reinterpret_cast<const GnFinProblem*>(dev_blob + go.table_off), dev_blob + go.tiles_off, (int)go.ntiles, go.outC,
+                                                      (hipStream_t)s)) return rc;
+                continue;
+            }
+            if (int rc = launch_conv_pipe_group(reinterpret_cast<const pipe::PipeParams*>(dev_blob + go.table_off),
+                                                reinterpret_cast<const pipe::GroupTile*>(dev_blob + go.tiles_off), go.ntiles, go.outC, go.bn, dtype,
+                                                (hipStream_t)s)) return rc;
+            continue;
+        }
+        for (int g = 0; g < P; ++g) {
+            if (k == n_ops - 1 && ops[g][k].code == STORM_OP_OUTPUT_HEAD) {
+                storm_op head = ops[g][k];
+                head.i[4] = negate ? 1 : 0;
+                if (int rc = run_ops(&head, 1, bufs[g], n_bufs, dtype, s, nullptr)) return rc;
+            } else if (int rc = run_ops(ops[g] + k, 1, bufs[g], n_bufs, dtype, s, nullptr)) return rc;
+        }
+    }
     return STORM_OK;
 }
 

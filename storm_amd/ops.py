@@ -6,6 +6,7 @@ enqueue on torch's current HIP stream; all compute happens in libstorm_hip.
 """
 import ctypes as C
 import math
+import threading
 
 import torch
 
@@ -107,6 +108,29 @@ def conv(segs, Cout, gn_partials=False, **kw):
         a.splitk_ws, a.splitk_ws_bytes = L.ptr(ws), need
     L.check(L.lib().storm_conv(C.byref(a), L.stream()), "storm_conv")
     return (out, part) if gn_partials else out
+
+
+def conv_group(problems, Cout, gn_partials=False, bn=0):
+    """ONE launch for several problems of one 3x3 layer (storm_conv_group): problems = [(segs, kw), ...] as conv() takes them, every
+    problem with its own tensors / batch size / width and the same weights.  Returns the outputs (and GroupNorm partials) per problem."""
+    P = len(problems)
+    arr = (L.ConvArgs * P)()
+    outs, parts, keep = [], [], []
+    for p, (segs, kw) in enumerate(problems):
+        a, out = _conv_args(segs, Cout, **kw)
+        part = None
+        if gn_partials:
+            tiles = L.lib().storm_conv_tiles(C.byref(a))
+            part = torch.zeros((a.B, tiles, a.outC, 2), dtype=torch.float32, device=out.device)
+            a.gn_part = L.ptr(part)
+        arr[p] = a
+        keep.append(a)
+        outs.append(out)
+        parts.append(part)
+    need = L.lib().storm_conv_group_blob_bytes(arr, P)
+    blob = torch.empty((need,), dtype=torch.uint8, device=outs[0].device)
+    L.check(L.lib().storm_conv_group(arr, P, L.ptr(blob), need, int(bn), L.stream()), "storm_conv_group")
+    return (outs, parts) if gn_partials else outs
 
 
 def conv_kernel_name(segs, Cout, **kw):
@@ -386,7 +410,7 @@ def rk_combine(x, K, coef, h, out=None):
 def rk_scaled_sumsq(xa, xb, K, coef, h, atol, rtol, mode=None):
     """Device scalar (float64 tensor [1]) = sum over complex elements of |v|^2 / (atol + max(|xa|, |xb|) rtol)^2 with
     v = h sum coef[j] K[j] (mode None), K[0] (mode -1) or K[0] - K[1] (mode -2); nothing is synchronised here."""
-    key = str(xa.device)
+    key = (str(xa.device), threading.get_ident())       # (per host thread: grouped micro-batches interleave their launches on one stream)
     if key not in _rk_scratch:
         _rk_scratch[key] = torch.empty(2048, dtype=torch.float64, device=xa.device)
     out = torch.empty(1, dtype=torch.float64, device=xa.device)
@@ -436,7 +460,7 @@ def rk_scaled_sumsq_rows(xa, xb, K, coef, h_rows, atol, rtol, mode=None):
                                                [k[i:i + RK_MAX_ROWS] for k in K], coef,
                                                h_rows[i:i + RK_MAX_ROWS] if h_rows is not None else None, atol, rtol, mode)
                           for i in range(0, B, RK_MAX_ROWS)])
-    key = (str(xa.device), "rows")
+    key = (str(xa.device), "rows", threading.get_ident())
     need = RK_ROW_BLOCKS * B
     if key not in _rk_scratch or _rk_scratch[key].numel() < need:
         _rk_scratch[key] = torch.empty(need, dtype=torch.float64, device=xa.device)

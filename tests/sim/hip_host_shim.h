@@ -172,6 +172,8 @@ enum hipMemcpyKind { hipMemcpyHostToHost = 0, hipMemcpyHostToDevice, hipMemcpyDe
 inline hipError_t hipMemcpyAsync(void* d, const void* s, size_t n, hipMemcpyKind, hipStream_t) { memcpy(d, s, n); return hipSuccess; }
 inline hipError_t hipMalloc(void** p, size_t n) { *p = malloc(n ? n : 1); return *p ? hipSuccess : 1; }
 inline hipError_t hipFree(void* p) { free(p); return hipSuccess; }
+inline hipError_t hipHostMalloc(void** p, size_t n, unsigned = 0) { *p = malloc(n ? n : 1); return *p ? hipSuccess : 1; }
+inline hipError_t hipHostFree(void* p) { free(p); return hipSuccess; }
 inline hipError_t hipGetDevice(int* d) { *d = 0; return hipSuccess; }
 inline hipError_t hipGetDeviceProperties(hipDeviceProp_t* p, int) {
     strcpy(p->gcnArchName, "host-sim"); p->multiProcessorCount = 0; p->totalGlobalMem = 0; return hipSuccess;

@@ -352,6 +352,60 @@ def test_configs4_real_shape_vs_reference_golden(golden, switch, prec, tol_fwd, 
     assert nfe_o == int(g["ode_nfe"]) if prec == "fp32" else abs(nfe_o - int(g["ode_nfe"])) <= 6
 
 
+@pytest.mark.parametrize("sampler", ["pc", "ode"])
+def test_enhance_stream_equals_its_micro_batches_own_runs(dev, sampler):
+    """ScoreModel.enhance_stream (BASELINE.json configs[4]): three ragged micro-batches of different frame buckets run their samplers in
+    lockstep on host threads and meet in ONE grouped network call per step (storm_amd.sampling.grouped -> storm_ncsnpp_forward_group).
+    With injected noise every micro-batch must return what its own enhance_batch call returns - here bit for bit (a nf = 8 network has
+    no layer with a grouped kernel, so the grouped call runs the very kernels of the single calls) - for the PC sampler and for the ODE
+    sampler, whose micro-batches need different numbers of evaluations (the early finishers leave the rendezvous) and whose per-row step
+    control must not notice the company."""
+    from storm_amd.model import ScoreModel
+    m = ScoreModel(backbone="ncsnpp", **dict(COMMON))
+    m.dnn.load_state_dict(NR.seeded_state_dict(NR.NCSNppConfig(nf=8, input_channels=4), seed=5))
+    m.eval(no_ema=True)
+    m = m.to(dev)
+    g = torch.Generator().manual_seed(31)
+    lens = [[5003, 4500], [9000], [16100, 15000, 14100]]              # 64-, 128- and 192-frame buckets
+    if dev.type == "cpu":
+        lens = [[5003], [9000]]                                       # (the simulator walks every lane: two one-row micro-batches)
+    batches = []
+    for bl in lens:
+        y = torch.zeros(len(bl), max(bl))
+        for k, n in enumerate(bl):
+            y[k, :n] = 0.1 * torch.randn(n, generator=g)
+        batches.append((y.to(dev), bl if len(set(bl)) > 1 else None))
+    frames = [-(-(1 + max(bl) // 128) // 64) * 64 for bl in lens]
+    ndraw = 1 + 2 * 2 if sampler == "pc" else 1
+    draws = [[SR.complex_randn((len(bl), 1, 256, f), torch.Generator().manual_seed(100 * p + i)).to(dev) for i in range(ndraw)] for p, (bl, f) in enumerate(zip(lens, frames))]
+    kw = dict(N=2, corrector="ald", snr=0.5) if sampler == "pc" else dict(sampler_type="ode", rtol=0.05, atol=0.05)
+
+    def fns():
+        its = [iter(d) for d in draws]
+        return [(lambda it=it: next(it)) for it in its]
+    own, own_nfe = [], []
+    for (yb, bl), fn in zip(batches, fns()):
+        o, n = m.enhance_batch(yb, lengths=bl, noise_fn=fn, return_nfe=True, **kw)
+        own.append(o)
+        own_nfe.append(n)
+    outs, nfe = m.enhance_stream(batches, noise_fns=fns(), return_nfe=True, **kw)
+    assert m.last_nfev_stream == own_nfe and m.last_group_calls is not None
+    calls, rows = m.last_group_calls
+    assert calls == max(own_nfe) and rows == sum(n * len(bl) for n, bl in zip(own_nfe, lens))
+    if sampler == "ode":
+        assert len(set(own_nfe)) > 1, "the micro-batches were meant to need different numbers of evaluations"
+    for p in range(len(lens)):
+        assert torch.equal(outs[p], own[p]), p
+    if dev.type != "cpu":
+        seq = m.enhance_stream(batches, grouped=False, noise_fns=fns(), **kw)
+        assert all(torch.equal(a, b) for a, b in zip(seq, own)) and m.last_group_calls is None
+    # an error inside one micro-batch's sampler reaches the caller (and releases the other threads)
+    boom = fns()
+    boom[1] = lambda: (_ for _ in ()).throw(RuntimeError("boom"))
+    with pytest.raises(Exception):
+        m.enhance_stream(batches, noise_fns=boom, **kw)
+
+
 def test_no_cpu_fallback():
     """the product path refuses CPU tensors when the real library is bound"""
     from storm_amd import _lib

@@ -195,6 +195,53 @@ def test_conv_pipe_half_tile_equals_full_tile_bit_for_bit(dev, cus, switch):
 
 
 
+@pytest.mark.parametrize("cus", [0, 3])
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+def test_conv_group_equals_its_problems_own_launches_bit_for_bit(dev, dtype, cus, switch):
+    """storm_conv_group (conv_pipe.hip, GROUP instantiation): ONE launch over the pixel tiles of three problems of one layer - the ragged
+    micro-batches of a stream (BASELINE.json configs[4]): different batch sizes and widths (ragged tile rows / columns), own tensors, the
+    same weights; 2 + 1 nine-tap chunks over a concat with a fused GroupNorm operand + 2 one-tap chunks of a fused shortcut, per-row
+    temb bias, skip operand, GroupNorm partials.  Every problem's output equals its OWN storm_conv launch bit for bit with both tiles (256 /
+    128 couts per workgroup; the partials to fp32 rounding for the other tile), with and without the persistent walk (3 pretend CUs: a
+    workgroup's consecutive tiles belong to different problems)."""
+    from storm_amd import ops
+    g = torch.Generator().manual_seed(78)
+    C0, Ca, Cb, Sa, Co = 8, 104, 56, 72, 264
+    wa, wb = torch.randn(Ca, C0, 3, 3, generator=g) * 0.4, torch.randn(Cb, C0, 1, 1, generator=g) * 0.7
+    w = ops.pack_conv_weight((torch.randn(Co, Ca + Cb, 3, 3, generator=g) * 0.05).to(dev), dtype)
+    w2 = ops.pack_conv_weight((torch.randn(Co, Sa, 1, 1, generator=g) * 0.1).to(dev), dtype)
+    wa, wb = ops.pack_conv_weight(wa.to(dev), dtype), ops.pack_conv_weight(wb.to(dev), dtype)
+    bias = torch.randn(Co, generator=g).to(dev)
+    gam, bet = (1 + 0.1 * torch.randn(Ca + Cb, generator=g)).to(dev), (0.1 * torch.randn(Ca + Cb, generator=g)).to(dev)
+    problems = []
+    for B, H, W in ((2, 11, 37), (1, 11, 70), (3, 11, 5)):
+        x0d = nhwc(torch.randn(B, C0, H, W, generator=g)).to(dtype).to(dev)
+        xa, pa = ops.conv([ops.Seg(x0d, wa, 9)], Ca, gn_partials=True)
+        xb, pb = ops.conv([ops.Seg(x0d, wb, 1)], Cb, gn_partials=True)
+        _, ss = ops.gn_finalize(pa, pb, gamma=gam, beta=bet, count=H * W)
+        segs = [ops.Seg(xa, w, 9, src_b=xb, gn_ss=ss, gn_silu=True), ops.Seg(nhwc(torch.randn(B, Sa, H, W, generator=g)).to(dtype).to(dev), w2, 1)]
+        skip = nhwc(torch.randn(B, Co, H, W, generator=g)).to(dtype).to(dev)
+        problems.append((segs, dict(bias=bias, tbias=torch.randn(B, Co, generator=g).to(dev), skip=skip, scale=0.5)))
+    if cus:
+        switch("STORM_CONV_CUS", cus)
+    own = {}
+    for variant in (3, 9):
+        switch("STORM_CONV_VARIANT", variant)
+        own[variant] = [ops.conv(segs, Co, gn_partials=True, **kw) for segs, kw in problems]
+    switch("STORM_CONV_VARIANT", -1)
+    for bn, variant in ((256, 3), (128, 9)):
+        outs, parts = ops.conv_group(problems, Co, gn_partials=True, bn=bn)
+        for p in range(3):
+            assert torch.equal(outs[p], own[variant][p][0]), (bn, p)
+            assert torch.equal(outs[p], own[3][p][0])                          # (the two tiles write the same bits, test above)
+            assert torch.equal(parts[p], own[variant][p][1]), (bn, p, "partials")
+    # not one layer (another weight tensor in problem 1): refused, the caller runs them one by one
+    other = ops.pack_conv_weight((torch.randn(Co, Sa, 1, 1, generator=g) * 0.1).to(dev), dtype)
+    bad = [problems[0], ([problems[1][0][0], ops.Seg(problems[1][0][1].src_a, other, 1)], problems[1][1])]
+    with pytest.raises(Exception):
+        ops.conv_group(bad, Co)
+
+
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
 @pytest.mark.parametrize("case", ["c128_gn", "c256_gn_walk", "c128_plain", "c256_two_planes"])
 def test_conv_narrow_output_kernel(dev, dtype, case, switch):
