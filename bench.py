@@ -73,6 +73,9 @@ def parse():
     p.add_argument("--no-other-configs", action="store_true",
                    help="skip the `other_configs` object: BASELINE.json configs[3], a configs[4]-style ragged stream (PC and a shortened ODE leg) and "
                         "one utterance per call, each timed AFTER the headline region on rank 0 of a one-GPU run (never inside it, never part of `value`)")
+    p.add_argument("--no-traffic", action="store_true",
+                   help="do not re-measure `roofline.traffic` (two rocprofv3 --pmc passes, FETCH_SIZE and WRITE_SIZE, over a short run of this same command, "
+                        "about a minute): keep the figure of profiles/conv_traffic.json")
     p.add_argument("--power", action="store_true",
                    help="sample socket power / clock with rocm-smi DURING the timed steps (perturbs rank 0: off by default; the default samples an "
                         "untimed repetition of the same step instead)")
@@ -266,6 +269,41 @@ def other_configs(model, dev, sync):
                        "evaluation_tflops": 8 * 2131.0e9 * nfe / el / 1e12, "mfma_frac": 8 * 2131.0e9 * nfe / el / 1e12 / BF16_MFMA_PEAK_TFLOPS}
     del large
     return out
+
+
+def measure_traffic(timeout_s=150):
+    """HBM bytes per launch of every kernel of this bench command, measured NOW: FETCH_SIZE and WRITE_SIZE in separate rocprofv3 --pmc
+    passes (MI355X_MICROARCH.md: separate passes, KiB units, FETCH_SIZE x2 on gfx950) over a short run of the same workload (one step of
+    two reverse steps = four score evaluations of the batch).  Returns (table, note) or (None, why)."""
+    import shutil
+    import subprocess
+    import tempfile
+    if shutil.which("rocprofv3") is None:
+        return None, "rocprofv3 not on this box"
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    from pmc_traffic import per_kernel
+    tmp = tempfile.mkdtemp(prefix="storm_pmc_", dir="/tmp")
+    env = dict(os.environ, TMPDIR="/tmp")
+    got = {}
+    try:
+        for c in ("FETCH_SIZE", "WRITE_SIZE"):
+            cmd = ["rocprofv3", "--kernel-trace", "--pmc", c, "--output-format", "csv", "-d", os.path.join(tmp, c), "-o", "p", "--", sys.executable,
+                   os.path.abspath(__file__), "--steps", "1", "--warmup", "0", "--N", "2", "--no-cpu-baseline", "--no-roofline", "--no-other-configs", "--no-h2d"]
+            r = subprocess.run(cmd, cwd="/tmp", env=env, capture_output=True, text=True, timeout=timeout_s)
+            files = [os.path.join(d, f) for d, _, fs in os.walk(os.path.join(tmp, c)) for f in fs if f.endswith("counter_collection.csv")]
+            if r.returncode != 0 or not files:
+                return None, f"rocprofv3 --pmc {c} failed (rc {r.returncode})"
+            got[c] = per_kernel(files[0], c)
+    except Exception as e:  # noqa: BLE001
+        return None, f"rocprofv3 pass failed: {type(e).__name__}"
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+    table = {}
+    for name, (fetch_kib, n) in got["FETCH_SIZE"].items():
+        write_kib = got["WRITE_SIZE"].get(name, (0.0, 0))[0]
+        table[name.split("(")[0].replace("void ", "").replace(" ", "")] = {"launches": n, "hbm_bytes_per_launch": (2.0 * fetch_kib + write_kib) * 1024.0}
+    return table, "measured in this run: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes, FETCH_SIZE x2 per the gfx950 correction) over a four-evaluation " \
+                  "run of this bench command, average per launch of the kernel"
 
 
 class PowerSampler:
@@ -473,13 +511,21 @@ def main():
         by_kind = {}
         for r in rows:
             by_kind[names.get(r["code"], str(r["code"]))] = by_kind.get(names.get(r["code"], str(r["code"])), 0.0) + r["ms"]
-        traffic, tsrc = None, None
+        traffic, tsrc, live = None, None, None
         tpath = os.path.join(ROOT, "profiles", "conv_traffic.json")     # PMC passes of scripts/pmc_bench.sh, per launch
-        if os.path.exists(tpath):
-            tj = json.load(open(tpath))
+        tj = json.load(open(tpath)) if os.path.exists(tpath) else {}
+        if world == 1 and not args.no_traffic and cfg_name == "configs[1]":
+            t0 = time.perf_counter()
+            live, why = measure_traffic()
+            why += f" ({time.perf_counter() - t0:.0f} s)"
+            if live is not None:
+                traffic = live.get(kname.replace(" ", ""), {}).get("hbm_bytes_per_launch")
+                tsrc = why
+        if traffic is None and tj:
             traffic = tj.get(kname.replace("storm::", "").replace(" ", ""), {}).get("hbm_bytes_per_launch")
             tsrc = "profiles/conv_traffic.json: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes, FETCH_SIZE x2 per the " \
-                   "gfx950 correction) over this bench command, average per launch of this kernel; not re-measured in this run"
+                   "gfx950 correction) over this bench command, average per launch of this kernel; not re-measured in this run" + \
+                   (f" ({why})" if not args.no_traffic and world == 1 and cfg_name == "configs[1]" else "")
         # socket power of each kernel family running sustained (tools/power_probe.py, profiles/r04_power_probe.txt: one kernel back to back for 4 s)
         probe_w = {"conv_pipe_kernel": 1397.0, "conv_pipe128_kernel": 1328.0, "conv_igemm_kernel": 1371.0, "conv_pipe_splitk_kernel": None}
         by_kernel = {}
@@ -536,7 +582,9 @@ def main():
             hk, hv = max(hbm_rows.items(), key=lambda kv: sum(r["ms"] for r in kv[1]))
             hb, hms = sum(r["algorithmic_bytes"] for r in hv), sum(r["ms"] for r in hv)
             htraffic = None
-            if os.path.exists(tpath):
+            if live is not None:
+                htraffic = live.get(hk.replace(" ", ""), {}).get("hbm_bytes_per_launch")
+            if htraffic is None and tj:
                 tkey = "void" + hk.replace(" ", "")                       # (rocprofv3 prints template kernels with their return type)
                 htraffic = next((v.get("hbm_bytes_per_launch") for k, v in tj.items() if k.replace(" ", "") in (tkey, tkey[4:])), None)
             result["roofline_hbm"] = {
