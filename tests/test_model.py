@@ -378,7 +378,7 @@ def test_enhance_stream_equals_its_micro_batches_own_runs(dev, sampler):
     frames = [-(-(1 + max(bl) // 128) // 64) * 64 for bl in lens]
     ndraw = 1 + 2 * 2 if sampler == "pc" else 1
     draws = [[SR.complex_randn((len(bl), 1, 256, f), torch.Generator().manual_seed(100 * p + i)).to(dev) for i in range(ndraw)] for p, (bl, f) in enumerate(zip(lens, frames))]
-    kw = dict(N=2, corrector="ald", snr=0.5) if sampler == "pc" else dict(sampler_type="ode", rtol=0.05, atol=0.05) if dev.type == "cpu" else \
+    kw = dict(N=2, corrector="ald", snr=0.5) if sampler == "pc" else dict(sampler_type="ode", rtol=0.5, atol=0.5) if dev.type == "cpu" else \
         dict(sampler_type="ode", rtol=2e-3, atol=2e-3)       # (GPU: tight enough for the micro-batches to need different numbers of steps - the early finishers leave)
 
     def fns():
@@ -401,10 +401,11 @@ def test_enhance_stream_equals_its_micro_batches_own_runs(dev, sampler):
         seq = m.enhance_stream(batches, grouped=False, noise_fns=fns(), **kw)
         assert all(torch.equal(a, b) for a, b in zip(seq, own)) and m.last_group_calls is None
     # an error inside one micro-batch's sampler reaches the caller (and releases the other threads)
-    boom = fns()
-    boom[1] = lambda: (_ for _ in ()).throw(RuntimeError("boom"))
-    with pytest.raises(Exception):
-        m.enhance_stream(batches, noise_fns=boom, **kw)
+    if sampler == "pc":
+        boom = fns()
+        boom[1] = lambda: (_ for _ in ()).throw(RuntimeError("boom"))
+        with pytest.raises(Exception):
+            m.enhance_stream(batches, noise_fns=boom, **kw)
 
 
 def test_no_cpu_fallback():
