@@ -50,6 +50,8 @@ def main():
     p.add_argument("--seed", type=int, default=None, help="Philox seed of the sampler noise (default: drawn from torch's RNG, as the reference)")
     p.add_argument("--batch-invariant", action="store_true", help="every utterance's result independent - bit for bit - of what it is batched with "
                    "(storm_amd.set_batch_invariant: launch decisions per image; costs the batch-aware kernel selections)")
+    p.add_argument("--group", type=int, default=8, help="score-only mode: this many micro-batches (frame buckets of different lengths) run their samplers in lockstep "
+                   "and share the launches of the score network (ScoreModel.enhance_stream); 1 = one micro-batch after the other")
     p.add_argument("--dist-world1", action="store_true", help="with ONE rank: form the RCCL process group anyway (dry run of the sharded path on one GPU)")
     args = p.parse_args()
 
@@ -95,7 +97,26 @@ def main():
             outs = [x_hat[k, :lens[k]] for k in range(len(ids))]
         return ids, outs
 
-    for batch in D.bucket_by_frames([lengths[i] for i in mine], args.batch):
+    buckets = D.bucket_by_frames([lengths[i] for i in mine], args.batch)
+    if args.mode == "score-only" and args.group > 1 and len(buckets) > 1:
+        # a ragged set of files: micro-batches of 2 - 3 rows each - their score evaluations share launches (storm_ncsnpp_forward_group)
+        for c in range(0, len(buckets), args.group):
+            chunk, metas = [], []
+            for batch in buckets[c:c + args.group]:
+                ids = [mine[k] for k in batch]
+                lens = [lengths[i] for i in ids]
+                y = torch.zeros(len(ids), max(lens))
+                for k, i in enumerate(ids):
+                    y[k, :lens[k]] = wavs[i][0]
+                chunk.append((y, None if len(set(lens)) == 1 else lens))
+                metas.append((ids, lens))
+            outs = model.enhance_stream(chunk, corrector=args.corrector, N=args.N, corrector_steps=args.corrector_steps, snr=args.snr,
+                                        seeds=None if args.seed is None else [args.seed + ids[0] for ids, _ in metas])     # (the draws of the one-by-one path)
+            for (ids, lens), x_hat in zip(metas, outs):
+                for k, i in enumerate(ids):
+                    write_wav(os.path.join(args.enhanced_dir, os.path.basename(files[i])), x_hat[k, :lens[k]].float().reshape(-1), 16000)
+        buckets = []
+    for batch in buckets:
         ids, outs = run(batch)
         for i, x in zip(ids, outs):
             write_wav(os.path.join(args.enhanced_dir, os.path.basename(files[i])), x.float().reshape(-1), 16000)

@@ -252,13 +252,13 @@ class ScoreModel(_Base):
         x_hat = self.data_module.spec_to_wav(sample, T_orig, peak, lengths=lengths)
         return (x_hat, nfe) if return_nfe else x_hat
 
-    def enhance_stream(self, batches, grouped=True, return_nfe=False, seed=None, noise_fns=None, **kwargs):
+    def enhance_stream(self, batches, grouped=True, return_nfe=False, seed=None, seeds=None, noise_fns=None, **kwargs):
         """A stream of ragged micro-batches (BASELINE.json configs[4]) in lockstep: `batches` = [(y [b, L], lengths or None), ...] as
         storm_amd.distributed.bucket_by_frames forms them.  Every micro-batch runs enhance_batch - the same sampler, noise stream and
         (ODE) per-row step control as its own call - but the score evaluations of all micro-batches that are still running share ONE
         grouped network call per step (storm_amd.sampling.grouped, storm_ncsnpp_forward_group): the layers with a grouped kernel see
         the whole stream's pixel tiles in one launch instead of 2 - 3 rows at a time.  grouped=False: one micro-batch after the other.
-        seed: micro-batch k draws from the Philox stream seed + k (noise_fns: one injected-noise callable per micro-batch instead).
+        seed: micro-batch k draws from the Philox stream seed + k (seeds: one seed per micro-batch; noise_fns: one injected-noise callable per micro-batch instead).
         Returns the list of enhanced batches (and the mean evaluations per utterance with return_nfe); self.last_nfev_stream = the
         evaluations every micro-batch executed."""
         from .sampling.grouped import run_grouped
@@ -267,7 +267,9 @@ class ScoreModel(_Base):
         def one(k):
             yb, bl = batches[k]
             kw = dict(kwargs)
-            if seed is not None:
+            if seeds is not None:
+                kw["seed"] = seeds[k]
+            elif seed is not None:
                 kw["seed"] = seed + k
             if noise_fns is not None:
                 kw["noise_fn"] = noise_fns[k]                  # (parity runs: the draws of micro-batch k)

@@ -443,6 +443,7 @@ def test_enhancement_cli(tmp_path):
     wavs = [0.1 * torch.randn(6000, generator=g), 0.1 * torch.randn(6000, generator=g)]
     for i, w in enumerate(wavs):
         wavfile.write(os.path.join(noisy, f"u{i}.wav"), 16000, w.numpy().astype(np.float32))
+    long_wav = 0.1 * torch.randn(9100, generator=g)           # a third file in another frame bucket (second run below: the grouped path)
     # under the launcher line a multi-GPU user types, with ONE rank and --dist-world1: D.init() forms an RCCL group (device_id bound), the
     # files are sharded over its ranks and D.finish() leaves through an RCCL barrier - the sharded CLI path executed on ROCm
     env = {k: v for k, v in dict(os.environ, PYTHONPATH=root, HSA_ENABLE_IPC_MODE_LEGACY="0").items()
@@ -463,6 +464,26 @@ def test_enhancement_cli(tmp_path):
     want = m.enhance_batch(torch.stack(wavs), corrector="ald", N=2, corrector_steps=1, snr=0.5, seed=123).cpu()
     for i in range(2):          # same Philox seed -> same noise -> same wav
         assert rel_l2(got[i], want[i].float()) < 1e-4
+    # a ragged set of files: two frame buckets -> two micro-batches whose samplers run in lockstep around grouped network calls
+    # (--group, ScoreModel.enhance_stream); every file must come out as from its own bucket's enhance_batch call with that bucket's seed
+    wavfile.write(os.path.join(noisy, "u2.wav"), 16000, long_wav.numpy().astype(np.float32))
+    out2 = os.path.join(tmp_path, "enhanced2")
+    r = subprocess.run([sys.executable, os.path.join(root, "enhancement.py"), "--test_dir", noisy, "--enhanced_dir", out2, "--ckpt", path, "--mode", "score-only",
+                        "--N", "2", "--corrector", "ald", "--seed", "123", "--group", "8"], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    from storm_amd import distributed as D
+    lens3 = [6000, 6000, 9100]
+    mine = D.shard_indices(3, 0, 1, lens3)                    # (the CLI's own dealing and bucketing)
+    for bk in D.bucket_by_frames([lens3[i] for i in mine], 16):
+        batch = [mine[k] for k in bk]
+        yb = torch.zeros(len(batch), max(lens3[i] for i in batch))
+        for k, i in enumerate(batch):
+            yb[k, :lens3[i]] = (wavs + [long_wav])[i]
+        bl = [lens3[i] for i in batch]
+        wantb = m.enhance_batch(yb, corrector="ald", N=2, corrector_steps=1, snr=0.5, seed=123 + batch[0], lengths=None if len(set(bl)) == 1 else bl).cpu()
+        for k, i in enumerate(batch):
+            sr, x = wavfile.read(os.path.join(out2, f"u{i}.wav"))
+            assert x.shape == (lens3[i],) and rel_l2(torch.from_numpy(x), wantb[k, :lens3[i]]) < 1e-5, i
 
 
 def test_discriminative_and_storm_surfaces(dev, golden):
