@@ -225,7 +225,7 @@ inline int cdiv(long long a, long long b) { return (int)((a + b - 1) / b); }
 // The ragged micro-batches of a stream run the same op sequence on tensors of different (B, T).  Op k of every problem is launched together
 // where a grouped kernel exists for it (16-bit 3x3 convolutions of the conv_pipe family: one launch over all problems' pixel tiles),
 // one after the other otherwise.  The tables of the grouped launches (absolute device pointers) live in a caller-owned device blob.
-struct GroupOp { int k, outC, bn, kind; long long table_off, tiles_off, ntiles; };   // kind 0: 3x3 convolution (conv_pipe), 1: GroupNorm finalize
+struct GroupOp { int k, outC, bn, kind; long long table_off, tiles_off, ntiles; };   // kind 0: 3x3 convolution (conv_pipe), 1: GroupNorm finalize, 2: 3x3 convolution to <= 4 planes (conv_narrow; outC = input channels, bn = fused GroupNorm / SiLU flags)
 // one problem of a grouped GroupNorm finalize (norm_resample.hip): the arguments of its own storm_gn_finalize(_ss) call
 struct GnFinProblem { const float* pa; const float* pb; double* stats; const float* gamma; const float* beta; float* ss; long long count;
                       int Ca, tiles_a, Cb, tiles_b; float eps; int pad_; };

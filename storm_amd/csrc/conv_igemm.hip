@@ -890,8 +890,19 @@ extern "C" int storm_conv_group(const storm_conv_args* a, int P, void* blob, lon
     STORM_CHECK(a != nullptr && P >= 1 && blob != nullptr, "storm_conv_group: bad arguments");
     const long long need = storm_conv_group_blob_bytes(a, P);
     STORM_CHECK(blob_bytes >= need, "storm_conv_group: blob %lld < %lld bytes", blob_bytes, need);
-    const long long tab = ((long long)P * (long long)sizeof(storm::pipe::PipeParams) + 255) / 256 * 256;
     std::vector<char> host((size_t)need);
+    if (storm::conv_narrow_supports(a[0])) {                 // the output pyramid's convolutions (<= 4 planes): conv_narrow.hip's grouped form
+        const long long tabn = storm::conv_narrow_group_bytes(P);
+        storm::pipe::GroupTile* tl = reinterpret_cast<storm::pipe::GroupTile*>(host.data() + tabn);
+        const long long ntn = storm::conv_narrow_group_prepare(a, P, host.data(), tl, (need - tabn) / (long long)sizeof(storm::pipe::GroupTile));
+        if (ntn <= 0) { storm::set_error("storm_conv_group: the problems are not one layer of the narrow-output 3x3 kernel"); return STORM_ERR_UNSUPPORTED; }
+        STORM_HIP(hipMemcpyAsync(blob, host.data(), (size_t)(tabn + ntn * (long long)sizeof(storm::pipe::GroupTile)), hipMemcpyHostToDevice, (hipStream_t)s));
+#ifndef STORM_HOST_SIM
+        STORM_HIP(hipStreamSynchronize((hipStream_t)s));
+#endif
+        return storm::launch_conv_narrow_group(a[0], blob, reinterpret_cast<const storm::pipe::GroupTile*>(static_cast<char*>(blob) + tabn), ntn, (hipStream_t)s);
+    }
+    const long long tab = ((long long)P * (long long)sizeof(storm::pipe::PipeParams) + 255) / 256 * 256;
     storm::pipe::PipeParams* table = reinterpret_cast<storm::pipe::PipeParams*>(host.data());
     storm::pipe::GroupTile* tiles = reinterpret_cast<storm::pipe::GroupTile*>(host.data() + tab);
     const long long nt = storm::conv_pipe_group_prepare(a, P, table, tiles, (need - tab) / (long long)sizeof(storm::pipe::GroupTile));

@@ -39,9 +39,10 @@ __host__ __device__ inline int lds_bytes(int C) { return Z_BYTES + (C / 8) * WRO
 
 // CG = C / 64: 64-byte pieces per lane and pixel; SILU: the activation behind the fused GroupNorm affine (compile time: as a run-time
 // flag it is if-converted into a select per value)
-template <typename T, int CG, bool SILU>
-__global__ __launch_bounds__(narrow::THREADS, 1)
-void conv_narrow_kernel(const narrow::Params p) {
+// GROUP: the tiles of several problems of ONE layer (ragged micro-batches of a stream, conv_params.h: GroupTile) in one persistent walk - the
+// problem's Params come from a device table (`p` is then problem 0: the weights, bias and channel counts every problem shares)
+template <typename T, int CG, bool SILU, bool GROUP>
+__device__ __forceinline__ void conv_narrow_body(const narrow::Params& p, const narrow::Params* __restrict__ gtab, const pipe::GroupTile* __restrict__ glist, const int ntiles_all) {
     using namespace narrow;
     typedef typename Mma<T>::Frag Frag;
     constexpr int C = CG * 64, NG8 = C / 8;
@@ -71,9 +72,24 @@ void conv_narrow_kernel(const narrow::Params p) {
 
     // ---- a fragment's raw pixels: lane (n, h) = region pixel 32 f + n, channels 64 G + 32 h ... + 32 of every G --------------------
     struct Raw { uint4 q[CG][4]; int qi; bool valid; };
+    // tile -> (problem's parameters, batch item, first row, first column)
+    struct At { const Params* q; int b, ty0, tx0, key; };
+    auto locate = [&](int tile) {
+        At a;
+        if constexpr (GROUP) {
+            const pipe::GroupTile te = glist[tile];
+            a.q = gtab + te.problem; a.b = (int)te.b; a.ty0 = (int)(te.yx & 0xffffu); a.tx0 = (int)(te.yx >> 16); a.key = (int)(te.problem << 16 | te.b);
+        } else {
+            a.q = &p; a.b = tile / p.tiles_per_img;
+            const int trem = tile - a.b * p.tiles_per_img;
+            a.ty0 = (trem / p.tiles_x) * TH; a.tx0 = (trem % p.tiles_x) * TW; a.key = a.b;
+        }
+        return a;
+    };
     auto fetch = [&](int tile, int f, Raw& r) {
-        const int b = tile / p.tiles_per_img, trem = tile - b * p.tiles_per_img;
-        const int ty0 = (trem / p.tiles_x) * TH, tx0 = (trem % p.tiles_x) * TW;
+        const At at = locate(tile);
+        const Params& p = *at.q;
+        const int b = at.b, ty0 = at.ty0, tx0 = at.tx0;
         const int qi = f * 32 + n, ry = qi / RW, rx = qi - ry * RW;
         const int y = ty0 - 1 + ry, x = tx0 - 1 + rx;
         r.qi = qi;
@@ -92,26 +108,28 @@ void conv_narrow_kernel(const narrow::Params p) {
         }
     };
 
+    const int ntiles = GROUP ? ntiles_all : p.ntiles;
     int tile = blockIdx.x;
-    if (tile >= p.ntiles) return;
+    if (tile >= ntiles) return;
     Raw cur, nxt;
     nxt.qi = 0; nxt.valid = false;
     fetch(tile, wave, cur);
     int ss_b = -1;
     for (;;) {
-        const int b = tile / p.tiles_per_img, trem = tile - b * p.tiles_per_img;
-        const int ty0 = (trem / p.tiles_x) * TH, tx0 = (trem % p.tiles_x) * TW;
-        if (gn && b != ss_b) {                               // (uniform) this batch item's affine table
+        const At at = locate(tile);
+        const Params& p = *at.q;
+        const int b = at.b, ty0 = at.ty0, tx0 = at.tx0;
+        if (gn && at.key != ss_b) {                          // (uniform) this batch item's affine table
             const float4* const g = reinterpret_cast<const float4*>(p.gn_ss + (long long)b * C * 2);
             for (int i = tid; i < C * 2 / 4; i += THREADS) reinterpret_cast<float4*>(SS)[i] = g[i];
-            ss_b = b;
+            ss_b = at.key;
         }
         __syncthreads();                                     // weight image / table visible; the previous tile's gather is done with Z
         const int next_tile = tile + (int)gridDim.x;
 #pragma unroll 1
         for (int k = 0; k < FPW; ++k) {
             if (k + 1 < FPW) fetch(tile, wave + NWAVES * (k + 1), nxt);
-            else if (next_tile < p.ntiles) fetch(next_tile, wave, nxt);
+            else if (next_tile < ntiles) fetch(next_tile, wave, nxt);
             f32x16 acc0, acc1;
 #pragma unroll
             for (int r = 0; r < 16; ++r) { acc0[r] = 0.f; acc1[r] = 0.f; }
@@ -159,9 +177,20 @@ void conv_narrow_kernel(const narrow::Params p) {
                 store8(out_b + ((long long)y * p.W + x) * 8, s);
             }
         }
-        if (next_tile >= p.ntiles) break;
+        if (next_tile >= ntiles) break;
         tile = next_tile;
     }
+}
+
+template <typename T, int CG, bool SILU>
+__global__ __launch_bounds__(narrow::THREADS, 1)
+void conv_narrow_kernel(const narrow::Params p) {
+    conv_narrow_body<T, CG, SILU, false>(p, nullptr, nullptr, 0);
+}
+template <typename T, int CG, bool SILU>
+__global__ __launch_bounds__(narrow::THREADS, 1)
+void conv_narrow_group_kernel(const narrow::Params* __restrict__ gtab, const pipe::GroupTile* __restrict__ glist, const int ntiles) {
+    conv_narrow_body<T, CG, SILU, true>(gtab[0], gtab, glist, ntiles);
 }
 
 // ---- host side ---------------------------------------------------------------------------------------------------
@@ -174,6 +203,64 @@ bool conv_narrow_supports(const storm_conv_args& a) {
     return (long long)a.H * a.W * g.Ca < (1LL << 31) && a.H >= 1 && a.W >= 1;
 }
 
+static long long narrow_params(const storm_conv_args& a, narrow::Params& p) {
+    memset(&p, 0, sizeof(p));
+    const storm_conv_seg& g = a.seg[0];
+    p.src = g.src_a; p.w = g.w; p.out = a.out; p.bias = a.bias; p.gn_ss = g.gn_ss; p.silu = g.gn_silu;
+    p.src_bstride = g.bstride_a; p.out_bstride = a.out_bstride; p.w_tapstride = g.w_tapstride;
+    p.B = a.B; p.H = a.H; p.W = a.W; p.C = g.Ca; p.Cout = a.Cout; p.CinP = g.CinP;
+    p.tiles_x = cdiv(a.W, narrow::TW);
+    p.tiles_per_img = p.tiles_x * cdiv(a.H, narrow::TH);
+    return (long long)a.B * p.tiles_per_img;
+}
+
+// grouped launch (common.h): host images of the table / tile list; -1 = the problems are not one layer of this kernel
+long long conv_narrow_group_bytes(int P) { return ((long long)P * (long long)sizeof(narrow::Params) + 255) / 256 * 256; }
+long long conv_narrow_group_tiles(const storm_conv_args& a) { return (long long)a.B * cdiv(a.W, narrow::TW) * cdiv(a.H, narrow::TH); }
+long long conv_narrow_group_prepare(const storm_conv_args* a, int P, void* table, pipe::GroupTile* tiles, long long max_tiles) {
+    narrow::Params* tab = static_cast<narrow::Params*>(table);
+    long long n = 0;
+    for (int g = 0; g < P; ++g) {
+        if (!conv_narrow_supports(a[g])) return -1;
+        const storm_conv_seg &s0 = a[0].seg[0], &sg = a[g].seg[0];
+        if (sg.w != s0.w || sg.Ca != s0.Ca || a[g].Cout != a[0].Cout || a[g].bias != a[0].bias || a[g].dtype != a[0].dtype ||
+            (sg.gn_ss != nullptr) != (s0.gn_ss != nullptr) || sg.gn_silu != s0.gn_silu || a[g].H >= 65536 || a[g].W >= 65536) return -1;
+        narrow_params(a[g], tab[g]);
+        const int tiles_x = tab[g].tiles_x, tiles_y = cdiv(a[g].H, narrow::TH);
+        for (int b = 0; b < a[g].B; ++b)
+            for (int ty = 0; ty < tiles_y; ++ty)
+                for (int tx = 0; tx < tiles_x; ++tx) {
+                    if (n >= max_tiles) return -1;
+                    pipe::GroupTile& t = tiles[n++];
+                    t.problem = (unsigned)g; t.b = (unsigned)b; t.yx = (unsigned)(ty * narrow::TH) | ((unsigned)(tx * narrow::TW) << 16); t.tile = 0;
+                }
+    }
+    return n;
+}
+
+template <typename T, int CG, bool SILU>
+static int launch_narrow_group(const void* dev_table, const pipe::GroupTile* dev_tiles, long long ntiles, hipStream_t st) {
+    auto kern = conv_narrow_group_kernel<T, CG, SILU>;
+    const int lds = narrow::lds_bytes(CG * 64);
+    static bool attr_set = false;
+    if (!attr_set) {
+        STORM_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+        attr_set = true;
+    }
+    const int grid = (int)(ntiles < device_cus() ? ntiles : device_cus());
+    hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(narrow::THREADS), lds, st, static_cast<const narrow::Params*>(dev_table), dev_tiles, (int)ntiles);
+    STORM_LAUNCH_CHECK();
+    return STORM_OK;
+}
+int launch_conv_narrow_group(const storm_conv_args& a0, const void* dev_table, const pipe::GroupTile* dev_tiles, long long ntiles, hipStream_t st) {
+    STORM_CHECK(dev_table && dev_tiles && ntiles > 0 && ntiles < (1LL << 31), "storm_conv (narrow group): bad arguments");
+    const bool c256 = a0.seg[0].Ca == 256, silu = a0.seg[0].gn_ss != nullptr && a0.seg[0].gn_silu != 0;
+#define STORM_NG(T_, CG_) (silu ? launch_narrow_group<T_, CG_, true>(dev_table, dev_tiles, ntiles, st) : launch_narrow_group<T_, CG_, false>(dev_table, dev_tiles, ntiles, st))
+    if (a0.dtype == STORM_F16) return c256 ? STORM_NG(half_t, 4) : STORM_NG(half_t, 2);
+    return c256 ? STORM_NG(bf16_t, 4) : STORM_NG(bf16_t, 2);
+#undef STORM_NG
+}
+
 template <typename T, int CG, bool SILU>
 static int launch_narrow(const storm_conv_args& a, hipStream_t st) {
     auto kern = conv_narrow_kernel<T, CG, SILU>;
@@ -184,14 +271,7 @@ static int launch_narrow(const storm_conv_args& a, hipStream_t st) {
         attr_set = true;
     }
     narrow::Params p;
-    memset(&p, 0, sizeof(p));
-    const storm_conv_seg& g = a.seg[0];
-    p.src = g.src_a; p.w = g.w; p.out = a.out; p.bias = a.bias; p.gn_ss = g.gn_ss; p.silu = g.gn_silu;
-    p.src_bstride = g.bstride_a; p.out_bstride = a.out_bstride; p.w_tapstride = g.w_tapstride;
-    p.B = a.B; p.H = a.H; p.W = a.W; p.C = g.Ca; p.Cout = a.Cout; p.CinP = g.CinP;
-    p.tiles_x = cdiv(a.W, narrow::TW);
-    p.tiles_per_img = p.tiles_x * cdiv(a.H, narrow::TH);
-    const long long ntiles = (long long)a.B * p.tiles_per_img;
+    const long long ntiles = narrow_params(a, p);
     STORM_CHECK(ntiles > 0 && ntiles < (1LL << 31), "storm_conv: grid %lld out of range", ntiles);
     p.ntiles = (int)ntiles;
     const int grid = (int)(ntiles < device_cus() ? ntiles : device_cus());

@@ -235,6 +235,11 @@ const char* conv_duo_kernel_name(int dtype);
 bool conv_thin_supports(const storm_conv_args& a);
 int launch_conv_thin(const storm_conv_args& a, hipStream_t st);
 const char* conv_thin_kernel_name(int dtype, int ntaps);
+// conv_narrow.hip, grouped (the output pyramid's convolutions of several problems in one launch): table = P narrow::Params, tiles of 20 x 32 pixels
+long long conv_narrow_group_bytes(int P);
+long long conv_narrow_group_tiles(const storm_conv_args& a);
+long long conv_narrow_group_prepare(const storm_conv_args* a, int P, void* table, pipe::GroupTile* tiles, long long max_tiles);
+int launch_conv_narrow_group(const storm_conv_args& a0, const void* dev_table, const pipe::GroupTile* dev_tiles, long long ntiles, hipStream_t st);
 // defined in conv_narrow.hip: 3x3 convolutions to <= 4 output channels (the output pyramid): one 36-row 1x1 GEMM + a nine-point gather
 bool conv_narrow_supports(const storm_conv_args& a);
 int launch_conv_narrow(const storm_conv_args& a, hipStream_t st);

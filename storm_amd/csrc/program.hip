@@ -140,6 +140,18 @@ bool group_candidate(const storm_op* const* ops, int k, int P, int dtype) {
     return true;
 }
 long long op_tiles(const storm_op& o) { return (long long)o.i[1] * cdiv(o.i[2], 8) * cdiv(o.i[3], 32); }   // B x 8-row x 32-pixel tiles
+// the output pyramid's 3x3 convolutions to <= 4 planes (conv_narrow.hip): 4 per evaluation, one 8-wave workgroup per CU walking 20 x 32-pixel tiles
+bool narrow_candidate(const storm_op* const* ops, int k, int P, int dtype) {
+    if (dtype != STORM_BF16 && dtype != STORM_F16) return false;
+    if (switches().conv_variant >= 0) return false;
+    for (int g = 0; g < P; ++g) {
+        const storm_op& o = ops[g][k];
+        if (o.code != STORM_OP_CONV || (int)o.i[4] != 8 || (int)o.i[0] != 1 || (int)o.i[8 + 4] != 9 || (int)o.i[7] != 0) return false;
+        if (o.i[5] != ops[0][k].i[5] || o.i[8] != ops[0][k].i[8] || o.i[9] != 0) return false;
+    }
+    return true;
+}
+long long narrow_tiles(const storm_op& o) { return (long long)o.i[1] * cdiv(o.i[2], 20) * cdiv(o.i[3], 32); }
 long long align256(long long v) { return (v + 255) / 256 * 256; }
 }  // namespace
 
@@ -160,6 +172,12 @@ long long storm::program_group_blob_bytes(const storm_op* const* ops, int n_ops,
             long long items = 0;
             for (int g = 0; g < P; ++g) items += ops[g][k].i[4];
             n += align256((long long)P * sizeof(GnFinProblem)) + align256(items * 8);
+            continue;
+        }
+        if (narrow_candidate(ops, k, P, dtype)) {
+            long long t = 0;
+            for (int g = 0; g < P; ++g) t += narrow_tiles(ops[g][k]);
+            n += conv_narrow_group_bytes(P) + align256(t * (long long)sizeof(pipe::GroupTile));
             continue;
         }
         if (!group_candidate(ops, k, P, dtype)) continue;
@@ -202,7 +220,8 @@ int storm::program_group_build(const storm_op* const* ops, int n_ops, void* cons
             off += tab + til;
             continue;
         }
-        if (!group_candidate(ops, k, P, dtype)) continue;
+        const bool narrow = narrow_candidate(ops, k, P, dtype);
+        if (!narrow && !group_candidate(ops, k, P, dtype)) continue;
         long long t = 0;
         for (int g = 0; g < P; ++g) {
             bool ok = true;
@@ -211,7 +230,18 @@ int storm::program_group_build(const storm_op* const* ops, int n_ops, void* cons
             STORM_CHECK(ok, "storm_program_group: op %d of problem %d references a missing buffer", k, g);
             conv_args_of(ops[g][k], p, dtype, args[(size_t)g]);
             args[(size_t)g].splitk_ws = nullptr; args[(size_t)g].splitk_ws_bytes = 0;      // (a grouped launch never splits K)
-            t += op_tiles(ops[g][k]);
+            t += narrow ? narrow_tiles(ops[g][k]) : op_tiles(ops[g][k]);
+        }
+        if (narrow) {
+            const long long tabn = conv_narrow_group_bytes(P), tiln = align256(t * (long long)sizeof(pipe::GroupTile));
+            STORM_CHECK(off + tabn + tiln <= blob_bytes && n < max_gops, "storm_program_group: table blob too small");
+            const long long gotn = conv_narrow_group_prepare(args.data(), P, host_blob + off, reinterpret_cast<pipe::GroupTile*>(host_blob + off + tabn), t);
+            if (gotn != t) continue;
+            GroupOp& go = gops[n++];
+            go.k = k; go.kind = 2; go.outC = args[0].seg[0].Ca; go.bn = (args[0].seg[0].gn_ss != nullptr ? 2 : 0) | (args[0].seg[0].gn_silu ? 1 : 0);
+            go.table_off = off; go.tiles_off = off + tabn; go.ntiles = t;
+            off += tabn + tiln;
+            continue;
         }
         const long long tab = align256((long long)P * sizeof(pipe::PipeParams)), til = align256(t * (long long)sizeof(pipe::GroupTile));
         STORM_CHECK(off + tab + til <= blob_bytes && n < max_gops, "storm_program_group: table blob too small");
@@ -233,6 +263,13 @@ int storm::program_run_group(const storm_op* const* ops, int n_ops, void* const*
     for (int k = 0; k < n_ops; ++k) {
         if (gi < n_gops && gops[gi].k == k) {
             const GroupOp& go = gops[gi++];
+            if (go.kind == 2) {
+                storm_conv_args a0;
+                memset(&a0, 0, sizeof(a0));
+                a0.dtype = dtype; a0.seg[0].Ca = go.outC; a0.seg[0].gn_ss = (go.bn & 2) ? reinterpret_cast<const float*>(uintptr_t(16)) : nullptr; a0.seg[0].gn_silu = go.bn & 1;
+                if (int rc = launch_conv_narrow_group(a0, dev_blob + go.table_off, reinterpret_cast<const pipe::GroupTile*>(dev_blob + go.tiles_off), go.ntiles, (hipStream_t)s)) return rc;
+                continue;
+            }
             if (go.kind == 1) {
                 if (int rc = launch_gn_finalize_group(reinterpret_cast<const GnFinProblem*>(dev_blob + go.table_off), dev_blob + go.tiles_off, (int)go.ntiles, go.outC,
                                                       (hipStream_t)s)) return rc;

@@ -242,6 +242,30 @@ def test_conv_group_equals_its_problems_own_launches_bit_for_bit(dev, dtype, cus
         ops.conv_group(bad, Co)
 
 
+@pytest.mark.parametrize("C,gn,cus", [(128, True, 0), (256, True, 3), (128, False, 0)])
+def test_conv_group_narrow_output_equals_own_launches(dev, C, gn, cus, switch):
+    """The grouped form of conv_narrow.hip (the output pyramid's conv3x3(act(GroupNorm(h))) -> 4 planes, ncsnpp.py:389-410): three problems of one
+    layer - different batch sizes and image sizes (tiles cut by both edges), own tensors and (scale, shift) tables - in ONE launch; every
+    problem equals its own storm_conv launch bit for bit, with and without the persistent walk across problems."""
+    from storm_amd import ops
+    dtype = torch.bfloat16
+    g = torch.Generator().manual_seed(79)
+    w = ops.pack_conv_weight((torch.randn(4, C, 3, 3, generator=g) * 0.05).to(dev), dtype)
+    bias = torch.randn(4, generator=g).to(dev)
+    problems = []
+    for B, H, W in ((2, 19, 45), (1, 21, 70), (3, 9, 33)):
+        x = nhwc(torch.randn(B, C, H, W, generator=g)).to(dtype).to(dev)
+        ss = ops.pack_gn_ss(1 + 0.1 * torch.randn(B, C, generator=g), 0.1 * torch.randn(B, C, generator=g)).to(dev) if gn else None
+        problems.append(([ops.Seg(x, w, 9, gn_ss=ss, gn_silu=True)], dict(bias=bias, outC=8)))
+    if cus:
+        switch("STORM_CONV_CUS", cus)
+    own = [ops.conv(segs, 4, **kw) for segs, kw in problems]
+    assert "conv_narrow" in ops.conv_kernel_name(problems[0][0], 4, **problems[0][1])
+    outs = ops.conv_group(problems, 4)
+    for p in range(3):
+        assert torch.equal(outs[p], own[p]), p
+
+
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
 @pytest.mark.parametrize("case", ["c128_gn", "c256_gn_walk", "c128_plain", "c256_two_planes"])
 def test_conv_narrow_output_kernel(dev, dtype, case, switch):
