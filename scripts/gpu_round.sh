@@ -11,7 +11,7 @@ python tools/power_trace.py gpurun_out/power_$TAG.csv & PT=$!
 timeout 900 python bench.py --ops-json gpurun_out/ops_$TAG.json > gpurun_out/bench_$TAG.json 2> gpurun_out/bench_$TAG.err; head -c 400 gpurun_out/bench_$TAG.json; echo
 kill $PT; sleep 0.3; python tools/power_trace.py --summary gpurun_out/power_$TAG.csv | tee gpurun_out/power_summary_$TAG.txt
 if [ "$2" != "short" ]; then
-timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_$TAG -o trace -- python bench.py --steps 1 --warmup 0 --no-cpu-baseline > gpurun_out/prof_bench_$TAG.json 2> gpurun_out/prof_$TAG.err
+timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_$TAG -o trace -- python bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-other-configs --no-traffic > gpurun_out/prof_bench_$TAG.json 2> gpurun_out/prof_$TAG.err
 f=$(find gpurun_out/prof_$TAG -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && head -8 "$f"
 find gpurun_out/prof_$TAG -name "*kernel_trace.csv" -size +20M -delete
 bash scripts/pmc_bench.sh pmcb_$TAG 2>&1 | tail -4
@@ -22,7 +22,7 @@ find gpurun_out/pmc_$TAG -name "*kernel_trace.csv" -delete
 fi
 run() { tag=$1; shift; timeout 900 python bench.py "$@" > gpurun_out/bench_${TAG}_$tag.json 2> gpurun_out/bench_${TAG}_$tag.err; python -c "
 import json,sys; r=json.load(open('gpurun_out/bench_${TAG}_$tag.json')); print('$tag', round(r['value'],3), r['unit'], 'ms/step', round(r['ms_per_step'],1), 'nfe', r['config']['nfe_per_utterance'], (r.get('roofline') or {}).get('frac'))" || tail -3 gpurun_out/bench_${TAG}_$tag.err; }
-run fp16 --precision fp16 --steps 1 --warmup 1 --no-cpu-baseline
+run fp16 --precision fp16 --steps 1 --warmup 1 --no-cpu-baseline --no-other-configs --no-traffic
 run cfg3 --backbone ncsnpplarge --seconds 8 --N 50 --batch 8 --steps 1 --warmup 1 --no-cpu-baseline
 run cfg4 --stream 32 --sampler ode --precision fp16 --batch 16 --steps 1 --warmup 0 --no-cpu-baseline
 run cfg4pc --stream 32 --precision fp16 --batch 16 --steps 1 --warmup 0 --no-cpu-baseline
