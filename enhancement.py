@@ -50,7 +50,7 @@ def main():
     p.add_argument("--seed", type=int, default=None, help="Philox seed of the sampler noise (default: drawn from torch's RNG, as the reference)")
     p.add_argument("--batch-invariant", action="store_true", help="every utterance's result independent - bit for bit - of what it is batched with "
                    "(storm_amd.set_batch_invariant: launch decisions per image; costs the batch-aware kernel selections)")
-    p.add_argument("--group", type=int, default=8, help="score-only mode: this many micro-batches (frame buckets of different lengths) run their samplers in lockstep "
+    p.add_argument("--group", type=int, default=8, help="score-only and storm modes: this many micro-batches (frame buckets of different lengths) run their samplers in lockstep "
                    "and share the launches of the score network (ScoreModel.enhance_stream); 1 = one micro-batch after the other")
     p.add_argument("--dist-world1", action="store_true", help="with ONE rank: form the RCCL process group anyway (dry run of the sharded path on one GPU)")
     args = p.parse_args()
@@ -98,7 +98,7 @@ def main():
         return ids, outs
 
     buckets = D.bucket_by_frames([lengths[i] for i in mine], args.batch)
-    if args.mode == "score-only" and args.group > 1 and len(buckets) > 1:
+    if args.mode in ("score-only", "storm") and args.group > 1 and len(buckets) > 1:
         # a ragged set of files: micro-batches of 2 - 3 rows each - their score evaluations share launches (storm_ncsnpp_forward_group)
         for c in range(0, len(buckets), args.group):
             chunk, metas = [], []

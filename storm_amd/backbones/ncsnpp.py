@@ -380,8 +380,9 @@ class NCSNpp(nn.Module):
                 ws = None
                 ws = torch.empty(n, dtype=torch.uint8, device=dev)
             self._workspaces[key] = ws
-        L.check(L.lib().storm_ncsnpp_forward_group(h, P, Bs, Ts, F, parts, n_parts, tptr if self.cfg.conditional else None, optr, L.ptr(ws), ws.numel(),
-                                                   int(self.negate_output), L.stream()), "storm_ncsnpp_forward_group")
+            # (launched under the lock: host threads that share this stream's scratch must not interleave the launches of two evaluations)
+            L.check(L.lib().storm_ncsnpp_forward_group(h, P, Bs, Ts, F, parts, n_parts, tptr if self.cfg.conditional else None, optr, L.ptr(ws), ws.numel(),
+                                                       int(self.negate_output), L.stream()), "storm_ncsnpp_forward_group")
         return outs
 
 

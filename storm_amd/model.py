@@ -170,6 +170,42 @@ class _Base(nn.Module):
         Y, peak = self.data_module.wav_to_spec(yd, pad_to=64, lengths=lengths)
         return Y, peak, y.size(1)
 
+    def _score_network(self):
+        """the network whose evaluations a grouped stream shares (ScoreModel: dnn; StoRM: score_net - its denoiser runs once per micro-batch)"""
+        return getattr(self, "score_net", None) or self.dnn
+
+    def enhance_stream(self, batches, grouped=True, return_nfe=False, seed=None, seeds=None, noise_fns=None, **kwargs):
+        """(ScoreModel and StochasticRegenerationModel.)  A stream of ragged micro-batches (BASELINE.json configs[4]) in lockstep: `batches` = [(y [b, L], lengths or None), ...] as
+        storm_amd.distributed.bucket_by_frames forms them.  Every micro-batch runs enhance_batch - the same sampler, noise stream and
+        (ODE) per-row step control as its own call - but the score evaluations of all micro-batches that are still running share ONE
+        grouped network call per step (storm_amd.sampling.grouped, storm_ncsnpp_forward_group): the layers with a grouped kernel see
+        the whole stream's pixel tiles in one launch instead of 2 - 3 rows at a time.  grouped=False: one micro-batch after the other.
+        seed: micro-batch k draws from the Philox stream seed + k (seeds: one seed per micro-batch; noise_fns: one injected-noise callable per micro-batch instead).
+        Returns the list of enhanced batches (and the mean evaluations per utterance with return_nfe); self.last_nfev_stream = the
+        evaluations every micro-batch executed."""
+        from .sampling.grouped import run_grouped
+        outs = [None] * len(batches)
+
+        def one(k):
+            yb, bl = batches[k]
+            kw = dict(kwargs)
+            if seeds is not None:
+                kw["seed"] = seeds[k]
+            elif seed is not None:
+                kw["seed"] = seed + k
+            if noise_fns is not None:
+                kw["noise_fn"] = noise_fns[k]                  # (parity runs: the draws of micro-batch k)
+            return self.enhance_batch(yb, lengths=bl, return_nfe=True, **kw)
+        fns = [(lambda k=k: one(k)) for k in range(len(batches))]
+        res, batcher = run_grouped(self._score_network(), fns, device=self.device) if grouped else ([f() for f in fns], None)
+        outs = [r[0] for r in res]
+        self.last_nfev_stream = [r[1] for r in res]
+        self.last_group_calls = None if batcher is None else (batcher.calls, batcher.rows)
+        if return_nfe:
+            rows = sum(b[0].shape[0] for b in batches)
+            return outs, sum(r[1] * b[0].shape[0] for r, b in zip(res, batches)) / rows
+        return outs
+
     def _sampler_minibatched(self, make, y, minibatch):
         M = y.shape[0]
 
@@ -251,38 +287,6 @@ class ScoreModel(_Base):
         self.last_nfev_rows = getattr(sampler, "nfev_rows", None)     # ODE: the evaluations every row needed on its own
         x_hat = self.data_module.spec_to_wav(sample, T_orig, peak, lengths=lengths)
         return (x_hat, nfe) if return_nfe else x_hat
-
-    def enhance_stream(self, batches, grouped=True, return_nfe=False, seed=None, seeds=None, noise_fns=None, **kwargs):
-        """A stream of ragged micro-batches (BASELINE.json configs[4]) in lockstep: `batches` = [(y [b, L], lengths or None), ...] as
-        storm_amd.distributed.bucket_by_frames forms them.  Every micro-batch runs enhance_batch - the same sampler, noise stream and
-        (ODE) per-row step control as its own call - but the score evaluations of all micro-batches that are still running share ONE
-        grouped network call per step (storm_amd.sampling.grouped, storm_ncsnpp_forward_group): the layers with a grouped kernel see
-        the whole stream's pixel tiles in one launch instead of 2 - 3 rows at a time.  grouped=False: one micro-batch after the other.
-        seed: micro-batch k draws from the Philox stream seed + k (seeds: one seed per micro-batch; noise_fns: one injected-noise callable per micro-batch instead).
-        Returns the list of enhanced batches (and the mean evaluations per utterance with return_nfe); self.last_nfev_stream = the
-        evaluations every micro-batch executed."""
-        from .sampling.grouped import run_grouped
-        outs = [None] * len(batches)
-
-        def one(k):
-            yb, bl = batches[k]
-            kw = dict(kwargs)
-            if seeds is not None:
-                kw["seed"] = seeds[k]
-            elif seed is not None:
-                kw["seed"] = seed + k
-            if noise_fns is not None:
-                kw["noise_fn"] = noise_fns[k]                  # (parity runs: the draws of micro-batch k)
-            return self.enhance_batch(yb, lengths=bl, return_nfe=True, **kw)
-        fns = [(lambda k=k: one(k)) for k in range(len(batches))]
-        res, batcher = run_grouped(self.dnn, fns, device=self.device) if grouped else ([f() for f in fns], None)
-        outs = [r[0] for r in res]
-        self.last_nfev_stream = [r[1] for r in res]
-        self.last_group_calls = None if batcher is None else (batcher.calls, batcher.rows)
-        if return_nfe:
-            rows = sum(b[0].shape[0] for b in batches)
-            return outs, sum(r[1] * b[0].shape[0] for r, b in zip(res, batches)) / rows
-        return outs
 
     def enhance(self, y, sampler_type="pc", predictor="reverse_diffusion", corrector="ald", N=50, corrector_steps=1,
                 snr=0.5, timeit=False, scale_factor=None, return_stft=False, **kwargs):

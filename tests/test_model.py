@@ -410,6 +410,31 @@ def test_enhance_stream_equals_its_micro_batches_own_runs(dev, sampler):
             m.enhance_stream(batches, noise_fns=boom, **kw)
 
 
+def test_enhance_stream_storm_mode(dev):
+    """StochasticRegenerationModel.enhance_stream (the paper's mode, model.py:720-780): two micro-batches of different frame buckets - every
+    micro-batch runs its denoiser on its own, the score network's evaluations of both are grouped - equal their own enhance_batch calls bit for
+    bit under injected noise (nf = 8: no layer with a grouped kernel)."""
+    from storm_amd.model import StochasticRegenerationModel
+    m = StochasticRegenerationModel(backbone_denoiser="ncsnpp", backbone_score="ncsnpp", condition="both", **dict(COMMON))
+    m.denoiser_net.load_state_dict(NR.seeded_state_dict(NR.NCSNppConfig(nf=8, input_channels=2, discriminative=True), seed=42))
+    m.score_net.load_state_dict(NR.seeded_state_dict(NR.NCSNppConfig(nf=8, input_channels=6), seed=43))
+    m.eval(no_ema=True)
+    m = m.to(dev)
+    g = torch.Generator().manual_seed(33)
+    lens = [[5003], [9000]]
+    batches = [((0.1 * torch.randn(1, n[0], generator=g)).to(dev), None) for n in lens]
+    frames = [-(-(1 + n[0] // 128) // 64) * 64 for n in lens]
+    draws = [[SR.complex_randn((1, 1, 256, f), torch.Generator().manual_seed(300 + 10 * p + i)).to(dev) for i in range(3)] for p, f in enumerate(frames)]
+
+    def fns():
+        return [(lambda it=iter(d): next(it)) for d in draws]
+    kw = dict(N=2, corrector="none", snr=0.5)
+    own = [m.enhance_batch(yb, lengths=bl, noise_fn=fn, **kw) for (yb, bl), fn in zip(batches, fns())]
+    outs = m.enhance_stream(batches, noise_fns=fns(), **kw)
+    assert m.last_group_calls == (2, 4)                                 # two grouped evaluations of the score net, two rows each
+    assert all(torch.equal(a, b) for a, b in zip(outs, own))
+
+
 def test_no_cpu_fallback():
     """the product path refuses CPU tensors when the real library is bound"""
     from storm_amd import _lib
