@@ -225,11 +225,15 @@ inline int cdiv(long long a, long long b) { return (int)((a + b - 1) / b); }
 // The ragged micro-batches of a stream run the same op sequence on tensors of different (B, T).  Op k of every problem is launched together
 // where a grouped kernel exists for it (16-bit 3x3 convolutions of the conv_pipe family: one launch over all problems' pixel tiles),
 // one after the other otherwise.  The tables of the grouped launches (absolute device pointers) live in a caller-owned device blob.
-struct GroupOp { int k, outC, bn, kind; long long table_off, tiles_off, ntiles; };   // kind 0: 3x3 convolution (conv_pipe), 1: GroupNorm finalize, 2: 3x3 convolution to <= 4 planes (conv_narrow; outC = input channels, bn = fused GroupNorm / SiLU flags)
+struct GroupOp { int k, outC, bn, kind; long long table_off, tiles_off, ntiles; };   // kind 0: 3x3 convolution (conv_pipe), 1: GroupNorm finalize, 2: 3x3 convolution to <= 4 planes (conv_narrow; outC = input channels, bn = fused GroupNorm / SiLU flags), 3: convolution over an 8-channel input (conv_thin; outC = problems, bn = taps), 4: FIR x2 of the 8-channel pyramids (outC = channels, bn = blocks << 2 | resample)
 // one problem of a grouped GroupNorm finalize (norm_resample.hip): the arguments of its own storm_gn_finalize(_ss) call
 struct GnFinProblem { const float* pa; const float* pb; double* stats; const float* gamma; const float* beta; float* ss; long long count;
                       int Ca, tiles_a, Cb, tiles_b; float eps; int pad_; };
 struct GnFinItem { int problem, b; };
+// one problem of a grouped FIR x2 launch (the 8-channel pyramids: fir_kernel): its own storm_fir_up2 / _down2 arguments + pixels per block
+struct FirProblem { const void* x; const void* add; void* out; int H, W, ppb, pad_; };
+int fir_group_problem(int resample, const void* x, const void* add, void* out, int B, int H, int W, int C, FirProblem& q);   // returns the problem's blocks
+int launch_fir_group(int resample, const FirProblem* dev_tab, const void* dev_items, int n_items, int max_blocks, int C, int dtype, hipStream_t st);
 int launch_gn_finalize_group(const GnFinProblem* dev_tab, const void* dev_items, int n_items, int groups, hipStream_t st);
 // bytes of the device blob for these shapes (a bound: every groupable op with all its tiles), 0 = nothing groups
 long long program_group_blob_bytes(const storm_op* const* ops, int n_ops, int P, int dtype);

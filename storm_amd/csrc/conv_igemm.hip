@@ -891,6 +891,18 @@ extern "C" int storm_conv_group(const storm_conv_args* a, int P, void* blob, lon
     const long long need = storm_conv_group_blob_bytes(a, P);
     STORM_CHECK(blob_bytes >= need, "storm_conv_group: blob %lld < %lld bytes", blob_bytes, need);
     std::vector<char> host((size_t)need);
+    if (storm::conv_thin_supports(a[0])) {                   // 8-channel inputs (stem, input-skip 1x1s): conv_thin.hip's grouped form
+        const long long img = storm::conv_thin_group_bytes(P);
+        STORM_CHECK(blob_bytes >= img, "storm_conv_group: blob %lld < %lld bytes", blob_bytes, img);
+        std::vector<char> image((size_t)img);
+        const long long nt = storm::conv_thin_group_prepare(a, P, image.data());
+        if (nt <= 0) { storm::set_error("storm_conv_group: the problems are not one layer of the 8-channel-input kernel"); return STORM_ERR_UNSUPPORTED; }
+        STORM_HIP(hipMemcpyAsync(blob, image.data(), (size_t)img, hipMemcpyHostToDevice, (hipStream_t)s));
+#ifndef STORM_HOST_SIM
+        STORM_HIP(hipStreamSynchronize((hipStream_t)s));
+#endif
+        return storm::launch_conv_thin_group(blob, P, nt, a[0].seg[0].ntaps, a[0].dtype, (hipStream_t)s);
+    }
     if (storm::conv_narrow_supports(a[0])) {                 // the output pyramid's convolutions (<= 4 planes): conv_narrow.hip's grouped form
         const long long tabn = storm::conv_narrow_group_bytes(P);
         storm::pipe::GroupTile* tl = reinterpret_cast<storm::pipe::GroupTile*>(host.data() + tabn);

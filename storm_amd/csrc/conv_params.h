@@ -235,6 +235,10 @@ const char* conv_duo_kernel_name(int dtype);
 bool conv_thin_supports(const storm_conv_args& a);
 int launch_conv_thin(const storm_conv_args& a, hipStream_t st);
 const char* conv_thin_kernel_name(int dtype, int ntaps);
+// conv_thin.hip, grouped (the stem / the input-skip 1x1s of several problems in one launch): image = P thin::Params + first[P + 1]
+long long conv_thin_group_bytes(int P);
+long long conv_thin_group_prepare(const storm_conv_args* a, int P, void* image);
+int launch_conv_thin_group(const void* dev_image, int P, long long ntiles, int ntaps, int dtype, hipStream_t st);
 // conv_narrow.hip, grouped (the output pyramid's convolutions of several problems in one launch): table = P narrow::Params, tiles of 20 x 32 pixels
 long long conv_narrow_group_bytes(int P);
 long long conv_narrow_group_tiles(const storm_conv_args& a);

@@ -31,15 +31,13 @@ struct Params {
 }  // namespace thin
 
 template <typename T, int TAPS>
-__global__ __launch_bounds__(thin::THREADS, 2)
-void conv_thin_kernel(const thin::Params p) {
+__device__ __forceinline__ void conv_thin_body(const thin::Params& p, const int tile) {
     using namespace thin;
     typedef typename Mma<T>::Frag Frag;
     constexpr int KS = (TAPS + 1) / 2;                      // k-steps: two taps (2 x 8 channels) each
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = uniform(tid >> 6);
     const int n = lane & 31, h = lane >> 5;
-    const int tile = blockIdx.x;
     const int b = tile / p.tiles_per_img, trem = tile - b * p.tiles_per_img;
     const int ty0 = TAPS == 9 ? (trem / p.tiles_x) * TILE_H : 0, tx0 = TAPS == 9 ? (trem % p.tiles_x) * TILE_W : 0;
     const long long lin0 = (long long)trem * (TILE_H * TILE_W);            // 1x1: linear pixel base of the tile
@@ -175,6 +173,22 @@ void conv_thin_kernel(const thin::Params p) {
     }
 }
 
+template <typename T, int TAPS>
+__global__ __launch_bounds__(thin::THREADS, 2)
+void conv_thin_kernel(const thin::Params p) {
+    conv_thin_body<T, TAPS>(p, (int)blockIdx.x);
+}
+// The tiles of several problems of ONE layer (ragged micro-batches of a stream) in one launch: problem g owns the workgroups
+// [first[g], first[g + 1]); its Params come from a device table.  A tile is computed by the code of its own launch.
+template <typename T, int TAPS>
+__global__ __launch_bounds__(thin::THREADS, 2)
+void conv_thin_group_kernel(const thin::Params* __restrict__ gtab, const int* __restrict__ first, const int P) {
+    int g = 0;
+    while (g + 1 < P && (int)blockIdx.x >= first[g + 1]) ++g;           // (uniform: P <= a few dozen)
+    const thin::Params p = gtab[g];
+    conv_thin_body<T, TAPS>(p, (int)blockIdx.x - first[g]);
+}
+
 // ---- host side ---------------------------------------------------------------------------------------------------
 bool conv_thin_supports(const storm_conv_args& a) {
     if (a.dtype != STORM_BF16 && a.dtype != STORM_F16) return false;
@@ -187,6 +201,57 @@ bool conv_thin_supports(const storm_conv_args& a) {
     return img * 16 < (1LL << 31) && (long long)g.ntaps * g.w_rows * 32 < (1LL << 31) && img * a.outC < (1LL << 31);
 }
 
+static long long thin_params(const storm_conv_args& a, thin::Params& p) {
+    memset(&p, 0, sizeof(p));
+    const storm_conv_seg& g = a.seg[0];
+    p.src = g.src_a; p.w = g.w; p.out = a.out; p.bias = a.bias; p.skip = a.skip; p.gn_part = a.gn_part;
+    p.src_bstride = g.bstride_a; p.out_bstride = a.out_bstride; p.skip_bstride = a.skip_bstride;
+    p.nt = (switches().gn_nt >> 2) & 1;
+    p.B = a.B; p.H = a.H; p.W = a.W; p.outC = a.outC; p.Cout = a.Cout; p.w_rows = g.w_rows; p.scale = a.scale;
+    p.tiles_x = cdiv(a.W, TILE_W);
+    p.tiles_per_img = g.ntaps == 9 ? p.tiles_x * cdiv(a.H, TILE_H) : cdiv((long long)a.H * a.W, TILE_H * TILE_W);
+    return (long long)a.B * p.tiles_per_img;
+}
+
+// grouped launch (conv_params.h): the host image = P Params, then first[P + 1] (the workgroup ranges); returns the workgroup count or -1
+long long conv_thin_group_bytes(int P) { return ((long long)P * (long long)sizeof(thin::Params) + (P + 1) * 4 + 255) / 256 * 256; }
+long long conv_thin_group_prepare(const storm_conv_args* a, int P, void* image) {
+    thin::Params* tab = static_cast<thin::Params*>(image);
+    int* first = reinterpret_cast<int*>(static_cast<char*>(image) + (long long)P * (long long)sizeof(thin::Params));
+    long long n = 0;
+    for (int g = 0; g < P; ++g) {
+        if (!conv_thin_supports(a[g])) return -1;
+        const storm_conv_seg &s0 = a[0].seg[0], &sg = a[g].seg[0];
+        if (sg.w != s0.w || sg.ntaps != s0.ntaps || a[g].outC != a[0].outC || a[g].Cout != a[0].Cout || a[g].bias != a[0].bias || a[g].dtype != a[0].dtype ||
+            a[g].scale != a[0].scale || (a[g].skip != nullptr) != (a[0].skip != nullptr) || (a[g].gn_part != nullptr) != (a[0].gn_part != nullptr)) return -1;
+        first[g] = (int)n;
+        n += thin_params(a[g], tab[g]);
+        if (n >= (1LL << 31)) return -1;
+    }
+    first[P] = (int)n;
+    return n;
+}
+template <typename T, int TAPS>
+static int launch_thin_group(const void* dev_image, int P, long long ntiles, hipStream_t st) {
+    auto kern = conv_thin_group_kernel<T, TAPS>;
+    static bool attr_set = false;
+    if (!attr_set) {
+        STORM_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, thin::LDS_BYTES));
+        attr_set = true;
+    }
+    const thin::Params* tab = static_cast<const thin::Params*>(dev_image);
+    const int* first = reinterpret_cast<const int*>(static_cast<const char*>(dev_image) + (long long)P * (long long)sizeof(thin::Params));
+    hipLaunchKernelGGL(kern, dim3((unsigned)ntiles), dim3(thin::THREADS), thin::LDS_BYTES, st, tab, first, P);
+    STORM_LAUNCH_CHECK();
+    return STORM_OK;
+}
+int launch_conv_thin_group(const void* dev_image, int P, long long ntiles, int ntaps, int dtype, hipStream_t st) {
+    STORM_CHECK(dev_image && P >= 1 && ntiles > 0, "storm_conv (thin group): bad arguments");
+    const bool nine = ntaps == 9;
+    if (dtype == STORM_F16) return nine ? launch_thin_group<half_t, 9>(dev_image, P, ntiles, st) : launch_thin_group<half_t, 1>(dev_image, P, ntiles, st);
+    return nine ? launch_thin_group<bf16_t, 9>(dev_image, P, ntiles, st) : launch_thin_group<bf16_t, 1>(dev_image, P, ntiles, st);
+}
+
 template <typename T, int TAPS>
 static int launch_thin(const storm_conv_args& a, hipStream_t st) {
     auto kern = conv_thin_kernel<T, TAPS>;
@@ -196,15 +261,7 @@ static int launch_thin(const storm_conv_args& a, hipStream_t st) {
         attr_set = true;
     }
     thin::Params p;
-    memset(&p, 0, sizeof(p));
-    const storm_conv_seg& g = a.seg[0];
-    p.src = g.src_a; p.w = g.w; p.out = a.out; p.bias = a.bias; p.skip = a.skip; p.gn_part = a.gn_part;
-    p.src_bstride = g.bstride_a; p.out_bstride = a.out_bstride; p.skip_bstride = a.skip_bstride;
-    p.nt = (switches().gn_nt >> 2) & 1;
-    p.B = a.B; p.H = a.H; p.W = a.W; p.outC = a.outC; p.Cout = a.Cout; p.w_rows = g.w_rows; p.scale = a.scale;
-    p.tiles_x = cdiv(a.W, TILE_W);
-    p.tiles_per_img = TAPS == 9 ? p.tiles_x * cdiv(a.H, TILE_H) : cdiv((long long)a.H * a.W, TILE_H * TILE_W);
-    const long long ntiles = (long long)a.B * p.tiles_per_img;
+    const long long ntiles = thin_params(a, p);
     STORM_CHECK(ntiles > 0 && ntiles < (1LL << 31), "storm_conv: grid %lld out of range", ntiles);
     hipLaunchKernelGGL(kern, dim3((unsigned)ntiles), dim3(thin::THREADS), thin::LDS_BYTES, st, p);
     STORM_LAUNCH_CHECK();

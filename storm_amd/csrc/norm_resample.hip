@@ -750,9 +750,9 @@ void gn_apply_up_kernel(const T* __restrict__ xa, int Ca, const T* __restrict__ 
 }
 
 template <typename T, int RESAMPLE>
-__global__ void fir_kernel(const T* __restrict__ x, const T* __restrict__ add, T* __restrict__ out,
-                           int H, int W, int C, int ppb, int C8, int PL) {
-    const int b = blockIdx.y, tid = threadIdx.x;
+__device__ __forceinline__ void fir_body(const T* __restrict__ x, const T* __restrict__ add, T* __restrict__ out,
+                                         int H, int W, int C, int ppb, int C8, int PL, const int b) {
+    const int tid = threadIdx.x;
     const int oct = tid % C8, pl = tid / C8, c = oct * 8;
     const int OH = RESAMPLE == 1 ? 2 * H : H / 2, OW = RESAMPLE == 1 ? 2 * W : W / 2;
     const long long ibase = (long long)b * H * W, obase = (long long)b * OH * OW;
@@ -771,6 +771,19 @@ __global__ void fir_kernel(const T* __restrict__ x, const T* __restrict__ add, T
         }
         store8(out + (obase + p) * C + c, v);
     }
+}
+
+template <typename T, int RESAMPLE>
+__global__ void fir_kernel(const T* __restrict__ x, const T* __restrict__ add, T* __restrict__ out,
+                           int H, int W, int C, int ppb, int C8, int PL) {
+    fir_body<T, RESAMPLE>(x, add, out, H, W, C, ppb, C8, PL, blockIdx.y);
+}
+// the same for the batch items of several problems in one launch (grouped evaluation, common.h): grid.x = the largest problem's blocks
+template <typename T, int RESAMPLE>
+__global__ void fir_group_kernel(const FirProblem* __restrict__ tab, const GnFinItem* __restrict__ items, int C, int C8, int PL) {
+    const GnFinItem it = items[blockIdx.y];
+    const FirProblem& q = tab[it.problem];
+    fir_body<T, RESAMPLE>(static_cast<const T*>(q.x), static_cast<const T*>(q.add), static_cast<T*>(q.out), q.H, q.W, C, q.ppb, C8, PL, it.b);
 }
 
 template <typename T>
@@ -905,6 +918,31 @@ static int upfirdn2d_t(const void* x, const float* k, void* out, int N, int H, i
                        int down_x, int down_y, int pad_x0, int pad_y0, hipStream_t st) {
     hipLaunchKernelGGL((upfirdn2d_planes_kernel<T>), dim3(cdiv((long long)OH * OW, 256), N), dim3(256), 0, st, (const T*)x, k, (T*)out, H, W, OH, OW,
                        kh, kw, up_x, up_y, down_x, down_y, pad_x0, pad_y0);
+    STORM_LAUNCH_CHECK();
+    return STORM_OK;
+}
+
+// grouped FIR x2 (8-channel pyramids): fills one problem's table entry and returns its block count
+template <int R>
+static int fir_problem(const void* x, const void* add, void* out, int B, int H, int W, int C, FirProblem& q) {
+    const GnGeom g = gn_geom(C);
+    const int OHW = R == 1 ? 4 * H * W : H * W / 4;
+    q.x = x; q.add = add; q.out = out; q.H = H; q.W = W;
+    q.ppb = g.PL * pixels_per_thread((long long)B * OHW, g.PL, 32);
+    return cdiv(OHW, q.ppb);
+}
+int fir_group_problem(int resample, const void* x, const void* add, void* out, int B, int H, int W, int C, FirProblem& q) {
+    return resample == 1 ? fir_problem<1>(x, add, out, B, H, W, C, q) : fir_problem<2>(x, add, out, B, H, W, C, q);
+}
+int launch_fir_group(int resample, const FirProblem* dev_tab, const void* dev_items, int n_items, int max_blocks, int C, int dtype, hipStream_t st) {
+    STORM_CHECK(dev_tab && dev_items && n_items > 0 && n_items < 65536 && max_blocks > 0 && C % 8 == 0 && C <= GN_MAX_C, "storm_fir (group): bad arguments");
+    const GnGeom g = gn_geom(C);
+    const GnFinItem* it = static_cast<const GnFinItem*>(dev_items);
+#define STORM_FIRG(T_, R_) hipLaunchKernelGGL((fir_group_kernel<T_, R_>), dim3(max_blocks, n_items), dim3(g.NT), 0, st, dev_tab, it, C, g.C8, g.PL)
+    if (dtype == STORM_BF16) { if (resample == 1) STORM_FIRG(bf16_t, 1); else STORM_FIRG(bf16_t, 2); }
+    else if (dtype == STORM_F16) { if (resample == 1) STORM_FIRG(half_t, 1); else STORM_FIRG(half_t, 2); }
+    else { if (resample == 1) STORM_FIRG(float, 1); else STORM_FIRG(float, 2); }
+#undef STORM_FIRG
     STORM_LAUNCH_CHECK();
     return STORM_OK;
 }

@@ -151,6 +151,17 @@ bool narrow_candidate(const storm_op* const* ops, int k, int P, int dtype) {
     }
     return true;
 }
+// the 8-channel-input convolutions (conv_thin.hip: the stem and the three input-skip 1x1s)
+bool thin_candidate(const storm_op* const* ops, int k, int P, int dtype) {
+    if (dtype != STORM_BF16 && dtype != STORM_F16) return false;
+    if (switches().conv_variant >= 0) return false;
+    for (int g = 0; g < P; ++g) {
+        const storm_op& o = ops[g][k];
+        if (o.code != STORM_OP_CONV || (int)o.i[0] != 1 || (int)o.i[8] != 8 || (int)o.i[9] != 0 || (int)o.i[4] < 64 || (int)o.i[7] != 0) return false;
+        if (o.i[4] != ops[0][k].i[4] || o.i[8 + 4] != ops[0][k].i[8 + 4]) return false;
+    }
+    return true;
+}
 long long narrow_tiles(const storm_op& o) { return (long long)o.i[1] * cdiv(o.i[2], 20) * cdiv(o.i[3], 32); }
 long long align256(long long v) { return (v + 255) / 256 * 256; }
 }  // namespace
@@ -164,10 +175,24 @@ static bool fin_candidate(const storm_op* const* ops, int k, int P) {
     return true;
 }
 
+static bool fir_candidate(const storm_op* const* ops, int k, int P) {
+    for (int g = 0; g < P; ++g) {
+        const storm_op& o = ops[g][k];
+        if ((o.code != STORM_OP_FIR_UP && o.code != STORM_OP_FIR_DOWN) || o.code != ops[0][k].code || o.i[3] != ops[0][k].i[3]) return false;
+    }
+    return true;
+}
+
 long long storm::program_group_blob_bytes(const storm_op* const* ops, int n_ops, int P, int dtype) {
     long long n = 0;
     if (P < 2) return 0;
     for (int k = 0; k < n_ops; ++k) {
+        if (fir_candidate(ops, k, P)) {
+            long long items = 0;
+            for (int g = 0; g < P; ++g) items += ops[g][k].i[0];
+            n += align256((long long)P * sizeof(FirProblem)) + align256(items * 8);
+            continue;
+        }
         if (fin_candidate(ops, k, P)) {
             long long items = 0;
             for (int g = 0; g < P; ++g) items += ops[g][k].i[4];
@@ -180,6 +205,7 @@ long long storm::program_group_blob_bytes(const storm_op* const* ops, int n_ops,
             n += conv_narrow_group_bytes(P) + align256(t * (long long)sizeof(pipe::GroupTile));
             continue;
         }
+        if (thin_candidate(ops, k, P, dtype)) { n += conv_thin_group_bytes(P); continue; }
         if (!group_candidate(ops, k, P, dtype)) continue;
         long long t = 0;
         for (int g = 0; g < P; ++g) t += op_tiles(ops[g][k]);
@@ -194,6 +220,34 @@ int storm::program_group_build(const storm_op* const* ops, int n_ops, void* cons
     long long off = 0;
     std::vector<storm_conv_args> args((size_t)P);
     for (int k = 0; k < n_ops; ++k) {
+        if (fir_candidate(ops, k, P)) {
+            long long items = 0;
+            for (int g = 0; g < P; ++g) items += ops[g][k].i[0];
+            const long long tab = align256((long long)P * sizeof(FirProblem)), til = align256(items * 8);
+            STORM_CHECK(off + tab + til <= blob_bytes && n < max_gops && items < 65536, "storm_program_group: table blob too small");
+            FirProblem* t = reinterpret_cast<FirProblem*>(host_blob + off);
+            int* it = reinterpret_cast<int*>(host_blob + off + tab);
+            const int up = ops[0][k].code == STORM_OP_FIR_UP ? 1 : 2;
+            long long ni = 0;
+            int max_blocks = 0;
+            for (int g = 0; g < P; ++g) {
+                const storm_op& o = ops[g][k];
+                bool ok = true;
+                void* p[STORM_OP_NPTR];
+                for (int j = 0; j < STORM_OP_NPTR; ++j) p[j] = resolve(o.p[j], bufs[g], n_bufs, ok);
+                STORM_CHECK(ok, "storm_program_group: op %d of problem %d references a missing buffer", k, g);
+                memset(&t[g], 0, sizeof(FirProblem));
+                // run_ops: FIR_UP (x, add, out; B, H, W, C) / FIR_DOWN (x, out; B, H, W, C)
+                const int nb = up == 1 ? fir_group_problem(1, p[0], p[1], p[2], (int)o.i[0], (int)o.i[1], (int)o.i[2], (int)o.i[3], t[g])
+                                       : fir_group_problem(2, p[0], nullptr, p[1], (int)o.i[0], (int)o.i[1], (int)o.i[2], (int)o.i[3], t[g]);
+                if (nb > max_blocks) max_blocks = nb;
+                for (int b = 0; b < (int)o.i[0]; ++b) { it[2 * ni] = g; it[2 * ni + 1] = b; ++ni; }
+            }
+            GroupOp& go = gops[n++];
+            go.k = k; go.kind = 4; go.outC = (int)ops[0][k].i[3]; go.bn = (max_blocks << 2) | up; go.table_off = off; go.tiles_off = off + tab; go.ntiles = ni;
+            off += tab + til;
+            continue;
+        }
         if (fin_candidate(ops, k, P)) {
             long long items = 0;
             for (int g = 0; g < P; ++g) items += ops[g][k].i[4];
@@ -220,8 +274,8 @@ int storm::program_group_build(const storm_op* const* ops, int n_ops, void* cons
             off += tab + til;
             continue;
         }
-        const bool narrow = narrow_candidate(ops, k, P, dtype);
-        if (!narrow && !group_candidate(ops, k, P, dtype)) continue;
+        const bool narrow = narrow_candidate(ops, k, P, dtype), thin = !narrow && thin_candidate(ops, k, P, dtype);
+        if (!narrow && !thin && !group_candidate(ops, k, P, dtype)) continue;
         long long t = 0;
         for (int g = 0; g < P; ++g) {
             bool ok = true;
@@ -231,6 +285,16 @@ int storm::program_group_build(const storm_op* const* ops, int n_ops, void* cons
             conv_args_of(ops[g][k], p, dtype, args[(size_t)g]);
             args[(size_t)g].splitk_ws = nullptr; args[(size_t)g].splitk_ws_bytes = 0;      // (a grouped launch never splits K)
             t += narrow ? narrow_tiles(ops[g][k]) : op_tiles(ops[g][k]);
+        }
+        if (thin) {
+            const long long img = conv_thin_group_bytes(P);
+            STORM_CHECK(off + img <= blob_bytes && n < max_gops, "storm_program_group: table blob too small");
+            const long long nt = conv_thin_group_prepare(args.data(), P, host_blob + off);
+            if (nt <= 0) continue;
+            GroupOp& go = gops[n++];
+            go.k = k; go.kind = 3; go.outC = P; go.bn = args[0].seg[0].ntaps; go.table_off = off; go.tiles_off = off; go.ntiles = nt;
+            off += img;
+            continue;
         }
         if (narrow) {
             const long long tabn = conv_narrow_group_bytes(P), tiln = align256(t * (long long)sizeof(pipe::GroupTile));
@@ -263,6 +327,15 @@ int storm::program_run_group(const storm_op* const* ops, int n_ops, void* const*
     for (int k = 0; k < n_ops; ++k) {
         if (gi < n_gops && gops[gi].k == k) {
             const GroupOp& go = gops[gi++];
+            if (go.kind == 4) {
+                if (int rc = launch_fir_group(go.bn & 3, reinterpret_cast<const FirProblem*>(dev_blob + go.table_off), dev_blob + go.tiles_off, (int)go.ntiles, go.bn >> 2, go.outC,
+                                              dtype, (hipStream_t)s)) return rc;
+                continue;
+            }
+            if (go.kind == 3) {
+                if (int rc = launch_conv_thin_group(dev_blob + go.table_off, go.outC, go.ntiles, go.bn, dtype, (hipStream_t)s)) return rc;
+                continue;
+            }
             if (go.kind == 2) {
                 storm_conv_args a0;
                 memset(&a0, 0, sizeof(a0));

@@ -362,6 +362,30 @@ def test_conv_thin_input_kernel(dev, dtype, case, switch):
     assert torch.allclose(st, sref, rtol=2e-3, atol=2e-3 * float(sref.abs().max()))
 
 
+@pytest.mark.parametrize("k,with_skip", [(3, False), (1, True)])
+def test_conv_group_thin_input_equals_own_launches(dev, k, with_skip):
+    """The grouped form of conv_thin.hip (the stem conv3x3 over the packed input planes, ncsnpp.py:183, and the input-skip conv1x1 + h of Combine,
+    layerspp.py:44-59): three problems of one layer with their own batch sizes / image sizes / tensors in ONE launch - outputs and GroupNorm
+    partials equal every problem's own storm_conv launch bit for bit."""
+    from storm_amd import ops
+    dtype = torch.bfloat16
+    g = torch.Generator().manual_seed(80)
+    Cout = 128
+    w = ops.pack_conv_weight((torch.randn(Cout, 8, k, k, generator=g) * 0.3).to(dev), dtype)
+    bias = torch.randn(Cout, generator=g).to(dev)
+    problems = []
+    for B, H, W in ((2, 16, 64), (1, 19, 45), (3, 8, 37)):
+        x = torch.randn(B, 8, H, W, generator=g)
+        x[:, 4:] = 0.0
+        skip = nhwc(torch.randn(B, Cout, H, W, generator=g)).to(dtype).to(dev) if with_skip else None
+        problems.append(([ops.Seg(nhwc(x).to(dtype).to(dev), w, k * k)], dict(bias=bias, skip=skip, scale=0.5 if with_skip else 1.0)))
+    own = [ops.conv(segs, Cout, gn_partials=True, **kw) for segs, kw in problems]
+    assert ops.conv_kernel_name(problems[0][0], Cout, **problems[0][1]).startswith("storm::conv_thin_kernel")
+    outs, parts = ops.conv_group(problems, Cout, gn_partials=True)
+    for p in range(3):
+        assert torch.equal(outs[p], own[p][0]) and torch.equal(parts[p], own[p][1]), p
+
+
 PIPE128_CASES = {
     # name: (B, H, W, Cout, (Ca, Cb) of the 3x3 operand, fused GroupNorm on it, (Sa, Sb) of the fused 1x1 shortcut or None, CUs)
     "plain": (2, 19, 45, 120, (72, 0), False, None, None),            # 3 chunks (the last ragged), ragged tile rows / columns
