@@ -163,6 +163,13 @@ long long storm_attention_scratch_bytes(int B, int L, int C, int dtype);
 int storm_attention_ws(const void* q, const void* k, const void* vT, const float* bias, void* out, int B, int L, int C, int ldv,
                        long long q_bstride, long long k_bstride, long long vT_bstride, long long out_bstride, float scale, int dtype,
                        void* scratch, long long scratch_bytes, storm_stream_t s);
+/* The same for P problems of one layer in ONE launch (ragged micro-batches of a stream: their own batch sizes and sequence lengths; 16-bit
+ * operands; the key loop is never split: the group fills the chip).  q / k / out: P pointers to contiguous [B_p][L_p][C], vT: [B_p][C][ldv_p].
+ * A query block computes what the unsplit storm_attention computes for it.  blob: device scratch >= storm_attention_group_blob_bytes. */
+long long storm_attention_group_blob_bytes(const int* B, const int* L, int P);
+int storm_attention_group(const void* const* q, const void* const* k, const void* const* vT, void* const* out, const int* B, const int* L,
+                          const int* ldv, int P, const float* bias, int C, float scale, int dtype, void* blob, long long blob_bytes,
+                          storm_stream_t s);
 
 /* ------------------------------------------------------------------------------------------
  * GroupNorm(min(C/4,32) groups, eps) [+ SiLU] [+ FIR x2 up / down of BOTH the activated and

@@ -89,6 +89,8 @@ _SIGNATURES = {
     "storm_attention": ([_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _ll, _ll, _ll, _ll, _f, _i, _vp], C.c_int),
     "storm_attention_scratch_bytes": ([_i, _i, _i, _i], C.c_longlong),
     "storm_attention_ws": ([_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _ll, _ll, _ll, _ll, _f, _i, _vp, _ll, _vp], C.c_int),
+    "storm_attention_group_blob_bytes": ([C.POINTER(C.c_int), C.POINTER(C.c_int), _i], C.c_longlong),
+    "storm_attention_group": ([C.POINTER(_vp)] * 4 + [C.POINTER(C.c_int)] * 3 + [_i, _vp, _i, _f, _i, _vp, _ll, _vp], C.c_int),
     "storm_softmax_rows": ([_vp, _vp, _ll, _i, _i, _i, _vp], C.c_int),
     "storm_pack_input": ([C.POINTER(_vp), _i, _vp, _i, _i, _i, _i, _vp], C.c_int),
     "storm_time_embedding": ([_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _vp], C.c_int),

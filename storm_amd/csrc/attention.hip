@@ -16,6 +16,7 @@
 //   * the rescale factor of the online softmax is a per-lane scalar (one query per lane column of O^T).
 // bf16 or fp16 operands (T), fp32 accumulation / softmax.  C = 32 * CT channels (CT in {1, 2, 4, 8}); any L (ragged tiles masked).
 // fp32 (the parity path): attention_f32_kernel below, the same structure on the exact-fp32 MFMA (v_mfma_f32_32x32x2_f32).
+#include <vector>
 #include "conv_params.h"
 
 namespace storm {
@@ -32,11 +33,12 @@ __device__ __forceinline__ uint4 ldg16(const void* p) { return *reinterpret_cast
 // blocks do not fill the chip - one utterance is 16 workgroups, each a serial chain of 64 key tiles (154 us of a 2.8-ms evaluation) -
 // the chain is what a launch lasts: splitting it 8 ways is 8 x the workgroups and an eighth of the chain.
 template <typename T, int CT, bool SPLIT>
-__global__ __launch_bounds__(ATTN_THREADS)
-void attention_kernel(const T* __restrict__ q, const T* __restrict__ k, const T* __restrict__ vT,
-                      const float* __restrict__ bias, T* __restrict__ out, int L, int ldv, long long q_bs,
-                      long long k_bs, long long v_bs, long long o_bs, float scale_log2e,
-                      float* __restrict__ part_o, float* __restrict__ part_ml, int nsplit) {
+__device__ __forceinline__
+void attention_body(const T* __restrict__ q, const T* __restrict__ k, const T* __restrict__ vT,
+                    const float* __restrict__ bias, T* __restrict__ out, int L, int ldv, long long q_bs,
+                    long long k_bs, long long v_bs, long long o_bs, float scale_log2e,
+                    float* __restrict__ part_o, float* __restrict__ part_ml, int nsplit,
+                    const int b, const int q0, const int zsplit, const int nbatch) {
     constexpr int C = 32 * CT, KG = C / 16;            // channels; 16-channel k-groups of the score product
     constexpr int KROW = C * 2, KSLOTS = KROW / 16;    // K tile row: bytes, 16-B slots
     constexpr int KTILE = BK * KROW, VTILE = C * 64;   // bytes per buffer
@@ -47,7 +49,6 @@ void attention_kernel(const T* __restrict__ q, const T* __restrict__ k, const T*
     char* const kbuf = smem;                            // [2][KTILE]
     char* const vbuf = smem + 2 * KTILE;                // [2][VTILE]
 
-    const int b = blockIdx.y, q0 = blockIdx.x * BQ;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int j = lane & 31, h = lane >> 5;
     const T* qb = q + (long long)b * q_bs;
@@ -112,8 +113,8 @@ void attention_kernel(const T* __restrict__ q, const T* __restrict__ k, const T*
     };
 
     const int ntiles_all = (L + BK - 1) / BK;
-    const int n_lo = SPLIT ? (int)blockIdx.z * ntiles_all / nsplit : 0;
-    const int ntiles = SPLIT ? ((int)blockIdx.z + 1) * ntiles_all / nsplit : ntiles_all;      // (one past this range's last tile)
+    const int n_lo = SPLIT ? zsplit * ntiles_all / nsplit : 0;
+    const int ntiles = SPLIT ? (zsplit + 1) * ntiles_all / nsplit : ntiles_all;      // (one past this range's last tile)
     load_tile(n_lo * BK);
     store_tile(0);
     __syncthreads();
@@ -184,7 +185,7 @@ void attention_kernel(const T* __restrict__ q, const T* __restrict__ k, const T*
     const int qrow = q0 + wave * 32 + j;
     if (SPLIT) {                                     // this key range's partial result: O (unnormalised), running maximum (log2 domain), sum
         if (qrow < L) {
-            const long long prow = ((long long)blockIdx.z * gridDim.y + b) * L + qrow;
+            const long long prow = ((long long)zsplit * nbatch + b) * L + qrow;
             float* po = part_o + prow * C;
 #pragma unroll
             for (int t = 0; t < CT; ++t)
@@ -210,6 +211,27 @@ void attention_kernel(const T* __restrict__ q, const T* __restrict__ k, const T*
                 *reinterpret_cast<uint2*>(orow + c) = make_uint2(pack2(v[0], v[1], (T*)nullptr), pack2(v[2], v[3], (T*)nullptr));
             }
     }
+}
+
+template <typename T, int CT, bool SPLIT>
+__global__ __launch_bounds__(ATTN_THREADS)
+void attention_kernel(const T* __restrict__ q, const T* __restrict__ k, const T* __restrict__ vT,
+                      const float* __restrict__ bias, T* __restrict__ out, int L, int ldv, long long q_bs,
+                      long long k_bs, long long v_bs, long long o_bs, float scale_log2e,
+                      float* __restrict__ part_o, float* __restrict__ part_ml, int nsplit) {
+    attention_body<T, CT, SPLIT>(q, k, vT, bias, out, L, ldv, q_bs, k_bs, v_bs, o_bs, scale_log2e, part_o, part_ml, nsplit,
+                                 (int)blockIdx.y, (int)blockIdx.x * BQ, (int)blockIdx.z, (int)gridDim.y);
+}
+// The query blocks of SEVERAL problems (ragged micro-batches of one stream: different L) in one launch, never split (the group fills the chip):
+// item = (problem, batch item, query block) from a host-built list, the problem's tensors from a device table.  A query block computes what
+// the unsplit kernel computes for it.
+template <typename T, int CT>
+__global__ __launch_bounds__(ATTN_THREADS)
+void attention_group_kernel(const AttnProblem* __restrict__ tab, const AttnItem* __restrict__ items, const float* __restrict__ bias, float scale_log2e) {
+    const AttnItem it = items[blockIdx.x];
+    const AttnProblem& p = tab[it.problem];
+    attention_body<T, CT, false>(static_cast<const T*>(p.q), static_cast<const T*>(p.k), static_cast<const T*>(p.vT), bias, static_cast<T*>(p.out), p.L, p.ldv,
+                                 p.q_bs, p.k_bs, p.v_bs, p.o_bs, scale_log2e, nullptr, nullptr, 1, it.b, it.qblock * BQ, 0, 1);
 }
 
 // Merge of the key ranges: out = sum_s O_s 2^(m_s - m) / sum_s l_s 2^(m_s - m) + bias, m = max_s m_s; ranges in index order (fixed: bit-reproducible).
@@ -430,6 +452,31 @@ static int attn_dispatch(int C, const void* q, const void* k, const void* vT, co
     }
 }
 
+// grouped launch (common.h): 16-bit operands only (the fp32 parity kernel runs problem by problem)
+template <typename T, int CT>
+static int attn_group_launch(const AttnProblem* dev_tab, const AttnItem* dev_items, int n_items, const float* bias, float scale, hipStream_t st) {
+    constexpr int C = 32 * CT;
+    constexpr int lds = 2 * (BK * C * 2) + 2 * (C * 64);
+    auto kern = attention_group_kernel<T, CT>;
+    static bool attr_set = false;
+    if (!attr_set) {
+        STORM_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(kern, dim3((unsigned)n_items), dim3(ATTN_THREADS), lds, st, dev_tab, dev_items, bias, scale * 1.44269504088896341f);
+    STORM_LAUNCH_CHECK();
+    return STORM_OK;
+}
+int attn_query_blocks(int L) { return cdiv(L, BQ); }
+int launch_attention_group(const AttnProblem* dev_tab, const AttnItem* dev_items, int n_items, const float* bias, int C, float scale, int dtype, hipStream_t st) {
+    STORM_CHECK(dev_tab && dev_items && n_items > 0 && (dtype == STORM_BF16 || dtype == STORM_F16) && (C == 32 || C == 64 || C == 128 || C == 256),
+                "storm_attention (group): bad arguments");
+#define STORM_AG(T_) (C == 32 ? attn_group_launch<T_, 1>(dev_tab, dev_items, n_items, bias, scale, st) : C == 64 ? attn_group_launch<T_, 2>(dev_tab, dev_items, n_items, bias, scale, st) : \
+                      C == 128 ? attn_group_launch<T_, 4>(dev_tab, dev_items, n_items, bias, scale, st) : attn_group_launch<T_, 8>(dev_tab, dev_items, n_items, bias, scale, st))
+    return dtype == STORM_F16 ? STORM_AG(half_t) : STORM_AG(bf16_t);
+#undef STORM_AG
+}
+
 }  // namespace storm
 
 extern "C" int storm_attention_supported(int C, int dtype) {
@@ -462,4 +509,45 @@ extern "C" int storm_attention(const void* q, const void* k, const void* vT, con
                                int ldv, long long q_bstride, long long k_bstride, long long vT_bstride, long long out_bstride,
                                float scale, int dtype, storm_stream_t s) {
     return storm_attention_ws(q, k, vT, bias, out, B, L, C, ldv, q_bstride, k_bstride, vT_bstride, out_bstride, scale, dtype, nullptr, 0, s);
+}
+
+// One launch for the fused attention of P problems (ragged micro-batches of a stream: different B and L, one layer): 16-bit operands, never
+// split.  blob: device scratch >= storm_attention_group_blob_bytes; this convenience entry fills it with a synchronous copy (the whole-network
+// object keeps a pinned image).  q / k: [B_p][L_p][C], vT: [B_p][C][ldv_p], out: [B_p][L_p][C] (contiguous per problem).
+extern "C" long long storm_attention_group_blob_bytes(const int* B, const int* L, int P) {
+    if (B == nullptr || L == nullptr || P < 1) return -1;
+    long long items = 0;
+    for (int g = 0; g < P; ++g) items += (long long)B[g] * storm::attn_query_blocks(L[g]);
+    return ((long long)P * (long long)sizeof(storm::AttnProblem) + 255) / 256 * 256 + items * (long long)sizeof(storm::AttnItem);
+}
+extern "C" int storm_attention_group(const void* const* q, const void* const* k, const void* const* vT, void* const* out, const int* B, const int* L,
+                                     const int* ldv, int P, const float* bias, int C, float scale, int dtype, void* blob, long long blob_bytes,
+                                     storm_stream_t s) {
+    using namespace storm;
+    STORM_CHECK(q && k && vT && out && B && L && ldv && P >= 1 && blob, "storm_attention_group: bad arguments");
+    if ((dtype != STORM_BF16 && dtype != STORM_F16) || !storm_attention_supported(C, dtype)) {
+        set_error("storm_attention_group: C=%d dtype=%d is outside the grouped kernel (16-bit operands, C in {32, 64, 128, 256})", C, dtype);
+        return STORM_ERR_UNSUPPORTED;
+    }
+    const long long need = storm_attention_group_blob_bytes(B, L, P);
+    STORM_CHECK(blob_bytes >= need, "storm_attention_group: blob %lld < %lld bytes", blob_bytes, need);
+    const long long tab = ((long long)P * (long long)sizeof(AttnProblem) + 255) / 256 * 256;
+    std::vector<char> host((size_t)need);
+    AttnProblem* t = reinterpret_cast<AttnProblem*>(host.data());
+    AttnItem* it = reinterpret_cast<AttnItem*>(host.data() + tab);
+    long long ni = 0;
+    for (int g = 0; g < P; ++g) {
+        STORM_CHECK(q[g] && k[g] && vT[g] && out[g] && B[g] > 0 && L[g] > 0 && ldv[g] >= L[g] && ldv[g] % 8 == 0, "storm_attention_group: problem %d", g);
+        memset(&t[g], 0, sizeof(AttnProblem));
+        t[g].q = q[g]; t[g].k = k[g]; t[g].vT = vT[g]; t[g].out = out[g]; t[g].L = L[g]; t[g].ldv = ldv[g];
+        t[g].q_bs = (long long)L[g] * C; t[g].k_bs = (long long)L[g] * C; t[g].v_bs = (long long)C * ldv[g]; t[g].o_bs = (long long)L[g] * C;
+        for (int b = 0; b < B[g]; ++b)
+            for (int qb = 0; qb < attn_query_blocks(L[g]); ++qb) { AttnItem& a = it[ni++]; a.problem = g; a.b = b; a.qblock = qb; a.pad_ = 0; }
+    }
+    STORM_HIP(hipMemcpyAsync(blob, host.data(), (size_t)need, hipMemcpyHostToDevice, (hipStream_t)s));
+#ifndef STORM_HOST_SIM
+    STORM_HIP(hipStreamSynchronize((hipStream_t)s));
+#endif
+    return launch_attention_group(reinterpret_cast<const AttnProblem*>(blob), reinterpret_cast<const AttnItem*>(static_cast<char*>(blob) + tab), (int)ni, bias, C, scale,
+                                  dtype, (hipStream_t)s);
 }

@@ -225,11 +225,16 @@ inline int cdiv(long long a, long long b) { return (int)((a + b - 1) / b); }
 // The ragged micro-batches of a stream run the same op sequence on tensors of different (B, T).  Op k of every problem is launched together
 // where a grouped kernel exists for it (16-bit 3x3 convolutions of the conv_pipe family: one launch over all problems' pixel tiles),
 // one after the other otherwise.  The tables of the grouped launches (absolute device pointers) live in a caller-owned device blob.
-struct GroupOp { int k, outC, bn, kind; long long table_off, tiles_off, ntiles; };   // kind 0: 3x3 convolution (conv_pipe), 1: GroupNorm finalize, 2: 3x3 convolution to <= 4 planes (conv_narrow; outC = input channels, bn = fused GroupNorm / SiLU flags), 3: convolution over an 8-channel input (conv_thin; outC = problems, bn = taps), 4: FIR x2 of the 8-channel pyramids (outC = channels, bn = blocks << 2 | resample)
+struct GroupOp { int k, outC, bn, kind; long long table_off, tiles_off, ntiles; const void* aux; float faux; int pad2_; };   // kind 0: 3x3 convolution (conv_pipe), 1: GroupNorm finalize, 2: 3x3 convolution to <= 4 planes (conv_narrow; outC = input channels, bn = fused GroupNorm / SiLU flags), 3: convolution over an 8-channel input (conv_thin; outC = problems, bn = taps), 4: FIR x2 of the 8-channel pyramids (outC = channels, bn = blocks << 2 | resample), 5: fused attention (outC = channels)
 // one problem of a grouped GroupNorm finalize (norm_resample.hip): the arguments of its own storm_gn_finalize(_ss) call
 struct GnFinProblem { const float* pa; const float* pb; double* stats; const float* gamma; const float* beta; float* ss; long long count;
                       int Ca, tiles_a, Cb, tiles_b; float eps; int pad_; };
 struct GnFinItem { int problem, b; };
+// one problem / one workgroup of a grouped fused attention (attention.hip): the arguments of the problem's own storm_attention call
+struct AttnProblem { const void* q; const void* k; const void* vT; void* out; long long q_bs, k_bs, v_bs, o_bs; int L, ldv; };
+struct AttnItem { int problem, b, qblock, pad_; };
+int attn_query_blocks(int L);
+int launch_attention_group(const AttnProblem* dev_tab, const AttnItem* dev_items, int n_items, const float* bias, int C, float scale, int dtype, hipStream_t st);
 // one problem of a grouped FIR x2 launch (the 8-channel pyramids: fir_kernel): its own storm_fir_up2 / _down2 arguments + pixels per block
 struct FirProblem { const void* x; const void* add; void* out; int H, W, ppb, pad_; };
 int fir_group_problem(int resample, const void* x, const void* add, void* out, int B, int H, int W, int C, FirProblem& q);   // returns the problem's blocks

@@ -175,6 +175,21 @@ static bool fin_candidate(const storm_op* const* ops, int k, int P) {
     return true;
 }
 
+// the fused attention of the bottleneck (16-bit): STORM_OP_ATTENTION (q, k, vT, bias, out, scratch; B, L, C, ldv; scale)
+static bool attn_candidate(const storm_op* const* ops, int k, int P, int dtype) {
+    if (dtype != STORM_BF16 && dtype != STORM_F16) return false;
+    for (int g = 0; g < P; ++g) {
+        const storm_op& o = ops[g][k];
+        if (o.code != STORM_OP_ATTENTION || o.i[2] != ops[0][k].i[2] || o.f[0] != ops[0][k].f[0]) return false;
+    }
+    return true;
+}
+static long long attn_items(const storm_op* const* ops, int k, int P) {
+    long long n = 0;
+    for (int g = 0; g < P; ++g) n += ops[g][k].i[0] * attn_query_blocks((int)ops[g][k].i[1]);
+    return n;
+}
+
 static bool fir_candidate(const storm_op* const* ops, int k, int P) {
     for (int g = 0; g < P; ++g) {
         const storm_op& o = ops[g][k];
@@ -193,6 +208,7 @@ long long storm::program_group_blob_bytes(const storm_op* const* ops, int n_ops,
             n += align256((long long)P * sizeof(FirProblem)) + align256(items * 8);
             continue;
         }
+        if (attn_candidate(ops, k, P, dtype)) { n += align256((long long)P * sizeof(AttnProblem)) + align256(attn_items(ops, k, P) * (long long)sizeof(AttnItem)); continue; }
         if (fin_candidate(ops, k, P)) {
             long long items = 0;
             for (int g = 0; g < P; ++g) items += ops[g][k].i[4];
@@ -245,6 +261,37 @@ int storm::program_group_build(const storm_op* const* ops, int n_ops, void* cons
             }
             GroupOp& go = gops[n++];
             go.k = k; go.kind = 4; go.outC = (int)ops[0][k].i[3]; go.bn = (max_blocks << 2) | up; go.table_off = off; go.tiles_off = off + tab; go.ntiles = ni;
+            off += tab + til;
+            continue;
+        }
+        if (attn_candidate(ops, k, P, dtype)) {
+            const long long items = attn_items(ops, k, P);
+            const long long tab = align256((long long)P * sizeof(AttnProblem)), til = align256(items * (long long)sizeof(AttnItem));
+            STORM_CHECK(off + tab + til <= blob_bytes && n < max_gops && items < (1LL << 31), "storm_program_group: table blob too small");
+            AttnProblem* t = reinterpret_cast<AttnProblem*>(host_blob + off);
+            AttnItem* it = reinterpret_cast<AttnItem*>(host_blob + off + tab);
+            long long ni = 0;
+            const void* bias = nullptr;
+            for (int g = 0; g < P; ++g) {
+                const storm_op& o = ops[g][k];
+                bool ok = true;
+                void* p[STORM_OP_NPTR];
+                for (int j = 0; j < STORM_OP_NPTR; ++j) p[j] = resolve(o.p[j], bufs[g], n_bufs, ok);
+                STORM_CHECK(ok, "storm_program_group: op %d of problem %d references a missing buffer", k, g);
+                const int B = (int)o.i[0], L = (int)o.i[1], Cc = (int)o.i[2], ldv = (int)o.i[3];
+                AttnProblem& q = t[g];
+                memset(&q, 0, sizeof(q));
+                q.q = p[0]; q.k = p[1]; q.vT = p[2]; q.out = p[4]; q.L = L; q.ldv = ldv;
+                q.q_bs = (long long)L * Cc; q.k_bs = (long long)L * Cc; q.v_bs = (long long)Cc * ldv; q.o_bs = (long long)L * Cc;     // (run_ops' strides)
+                bias = p[3];
+                const int nq = attn_query_blocks(L);
+                // long rows first inside the list would balance better; the order is the problems' (deterministic, the result does not depend on it)
+                for (int b = 0; b < B; ++b)
+                    for (int qb = 0; qb < nq; ++qb) { AttnItem& a = it[ni++]; a.problem = g; a.b = b; a.qblock = qb; a.pad_ = 0; }
+            }
+            GroupOp& go = gops[n++];
+            go.k = k; go.kind = 5; go.outC = (int)ops[0][k].i[2]; go.bn = 0; go.table_off = off; go.tiles_off = off + tab; go.ntiles = ni;
+            go.aux = bias; go.faux = ops[0][k].f[0];
             off += tab + til;
             continue;
         }
@@ -327,6 +374,11 @@ int storm::program_run_group(const storm_op* const* ops, int n_ops, void* const*
     for (int k = 0; k < n_ops; ++k) {
         if (gi < n_gops && gops[gi].k == k) {
             const GroupOp& go = gops[gi++];
+            if (go.kind == 5) {
+                if (int rc = launch_attention_group(reinterpret_cast<const AttnProblem*>(dev_blob + go.table_off), reinterpret_cast<const AttnItem*>(dev_blob + go.tiles_off),
+                                                    (int)go.ntiles, static_cast<const float*>(go.aux), go.outC, go.faux, dtype, (hipStream_t)s)) return rc;
+                continue;
+            }
             if (go.kind == 4) {
                 if (int rc = launch_fir_group(go.bn & 3, reinterpret_cast<const FirProblem*>(dev_blob + go.table_off), dev_blob + go.tiles_off, (int)go.ntiles, go.bn >> 2, go.outC,
                                               dtype, (hipStream_t)s)) return rc;

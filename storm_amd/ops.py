@@ -176,6 +176,24 @@ def attention(q, k, vT, bias, scale):
     return out
 
 
+def attention_group(problems, bias, scale):
+    """ONE launch for the fused attention of several problems of one layer (storm_attention_group): problems = [(q, k, vT), ...] as
+    attention() takes them (own batch sizes / sequence lengths).  Returns the outputs per problem."""
+    P = len(problems)
+    Cc = problems[0][0].shape[-1]
+    arr = lambda vals: (C.c_void_p * P)(*vals)
+    outs = [torch.empty_like(q) for q, _, _ in problems]
+    Bs = (C.c_int * P)(*[q.shape[0] for q, _, _ in problems])
+    Ls = (C.c_int * P)(*[q.shape[1] for q, _, _ in problems])
+    ld = (C.c_int * P)(*[v.shape[-1] for _, _, v in problems])
+    need = L.lib().storm_attention_group_blob_bytes(Bs, Ls, P)
+    blob = torch.empty((need,), dtype=torch.uint8, device=outs[0].device)
+    L.check(L.lib().storm_attention_group(arr([L.ptr(q) for q, _, _ in problems]), arr([L.ptr(k) for _, k, _ in problems]),
+                                          arr([L.ptr(v) for _, _, v in problems]), arr([L.ptr(o) for o in outs]), Bs, Ls, ld, P, L.ptr(bias), Cc,
+                                          float(scale), L.dt(problems[0][0]), L.ptr(blob), need, L.stream()), "storm_attention_group")
+    return outs
+
+
 # ---------------------------------------------------------------- norm / resample ---------
 def gn_groups(C):
     return min(C // 4, 32)

@@ -958,6 +958,35 @@ def test_conv_wait_placement_under_late_dma_landing():
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-1000:]
 
 
+@pytest.mark.parametrize("dt", [torch.bfloat16, torch.float16])
+def test_attention_group_equals_own_unsplit_calls(dev, dt, switch):
+    """storm_attention_group: the fused attention (AttnBlockpp, layerspp.py:82-86) of three problems with their own batch sizes and sequence
+    lengths (ragged query / key tiles) in ONE launch - every problem equals its own UNSPLIT storm_attention call bit for bit (the grouped
+    launch never splits the key loop; a small call on its own would, and then agrees to fp32 rounding of the merge)."""
+    from storm_amd import ops
+    g = torch.Generator().manual_seed(44)
+    Cc = 64
+    bias = (0.1 * torch.randn(Cc, generator=g)).to(dev)
+    problems = []
+    for B, Lq in ((2, 100), (1, 260), (3, 33)):
+        q, k, v = (torch.randn(B, Lq, Cc, generator=g) for _ in range(3))
+        ldv = ops.round_up(Lq, 8)
+        vT = torch.zeros(B, Cc, ldv)
+        vT[:, :, :Lq] = v.transpose(1, 2)
+        problems.append(((q * 1.5).to(dt).to(dev), k.to(dt).to(dev), vT.to(dt).to(dev)))
+    switch("STORM_ATTN_SPLIT", 1)
+    own = [ops.attention(q, k, vT, bias, Cc ** -0.5) for q, k, vT in problems]
+    outs = ops.attention_group(problems, bias, Cc ** -0.5)
+    for p in range(3):
+        assert torch.equal(outs[p], own[p]), p
+    switch("STORM_ATTN_SPLIT", 0)
+    split = [ops.attention(q, k, vT, bias, Cc ** -0.5) for q, k, vT in problems]          # the small-call rule may split these
+    for p in range(3):
+        assert rel_l2(outs[p].float().cpu(), split[p].float().cpu()) < (8e-3 if dt == torch.bfloat16 else 1.5e-3)
+    with pytest.raises(Exception):
+        ops.attention_group([tuple(t.float() for t in problems[0])], bias, 1.0)       # fp32: outside the grouped kernel
+
+
 @pytest.mark.parametrize("dt,tol", [(torch.bfloat16, 8e-3), (torch.float16, 1.5e-3), (torch.float32, 2e-6)])
 @pytest.mark.parametrize("C,Lq", [(32, 100), (64, 32), (256, 70)])
 def test_fused_attention(dev, C, Lq, dt, tol):
