@@ -243,8 +243,10 @@ int launch_gn_finalize_group(const GnFinProblem* dev_tab, const void* dev_items,
 // bytes of the device blob for these shapes (a bound: every groupable op with all its tiles), 0 = nothing groups
 long long program_group_blob_bytes(const storm_op* const* ops, int n_ops, int P, int dtype);
 // fill the host image of the blob (tables hold pointers resolved against bufs[p]) and the list of grouped ops; returns their count or < 0
+// (stable_bufs: buffers [0, stable_bufs) keep their addresses from call to call - the workspace and the weight arena; an op that references any
+//  other buffer - the caller's input / time / output tensors - is never grouped, so the tables depend on those addresses only)
 int program_group_build(const storm_op* const* ops, int n_ops, void* const* const* bufs, int n_bufs, int P, int dtype, char* host_blob,
-                        long long blob_bytes, GroupOp* gops, int max_gops);
+                        long long blob_bytes, GroupOp* gops, int max_gops, int stable_bufs);
 // run ops [0, n_ops) of the P problems: grouped ops from the DEVICE copy of the blob, every other op problem by problem; the last op
 // (output head) with `negate`
 int program_run_group(const storm_op* const* ops, int n_ops, void* const* const* bufs, int n_bufs, int P, int dtype, const char* dev_blob,

@@ -563,9 +563,12 @@ struct storm_ncsnpp {
         long long blob_bytes = 0, ws_bytes = 0;
         std::vector<GroupOp> gops;
         char* host_blob = nullptr;              // PINNED host image of the tables: the per-call upload is a true asynchronous copy
-        std::vector<const void*> built_for;     // ws + every caller pointer the tables were built with
+        std::vector<const void*> built_for;     // the workspace / arena addresses the tables were built with (grouped ops reference nothing else)
         unsigned long long epoch = 0, used = 0;
-        ~GroupPlan() { if (host_blob) (void)hipHostFree(host_blob); }
+        // the image is read by an ASYNCHRONOUS copy: before it is rewritten (a caller pointer changed) the last copy that was enqueued from it
+        // must have executed - the host may be a whole evaluation ahead of the device
+        hipEvent_t copied{}; bool have_event = false, copy_pending = false;
+        ~GroupPlan() { if (have_event) { (void)hipEventSynchronize(copied); (void)hipEventDestroy(copied); } if (host_blob) (void)hipHostFree(host_blob); }
     };
     std::map<std::vector<int>, std::shared_ptr<GroupPlan>> groups;
     static constexpr size_t MAX_GROUPS = 16;
@@ -918,18 +921,16 @@ extern "C" int storm_ncsnpp_forward_group(storm_ncsnpp* h, int P, const int* B, 
     std::vector<void*> bufs((size_t)P * N_BUFS, nullptr);
     std::vector<void* const*> bufp((size_t)P);
     std::vector<const storm_op*> ops((size_t)P);
-    std::vector<const void*> sig;
-    sig.push_back(ws);
+    std::vector<const void*> sig;                           // what the tables of the grouped launches depend on: the workspace and the weight arena
+    sig.push_back(ws); sig.push_back(h->arena);
     for (int g = 0; g < P; ++g) {
         void** b = bufs.data() + (size_t)g * N_BUFS;
         b[BUF_WS] = static_cast<char*>(ws) + gp->ws_off[(size_t)g]; b[BUF_PARAMS] = h->arena;
         for (int j = 0; j < n_parts; ++j) {
             STORM_CHECK(parts[g * n_parts + j] != nullptr, "storm_ncsnpp_forward_group: input %d of problem %d is NULL", j, g);
             b[BUF_IN0 + j] = const_cast<void*>(parts[g * n_parts + j]);
-            sig.push_back(parts[g * n_parts + j]);
         }
         b[BUF_T] = t ? const_cast<float*>(t[g]) : nullptr; b[BUF_OUT] = out[g];
-        sig.push_back(b[BUF_T]); sig.push_back(out[g]);
         bufp[(size_t)g] = b;
         ops[(size_t)g] = gp->progs[(size_t)g]->ops.data();
     }
@@ -937,15 +938,21 @@ extern "C" int storm_ncsnpp_forward_group(storm_ncsnpp* h, int P, const int* B, 
     if (gp->blob_bytes > 0) {
         std::lock_guard<std::mutex> lk(h->mu);               // (one builder; the upload is ordered on the caller's stream before the launches below)
         if (gp->built_for != sig) {
+            if (gp->copy_pending) { STORM_HIP(hipEventSynchronize(gp->copied)); gp->copy_pending = false; }
             gp->gops.assign((size_t)n_ops, GroupOp());
-            const int n = program_group_build(ops.data(), n_ops, bufp.data(), N_BUFS, P, h->dtype, gp->host_blob, gp->blob_bytes, gp->gops.data(), n_ops);
+            const int n = program_group_build(ops.data(), n_ops, bufp.data(), N_BUFS, P, h->dtype, gp->host_blob, gp->blob_bytes, gp->gops.data(), n_ops, BUF_PARAMS + 1);
             if (n < 0) return n;
             gp->gops.resize((size_t)n);
             gp->built_for = sig;
         }
         // the tables travel with every call: 14 problems x 32 layers are ~1.5 MB, one asynchronous copy ahead of the evaluation's ~100 launches
         // (a cached device copy would be wrong as soon as two callers alternate workspaces or tensors on one handle)
-        if (!gp->gops.empty()) STORM_HIP(hipMemcpyAsync(ws, gp->host_blob, (size_t)gp->blob_bytes, hipMemcpyHostToDevice, (hipStream_t)s));
+        if (!gp->gops.empty()) {
+            STORM_HIP(hipMemcpyAsync(ws, gp->host_blob, (size_t)gp->blob_bytes, hipMemcpyHostToDevice, (hipStream_t)s));
+            if (!gp->have_event) { STORM_HIP(hipEventCreate(&gp->copied)); gp->have_event = true; }
+            STORM_HIP(hipEventRecord(gp->copied, (hipStream_t)s));
+            gp->copy_pending = true;
+        }
     }
     h->group_launches.fetch_add((long long)gp->gops.size(), std::memory_order_relaxed);
     return program_run_group(ops.data(), n_ops, bufp.data(), N_BUFS, P, h->dtype, static_cast<const char*>(ws), gp->gops.data(), (int)gp->gops.size(), negate, s);

@@ -231,11 +231,15 @@ long long storm::program_group_blob_bytes(const storm_op* const* ops, int n_ops,
 }
 
 int storm::program_group_build(const storm_op* const* ops, int n_ops, void* const* const* bufs, int n_bufs, int P, int dtype, char* host_blob,
-                               long long blob_bytes, GroupOp* gops, int max_gops) {
+                               long long blob_bytes, GroupOp* gops, int max_gops, int stable_bufs) {
     int n = 0;
     long long off = 0;
     std::vector<storm_conv_args> args((size_t)P);
     for (int k = 0; k < n_ops; ++k) {
+        bool stable = true;                                  // (tables are rebuilt only when a stable buffer moves: nothing else may be in them)
+        for (int g = 0; g < P && stable; ++g)
+            for (int j = 0; j < STORM_OP_NPTR; ++j) stable = stable && ops[g][k].p[j].buf < stable_bufs;
+        if (!stable) continue;
         if (fir_candidate(ops, k, P)) {
             long long items = 0;
             for (int g = 0; g < P; ++g) items += ops[g][k].i[0];
