@@ -435,6 +435,33 @@ def test_enhance_stream_storm_mode(dev):
     assert all(torch.equal(a, b) for a, b in zip(outs, own))
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("prec,tol", [("fp32", 1e-4), ("bf16", 3e-2), ("fp16", 3e-2)])
+def test_configs4_real_shape_grouped_stream_vs_reference(golden, prec, tol):
+    """The grouped evaluation against the REFERENCE at configs[4]'s real shape (fixture F16): the three 10-s utterances as THREE micro-batches of
+    one stream (ScoreModel.enhance_stream: their samplers in lockstep, the score network's 6 evaluations as storm_ncsnpp_forward_group calls over
+    three 256 x 1280 problems - grouped 3x3 / finalize / pyramid / attention launches at L = 5120), every utterance against the reference's own
+    run of it (model.py:273-310) under the noise the reference consumed."""
+    from tests.backend import setup_backend
+    from storm_amd.model import ScoreModel
+    dev = setup_backend("hip")
+    g = golden["f16_cfg4_shape"]
+    inp = _f16_inputs(g)
+    m = ScoreModel(backbone="ncsnpp", sde="ouve", theta=1.5, sigma_min=0.05, sigma_max=0.5, spec_factor=0.15, spec_abs_exponent=0.5)
+    m.dnn.load_state_dict(inp["sd"])
+    m._error_loading_ema = True
+    m = m.eval().to(dev)
+    m.set_precision(prec)
+    batches = [(w.to(dev), None) for w in inp["wavs"]]
+    fns = [(lambda it=iter([z.to(dev) for z in inp["noises"][b]]): next(it)) for b in range(3)]
+    n0 = m.dnn.group_launches()
+    outs, nfe = m.enhance_stream(batches, noise_fns=fns, N=int(g["pc_N"]), corrector="ald", corrector_steps=1, snr=0.5, return_nfe=True)
+    errs = [rel_l2(outs[k][0].cpu(), g[f"pc_out{k}"]) for k in range(3)]
+    print(f"F16 as a grouped stream of three micro-batches (27.8 M ncsnpp @ 256 x 1280) {prec}: wav rel-L2 vs reference " + " ".join(f"{e:.3e}" for e in errs))
+    assert nfe == int(g["pc_nfe"]) and m.last_group_calls == (6, 18) and m.dnn.group_launches() > n0
+    assert max(errs) < tol
+
+
 def test_no_cpu_fallback():
     """the product path refuses CPU tensors when the real library is bound"""
     from storm_amd import _lib
