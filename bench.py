@@ -61,6 +61,7 @@ def parse():
                    help="configs[4]: a step = N synthetic utterances of 2-10 s (seeded lengths), micro-batched by padded frame count "
                         "(<= --batch per launch, ragged rows) instead of one equal-length batch")
     p.add_argument("--no-group", action="store_true", help="--stream: one micro-batch after the other instead of grouped score evaluations (A/B)")
+    p.add_argument("--ode-idle", action="store_true", help="--sampler ode: rows that reached eps idle in their micro-batch instead of leaving it (A/B of the row compaction)")
     p.add_argument("--dist-world1", action="store_true",
                    help="with ONE rank: initialise the RCCL process group anyway and run the barrier / gather lines through it (dry run of the "
                         "N-rank path on one GPU; the driver launches the real one)")
@@ -253,7 +254,8 @@ def other_configs(model, dev, sync):
     out["configs4_stream_ode"] = {"workload": f"configs[4] as configured, shortened: ncsnpp, {n_sel} utterances of 2-10 s in {len(sel)} ragged micro-batches of the same stream, "
                                               "probability-flow ODE sampler (RK45, rtol = atol = 1e-5, one step controller per row), fp16, wav->wav",
                                   "value": n_sel / el, "unit": "utterances/s", "steps": 1, "ms_per_step": 1e3 * el, "dtype": "fp16",
-                                  "nfe_per_utterance": nfe, "micro_batches": len(sel), "grouped": True}
+                                  "nfe_per_utterance": nfe, "micro_batches": len(sel), "grouped": True,
+                                  "grouped_calls_rows": list(model.last_group_calls or ()), "rows_leave_their_micro_batch_at_eps": True}
     model.set_precision("bf16")
     # ---- configs[3]: ncsnpplarge (65.6 M), 8 utterances of 8 s per GPU, 50-step PC + 1 corrector step = 100 evaluations
     large = ScoreModel(backbone="ncsnpplarge", sde="ouve", theta=1.5, sigma_min=0.05, sigma_max=0.5, spec_factor=0.15, spec_abs_exponent=0.5)
@@ -413,7 +415,7 @@ def main():
     wav = (0.1 * torch.randn(args.batch, L, generator=g)).to(dev)          # inputs resident in HBM
 
     skw = dict(sampler_type="pc", predictor="reverse_diffusion", corrector=args.corrector, N=args.N, corrector_steps=args.corrector_steps,
-               snr=0.5) if args.sampler == "pc" else dict(sampler_type="ode", N=args.N)
+               snr=0.5) if args.sampler == "pc" else dict(sampler_type="ode", N=args.N, compact=not args.ode_idle)
     units = args.batch
     if args.stream:                                         # configs[4]: ragged micro-batches (2-10 s), resident in HBM
         batches, _ = ragged_stream(args.stream, args.batch, 77 + rank, g, dev)
@@ -470,6 +472,9 @@ def main():
         "rtf": None if args.stream else elapsed / args.steps / args.seconds,
         "rtf_per_audio_second": None if args.stream else elapsed / args.steps / (args.seconds * args.batch),
         "graph": {"mode": args.graph, "hip_graph_launches": model.dnn.graph_launches()},
+        # --stream: (grouped network calls, rows they evaluated) of the last step - with the ODE sampler's row compaction the rows are
+        # the evaluations the utterances needed, not micro-batch size x the slowest row's count
+        "grouped_calls_rows": list(getattr(model, "last_group_calls", None) or ()) if args.stream else None,
         # what the barrier / gather lines of the timed region ran through: the RCCL group the launcher's ranks formed, or nothing (one rank)
         "process_group": ({"backend": dist.get_backend(), "world_size": dist.get_world_size()} if dist is not None
                           else {"backend": None, "world_size": 1}),

@@ -13,8 +13,10 @@ Batches.  solve_ivp sees ONE flattened state, so `get_ode_sampler(sde, score_fn,
 the error norm exactly like the reference function does (per_row=False, the default: reference semantics for whatever
 batch it is handed).  The reference MODEL never hands it more than one utterance (model.py:224-244, minibatch = 1): every
 utterance has its own accepted / rejected step sequence.  per_row=True keeps that inside a batch: every row has its own
-t, h, error norm and accept / reject decision (rows that reached eps idle with h = 0 until the slowest row is done), so
-row b of a batched run equals the batch-1 run of utterance b - this is what ScoreModel.enhance_batch uses.
+t, h, error norm and accept / reject decision, so row b of a batched run equals the batch-1 run of utterance b - this is
+what ScoreModel.enhance_batch uses.  A row that has reached eps LEAVES the batch (compact=True, the default with per_row):
+its end state is set aside and the state tensors shrink to the rows still integrating, so the network is never evaluated
+on a finished row (compact=False: finished rows idle with h = 0 until the slowest row is done - the round-5 behaviour).
 """
 import math
 
@@ -36,14 +38,16 @@ _ERR_EXP = -1.0 / 5.0
 
 
 def get_ode_sampler(sde, score_fn, y, inverse_scaler=None, denoise=True, rtol=1e-5, atol=1e-5, method="RK45",
-                    eps=3e-2, device=None, noise_fn=None, seed=None, conditioning=None, per_row=False, **kwargs):
+                    eps=3e-2, device=None, noise_fn=None, seed=None, conditioning=None, per_row=False, compact=True, **kwargs):
     """Probability-flow ODE sampler: Dormand-Prince RK45 with scipy's step controller (solve_ivp's `RK45`, which
     sampling/__init__.py:71-141 runs on the host over the flattened COMPLEX state: its norms are
     ||v|| / sqrt(n) over the n complex elements).  Everything per element runs in HIP kernels: one fused pass per
     stage (storm_rk_combine_rows) and one for the scaled error sums (storm_rk_scaled_sumsq_rows); the host reads the B row
     sums once per attempted step (they decide acceptance) - no per-stage synchronisation.
     per_row: one step controller per row instead of one for the whole batch (module docstring).
-    Returns fn() -> (x, nfe); nfe = score evaluations executed; fn.nfev_rows = evaluations each row needed on its own."""
+    compact (per_row only): rows that reached eps leave the batch instead of idling in every further evaluation.
+    Returns fn() -> (x, nfe); nfe = score evaluations executed; fn.nfev_rows = evaluations each row needed on its own;
+    fn.rows_evaluated = rows summed over the executed evaluations (what the network really computed)."""
     if method != "RK45":
         raise NotImplementedError("only RK45 (Dormand-Prince) is implemented on the device")
     from .. import ops
@@ -59,18 +63,24 @@ def get_ode_sampler(sde, score_fn, y, inverse_scaler=None, denoise=True, rtol=1e
             n_row = yy.numel() // B
             groups = [[b] for b in range(B)] if per_row else [list(range(B))]
             G = len(groups)
-            rows = lambda vals: [vals[g] for g, ids in enumerate(groups) for _ in ids]      # per group -> per row
-            executed = 0
+            shrink = bool(compact) and per_row and B > 1
+            executed = rows_evaluated = 0
+            # what the right-hand side reads besides x: the rows still integrating (all of them until a row leaves)
+            y_c, cond_c = yy, conditioning
+
+            def rows(vals):                                   # per group -> per row
+                return [vals[g] for g, ids in enumerate(groups) for _ in ids]
 
             def f(t_g, x):
-                nonlocal executed
+                nonlocal executed, rows_evaluated
                 executed += 1
+                rows_evaluated += x.shape[0]
                 t_host = torch.tensor(rows(t_g), dtype=torch.float32)
                 vec_t = t_host.to(yy.device)
                 if isinstance(sde, OUVESDE):               # fused: theta (y - x) - 1/2 g^2 score in one pass; g(t) for the B
-                    score = rsde._score(x, vec_t, (yy,), dict(conditioning=conditioning))      # rows in the reference's own ops
-                    return ops.ouve_pf_drift_g(sde, x, yy, score.contiguous(), sde.diffusion(t_host))
-                return rsde.sde(x, vec_t, yy, conditioning=conditioning)[0].contiguous()
+                    score = rsde._score(x, vec_t, (y_c,), dict(conditioning=cond_c))           # rows in the reference's own ops
+                    return ops.ouve_pf_drift_g(sde, x, y_c, score.contiguous(), sde.diffusion(t_host))
+                return rsde.sde(x, vec_t, y_c, conditioning=cond_c)[0].contiguous()
 
             def norms(sumsq_rows):                            # scipy: ||v|| / sqrt(size) per solver state; ONE host read
                 s = sumsq_rows.cpu().tolist()
@@ -100,6 +110,9 @@ def get_ode_sampler(sde, score_fn, y, inverse_scaler=None, denoise=True, rtol=1e
             new_step, rejected = [True] * G, [False] * G
             min_step = [0.0] * G
             active = [(t[g] - t_end) * direction < 0 for g in range(G)]
+            # compaction (per_row): `orig[g]` = the batch row that solver state g integrates; finished rows are parked in x_done
+            orig = list(range(G))
+            x_done, nfev_done = None, [0] * G
             while any(active):
                 h, t_new = [0.0] * G, list(t)
                 for g in range(G):
@@ -148,8 +161,36 @@ def get_ode_sampler(sde, score_fn, y, inverse_scaler=None, denoise=True, rtol=1e
                     ops.copy_rows(x, x_new, acc_rows)
                     ops.copy_rows(x32, x_new32, acc_rows)
                     fk = ops.copy_rows(fk.clone() if fk is f0 else fk, f_new, acc_rows)
-            x = x32
-            ode_sampler.nfev_rows = rows(nfev)
+                if shrink and not all(active) and any(active):
+                    # rows that reached eps leave: park their end state, shrink every per-row tensor to the rows still integrating
+                    if x_done is None:
+                        x_done = torch.empty_like(yy, dtype=x32.dtype)
+                    gone = [g for g in range(G) if not active[g]]
+                    keep = [g for g in range(G) if active[g]]
+                    x_done.index_copy_(0, torch.tensor([orig[g] for g in gone], device=yy.device),
+                                       x32.index_select(0, torch.tensor(gone, device=yy.device)))
+                    for g in gone:
+                        nfev_done[orig[g]] = nfev[g]
+                    ki = torch.tensor(keep, device=yy.device)
+                    x, x32, fk, y_c = x.index_select(0, ki), x32.index_select(0, ki), fk.index_select(0, ki), y_c.index_select(0, ki)
+                    if isinstance(cond_c, (list, tuple)):
+                        cond_c = [c.index_select(0, ki) for c in cond_c]
+                    elif torch.is_tensor(cond_c):
+                        cond_c = cond_c.index_select(0, ki)
+                    pick = lambda vals: [vals[g] for g in keep]
+                    t, h_abs, nfev, new_step, rejected, min_step, active, orig = (pick(t), pick(h_abs), pick(nfev), pick(new_step),
+                                                                                    pick(rejected), pick(min_step), pick(active), pick(orig))
+                    G = len(keep)
+                    groups = [[g] for g in range(G)]
+            if x_done is not None:                            # the rows that were still in the batch at the end join the parked ones
+                x_done.index_copy_(0, torch.tensor(orig, device=yy.device), x32)
+                for g in range(G):
+                    nfev_done[orig[g]] = nfev[g]
+                x, nfev_rows = x_done, nfev_done
+            else:
+                x, nfev_rows = x32, rows(nfev)
+            ode_sampler.nfev_rows = nfev_rows
+            ode_sampler.rows_evaluated = rows_evaluated
             nfe = executed
             if denoise:
                 vec_eps = torch.ones(B, device=yy.device) * eps
@@ -159,4 +200,5 @@ def get_ode_sampler(sde, score_fn, y, inverse_scaler=None, denoise=True, rtol=1e
             return x, nfe
 
     ode_sampler.nfev_rows = None
+    ode_sampler.rows_evaluated = None
     return ode_sampler

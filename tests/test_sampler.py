@@ -121,6 +121,11 @@ def test_ode_per_row_control_equals_the_reference_per_utterance_runs(dev, golden
     coupled = get_ode_sampler(sde, score, y=y, eps=0.03, noise_fn=lambda: z)     # solve_ivp over the flattened batch
     xc, nc = coupled()
     assert coupled.nfev_rows == [nc] * 3 and not torch.equal(xc.cpu(), x.cpu())
+    # rows that reached eps leave the batch (compact, the default): the same bits and counts as idling them to the end, fewer rows evaluated
+    idle = get_ode_sampler(sde, score, y=y, eps=0.03, noise_fn=lambda: z, per_row=True, compact=False)
+    xi, ni = idle()
+    assert torch.equal(xi.cpu(), x.cpu()) and ni == nfe and idle.nfev_rows == sampler.nfev_rows
+    assert idle.rows_evaluated == 3 * nfe and sampler.rows_evaluated == sum(sampler.nfev_rows) < idle.rows_evaluated
 
 
 def full_sampler_noises(g):
