@@ -386,16 +386,20 @@ def test_enhance_stream_equals_its_micro_batches_own_runs(dev, sampler):
     def fns():
         its = [iter(d) for d in draws]
         return [(lambda it=it: next(it)) for it in its]
-    own, own_nfe = [], []
+    own, own_nfe, own_rows = [], [], []
     for (yb, bl), fn in zip(batches, fns()):
         o, n = m.enhance_batch(yb, lengths=bl, noise_fn=fn, return_nfe=True, **kw)
         own.append(o)
         own_nfe.append(n)
+        # rows the network evaluated: PC - every row in every evaluation; ODE - a row leaves its micro-batch when it reaches eps
+        # (sampling/ode.py: compact), so every row counts the evaluations IT needed
+        own_rows.append(sum(m.last_nfev_rows) if sampler == "ode" else n * len(bl))
+        assert sampler != "ode" or max(m.last_nfev_rows) == n
     outs, nfe = m.enhance_stream(batches, noise_fns=fns(), return_nfe=True, **kw)
     assert m.last_nfev_stream == own_nfe and m.last_group_calls is not None
     calls, rows = m.last_group_calls
     extra = 1 if sampler == "ode" else 0                       # (the ODE sampler's closing denoising step evaluates the score once more, sampling/__init__.py:97-100)
-    assert calls == max(own_nfe) + extra and rows == sum((n + extra) * len(bl) for n, bl in zip(own_nfe, lens))
+    assert calls == max(own_nfe) + extra and rows == sum(r + extra * len(bl) for r, bl in zip(own_rows, lens))
     print(f"enhance_stream {sampler}: evaluations per micro-batch {own_nfe}, grouped calls {calls} over {rows} rows")
     for p in range(len(lens)):
         assert torch.equal(outs[p], own[p]), p
