@@ -182,6 +182,13 @@ def profile_ops(net, Y, nfe_count):
             n_in = Bq * H * W * Cc
             row.update(algorithmic_bytes=(n_in + (4 * n_in if op.code == 7 else n_in // 4) + (4 * n_in if op.code == 7 else 0)) * esz,
                        kernel=f"storm::fir_kernel<{tname}, {1 if op.code == 7 else 2}>")
+        elif op.code in (13, 14):                           # the 8-channel pyramids, one launch each (csrc/pyramid.hip)
+            Bq, H, W, nl = int(op.i[1]), int(op.i[2]), int(op.i[3]), int(op.i[4] if op.code == 13 else op.i[5])
+            esz = 4 if code == 0 else 2
+            lv = sum(Bq * (H >> k) * (W >> k) * 8 * esz for k in range(nl))        # every level once
+            # input: the complex inputs read (8 B each) + every level written; output: every ph read + the complex score written
+            row.update(algorithmic_bytes=lv + Bq * H * W * 8 * (int(op.i[0]) if op.code == 13 else 1), H=H, W=W, levels=nl,
+                       kernel=f"storm::{'input_pyramid_kernel' if op.code == 13 else 'output_pyramid_kernel'}<{tname}" + (", true>" if op.code == 13 else ">"))
         rows.append(row)
     net.release_program(ops)                               # (the rows above hold plain numbers: the op list may go)
     return rows
@@ -512,7 +519,7 @@ def main():
         peak = F32_MFMA_PEAK_TFLOPS if args.precision == "fp32" else BF16_MFMA_PEAK_TFLOPS     # (fp16 MFMA peak = bf16 peak)
         ach = flops / (ms * 1e-3) / 1e12
         names = {0: "memset", 1: "pack_input", 2: "temb", 3: "dense", 4: "conv", 5: "gn_stats", 6: "gn_apply",
-                 7: "fir_up", 8: "fir_down", 9: "softmax", 10: "output_head", 11: "gn_finalize", 12: "attention"}
+                 7: "fir_up", 8: "fir_down", 9: "softmax", 10: "output_head", 11: "gn_finalize", 12: "attention", 13: "input_pyramid", 14: "output_pyramid"}
         by_kind = {}
         for r in rows:
             by_kind[names.get(r["code"], str(r["code"]))] = by_kind.get(names.get(r["code"], str(r["code"])), 0.0) + r["ms"]

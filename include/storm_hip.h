@@ -249,6 +249,21 @@ int storm_dense(const float* x, const float* W, const float* bias, float* out, i
 int storm_output_head(const void* pyr, const float* t /* NULL: no division */, const float* W,
                       const float* bias, int cin, float* out_cplx, int B, int F, int T,
                       int negate, int dtype, storm_stream_t s);
+/* The progressive input pyramid in ONE launch (csrc/pyramid.hip): levels[0] = the packed inputs (exactly storm_pack_input),
+ * levels[k] = FIR x2 down of levels[k - 1] (exactly storm_fir_down2), k < n_levels <= 4; levels[k]: NHWC [B][F >> k][T >> k][8].
+ * cplx_in == NULL: levels[0] is READ instead of written (the continuation of a pyramid deeper than three steps: ncsnpplarge has six).
+ * Replaces the packing above and pyramid_downsample before every Combine (ncsnpp.py:352-355; up_or_down_sampling.py:230-257): the input
+ * pyramid depends on the network input alone, so it is built once, ahead of the U-Net.                                            */
+int storm_input_pyramid(const float* const* cplx_in /* host array of n_in device ptrs, or NULL */, int n_in,
+                        void* const* levels /* host array of n_levels device ptrs */, int n_levels, int B, int F, int T,
+                        int dtype, storm_stream_t s);
+/* The progressive output pyramid and the head in ONE launch: p_{L-1} = ph[L-1]; p_k = up2(p_{k+1}) + ph[k] (exactly storm_fir_up2 with
+ * its add operand, every level rounded to the storage type); out = storm_output_head(p_0, ...).  ph[k]: NHWC [B][F >> k][T >> k][8], the
+ * outputs of the pyramid's 3x3 convolutions, finest first, n_levels <= 8.  Replaces pyramid_upsample + "pyramid = pyramid + pyramid_h"
+ * after every decoder level (ncsnpp.py:389-410) and the head (ncsnpp.py:441-449).                                                   */
+int storm_output_pyramid(const void* const* ph /* host array of n_levels device ptrs */, int n_levels, const float* t /* NULL: no division */,
+                         const float* W, const float* bias, int cin, float* out_cplx, int B, int F, int T, int negate, int dtype,
+                         storm_stream_t s);
 
 /* ------------------------------------------------------------------------------------------
  * OUVE SDE steps on the complex64 state [B, n] (n = F*T complex per batch item).
@@ -366,7 +381,9 @@ enum {
     STORM_OP_MEMSET = 0, STORM_OP_PACK_INPUT = 1, STORM_OP_TEMB = 2, STORM_OP_DENSE = 3,
     STORM_OP_CONV = 4, STORM_OP_GN_STATS = 5, STORM_OP_GN_APPLY = 6, STORM_OP_FIR_UP = 7,
     STORM_OP_FIR_DOWN = 8, STORM_OP_SOFTMAX = 9, STORM_OP_OUTPUT_HEAD = 10, STORM_OP_GN_FINALIZE = 11,
-    STORM_OP_ATTENTION = 12
+    STORM_OP_ATTENTION = 12,
+    STORM_OP_INPUT_PYRAMID = 13,    /* p[0..2] complex inputs (or none: level 0 is read), p[3..6] levels; i = n_in, B, F, T, n_levels */
+    STORM_OP_OUTPUT_PYRAMID = 14    /* p[0..7] ph (finest first), p[8] t, p[9] W, p[10] bias, p[11] out; i = cin, B, F, T, negate, n_levels */
 };
 #define STORM_OP_NPTR 13
 #define STORM_OP_NINT 24

@@ -17,7 +17,7 @@ find gpurun_out/prof_$TAG -name "*kernel_trace.csv" -size +20M -delete
 bash scripts/pmc_bench.sh pmcb_$TAG 2>&1 | tail -4
 rm -rf gpurun_out/pmc_$TAG; mkdir -p gpurun_out/pmc_$TAG
 timeout 600 rocprofv3 --kernel-trace --pmc GRBM_GUI_ACTIVE SQ_VALU_MFMA_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_LDS_BANK_CONFLICT --output-format csv -d gpurun_out/pmc_$TAG/sq -o p -- python bench.py --steps 1 --warmup 0 --N 2 --no-cpu-baseline --no-roofline > gpurun_out/pmc_$TAG/sq.log 2>&1
-python tools/pmc_cycles.py gpurun_out/pmc_$TAG/sq "$TAG" "conv_,gn_apply,attention,gn_finalize,fir_" | tee gpurun_out/pmc_summary_$TAG.txt | head -30
+python tools/pmc_cycles.py gpurun_out/pmc_$TAG/sq "$TAG" "conv_,gn_apply,attention,gn_finalize,fir_,pyramid" | tee gpurun_out/pmc_summary_$TAG.txt | head -30
 find gpurun_out/pmc_$TAG -name "*kernel_trace.csv" -delete
 fi
 run() { tag=$1; shift; timeout 900 python bench.py "$@" > gpurun_out/bench_${TAG}_$tag.json 2> gpurun_out/bench_${TAG}_$tag.err; python -c "

@@ -96,6 +96,8 @@ _SIGNATURES = {
     "storm_time_embedding": ([_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _vp], C.c_int),
     "storm_dense": ([_vp, _vp, _vp, _vp, _i, _i, _i, _vp], C.c_int),
     "storm_output_head": ([_vp, _vp, _vp, _vp, _i, _vp, _i, _i, _i, _i, _i, _vp], C.c_int),
+    "storm_input_pyramid": ([C.POINTER(_vp), _i, C.POINTER(_vp), _i, _i, _i, _i, _i, _vp], C.c_int),
+    "storm_output_pyramid": ([C.POINTER(_vp), _i, _vp, _vp, _vp, _i, _vp, _i, _i, _i, _i, _i, _vp], C.c_int),
     "storm_ouve_prior": ([_vp, _vp, _vp, _i, _ll, Ouve, _u64, _u64, _vp], C.c_int),
     "storm_ouve_ald_step": ([_vp, _vp, _vp, _vp, _vp, _i, _ll, Ouve, _f, _u64, _u64, _vp], C.c_int),
     "storm_ouve_predictor_step": ([_vp, _vp, _vp, _vp, _vp, _vp, _i, _ll, Ouve, _i, _i, _u64, _u64, _vp], C.c_int),

@@ -14,7 +14,7 @@ from .. import _lib as L
 
 # op codes (include/storm_hip.h)
 OP_MEMSET, OP_PACK_INPUT, OP_TEMB, OP_DENSE, OP_CONV, OP_GN_STATS, OP_GN_APPLY, OP_FIR_UP, OP_FIR_DOWN, \
-    OP_SOFTMAX, OP_OUTPUT_HEAD, OP_GN_FINALIZE, OP_ATTENTION = range(13)
+    OP_SOFTMAX, OP_OUTPUT_HEAD, OP_GN_FINALIZE, OP_ATTENTION, OP_INPUT_PYRAMID, OP_OUTPUT_PYRAMID = range(15)
 
 # buffer slots of storm_program_run
 BUF_WS, BUF_PARAMS, BUF_IN0, BUF_IN1, BUF_IN2, BUF_T, BUF_OUT = range(7)

@@ -438,8 +438,18 @@ struct Program {
         stats_off = arena.alloc(stats_bytes); stats_cursor = stats_off;
         { storm_op& o = op(STORM_OP_MEMSET); ws(o, 0, stats_off); o.i[0] = stats_bytes; }
         const int n_in = total / 2;
-        Act x0 = new_act(F, T, 8);
-        { storm_op& o = op(STORM_OP_PACK_INPUT); for (int j = 0; j < n_in; ++j) ref(o, j, BUF_IN0 + j, 0); ws(o, 3, x0.off); o.i[0] = n_in; o.i[1] = B; o.i[2] = F; o.i[3] = T; }
+        // the input pyramid (input_skip): a function of the network input alone, so every level is built here, ahead of the U-Net - the packing and
+        // up to three FIR x2 down steps per launch (csrc/pyramid.hip; `ncsnpp`: one launch, `ncsnpplarge` with its six steps: two)
+        std::vector<Act> ips;
+        for (int lvl = 0; lvl < nres; ++lvl) ips.push_back(new_act(F >> lvl, T >> lvl, 8));
+        for (int l0 = 0; l0 == 0 || l0 < nres - 1; l0 += 3) {
+            const int nl = std::min(4, nres - l0);
+            storm_op& o = op(STORM_OP_INPUT_PYRAMID);
+            if (l0 == 0) for (int j = 0; j < n_in; ++j) ref(o, j, BUF_IN0 + j, 0);
+            for (int k = 0; k < nl; ++k) ws(o, 3 + k, ips[(size_t)(l0 + k)].off);
+            o.i[0] = l0 == 0 ? n_in : 0; o.i[1] = B; o.i[2] = F >> l0; o.i[3] = T >> l0; o.i[4] = nl;
+        }
+        Act x0 = ips[0];
         int midx = 1;
         if (cfg.conditional()) {
             const long long temb = arena.alloc((long long)B * 4 * cfg.nf * 4);
@@ -463,9 +473,7 @@ struct Program {
             }
             if (lvl != nres - 1) {
                 Act h = resblock(midx, mods[midx], hs.back(), nullptr, 2); ++midx;
-                Act ipd = new_act(ip.H / 2, ip.W / 2, 8);
-                { storm_op& o = op(STORM_OP_FIR_DOWN); ws(o, 0, ip.off); ws(o, 1, ipd.off); o.i[0] = B; o.i[1] = ip.H; o.i[2] = ip.W; o.i[3] = 8; }
-                free_act(ip); ip = ipd;
+                free_act(ip); ip = ips[(size_t)lvl + 1];
                 const std::string kk = "all_modules." + std::to_string(midx) + ".";
                 ConvOpt c; c.bias = kk + "Conv_0.bias"; c.skip = &h; c.want_part = fuse_stats;
                 Act hc = conv({wseg(ip, kk + "Conv_0.weight", 1)}, h.C, h.H, h.W, c); ++midx;
@@ -480,7 +488,7 @@ struct Program {
         free_act(h1);
         h = resblock(midx, mods[midx], h2, nullptr, 0); ++midx;
         free_act(h2);
-        Act pyramid;
+        std::vector<Act> phs;
         for (int lvl = nres - 1; lvl >= 0; --lvl) {
             for (int r = 0; r < cfg.num_res_blocks + 1; ++r) {
                 Act skip = hs.back(); hs.pop_back();
@@ -502,23 +510,18 @@ struct Program {
                 free_act(pr.first);
             }
             midx += 2;
-            if (!pyramid.valid) pyramid = ph;
-            else {
-                Act pn = new_act(h.H, h.W, 8);
-                storm_op& o = op(STORM_OP_FIR_UP);
-                ws(o, 0, pyramid.off); ws(o, 1, ph.off); ws(o, 2, pn.off); o.i[0] = B; o.i[1] = pyramid.H; o.i[2] = pyramid.W; o.i[3] = 8;
-                free_act(pyramid); free_act(ph);
-                pyramid = pn;
-            }
+            phs.push_back(ph);                                   // (coarsest first; the up chain and the head run in ONE launch at the end)
             if (lvl != 0) { Act hn = resblock(midx, mods[midx], h, nullptr, 1); ++midx; free_act(h); h = hn; }
         }
         if (!hs.empty() || midx != (int)mods.size()) { set_error("storm_ncsnpp: planner walked %d of %zu modules", midx, mods.size()); return STORM_ERR_INVALID; }
         free_act(h);
-        storm_op& o = op(STORM_OP_OUTPUT_HEAD);
-        ws(o, 0, pyramid.off); if (cfg.conditional()) ref(o, 1, BUF_T, 0);
-        par(o, 2, "output_layer.weight"); par(o, 3, "output_layer.bias"); ref(o, 4, BUF_OUT, 0);
-        o.i[0] = total; o.i[1] = B; o.i[2] = F; o.i[3] = T; o.i[4] = 0;
-        free_act(pyramid);
+        // output pyramid (output_skip) + head: p = ph_0 + up(ph_1 + up(ph_2 + ...)), then output_layer / t - one launch (csrc/pyramid.hip)
+        storm_op& o = op(STORM_OP_OUTPUT_PYRAMID);
+        for (int k = 0; k < nres; ++k) ws(o, k, phs[(size_t)(nres - 1 - k)].off);
+        if (cfg.conditional()) ref(o, 8, BUF_T, 0);
+        par(o, 9, "output_layer.weight"); par(o, 10, "output_layer.bias"); ref(o, 11, BUF_OUT, 0);
+        o.i[0] = total; o.i[1] = B; o.i[2] = F; o.i[3] = T; o.i[4] = 0; o.i[5] = nres;
+        for (const Act& a : phs) free_act(a);
         ws_bytes = arena.top;
         return STORM_OK;
     }

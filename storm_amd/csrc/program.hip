@@ -115,6 +115,15 @@ static int run_ops(const storm_op* ops, int n_ops, void* const* bufs, int n_bufs
                 rc = storm_output_head(p[0], (const float*)p[1], (const float*)p[2], (const float*)p[3], (int)i[0],
                                        (float*)p[4], (int)i[1], (int)i[2], (int)i[3], (int)i[4], dtype, s);
                 break;
+            case STORM_OP_INPUT_PYRAMID: {
+                const float* in[3] = {(const float*)p[0], (const float*)p[1], (const float*)p[2]};
+                rc = storm_input_pyramid(i[0] > 0 ? in : nullptr, (int)i[0], p + 3, (int)i[4], (int)i[1], (int)i[2], (int)i[3], dtype, s);
+                break;
+            }
+            case STORM_OP_OUTPUT_PYRAMID:
+                rc = storm_output_pyramid(p, (int)i[5], (const float*)p[8], (const float*)p[9], (const float*)p[10], (int)i[0],
+                                          (float*)p[11], (int)i[1], (int)i[2], (int)i[3], (int)i[4], dtype, s);
+                break;
             default:
                 STORM_CHECK(false, "storm_program_run: op %d has unknown code %d", k, op.code);
         }
@@ -410,7 +419,7 @@ int storm::program_run_group(const storm_op* const* ops, int n_ops, void* const*
             continue;
         }
         for (int g = 0; g < P; ++g) {
-            if (k == n_ops - 1 && ops[g][k].code == STORM_OP_OUTPUT_HEAD) {
+            if (k == n_ops - 1 && (ops[g][k].code == STORM_OP_OUTPUT_HEAD || ops[g][k].code == STORM_OP_OUTPUT_PYRAMID)) {
                 storm_op head = ops[g][k];
                 head.i[4] = negate ? 1 : 0;
                 if (int rc = run_ops(&head, 1, bufs[g], n_bufs, dtype, s, nullptr)) return rc;

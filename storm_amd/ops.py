@@ -300,6 +300,38 @@ def output_head(pyr, t, W, bias, negate):
     return out
 
 
+def input_pyramid(cplx, dtype, n_levels, level0=None):
+    """The progressive input pyramid in ONE launch (storm_input_pyramid): level 0 = pack_input(cplx), level k = fir_down2 of level k - 1.
+    cplx None: `level0` (NHWC [B,F,T,8]) is read instead.  Returns the list of levels."""
+    if cplx is not None:
+        B, F, T = cplx[0].shape
+        views = [torch.view_as_real(c.contiguous()) for c in cplx]
+        arr = (C.c_void_p * len(views))(*[L.ptr(v) for v in views])
+        like, n_in = views[0], len(views)
+        levels = [_alloc((B, F, T, 8), dtype, like)]
+    else:
+        B, F, T, _ = level0.shape
+        arr, like, n_in = None, level0, 0
+        levels = [level0]
+    levels += [_alloc((B, F >> k, T >> k, 8), dtype, like) for k in range(1, n_levels)]
+    lv = (C.c_void_p * n_levels)(*[L.ptr(v) for v in levels])
+    L.check(L.lib().storm_input_pyramid(arr, n_in, lv, n_levels, B, F, T, L.dt(dtype), L.stream()), "storm_input_pyramid")
+    return levels
+
+
+def output_pyramid(phs, t, W, bias, negate):
+    """The progressive output pyramid + head in ONE launch (storm_output_pyramid): phs = the pyramid convolutions' outputs NHWC [B, F >> k, T >> k, 8],
+    finest first; p = phs[0] + up(phs[1] + up(...)); returns complex64 [B,F,T] = output_head(p, t, W, bias, negate)."""
+    B, F, T, _ = phs[0].shape
+    cin = W.shape[1]
+    out = torch.empty((B, F, T), dtype=torch.complex64, device=phs[0].device)
+    W2 = W.reshape(2, cin).contiguous()
+    arr = (C.c_void_p * len(phs))(*[L.ptr(v) for v in phs])
+    L.check(L.lib().storm_output_pyramid(arr, len(phs), L.ptr(t), L.ptr(W2), L.ptr(bias), cin, L.ptr(torch.view_as_real(out)), B, F, T, int(negate),
+                                         L.dt(phs[0]), L.stream()), "storm_output_pyramid")
+    return out
+
+
 # ---------------------------------------------------------------- SDE steps ---------------
 def _ouve(sde):
     return L.Ouve(float(sde.theta), float(sde.sigma_min), float(sde.sigma_max), int(sde.N))

@@ -9,7 +9,7 @@ from typing import Dict, List, Optional, Tuple
 from storm_amd import _lib as L
 from storm_amd.backbones.plan import (ALIGN, BUF_IN0, BUF_OUT, BUF_PARAMS, BUF_T, BUF_WS, N_BUFS, OP_ATTENTION, OP_CONV, OP_DENSE,
                                       OP_FIR_DOWN, OP_FIR_UP, OP_GN_APPLY, OP_GN_FINALIZE, OP_GN_STATS, OP_MEMSET, OP_OUTPUT_HEAD,
-                                      OP_PACK_INPUT, OP_SOFTMAX, OP_TEMB, NCSNppConfig, _up, module_list)
+                                      OP_PACK_INPUT, OP_SOFTMAX, OP_TEMB, OP_INPUT_PYRAMID, OP_OUTPUT_PYRAMID, NCSNppConfig, _up, module_list)
 
 
 # ------------------------------------------------------------------------------------------
@@ -499,12 +499,20 @@ class Program:
         self._ws(op, 0, self.stats_off)
         op.i[0] = self.stats_bytes
 
-        x0 = self.new_act(F, T, 8)
-        op = self._op(OP_PACK_INPUT)
-        for j in range(self.n_in):
-            self._ref(op, j, BUF_IN0 + j, 0)
-        self._ws(op, 3, x0)
-        op.i[0], op.i[1], op.i[2], op.i[3] = self.n_in, B, F, T
+        # the input pyramid is a function of the network input alone: packing + every FIR x2 down step ahead of the U-Net, up to three steps per launch
+        ips = [self.new_act(F >> lvl, T >> lvl, 8) for lvl in range(nres)]
+        l0 = 0
+        while l0 == 0 or l0 < nres - 1:
+            nl = min(4, nres - l0)
+            op = self._op(OP_INPUT_PYRAMID)
+            if l0 == 0:
+                for j in range(self.n_in):
+                    self._ref(op, j, BUF_IN0 + j, 0)
+            for k in range(nl):
+                self._ws(op, 3 + k, ips[l0 + k])
+            op.i[0], op.i[1], op.i[2], op.i[3], op.i[4] = (self.n_in if l0 == 0 else 0), B, F >> l0, T >> l0, nl
+            l0 += 3
+        x0 = ips[0]
 
         midx = 1
         if cfg.conditional:
@@ -536,11 +544,7 @@ class Program:
                 hs.append(h)
             if lvl != nres - 1:
                 h = self.resblock(midx, mods[midx][1], hs[-1], resample=2); midx += 1
-                ipd = self.new_act(ip.H // 2, ip.W // 2, 8)
-                op = self._op(OP_FIR_DOWN)
-                self._ws(op, 0, ip); self._ws(op, 1, ipd)
-                op.i[0], op.i[1], op.i[2], op.i[3] = B, ip.H, ip.W, 8
-                self.free(ip); ip = ipd
+                self.free(ip); ip = ips[lvl + 1]
                 kk = f"all_modules.{midx}."                          # Combine (layerspp.py:52-57), method 'sum'
                 hc = self.conv([self.wseg(ip, kk + "Conv_0.weight", 1)], h.C, h.H, h.W, bias_key=kk + "Conv_0.bias", skip=h,
                                want_part=self.fuse_stats)
@@ -554,7 +558,7 @@ class Program:
         self.free(h1)
         h = self.resblock(midx, mods[midx][1], h2); midx += 1
         self.free(h2)
-        pyramid = None
+        phs = []
         for lvl in reversed(range(nres)):
             for _ in range(cfg.num_res_blocks + 1):
                 skip = hs.pop()
@@ -574,25 +578,19 @@ class Program:
                 ph = self.conv([self.wseg(a, kc + "weight", 9)], total, h.H, h.W, outC=8, bias_key=kc + "bias")
                 self.free(a)
             midx += 2
-            if pyramid is None:
-                pyramid = ph
-            else:
-                pn = self.new_act(h.H, h.W, 8)
-                op = self._op(OP_FIR_UP)
-                self._ws(op, 0, pyramid); self._ws(op, 1, ph); self._ws(op, 2, pn)
-                op.i[0], op.i[1], op.i[2], op.i[3] = B, pyramid.H, pyramid.W, 8
-                self.free(pyramid); self.free(ph)
-                pyramid = pn
+            phs.append(ph)                                           # (coarsest first; the up chain and the head are one launch at the end)
             if lvl != 0:
                 hn = self.resblock(midx, mods[midx][1], h, resample=1); midx += 1
                 self.free(h); h = hn
         assert not hs and midx == len(mods)
         self.free(h)
-        op = self._op(OP_OUTPUT_HEAD)
-        self._ws(op, 0, pyramid)
+        op = self._op(OP_OUTPUT_PYRAMID)
+        for k in range(nres):
+            self._ws(op, k, phs[nres - 1 - k])
         if cfg.conditional:
-            self._ref(op, 1, BUF_T, 0)
-        self._par(op, 2, "output_layer.weight"); self._par(op, 3, "output_layer.bias")
-        self._ref(op, 4, BUF_OUT, 0)
-        op.i[0], op.i[1], op.i[2], op.i[3], op.i[4] = total, B, F, T, 0
-        self.free(pyramid)
+            self._ref(op, 8, BUF_T, 0)
+        self._par(op, 9, "output_layer.weight"); self._par(op, 10, "output_layer.bias")
+        self._ref(op, 11, BUF_OUT, 0)
+        op.i[0], op.i[1], op.i[2], op.i[3], op.i[4], op.i[5] = total, B, F, T, 0, nres
+        for a in phs:
+            self.free(a)

@@ -11,7 +11,7 @@ ROOT = os.path.dirname(os.path.dirname(HERE))
 CSRC = os.path.join(ROOT, "storm_amd", "csrc")
 OUT = os.path.join(HERE, "libstorm_sim.so")
 CXX = os.environ.get("STORM_SIM_CXX", "/opt/rocm/lib/llvm/bin/clang++")
-SOURCES = ["abi", "conv_igemm", "conv_pipe", "conv_pipe128", "conv_duo", "conv_thin", "conv_narrow", "attention", "ncsnpp_graph", "norm_resample", "elementwise", "sde", "spectral", "program"]
+SOURCES = ["abi", "conv_igemm", "conv_pipe", "conv_pipe128", "conv_duo", "conv_thin", "conv_narrow", "attention", "ncsnpp_graph", "norm_resample", "elementwise", "pyramid", "sde", "spectral", "program"]
 
 
 def build(force=False):

@@ -393,7 +393,7 @@ def test_enhance_stream_equals_its_micro_batches_own_runs(dev, sampler):
         own_nfe.append(n)
         # rows the network evaluated: PC - every row in every evaluation; ODE - a row leaves its micro-batch when it reaches eps
         # (sampling/ode.py: compact), so every row counts the evaluations IT needed
-        own_rows.append(sum(m.last_nfev_rows) if sampler == "ode" else n * len(bl))
+        own_rows.append(sum(m.last_nfev_rows) if sampler == "ode" else n * yb.shape[0])
         assert sampler != "ode" or max(m.last_nfev_rows) == n
     outs, nfe = m.enhance_stream(batches, noise_fns=fns(), return_nfe=True, **kw)
     assert m.last_nfev_stream == own_nfe and m.last_group_calls is not None

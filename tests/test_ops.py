@@ -734,6 +734,48 @@ def test_fir_golden(dev, golden):
     assert rel_l2(nchw(up2)[:, :5], torch.from_numpy(g["fir_up"]) + add[:, :5]) < 1e-6
 
 
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16, torch.float16])
+def test_pyramids_equal_their_chains(dev, dtype):
+    """csrc/pyramid.hip: the progressive input pyramid (pack + every FIR x2 down step) and the output pyramid (every FIR x2 up step + `+ ph` + the
+    head) as ONE launch each, against the chains of launches they replace - storm_pack_input / storm_fir_down2 and storm_fir_up2 (add) /
+    storm_output_head, themselves pinned by the reference's fixtures (test_fir_golden, the network fixtures) - BIT for bit: every level goes through
+    the same taps in the same order and is rounded to the storage type where the chain stored it.  Shapes with several workgroup tiles per axis,
+    one to three steps per launch, the continuation launch of a pyramid deeper than three steps (ncsnpplarge: six), seven output levels."""
+    from storm_amd import ops
+    g = torch.Generator().manual_seed(77)
+    big = dev.type != "cpu"
+    for (B, F_, T_, n_levels) in ([(2, 64, 128, 4), (1, 32, 192, 3), (2, 32, 64, 2), (1, 8, 24, 1)] if big else [(1, 64, 128, 4), (1, 16, 64, 2)]):
+        cplx = [torch.complex(torch.randn(B, F_, T_, generator=g), torch.randn(B, F_, T_, generator=g)).to(dev) for _ in range(2)]
+        chain = [ops.pack_input(cplx, dtype)]
+        for _ in range(n_levels - 1):
+            chain.append(ops.fir_down2(chain[-1]))
+        got = ops.input_pyramid(cplx, dtype, n_levels)
+        assert len(got) == n_levels
+        for k in range(n_levels):
+            assert got[k].shape == chain[k].shape and torch.equal(got[k], chain[k]), (B, F_, T_, n_levels, k)
+        if n_levels >= 3:                                   # a pyramid continued from a given level (levels 3 .. 6 of ncsnpplarge)
+            cont = ops.input_pyramid(None, dtype, n_levels - 1, level0=chain[1].clone())
+            for k in range(1, n_levels):
+                assert torch.equal(cont[k - 1], chain[k]), ("continued", k)
+    t = (0.2 + 0.7 * torch.rand(2, generator=g)).to(dev)
+    for (B, F_, T_, n_levels, cin) in ([(2, 64, 192, 4, 4), (1, 64, 128, 7, 6), (2, 40, 72, 1, 2), (1, 96, 64, 3, 4)] if big else [(1, 64, 128, 4, 4), (1, 64, 64, 7, 2)]):
+        phs = []
+        for k in range(n_levels):
+            ph = torch.zeros(B, F_ >> k, T_ >> k, 8)
+            ph[..., :cin] = torch.randn(B, F_ >> k, T_ >> k, cin, generator=g)
+            phs.append(ph.to(dtype).to(dev))
+        W, bias = (0.5 * torch.randn(2, cin, generator=g)).to(dev), torch.randn(2, generator=g).to(dev)
+        p = phs[-1]
+        for k in range(n_levels - 2, -1, -1):
+            p = ops.fir_up2(p, add=phs[k])
+        for tt, neg in ((t[:B].contiguous(), True), (None, False)):
+            want = ops.output_head(p, tt, W, bias, neg)
+            got = ops.output_pyramid(phs, tt, W, bias, neg)
+            assert torch.equal(torch.view_as_real(got), torch.view_as_real(want)), (B, F_, T_, n_levels, neg)
+    with pytest.raises(Exception):
+        ops.input_pyramid([torch.zeros(1, 12, 16, dtype=torch.complex64, device=dev)], dtype, 4)       # 12 rows: not divisible by 2^3
+
+
 @pytest.mark.parametrize("name", ["up2", "down2", "mixed", "updown"])
 def test_upfirdn2d_reference_argument_list(dev, golden, name):
     """storm_upfirdn2d = the reference's one native-op ABI with its own argument list (op/upfirdn2d.cpp:12-22: input [N,H,W,1], kernel
