@@ -225,7 +225,7 @@ inline int cdiv(long long a, long long b) { return (int)((a + b - 1) / b); }
 // The ragged micro-batches of a stream run the same op sequence on tensors of different (B, T).  Op k of every problem is launched together
 // where a grouped kernel exists for it (16-bit 3x3 convolutions of the conv_pipe family: one launch over all problems' pixel tiles),
 // one after the other otherwise.  The tables of the grouped launches (absolute device pointers) live in a caller-owned device blob.
-struct GroupOp { int k, outC, bn, kind; long long table_off, tiles_off, ntiles; const void* aux; float faux; int pad2_; };   // kind 0: 3x3 convolution (conv_pipe), 1: GroupNorm finalize, 2: 3x3 convolution to <= 4 planes (conv_narrow; outC = input channels, bn = fused GroupNorm / SiLU flags), 3: convolution over an 8-channel input (conv_thin; outC = problems, bn = taps), 4: FIR x2 of the 8-channel pyramids (outC = channels, bn = blocks << 2 | resample), 5: fused attention (outC = channels)
+struct GroupOp { int k, outC, bn, kind; long long table_off, tiles_off, ntiles; const void* aux; float faux; int pad2_; const void* aux2; int x[4]; };   // kind 0: 3x3 convolution (conv_pipe), 1: GroupNorm finalize, 2: 3x3 convolution to <= 4 planes (conv_narrow; outC = input channels, bn = fused GroupNorm / SiLU flags), 3: convolution over an 8-channel input (conv_thin; outC = problems, bn = taps), 4: FIR x2 of the 8-channel pyramids (outC = channels, bn = blocks << 2 | resample), 5: fused attention (outC = channels), 6: GroupNorm-apply + SiLU + FIR x2 (outC = Ca, bn = Cb, x = {groups, resample, rows per strip << 1 | shared-activation kernel, widest problem's column blocks}, aux / aux2 = gamma / beta, faux = eps)
 // one problem of a grouped GroupNorm finalize (norm_resample.hip): the arguments of its own storm_gn_finalize(_ss) call
 struct GnFinProblem { const float* pa; const float* pb; double* stats; const float* gamma; const float* beta; float* ss; long long count;
                       int Ca, tiles_a, Cb, tiles_b; float eps; int pad_; };
@@ -240,6 +240,16 @@ struct FirProblem { const void* x; const void* add; void* out; int H, W, ppb, pa
 int fir_group_problem(int resample, const void* x, const void* add, void* out, int B, int H, int W, int C, FirProblem& q);   // returns the problem's blocks
 int launch_fir_group(int resample, const FirProblem* dev_tab, const void* dev_items, int n_items, int max_blocks, int C, int dtype, hipStream_t st);
 int launch_gn_finalize_group(const GnFinProblem* dev_tab, const void* dev_items, int n_items, int groups, hipStream_t st);
+// one problem of a grouped GroupNorm-apply + SiLU + FIR x2 launch (norm_resample.hip: gn_apply_up / gn_apply_down(_share)): the arguments of its own
+// storm_gn_apply call + the geometry of the strips; items = (problem, y index of the problem's own launch) as GnFinItem
+struct GnApplyProblem { const void* xa; const void* xb; const double* stats; void* out_act; void* out_raw; int H, W, ncg, nstrips, cols, pad_; };
+struct GnApplyGroupPlan { int rows_per_strip, share, max_cols; long long items; };
+// the strips of the GROUP (any strip length / either down-sampling kernel gives the same bits: chosen by the group's workgroup count); 16-bit, SiLU only
+bool gn_apply_group_plan(int resample, int C, int P, const int* B, const int* H, const int* W, int dtype, GnApplyGroupPlan& plan);
+// fills problem g's geometry (pointers are the caller's) and appends its items; returns the items written
+long long gn_apply_group_problem(int resample, int C, int B, int dtype, const GnApplyGroupPlan& plan, int g, GnApplyProblem& q, GnFinItem* items);
+int launch_gn_apply_group(int resample, const GnApplyProblem* dev_tab, const void* dev_items, const GnApplyGroupPlan& plan, int Ca, int Cb, int G,
+                          const float* gamma, const float* beta, float eps, int dtype, hipStream_t st);
 // bytes of the device blob for these shapes (a bound: every groupable op with all its tiles), 0 = nothing groups
 long long program_group_blob_bytes(const storm_op* const* ops, int n_ops, int P, int dtype);
 // fill the host image of the blob (tables hold pointers resolved against bufs[p]) and the list of grouped ops; returns their count or < 0

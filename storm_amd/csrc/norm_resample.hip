@@ -7,6 +7,7 @@
 // reduced per thread in fp32 over <=256 pixels, then in fp64 across threads / workgroups
 // (one fp64 atomicAdd per (batch, group) per workgroup).  The resampling variants fuse
 // GN-apply + SiLU + FIR of BOTH the activated and the raw tensor (BigGAN block) in one pass.
+#include <algorithm>
 #include <cstdio>
 #include <cstdlib>
 #include "common.h"
@@ -264,11 +265,10 @@ constexpr int DN_ROWS = 16;                         // output rows per strip
 // where a plain fill reaches 6.9, profiles/r04f_hbm_probe.txt).
 // SILU: the activation as a compile-time choice (as a run-time flag it is if-converted: both results computed, a select per value)
 template <typename T, bool SILU, int NS>
-__global__ __launch_bounds__(256)
-void gn_apply_down_kernel(const T* __restrict__ xa, int Ca, const T* __restrict__ xb, int Cb,
+__device__ __forceinline__ void gn_apply_down_body(const T* __restrict__ xa, int Ca, const T* __restrict__ xb, int Cb,
                           int H, int W, int G, const double* __restrict__ stats,
                           const float* __restrict__ gamma, const float* __restrict__ beta, float eps,
-                          T* __restrict__ out_act, T* __restrict__ out_raw, int ncg, int nstrips, int nt_stores) {
+                          T* __restrict__ out_act, T* __restrict__ out_raw, int ncg, int nstrips, int nt_stores, const int by, const int bx) {
     constexpr int PER16 = Elem<T>::PER16;
     constexpr int CG = NS * PER16;                  // channels per workgroup
     constexpr int DN_COLS = 256 / NS;               // output columns per workgroup
@@ -276,7 +276,7 @@ void gn_apply_down_kernel(const T* __restrict__ xa, int Ca, const T* __restrict_
     const int C = Ca + Cb, tid = threadIdx.x;
     const int slot = tid % NS, col = tid / NS;
     const int OH = H / 2, OW = W / 2;
-    int t = blockIdx.y;                             // (channel group, strip, batch item)
+    int t = by;                             // (channel group, strip, batch item)
     const int cg = t % ncg; t /= ncg;
     const int strip = t % nstrips, b = t / nstrips;
     const int gs = C / G;
@@ -297,7 +297,7 @@ void gn_apply_down_kernel(const T* __restrict__ xa, int Ca, const T* __restrict_
     }
     __syncthreads();
     const int c = cg * CG + slot * PER16;
-    const int ox = blockIdx.x * DN_COLS + col;
+    const int ox = bx * DN_COLS + col;
     if (c >= C || ox >= OW) return;
     float pa[PER16], pb[PER16];
 #pragma unroll
@@ -397,6 +397,25 @@ void gn_apply_down_kernel(const T* __restrict__ xa, int Ca, const T* __restrict_
         }
     }
 }
+template <typename T, bool SILU, int NS>
+__global__ __launch_bounds__(256)
+void gn_apply_down_kernel(const T* __restrict__ xa, int Ca, const T* __restrict__ xb, int Cb, int H, int W, int G, const double* __restrict__ stats,
+          const float* __restrict__ gamma, const float* __restrict__ beta, float eps, T* __restrict__ out_act, T* __restrict__ out_raw,
+          int ncg, int nstrips, int nt_stores) {
+    gn_apply_down_body<T, SILU, NS>(xa, Ca, xb, Cb, H, W, G, stats, gamma, beta, eps, out_act, out_raw, ncg, nstrips, nt_stores, blockIdx.y, blockIdx.x);
+}
+// the strips of SEVERAL problems in one launch (grouped evaluation of a ragged stream's micro-batches, common.h): blockIdx.y = an item
+// (problem, the y index of the problem's own launch) of a host-built list; a strip is computed by the code of its own launch
+template <typename T, bool SILU, int NS>
+__global__ __launch_bounds__(256)
+void gn_apply_down_group_kernel(const GnApplyProblem* __restrict__ tab, const GnFinItem* __restrict__ items, int Ca, int Cb, int G,
+           const float* __restrict__ gamma, const float* __restrict__ beta, float eps, int nt_stores) {
+    const GnFinItem it = items[blockIdx.y];
+    const GnApplyProblem& q = tab[it.problem];
+    if ((int)blockIdx.x >= q.cols) return;
+    gn_apply_down_body<T, SILU, NS>(static_cast<const T*>(q.xa), Ca, static_cast<const T*>(q.xb), Cb, q.H, q.W, G, q.stats, gamma, beta, eps,
+                      static_cast<T*>(q.out_act), static_cast<T*>(q.out_raw), q.ncg, q.nstrips, nt_stores, it.b, blockIdx.x);
+}
 
 // Round 5: the down-sampling kernel with the ACTIVATION shared between neighbouring threads.  Timed without its SiLU the kernel above runs at the
 // memory time (169 of 280 us at the bench batch's level-0 launch, tools/debug/probe_gn_silu.py): it is bound by the activation - two quarter-rate
@@ -408,11 +427,10 @@ void gn_apply_down_kernel(const T* __restrict__ xa, int Ca, const T* __restrict_
 // each output keeps its own tap order: the same bits (test_groupnorm_fir_fused).  Wider register windows instead (two output columns per thread)
 // paid the saved instructions back in occupancy: tools/experiments/gn_down_two_columns.patch.
 template <typename T, bool SILU, int NS>
-__global__ __launch_bounds__(256)
-void gn_apply_down_share_kernel(const T* __restrict__ xa, int Ca, const T* __restrict__ xb, int Cb,
+__device__ __forceinline__ void gn_apply_down_share_body(const T* __restrict__ xa, int Ca, const T* __restrict__ xb, int Cb,
                                 int H, int W, int G, const double* __restrict__ stats,
                                 const float* __restrict__ gamma, const float* __restrict__ beta, float eps,
-                                T* __restrict__ out_act, T* __restrict__ out_raw, int ncg, int nstrips, int nt_stores) {
+                                T* __restrict__ out_act, T* __restrict__ out_raw, int ncg, int nstrips, int nt_stores, const int by, const int bx) {
     constexpr int PER16 = Elem<T>::PER16;
     constexpr int CG = NS * PER16;                  // channels per workgroup
     constexpr int DN_COLS = 256 / NS;               // output columns per workgroup
@@ -422,7 +440,7 @@ void gn_apply_down_share_kernel(const T* __restrict__ xa, int Ca, const T* __res
     const int C = Ca + Cb, tid = threadIdx.x;
     const int slot = tid % NS, col = tid / NS;
     const int OH = H / 2, OW = W / 2;
-    int t = blockIdx.y;                             // (channel group, strip, batch item)
+    int t = by;                             // (channel group, strip, batch item)
     const int cg = t % ncg; t /= ncg;
     const int strip = t % nstrips, b = t / nstrips;
     const int gs = C / G;
@@ -443,7 +461,7 @@ void gn_apply_down_share_kernel(const T* __restrict__ xa, int Ca, const T* __res
     }
     __syncthreads();
     const int c = cg * CG + slot * PER16;
-    const int ox = blockIdx.x * DN_COLS + col;
+    const int ox = bx * DN_COLS + col;
     const bool chan = c < C;                        // (a slot past a ragged last channel group loads nothing - but every thread takes part in the barriers)
     const bool live = chan && ox < OW;              // (a column past the image may still own input columns a live neighbour filters)
     float pa[PER16], pb[PER16];
@@ -600,6 +618,25 @@ void gn_apply_down_share_kernel(const T* __restrict__ xa, int Ca, const T* __res
         }
     }
 }
+template <typename T, bool SILU, int NS>
+__global__ __launch_bounds__(256)
+void gn_apply_down_share_kernel(const T* __restrict__ xa, int Ca, const T* __restrict__ xb, int Cb, int H, int W, int G, const double* __restrict__ stats,
+          const float* __restrict__ gamma, const float* __restrict__ beta, float eps, T* __restrict__ out_act, T* __restrict__ out_raw,
+          int ncg, int nstrips, int nt_stores) {
+    gn_apply_down_share_body<T, SILU, NS>(xa, Ca, xb, Cb, H, W, G, stats, gamma, beta, eps, out_act, out_raw, ncg, nstrips, nt_stores, blockIdx.y, blockIdx.x);
+}
+// the strips of SEVERAL problems in one launch (grouped evaluation of a ragged stream's micro-batches, common.h): blockIdx.y = an item
+// (problem, the y index of the problem's own launch) of a host-built list; a strip is computed by the code of its own launch
+template <typename T, bool SILU, int NS>
+__global__ __launch_bounds__(256)
+void gn_apply_down_share_group_kernel(const GnApplyProblem* __restrict__ tab, const GnFinItem* __restrict__ items, int Ca, int Cb, int G,
+           const float* __restrict__ gamma, const float* __restrict__ beta, float eps, int nt_stores) {
+    const GnFinItem it = items[blockIdx.y];
+    const GnApplyProblem& q = tab[it.problem];
+    if ((int)blockIdx.x >= q.cols) return;
+    gn_apply_down_share_body<T, SILU, NS>(static_cast<const T*>(q.xa), Ca, static_cast<const T*>(q.xb), Cb, q.H, q.W, G, q.stats, gamma, beta, eps,
+                      static_cast<T*>(q.out_act), static_cast<T*>(q.out_raw), q.ncg, q.nstrips, nt_stores, it.b, blockIdx.x);
+}
 
 // The same for x2 UP: out[2i] = 3/4 x[i] + 1/4 x[i - 1], out[2i + 1] = 3/4 x[i] + 1/4 x[i + 1] per axis (k = [1,3,3,1], gain 2 per
 // axis, zero boundary).  A thread owns one 16-byte channel slot of one INPUT column and walks down a strip of input rows: per
@@ -609,11 +646,10 @@ void gn_apply_down_share_kernel(const T* __restrict__ xa, int Ca, const T* __res
 // 4.1 TB/s, exactly what the LDS-tiled predecessor reached - a write-dominated stream does not get the copy rate on this part.
 constexpr int UP_ROWS = 16;                         // input rows per strip
 template <typename T, bool SILU, int NS>
-__global__ __launch_bounds__(256)
-void gn_apply_up_kernel(const T* __restrict__ xa, int Ca, const T* __restrict__ xb, int Cb,
+__device__ __forceinline__ void gn_apply_up_body(const T* __restrict__ xa, int Ca, const T* __restrict__ xb, int Cb,
                         int H, int W, int G, const double* __restrict__ stats,
                         const float* __restrict__ gamma, const float* __restrict__ beta, float eps,
-                        T* __restrict__ out_act, T* __restrict__ out_raw, int ncg, int nstrips, int nt_stores) {
+                        T* __restrict__ out_act, T* __restrict__ out_raw, int ncg, int nstrips, int nt_stores, const int by, const int bx) {
     constexpr int PER16 = Elem<T>::PER16;
     constexpr int CG = NS * PER16;
     constexpr int UP_COLS = 256 / NS;               // input columns per workgroup
@@ -621,7 +657,7 @@ void gn_apply_up_kernel(const T* __restrict__ xa, int Ca, const T* __restrict__ 
     const int C = Ca + Cb, tid = threadIdx.x;
     const int slot = tid % NS, col = tid / NS;
     const int OH = 2 * H, OW = 2 * W;
-    int t = blockIdx.y;
+    int t = by;
     const int cg = t % ncg; t /= ncg;
     const int strip = t % nstrips, b = t / nstrips;
     const int gs = C / G;
@@ -642,7 +678,7 @@ void gn_apply_up_kernel(const T* __restrict__ xa, int Ca, const T* __restrict__ 
     }
     __syncthreads();
     const int c = cg * CG + slot * PER16;
-    const int ix = blockIdx.x * UP_COLS + col;
+    const int ix = bx * UP_COLS + col;
     if (c >= C || ix >= W) return;
     float pa[PER16], pb[PER16];
 #pragma unroll
@@ -747,6 +783,25 @@ void gn_apply_up_kernel(const T* __restrict__ xa, int Ca, const T* __restrict__ 
         if (i + 1 < iy1) store_row(2 * i + 2, h1, 0.75f, h0, 0.25f);
         h0 = h1;
     }
+}
+template <typename T, bool SILU, int NS>
+__global__ __launch_bounds__(256)
+void gn_apply_up_kernel(const T* __restrict__ xa, int Ca, const T* __restrict__ xb, int Cb, int H, int W, int G, const double* __restrict__ stats,
+          const float* __restrict__ gamma, const float* __restrict__ beta, float eps, T* __restrict__ out_act, T* __restrict__ out_raw,
+          int ncg, int nstrips, int nt_stores) {
+    gn_apply_up_body<T, SILU, NS>(xa, Ca, xb, Cb, H, W, G, stats, gamma, beta, eps, out_act, out_raw, ncg, nstrips, nt_stores, blockIdx.y, blockIdx.x);
+}
+// the strips of SEVERAL problems in one launch (grouped evaluation of a ragged stream's micro-batches, common.h): blockIdx.y = an item
+// (problem, the y index of the problem's own launch) of a host-built list; a strip is computed by the code of its own launch
+template <typename T, bool SILU, int NS>
+__global__ __launch_bounds__(256)
+void gn_apply_up_group_kernel(const GnApplyProblem* __restrict__ tab, const GnFinItem* __restrict__ items, int Ca, int Cb, int G,
+           const float* __restrict__ gamma, const float* __restrict__ beta, float eps, int nt_stores) {
+    const GnFinItem it = items[blockIdx.y];
+    const GnApplyProblem& q = tab[it.problem];
+    if ((int)blockIdx.x >= q.cols) return;
+    gn_apply_up_body<T, SILU, NS>(static_cast<const T*>(q.xa), Ca, static_cast<const T*>(q.xb), Cb, q.H, q.W, G, q.stats, gamma, beta, eps,
+                      static_cast<T*>(q.out_act), static_cast<T*>(q.out_raw), q.ncg, q.nstrips, nt_stores, it.b, blockIdx.x);
 }
 
 template <typename T, int RESAMPLE>
@@ -934,6 +989,60 @@ static int fir_problem(const void* x, const void* add, void* out, int B, int H, 
 int fir_group_problem(int resample, const void* x, const void* add, void* out, int B, int H, int W, int C, FirProblem& q) {
     return resample == 1 ? fir_problem<1>(x, add, out, B, H, W, C, q) : fir_problem<2>(x, add, out, B, H, W, C, q);
 }
+// ---- grouped GroupNorm-apply + SiLU + FIR x2 (common.h) -----------------------------------------------------------------------------------
+static int gn_group_ns(int C, int dtype) {
+    const int per16 = dtype == STORM_F32 ? 4 : 8, slots = C / per16;
+    return switches().gn_wide == 0 ? 8 : (slots % 32 == 0 ? 32 : slots % 16 == 0 ? 16 : 8);
+}
+bool gn_apply_group_plan(int resample, int C, int P, const int* B, const int* H, const int* W, int dtype, GnApplyGroupPlan& plan) {
+    if ((dtype != STORM_BF16 && dtype != STORM_F16) || (resample != 1 && resample != 2) || C % 8 != 0 || C > GN_MAX_C) return false;
+    const int NSr = gn_group_ns(C, dtype), ncg = cdiv(C, NSr * 8);
+    auto rows_of = [&](int g) { return resample == 1 ? H[g] : H[g] / 2; };
+    auto cols_of = [&](int g) { return cdiv(resample == 1 ? W[g] : W[g] / 2, 256 / NSr); };
+    auto wgs = [&](int r) { long long n = 0; for (int g = 0; g < P; ++g) n += (long long)cols_of(g) * ncg * B[g] * cdiv(rows_of(g), r); return n; };
+    int r = resample == 1 ? UP_ROWS : DN_ROWS;
+    if (switches().gn_rows > 0) r = switches().gn_rows;
+    else while (r > 4 && wgs(r) < 4LL * device_cus()) r >>= 1;      // strip_rows' rule on the GROUP's workgroups
+    plan.rows_per_strip = r;
+    const int shsw = switches().gn_down_share;
+    plan.share = resample == 2 && (shsw == 2 || (shsw == 0 && wgs(r) >= 4LL * device_cus()));
+    plan.max_cols = 0; plan.items = 0;
+    for (int g = 0; g < P; ++g) {
+        if (rows_of(g) < 1 || (resample == 2 && (H[g] % 2 || W[g] % 2))) return false;
+        plan.max_cols = std::max(plan.max_cols, cols_of(g));
+        plan.items += (long long)ncg * cdiv(rows_of(g), r) * B[g];
+    }
+    return plan.items > 0 && plan.items < 65536;
+}
+long long gn_apply_group_problem(int resample, int C, int B, int dtype, const GnApplyGroupPlan& plan, int g, GnApplyProblem& q, GnFinItem* items) {
+    const int NSr = gn_group_ns(C, dtype);
+    q.ncg = cdiv(C, NSr * 8);
+    q.nstrips = cdiv(resample == 1 ? q.H : q.H / 2, plan.rows_per_strip);
+    q.cols = cdiv(resample == 1 ? q.W : q.W / 2, 256 / NSr);
+    const long long gy = (long long)q.ncg * q.nstrips * B;
+    for (long long y = 0; y < gy; ++y) { items[y].problem = g; items[y].b = (int)y; }
+    return gy;
+}
+int launch_gn_apply_group(int resample, const GnApplyProblem* dev_tab, const void* dev_items, const GnApplyGroupPlan& plan, int Ca, int Cb, int G,
+                          const float* gamma, const float* beta, float eps, int dtype, hipStream_t st) {
+    STORM_CHECK(dev_tab && dev_items && gamma && beta && plan.items > 0 && plan.items < 65536 && plan.max_cols > 0, "storm_gn_apply (group): bad arguments");
+    const int NSr = gn_group_ns(Ca + Cb, dtype);
+    const GnFinItem* it = static_cast<const GnFinItem*>(dev_items);
+    const int nt = resample == 1 ? (switches().gn_nt & 1) : ((switches().gn_nt >> 1) & 1);
+#define STORM_GAG1(KERN_, T_, NS_) hipLaunchKernelGGL((KERN_<T_, true, NS_>), dim3((unsigned)plan.max_cols, (unsigned)plan.items), dim3(256), 0, st, dev_tab, it, Ca, Cb, G, gamma, beta, eps, nt)
+#define STORM_GAG(KERN_, T_) do { if (NSr == 32) STORM_GAG1(KERN_, T_, 32); else if (NSr == 16) STORM_GAG1(KERN_, T_, 16); else STORM_GAG1(KERN_, T_, 8); } while (0)
+#define STORM_GAGT(T_) do { if (resample == 1) STORM_GAG(gn_apply_up_group_kernel, T_); else if (plan.share) STORM_GAG(gn_apply_down_share_group_kernel, T_); \
+                            else STORM_GAG(gn_apply_down_group_kernel, T_); } while (0)
+    if (dtype == STORM_BF16) STORM_GAGT(bf16_t);
+    else if (dtype == STORM_F16) STORM_GAGT(half_t);
+    else STORM_CHECK(false, "storm_gn_apply (group): dtype %d", dtype);
+#undef STORM_GAGT
+#undef STORM_GAG
+#undef STORM_GAG1
+    STORM_LAUNCH_CHECK();
+    return STORM_OK;
+}
+
 int launch_fir_group(int resample, const FirProblem* dev_tab, const void* dev_items, int n_items, int max_blocks, int C, int dtype, hipStream_t st) {
     STORM_CHECK(dev_tab && dev_items && n_items > 0 && n_items < 65536 && max_blocks > 0 && C % 8 == 0 && C <= GN_MAX_C, "storm_fir (group): bad arguments");
     const GnGeom g = gn_geom(C);

@@ -207,6 +207,25 @@ static bool fir_candidate(const storm_op* const* ops, int k, int P) {
     return true;
 }
 
+// GroupNorm-apply + SiLU + FIR x2 of h and x (the up / down resblocks' first op: STORM_OP_GN_APPLY with resample 1 / 2): same channels, groups and
+// affine parameters in every problem
+static bool apply_candidate(const storm_op* const* ops, int k, int P, int dtype, GnApplyGroupPlan* plan) {
+    if (dtype != STORM_BF16 && dtype != STORM_F16) return false;
+    const storm_op& o0 = ops[0][k];
+    if (o0.code != STORM_OP_GN_APPLY || (o0.i[7] != 1 && o0.i[7] != 2) || o0.i[6] == 0 || P > 64) return false;
+    int B[64], H[64], W[64];
+    for (int g = 0; g < P; ++g) {
+        const storm_op& o = ops[g][k];
+        if (o.code != STORM_OP_GN_APPLY || o.i[0] != o0.i[0] || o.i[1] != o0.i[1] || o.i[5] != o0.i[5] || o.i[6] != o0.i[6] || o.i[7] != o0.i[7] || o.f[0] != o0.f[0]) return false;
+        if (o.p[6].buf < 0) return false;                    // (the resampling form always writes both tensors)
+        B[g] = (int)o.i[2]; H[g] = (int)o.i[3]; W[g] = (int)o.i[4];
+    }
+    GnApplyGroupPlan pl;
+    if (!gn_apply_group_plan((int)o0.i[7], (int)(o0.i[0] + o0.i[1]), P, B, H, W, dtype, pl)) return false;
+    if (plan) *plan = pl;
+    return true;
+}
+
 long long storm::program_group_blob_bytes(const storm_op* const* ops, int n_ops, int P, int dtype) {
     long long n = 0;
     if (P < 2) return 0;
@@ -224,6 +243,7 @@ long long storm::program_group_blob_bytes(const storm_op* const* ops, int n_ops,
             n += align256((long long)P * sizeof(GnFinProblem)) + align256(items * 8);
             continue;
         }
+        { GnApplyGroupPlan pl; if (apply_candidate(ops, k, P, dtype, &pl)) { n += align256((long long)P * sizeof(GnApplyProblem)) + align256(pl.items * 8); continue; } }
         if (narrow_candidate(ops, k, P, dtype)) {
             long long t = 0;
             for (int g = 0; g < P; ++g) t += narrow_tiles(ops[g][k]);
@@ -334,6 +354,36 @@ int storm::program_group_build(const storm_op* const* ops, int n_ops, void* cons
             off += tab + til;
             continue;
         }
+        { GnApplyGroupPlan pl;
+          if (apply_candidate(ops, k, P, dtype, &pl)) {
+            const long long tab = align256((long long)P * sizeof(GnApplyProblem)), til = align256(pl.items * 8);
+            STORM_CHECK(off + tab + til <= blob_bytes && n < max_gops, "storm_program_group: table blob too small");
+            GnApplyProblem* t = reinterpret_cast<GnApplyProblem*>(host_blob + off);
+            GnFinItem* it = reinterpret_cast<GnFinItem*>(host_blob + off + tab);
+            const storm_op& o0 = ops[0][k];
+            long long ni = 0;
+            const void *gamma = nullptr, *beta = nullptr;
+            for (int g = 0; g < P; ++g) {
+                const storm_op& o = ops[g][k];
+                bool ok = true;
+                void* p[STORM_OP_NPTR];
+                for (int j = 0; j < STORM_OP_NPTR; ++j) p[j] = resolve(o.p[j], bufs[g], n_bufs, ok);
+                STORM_CHECK(ok, "storm_program_group: op %d of problem %d references a missing buffer", k, g);
+                // run_ops: GN_APPLY (xa, xb, stats, gamma, beta, out_act, out_raw; Ca, Cb, B, H, W, G, silu, resample; eps)
+                GnApplyProblem& q = t[g];
+                memset(&q, 0, sizeof(q));
+                q.xa = p[0]; q.xb = p[1]; q.stats = (const double*)p[2]; q.out_act = p[5]; q.out_raw = p[6]; q.H = (int)o.i[3]; q.W = (int)o.i[4];
+                gamma = p[3]; beta = p[4];
+                ni += gn_apply_group_problem((int)o0.i[7], (int)(o0.i[0] + o0.i[1]), (int)o.i[2], dtype, pl, g, q, it + ni);
+            }
+            STORM_CHECK(ni == pl.items, "storm_program_group: GroupNorm-apply items %lld != %lld", ni, pl.items);
+            GroupOp& go = gops[n++];
+            go.k = k; go.kind = 6; go.outC = (int)o0.i[0]; go.bn = (int)o0.i[1]; go.table_off = off; go.tiles_off = off + tab; go.ntiles = ni;
+            go.aux = gamma; go.aux2 = beta; go.faux = o0.f[0];
+            go.x[0] = (int)o0.i[5]; go.x[1] = (int)o0.i[7]; go.x[2] = (pl.rows_per_strip << 1) | (pl.share ? 1 : 0); go.x[3] = pl.max_cols;
+            off += tab + til;
+            continue;
+          } }
         const bool narrow = narrow_candidate(ops, k, P, dtype), thin = !narrow && thin_candidate(ops, k, P, dtype);
         if (!narrow && !thin && !group_candidate(ops, k, P, dtype)) continue;
         long long t = 0;
@@ -387,6 +437,13 @@ int storm::program_run_group(const storm_op* const* ops, int n_ops, void* const*
     for (int k = 0; k < n_ops; ++k) {
         if (gi < n_gops && gops[gi].k == k) {
             const GroupOp& go = gops[gi++];
+            if (go.kind == 6) {
+                GnApplyGroupPlan pl;
+                pl.rows_per_strip = go.x[2] >> 1; pl.share = go.x[2] & 1; pl.max_cols = go.x[3]; pl.items = go.ntiles;
+                if (int rc = launch_gn_apply_group(go.x[1], reinterpret_cast<const GnApplyProblem*>(dev_blob + go.table_off), dev_blob + go.tiles_off, pl, go.outC, go.bn, go.x[0],
+                                                   static_cast<const float*>(go.aux), static_cast<const float*>(go.aux2), go.faux, dtype, (hipStream_t)s)) return rc;
+                continue;
+            }
             if (go.kind == 5) {
                 if (int rc = launch_attention_group(reinterpret_cast<const AttnProblem*>(dev_blob + go.table_off), reinterpret_cast<const AttnItem*>(dev_blob + go.tiles_off),
                                                     (int)go.ntiles, static_cast<const float*>(go.aux), go.outC, go.faux, dtype, (hipStream_t)s)) return rc;

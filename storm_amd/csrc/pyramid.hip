@@ -20,7 +20,7 @@
 
 namespace storm {
 namespace pyr {
-constexpr int THREADS = 256;
+constexpr int THREADS = 1024;                  // 16 waves: the levels are short dependent phases - the parallelism has to come from the width
 constexpr int MAXD = 3;                      // FIR x2 down steps per launch
 constexpr int MAXL = 8;                      // levels of the output pyramid
 constexpr int OTH = 32, OTW = 64;            // finest-level tile of the output pyramid
@@ -83,20 +83,38 @@ void input_pyramid_kernel(const pyr::InParams p) {
         const int H = p.H, W = p.W;
         const int oy0 = (ty * p.th) << nd, ox0 = (tx * p.tw) << nd, oy1 = oy0 + (p.th << nd), ox1 = ox0 + (p.tw << nd);
         T* const g0 = static_cast<T*>(p.lvl[0]) + (long long)b * H * W * 8;
-        for (int q = tid; q < nr[0] * nc[0]; q += THREADS) {
-            const int ry = q / nc[0], rx = q - ry * nc[0];
-            const int gy = r0[0] + ry, gx = c0[0] + rx;
-            float v[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-            if (gy >= 0 && gy < H && gx >= 0 && gx < W) {
-                const long long px = (long long)gy * W + gx;
-                if constexpr (PACK) {
-                    pack_pixel(p.in, p.n_in, (long long)b * H * W + px, v);
-                    if (gy >= oy0 && gy < oy1 && gx >= ox0 && gx < ox1) store8(g0 + px * 8, v);
-                } else {
-                    load8(g0 + px * 8, v);
+        // (every load of a thread's pixels is issued before the first store: one memory round trip per U pixels, not per pixel)
+        constexpr int U = 4;
+        const int n0 = nr[0] * nc[0];
+        for (int q0 = tid; q0 < n0; q0 += U * THREADS) {
+            float v[U][8];
+            long long gpx[U];
+            bool own[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const int q = q0 + u * THREADS;
+                const int ry = q / nc[0], rx = q - ry * nc[0];
+                const int gy = r0[0] + ry, gx = c0[0] + rx;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v[u][e] = 0.f;
+                own[u] = false; gpx[u] = 0;
+                if (q < n0 && gy >= 0 && gy < H && gx >= 0 && gx < W) {
+                    gpx[u] = (long long)gy * W + gx;
+                    if constexpr (PACK) {
+                        pack_pixel(p.in, p.n_in, (long long)b * H * W + gpx[u], v[u]);
+                        own[u] = gy >= oy0 && gy < oy1 && gx >= ox0 && gx < ox1;
+                    } else {
+                        load8(g0 + gpx[u] * 8, v[u]);
+                    }
                 }
             }
-            store8(lds + (long long)q * 8, v);
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const int q = q0 + u * THREADS;
+                if (q >= n0) continue;
+                if (PACK && own[u]) store8(g0 + gpx[u] * 8, v[u]);
+                store8(lds + (long long)q * 8, v[u]);
+            }
         }
     }
     __syncthreads();
@@ -191,15 +209,26 @@ void output_pyramid_kernel(const pyr::OutParams p) {
     const float tb = p.t ? p.t[b] : 1.0f;
     const int cin = p.cin;
     float2* const out_b = reinterpret_cast<float2*>(p.out) + (long long)b * p.H * p.Wd;
-    for (int q = tid; q < OTH * OTW; q += THREADS) {
-        const int ry = q / OTW, rx = q - ry * OTW;
-        const int gy = r0[0] + ry, gx = c0[0] + rx;
-        if (gy >= p.H || gx >= p.Wd) continue;
-        float v[8];
-        level_value(0, gy, gx, p.Wd, v);
+    // (both pixels of a thread are computed before either is stored: their loads share one round trip)
+    constexpr int PPT = OTH * OTW / THREADS;
+    static_assert(OTH * OTW % THREADS == 0, "whole pixels per thread");
+    float v[PPT][8];
+    bool ok[PPT];
+#pragma unroll
+    for (int j = 0; j < PPT; ++j) {
+        const int q = tid + j * THREADS;
+        const int gy = r0[0] + q / OTW, gx = c0[0] + q % OTW;
+        ok[j] = gy < p.H && gx < p.Wd;
+        if (ok[j]) level_value(0, gy, gx, p.Wd, v[j]);
+    }
+#pragma unroll
+    for (int j = 0; j < PPT; ++j) {
+        if (!ok[j]) continue;
+        const int q = tid + j * THREADS;
+        const int gy = r0[0] + q / OTW, gx = c0[0] + q % OTW;
         float o0 = 0.f, o1 = 0.f;
         for (int c = 0; c < cin; ++c) {
-            const float h = p.t ? v[c] / tb : v[c];
+            const float h = p.t ? v[j][c] / tb : v[j][c];
             o0 = fmaf(p.W[c], h, o0);
             o1 = fmaf(p.W[cin + c], h, o1);
         }
