@@ -61,6 +61,7 @@ def parse():
                    help="configs[4]: a step = N synthetic utterances of 2-10 s (seeded lengths), micro-batched by padded frame count "
                         "(<= --batch per launch, ragged rows) instead of one equal-length batch")
     p.add_argument("--no-group", action="store_true", help="--stream: one micro-batch after the other instead of grouped score evaluations (A/B)")
+    p.add_argument("--width", type=int, default=None, help="--stream: at most this many micro-batches in flight (a finished one is replaced by the next); default: all of them")
     p.add_argument("--ode-idle", action="store_true", help="--sampler ode: rows that reached eps idle in their micro-batch instead of leaving it (A/B of the row compaction)")
     p.add_argument("--dist-world1", action="store_true",
                    help="with ONE rank: initialise the RCCL process group anyway and run the barrier / gather lines through it (dry run of the "
@@ -433,7 +434,7 @@ def main():
             return model.enhance_batch(wav, seed=1000 * rank + i, return_nfe=True, **skw)
         # one stream (kernels of concurrent queues corrupt each other on this platform, profiles/r06_concurrent_repro.txt); the micro-batches
         # share LAUNCHES instead: ScoreModel.enhance_stream runs their samplers in lockstep around one grouped network call per step
-        outs, n_ = model.enhance_stream(batches, grouped=not args.no_group, seed=1000 * rank + 100 * i, return_nfe=True, **skw)
+        outs, n_ = model.enhance_stream(batches, grouped=not args.no_group, seed=1000 * rank + 100 * i, return_nfe=True, width=args.width, **skw)
         return outs[-1], n_                                 # mean score evaluations per utterance
 
     # socket power: by default NOT sampled inside the timed region (the sampler spawns rocm-smi every 0.2 s on rank 0's host cores and

@@ -174,13 +174,14 @@ class _Base(nn.Module):
         """the network whose evaluations a grouped stream shares (ScoreModel: dnn; StoRM: score_net - its denoiser runs once per micro-batch)"""
         return getattr(self, "score_net", None) or self.dnn
 
-    def enhance_stream(self, batches, grouped=True, return_nfe=False, seed=None, seeds=None, noise_fns=None, **kwargs):
+    def enhance_stream(self, batches, grouped=True, return_nfe=False, seed=None, seeds=None, noise_fns=None, width=None, **kwargs):
         """(ScoreModel and StochasticRegenerationModel.)  A stream of ragged micro-batches (BASELINE.json configs[4]) in lockstep: `batches` = [(y [b, L], lengths or None), ...] as
         storm_amd.distributed.bucket_by_frames forms them.  Every micro-batch runs enhance_batch - the same sampler, noise stream and
         (ODE) per-row step control as its own call - but the score evaluations of all micro-batches that are still running share ONE
         grouped network call per step (storm_amd.sampling.grouped, storm_ncsnpp_forward_group): the layers with a grouped kernel see
         the whole stream's pixel tiles in one launch instead of 2 - 3 rows at a time.  grouped=False: one micro-batch after the other.
         seed: micro-batch k draws from the Philox stream seed + k (seeds: one seed per micro-batch; noise_fns: one injected-noise callable per micro-batch instead).
+        width: at most this many micro-batches in flight (None = all); a finished one is replaced by the next of the list (storm_amd.sampling.grouped.run_grouped).
         Returns the list of enhanced batches (and the mean evaluations per utterance with return_nfe); self.last_nfev_stream = the
         evaluations every micro-batch executed."""
         from .sampling.grouped import run_grouped
@@ -197,7 +198,7 @@ class _Base(nn.Module):
                 kw["noise_fn"] = noise_fns[k]                  # (parity runs: the draws of micro-batch k)
             return self.enhance_batch(yb, lengths=bl, return_nfe=True, **kw)
         fns = [(lambda k=k: one(k)) for k in range(len(batches))]
-        res, batcher = run_grouped(self._score_network(), fns, device=self.device) if grouped else ([f() for f in fns], None)
+        res, batcher = run_grouped(self._score_network(), fns, device=self.device, width=width) if grouped else ([f() for f in fns], None)
         outs = [r[0] for r in res]
         self.last_nfev_stream = [r[1] for r in res]
         self.last_group_calls = None if batcher is None else (batcher.calls, batcher.rows)

@@ -80,31 +80,46 @@ class ScoreBatcher:
             self.cond.notify_all()
 
 
-def run_grouped(net, fns, device=None):
+def run_grouped(net, fns, device=None, width=None):
     """Run the callables `fns` (one per micro-batch; each runs a whole sampler that evaluates `net`) on threads whose evaluations of
     `net` are grouped.  Returns (results in order, batcher).  With one callable, or on a net without grouped evaluation, runs them
-    one after the other."""
+    one after the other.
+    width: at most this many micro-batches in flight (None = all of them).  A worker that finishes its micro-batch takes the next one
+    from the list, so the group stays full until the list runs dry - a long stream holds the scratch of `width` problems instead of
+    all of them, and samplers whose micro-batches need different numbers of evaluations (ODE) do not thin the group out before the
+    list's end.  Every micro-batch still computes what its own call computes (module docstring), whatever it is grouped with."""
     if len(fns) < 2 or not hasattr(net, "forward_parts_group"):
         return [f() for f in fns], None
-    batcher = ScoreBatcher(net, len(fns))
+    n_workers = len(fns) if width is None else max(1, min(int(width), len(fns)))
+    if n_workers < 2:
+        return [f() for f in fns], None
+    batcher = ScoreBatcher(net, n_workers)
     results, errors = [None] * len(fns), [None] * len(fns)
     grad = torch.is_grad_enabled()
+    todo = iter(range(len(fns)))
+    todo_lock = threading.Lock()
 
-    def worker(k):
-        _tls.batcher, _tls.pid = batcher, k
+    def worker(w):
+        _tls.batcher, _tls.pid = batcher, w
+        k = None
         try:
             if device is not None and torch.device(device).type == "cuda":
                 torch.cuda.set_device(device)
             with torch.set_grad_enabled(grad):
-                results[k] = fns[k]()
+                while batcher.error is None:
+                    with todo_lock:
+                        k = next(todo, None)
+                    if k is None:
+                        break
+                    results[k] = fns[k]()
         except BaseException as e:  # noqa: BLE001
-            errors[k] = e
+            errors[k if k is not None else 0] = e
             batcher.fail(e)
         finally:
             _tls.batcher = None
             batcher.leave()
 
-    threads = [threading.Thread(target=worker, args=(k,), daemon=True) for k in range(len(fns))]
+    threads = [threading.Thread(target=worker, args=(w,), daemon=True) for w in range(n_workers)]
     for th in threads:
         th.start()
     for th in threads:

@@ -406,6 +406,9 @@ def test_enhance_stream_equals_its_micro_batches_own_runs(dev, sampler):
     if dev.type != "cpu":
         seq = m.enhance_stream(batches, grouped=False, noise_fns=fns(), **kw)
         assert all(torch.equal(a, b) for a, b in zip(seq, own)) and m.last_group_calls is None
+        # rolling admission: two micro-batches in flight, the third joins when one of them is done - the same bits
+        roll = m.enhance_stream(batches, noise_fns=fns(), width=2, **kw)
+        assert all(torch.equal(a, b) for a, b in zip(roll, own)) and m.last_nfev_stream == own_nfe and m.last_group_calls is not None
     # an error inside one micro-batch's sampler reaches the caller (and releases the other threads)
     if sampler == "pc":
         boom = fns()

@@ -257,3 +257,45 @@ def test_time_argument_dtype_is_normalised(dev):
     b, _ = ops.ouve_ald_step(sde, x.clone().to(dev), s.to(dev), t32.double().to(dev), 0.5, z=z.to(dev))
     c, _ = ops.ouve_ald_step(sde, x.clone().to(dev), s.to(dev), torch.stack([t32, t32], 1).to(dev)[:, 0], 0.5, z=z.to(dev))
     assert torch.equal(a.cpu(), b.cpu()) and torch.equal(a.cpu(), c.cpu())
+
+
+def test_run_grouped_rolling_admission():
+    """storm_amd.sampling.grouped.run_grouped(width=): at most `width` micro-batches in flight, a finished one is replaced by the next of the
+    list, every callable gets the evaluations it asked for (here: a fake network that records who shared a call), errors reach the caller."""
+    from storm_amd.sampling.grouped import grouped_forward_parts, run_grouped
+
+    class FakeNet:
+        def __init__(self):
+            self.calls = []
+
+        def forward_parts_group(self, ins_list, time_conds=None):
+            self.calls.append(sorted(int(i[0][0]) for i in ins_list))
+            return [i[0] * 2 + t for i, t in zip(ins_list, time_conds)]
+
+    net = FakeNet()
+    need = [3, 7, 2, 5, 4, 1]                                # evaluations per micro-batch (an ODE stream: different counts)
+
+    def job(k):
+        def run():
+            acc = 0
+            for step in range(need[k]):
+                out = grouped_forward_parts(net, [torch.tensor([k])], torch.tensor([step]))
+                assert out is not None and int(out[0]) == 2 * k + step
+                acc += int(out[0])
+            return k, acc
+        return run
+    res, batcher = run_grouped(net, [job(k) for k in range(len(need))], width=3)
+    assert [r[0] for r in res] == list(range(len(need))) and [r[1] for r in res] == [2 * k * n + n * (n - 1) // 2 for k, n in enumerate(need)]
+    assert max(len(c) for c in net.calls) <= 3 and sum(len(c) for c in net.calls) == sum(need) == batcher.rows
+    assert any(c == [0, 1, 2] for c in net.calls) and any(3 in c for c in net.calls)      # 0, 1, 2 started together; 3 joined when one of them left
+    # without a width all six share the first call; width 1 = one after the other, no batcher
+    net.calls.clear()
+    res, batcher = run_grouped(net, [job(k) for k in range(len(need))])
+    assert net.calls[0] == list(range(6)) and [r[0] for r in res] == list(range(6))
+    res, batcher = run_grouped(net, [lambda: 1, lambda: 2], width=1)
+    assert res == [1, 2] and batcher is None
+
+    def boom():
+        raise RuntimeError("boom")
+    with pytest.raises(RuntimeError):
+        run_grouped(net, [job(1), boom, job(2), job(3)], width=2)
