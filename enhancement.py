@@ -45,6 +45,8 @@ def main():
     p.add_argument("--corrector-steps", type=int, default=1)
     p.add_argument("--snr", type=float, default=0.5)
     p.add_argument("--N", type=int, default=50)
+    p.add_argument("--sampler", choices=("pc", "ode"), default="pc", help="(extension) ode: the probability-flow RK45 sampler of ScoreModel.enhance(sampler_type='ode') - "
+                   "BASELINE.json configs[4]; score-only mode, one step controller per file (the reference integrates one file per solve_ivp call)")
     p.add_argument("--precision", choices=("fp32", "bf16", "fp16"), default="fp32")
     p.add_argument("--batch", type=int, default=16)
     p.add_argument("--seed", type=int, default=None, help="Philox seed of the sampler noise (default: drawn from torch's RNG, as the reference)")
@@ -54,6 +56,8 @@ def main():
                    "and share the launches of the score network (ScoreModel.enhance_stream); 1 = one micro-batch after the other")
     p.add_argument("--dist-world1", action="store_true", help="with ONE rank: form the RCCL process group anyway (dry run of the sharded path on one GPU)")
     args = p.parse_args()
+    if args.sampler == "ode" and args.mode != "score-only":
+        raise SystemExit("--sampler ode: score-only mode (the reference's StoRM ODE path drops the conditioning, model.py:671-691)")
 
     from storm_amd import distributed as D
     from storm_amd.model import DiscriminativeModel, ScoreModel, StochasticRegenerationModel
@@ -92,29 +96,29 @@ def main():
             outs = [model.enhance(wavs[i]) for i in ids]
         else:
             kw = {} if args.seed is None else dict(seed=args.seed + ids[0])     # distinct, reproducible draws per batch
-            x_hat = model.enhance_batch(y, corrector=args.corrector, N=args.N, corrector_steps=args.corrector_steps, snr=args.snr,
-                                        lengths=ragged, **kw)
+            x_hat = model.enhance_batch(y, lengths=ragged, **skw, **kw)
             outs = [x_hat[k, :lens[k]] for k in range(len(ids))]
         return ids, outs
 
+    skw = dict(sampler_type="ode", N=args.N) if args.sampler == "ode" else dict(corrector=args.corrector, N=args.N, corrector_steps=args.corrector_steps, snr=args.snr)
     buckets = D.bucket_by_frames([lengths[i] for i in mine], args.batch)
     if args.mode in ("score-only", "storm") and args.group > 1 and len(buckets) > 1:
         # a ragged set of files: micro-batches of 2 - 3 rows each - their score evaluations share launches (storm_ncsnpp_forward_group)
-        for c in range(0, len(buckets), args.group):
-            chunk, metas = [], []
-            for batch in buckets[c:c + args.group]:
-                ids = [mine[k] for k in batch]
-                lens = [lengths[i] for i in ids]
-                y = torch.zeros(len(ids), max(lens))
-                for k, i in enumerate(ids):
-                    y[k, :lens[k]] = wavs[i][0]
-                chunk.append((y, None if len(set(lens)) == 1 else lens))
-                metas.append((ids, lens))
-            outs = model.enhance_stream(chunk, corrector=args.corrector, N=args.N, corrector_steps=args.corrector_steps, snr=args.snr,
-                                        seeds=None if args.seed is None else [args.seed + ids[0] for ids, _ in metas])     # (the draws of the one-by-one path)
-            for (ids, lens), x_hat in zip(metas, outs):
-                for k, i in enumerate(ids):
-                    write_wav(os.path.join(args.enhanced_dir, os.path.basename(files[i])), x_hat[k, :lens[k]].float().reshape(-1), 16000)
+        # (--group micro-batches in flight; one that finishes - an ODE micro-batch needs its own number of evaluations - is replaced by the next)
+        chunk, metas = [], []
+        for batch in buckets:
+            ids = [mine[k] for k in batch]
+            lens = [lengths[i] for i in ids]
+            y = torch.zeros(len(ids), max(lens))
+            for k, i in enumerate(ids):
+                y[k, :lens[k]] = wavs[i][0]
+            chunk.append((y, None if len(set(lens)) == 1 else lens))
+            metas.append((ids, lens))
+        outs = model.enhance_stream(chunk, width=args.group, seeds=None if args.seed is None else [args.seed + ids[0] for ids, _ in metas],     # (the draws of the one-by-one path)
+                                    **skw)
+        for (ids, lens), x_hat in zip(metas, outs):
+            for k, i in enumerate(ids):
+                write_wav(os.path.join(args.enhanced_dir, os.path.basename(files[i])), x_hat[k, :lens[k]].float().reshape(-1), 16000)
         buckets = []
     for batch in buckets:
         ids, outs = run(batch)

@@ -545,6 +545,25 @@ def test_enhancement_cli(tmp_path):
         for k, i in enumerate(batch):
             sr, x = wavfile.read(os.path.join(out2, f"u{i}.wav"))
             assert x.shape == (lens3[i],) and rel_l2(torch.from_numpy(x), wantb[k, :lens3[i]]) < 1e-5, i
+    # (extension) --sampler ode: BASELINE.json configs[4] from the command line - the probability-flow RK45 sampler over the same ragged file set, the
+    # micro-batches grouped with rolling admission (--group 2); every file as from its own bucket's enhance_batch(sampler_type="ode") call
+    out3 = os.path.join(tmp_path, "enhanced3")
+    r = subprocess.run([sys.executable, os.path.join(root, "enhancement.py"), "--test_dir", noisy, "--enhanced_dir", out3, "--ckpt", path, "--mode", "score-only",
+                        "--sampler", "ode", "--N", "30", "--seed", "321", "--group", "2"], env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-2000:]
+    for bk in D.bucket_by_frames([lens3[i] for i in mine], 16):
+        batch = [mine[k] for k in bk]
+        yb = torch.zeros(len(batch), max(lens3[i] for i in batch))
+        for k, i in enumerate(batch):
+            yb[k, :lens3[i]] = (wavs + [long_wav])[i]
+        bl = [lens3[i] for i in batch]
+        wantb = m.enhance_batch(yb, sampler_type="ode", N=30, seed=321 + batch[0], lengths=None if len(set(bl)) == 1 else bl).cpu()
+        for k, i in enumerate(batch):
+            sr, x = wavfile.read(os.path.join(out3, f"u{i}.wav"))
+            assert x.shape == (lens3[i],) and rel_l2(torch.from_numpy(x), wantb[k, :lens3[i]]) < 1e-5, ("ode", i)
+    r = subprocess.run([sys.executable, os.path.join(root, "enhancement.py"), "--test_dir", noisy, "--enhanced_dir", out3, "--ckpt", path, "--mode", "storm", "--sampler", "ode"],
+                       env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode != 0 and "score-only" in (r.stderr + r.stdout)
 
 
 def test_discriminative_and_storm_surfaces(dev, golden):
