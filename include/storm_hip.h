@@ -307,6 +307,20 @@ int storm_ouve_pf_drift(float* out, const float* x, const float* y, const float*
  * sdes.py:203-207, so the right-hand side matches the reference's to the last bit) */
 int storm_ouve_pf_drift_g(float* out, const float* x, const float* y, const float* score, const float* g_rows, int B,
                           long long n, float theta, storm_stream_t s);
+/* ---- coefficient-table forms for any SDE  dx = a(t) (y - x) dt + g(t) dw: the second SDE the reference registers, OUVPSDE
+ * (sdes.py:255-326: a = 1/2 stiffness beta(t), g = sqrt(beta(t)), beta(t) = beta_min + t (beta_max - beta_min)).  a_rows / g_rows /
+ * std_rows = the per-row values at t_b (device fp32 [B]); the host side forms them with the reference's own fp32 expressions
+ * (sdes.py:286-301), the kernels do the state-sized work of OUVPSDE.prior_sampling (:306-310), SDE.discretize (:73-90),
+ * RSDE.discretize / rsde_parts (:123-157) and the predictors' update_fn (predictors.py:46-69) exactly as the storm_ouve_* ones do.
+ * kind / noise_free / z == NULL as in storm_ouve_predictor_step; N = the SDE's discretisation steps (dt = 1 / N). */
+int storm_sde_prior_rows(const float* y, const float* z, float* x, const float* std_rows, int B, long long n,
+                         uint64_t seed, uint64_t offset, storm_stream_t s);
+int storm_sde_predictor_step_rows(float* x, float* x_mean, const float* score, const float* y, const float* z,
+                                  const float* a_rows, const float* g_rows, int B, long long n, int N, int kind,
+                                  int noise_free, uint64_t seed, uint64_t offset, storm_stream_t s);
+/* out = a_b (y - x) - 1/2 g_b^2 score: the probability-flow right-hand side (sdes.py:92-145 with probability_flow=True) */
+int storm_sde_pf_drift_rows(float* out, const float* x, const float* y, const float* score, const float* a_rows,
+                            const float* g_rows, int B, long long n, storm_stream_t s);
 /* ---- probability-flow ODE sampler (sampling/__init__.py:71-141 hands the state to scipy's RK45 on the host) ----
  * out = x + h * sum_{j<n_terms} coef[j] K[j]   (one Runge-Kutta stage; K = host array of device pointers, <= 7) */
 int storm_rk_combine(float* out, const float* x, const float* const* K, const float* coef, int n_terms, float h,

@@ -33,6 +33,12 @@ TINY = {
 }
 
 
+# F18: OUVPSDE parameter sets (beta_min, beta_max, stiffness) and sampler settings (N, predictor, corrector, corrector steps)
+OUVP_CASES = {"a": (0.1, 2.0, 1), "b": (0.05, 1.2, 2.0)}
+OUVP_SAMPLERS = {"lang": (5, "reverse_diffusion", "langevin", 1), "em": (6, "euler_maruyama", "none", 1),
+                 "none": (4, "reverse_diffusion", "none", 1), "lang2": (3, "euler_maruyama", "langevin", 2)}
+
+
 def sd_hash(sd):
     h = hashlib.sha256()
     for k in sorted(sd):
@@ -533,6 +539,119 @@ def gen_f17(ref):
     np.savez_compressed(os.path.join(OUT, "f17_upfirdn2d.npz"), **f17)
 
 
+def gen_f18(ref):
+    """F18: the reference's second registered SDE, OUVPSDE (sdes.py:255-326).  (a) scalars: _beta / _std / _mean / sde / discretize /
+    prior_sampling at three times for two parameter sets; (b) pc_sampler traces with recorded noise and an analytic score:
+    reverse_diffusion + langevin, euler_maruyama + none, reverse_diffusion + none (the `ald` corrector rejects this SDE upstream,
+    correctors.py:69 - asserted); (c) the ODE sampler (sampling/__init__.py:71-141) on one utterance; (d) ScoreModel(sde="ouvp").enhance
+    wav -> wav with a tiny NCSN++ (reverse_diffusion + langevin, N = 4).  The oracle restatement (oracle/sde_ref.py::OUVP) is checked
+    against every one of them on the way."""
+    print("F18 OUVPSDE")
+    f18 = {}
+    g = torch.Generator().manual_seed(1818)
+    orig = torch.randn_like
+    for tag, (b0, b1, st) in OUVP_CASES.items():
+        rs = ref["sdes"].OUVPSDE(beta_min=b0, beta_max=b1, stiffness=st, N=30)
+        osde = SR.OUVP(b0, b1, st, N=30)
+        tt = torch.tensor([1.0, 0.5, 0.03])
+        xx = torch.randn(3, 1, 4, 4, dtype=torch.complex64, generator=g)
+        yy = torch.randn(3, 1, 4, 4, dtype=torch.complex64, generator=g)
+        zz = SR.complex_randn(xx.shape, g)
+        std_ref, mean_ref = rs._std(tt), rs._mean(xx, tt, yy)
+        drift_ref, diff_ref = rs.sde(xx, tt, yy)
+        f_ref, G_ref = rs.discretize(xx, tt, yy)
+        torch.randn_like = lambda x, *a, **k: zz.to(x.dtype)
+        try:
+            prior_ref = rs.prior_sampling(yy.shape, yy)
+        finally:
+            torch.randn_like = orig
+        assert torch.equal(std_ref, osde.std(tt)) and torch.equal(mean_ref, osde.mean(xx, tt, yy))
+        d_or, g_or = osde.sde(xx, tt, yy)
+        assert torch.equal(drift_ref, d_or) and torch.equal(diff_ref, g_or)
+        f_or, G_or = osde.discretize(xx, tt, yy)
+        assert torch.equal(f_ref, f_or) and torch.equal(G_ref, G_or)
+        assert torch.equal(prior_ref, osde.prior(yy, zz))
+        f18.update({f"{tag}_t": tt.numpy(), f"{tag}_x": c2np(xx), f"{tag}_y": c2np(yy), f"{tag}_z": c2np(zz), f"{tag}_std": std_ref.numpy(),
+                    f"{tag}_mean": c2np(mean_ref), f"{tag}_drift": c2np(drift_ref), f"{tag}_diff": diff_ref.numpy(), f"{tag}_f": c2np(f_ref),
+                    f"{tag}_G": G_ref.numpy(), f"{tag}_prior": c2np(prior_ref)})
+
+        def analytic_score(x, t, y, rs=rs):
+            return -(x - y) / (rs._std(t)[:, None, None, None] ** 2 + 0.1)
+
+        ysam = torch.randn(2, 1, 8, 16, dtype=torch.complex64, generator=g) * 0.3
+        f18[f"{tag}_sam_y"] = c2np(ysam)
+        for stag, (N, pred, corr, steps) in OUVP_SAMPLERS.items():
+            ndraw = 1 + N * ((0 if corr == "none" else steps) + 1)
+            noises = [SR.complex_randn(ysam.shape, g) for _ in range(ndraw)]
+            it = iter(noises)
+            torch.randn_like = lambda x, *a, **k: next(it).to(x.dtype)
+            try:
+                sde = ref["sdes"].OUVPSDE(beta_min=b0, beta_max=b1, stiffness=st, N=N)
+                x_ref, nfe_ref = ref["sampling"].get_pc_sampler(pred, corr, sde=sde, score_fn=analytic_score, y=ysam, eps=0.03, snr=0.5,
+                                                                corrector_steps=steps)()
+            finally:
+                torch.randn_like = orig
+            it = iter(noises)
+            x_or, nfe_or = SR.pc_sample(SR.OUVP(b0, b1, st, N=N), analytic_score, ysam, lambda: next(it), predictor=pred, corrector=corr,
+                                        corrector_steps=steps, snr=0.5)
+            assert nfe_ref == nfe_or
+            print(f"  {tag} sampler {stag}: nfe {nfe_ref}, bit-exact vs reference: {torch.equal(x_ref, x_or)}, rel {rel_l2(x_or, x_ref):.2e}")
+            assert rel_l2(x_or, x_ref) < 1e-6
+            f18.update({f"{tag}_{stag}_noise": np.stack([c2np(n) for n in noises]), f"{tag}_{stag}_out": c2np(x_ref),
+                        f"{tag}_{stag}_nfe": np.array(nfe_ref)})
+        try:                                                # upstream's ald corrector takes OUVE only
+            ref["sampling"].get_pc_sampler("reverse_diffusion", "ald", sde=rs, score_fn=analytic_score, y=ysam)
+            raise AssertionError("ald accepted an OUVPSDE")
+        except NotImplementedError:
+            pass
+
+        # probability-flow right-hand side and the ODE sampler, one utterance (scipy RK45, rtol = atol = 1e-5)
+        rsde = rs.reverse(analytic_score, probability_flow=True)
+        pf_ref = rsde.sde(xx, tt, yy)[0]
+        assert torch.equal(pf_ref, SR.pf_drift(osde, analytic_score, xx, tt, yy))
+        f18[f"{tag}_pf"] = c2np(pf_ref)
+        yo = ysam[:1]
+        zo = SR.complex_randn(yo.shape, g)
+        torch.randn_like = lambda x, *a, **k: zo.to(x.dtype)
+        try:
+            x_ode, nfe_ode = ref["sampling"].get_ode_sampler(rs, analytic_score, y=yo, eps=0.03, device="cpu")()
+        finally:
+            torch.randn_like = orig
+        print(f"  {tag} ode: nfev {nfe_ode}")
+        f18.update({f"{tag}_ode_z": c2np(zo), f"{tag}_ode_out": c2np(x_ode), f"{tag}_ode_nfe": np.array(nfe_ode)})
+
+    # ScoreModel(sde="ouvp").enhance wav -> wav, tiny NCSN++
+    M, DM = ref["model"], ref["data_module"].SpecsDataModule
+    b0, b1, st = OUVP_CASES["a"]
+    m = M.ScoreModel(backbone="ncsnpp", sde="ouvp", data_module_cls=DM, beta_min=b0, beta_max=b1, stiffness=st, spec_factor=0.15,
+                     spec_abs_exponent=0.5, nf=8)
+    cfg = NR.NCSNppConfig(nf=8, input_channels=4)
+    sd = NR.seeded_state_dict(cfg, seed=81)
+    m.dnn.load_state_dict(sd)
+    m.eval(no_ema=True)
+    wav = torch.randn(1, 8000, generator=g) * 0.1
+    N = 4
+    noises = [SR.complex_randn((1, 1, 256, 64), g) for _ in range(1 + 2 * N)]
+    it = iter(noises)
+    torch.randn_like = lambda x, *a, **k: next(it).to(x.dtype)
+    try:
+        with torch.no_grad():
+            xh, nfe, _ = m.enhance(wav.clone(), predictor="reverse_diffusion", corrector="langevin", N=N, corrector_steps=1, snr=0.5,
+                                   timeit=True, device="cpu")
+    finally:
+        torch.randn_like = orig
+    Y, nf_, _ = FR.wav_to_spec(wav, 0.15, 0.5)
+    it = iter(noises)
+    with torch.no_grad():
+        samp, nfe_or = SR.pc_sample(SR.OUVP(b0, b1, st, N=N), lambda x, t, y: -NR.ncsnpp_forward(sd, cfg, torch.cat([x, y], 1), t), Y,
+                                    lambda: next(it), predictor="reverse_diffusion", corrector="langevin", corrector_steps=1, snr=0.5)
+    w_or = FR.istft(FR.spec_back(samp.squeeze(), 0.15, 0.5), wav.shape[1]) * nf_
+    check("ouvp enhance tiny net", w_or, xh, 1e-4)
+    f18.update(enh_wav=wav.numpy(), enh_noise=np.stack([c2np(n) for n in noises]), enh_out=xh.numpy(), enh_nfe=np.array(int(nfe)),
+               enh_sdhash=np.array(sd_hash(sd)))
+    np.savez_compressed(os.path.join(OUT, "f18_ouvp.npz"), **f18)
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
     if "--only-f9" in sys.argv:
@@ -544,7 +663,7 @@ def main():
     if "--only-f8" in sys.argv:
         gen_f8(import_reference())
         return
-    for flag, fn in (("--only-f10", gen_f10), ("--only-f11", gen_f11), ("--only-f12", gen_f12), ("--only-f13", gen_f13), ("--only-f14", gen_f14), ("--only-f15", gen_f15), ("--only-f16", gen_f16), ("--only-f17", gen_f17)):
+    for flag, fn in (("--only-f10", gen_f10), ("--only-f11", gen_f11), ("--only-f12", gen_f12), ("--only-f13", gen_f13), ("--only-f14", gen_f14), ("--only-f15", gen_f15), ("--only-f16", gen_f16), ("--only-f17", gen_f17), ("--only-f18", gen_f18)):
         if flag in sys.argv:
             fn(import_reference())
             return
@@ -796,6 +915,8 @@ def main():
     gen_f13(ref)
     gen_f14(ref)
     gen_f15(ref)
+    gen_f17(ref)
+    gen_f18(ref)                                 # (F16, the 27.8 M net at 256 x 1280, is generated on request: --only-f16)
     for fn in sorted(os.listdir(OUT)):
         print(f"  {fn}: {os.path.getsize(os.path.join(OUT, fn))/1024:.0f} KiB")
     print("golden fixtures written to", OUT)

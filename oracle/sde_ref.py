@@ -1,7 +1,8 @@
-"""Oracle: OUVE SDE terms and the predictor-corrector sampler, PyTorch CPU fp32.
+"""Oracle: OUVE / OUVP SDE terms and the predictor-corrector sampler, PyTorch CPU fp32.
 
 TEST INFRASTRUCTURE (see oracle/__init__.py).  Restates
   * OUVESDE.sde/_std/prior_sampling and SDE.discretize  (sgmse/sdes.py:200-237, 73-90)
+  * OUVPSDE.sde/_mean/_std/prior_sampling                (sgmse/sdes.py:255-310)
   * RSDE.discretize                                      (sgmse/sdes.py:147-157)
   * ReverseDiffusionPredictor / EulerMaruyamaPredictor   (sgmse/sampling/predictors.py:41-69)
   * AnnealedLangevinDynamics / LangevinCorrector         (sgmse/sampling/correctors.py:37-93)
@@ -48,6 +49,44 @@ class OUVE:
     def prior(self, y, z):                                           # sdes.py:233-237
         std = self.std(torch.ones((y.shape[0],)))
         return y + z * std[:, None, None, None]
+
+
+class OUVP:
+    """OUVPSDE (sdes.py:255-326): dx = 1/2 beta(t) stiffness (y - x) dt + sqrt(beta(t)) dw."""
+
+    def __init__(self, beta_min, beta_max, stiffness=1, N=30):
+        self.beta_min, self.beta_max, self.stiffness, self.N = beta_min, beta_max, stiffness, N
+        self.T = 1
+
+    def beta(self, t):                                               # sdes.py:290-291
+        return self.beta_min + t * (self.beta_max - self.beta_min)
+
+    def sde(self, x, t, y):                                          # sdes.py:293-296
+        b = self.beta(t)
+        drift = 0.5 * self.stiffness * b.view(-1, *((1,) * (y.ndim - 1))) * (y - x)
+        return drift, torch.sqrt(b)
+
+    def mean(self, x0, t, y):                                        # sdes.py:298-301
+        b0, b1, s = self.beta_min, self.beta_max, self.stiffness
+        fac = torch.exp(-0.25 * s * t * (t * (b1 - b0) + 2 * b0))[:, None, None, None]
+        return y + fac * (x0 - y)
+
+    def std(self, t):                                                # sdes.py:303-305
+        b0, b1, s = self.beta_min, self.beta_max, self.stiffness
+        return (1 - torch.exp(-0.5 * s * t * (t * (b1 - b0) + 2 * b0))) / s
+
+    discretize = OUVE.discretize                                     # SDE.discretize is shared (sdes.py:73-90)
+
+    def prior(self, y, z):                                           # sdes.py:306-310
+        std = self.std(torch.ones((y.shape[0],)))
+        return y + z * std[:, None, None, None]
+
+
+def pf_drift(sde, score_fn, x, t, y):
+    """RSDE.sde with probability_flow=True (sdes.py:117-145): sde_drift + (-(g^2) score 1/2)."""
+    drift, diffusion = sde.sde(x, t, y)
+    diffusion = _bc(diffusion, x)
+    return drift + (-diffusion ** 2 * score_fn(x, t, y) * 0.5)
 
 
 def _bc(v, x):

@@ -106,6 +106,9 @@ _SIGNATURES = {
     "storm_si_sdr": ([_vp, _vp, _vp, _i, _ll, _ll, _ll, _f, _vp], C.c_int),
     "storm_ouve_pf_drift": ([_vp, _vp, _vp, _vp, _vp, _i, _ll, Ouve, _vp], C.c_int),
     "storm_ouve_pf_drift_g": ([_vp, _vp, _vp, _vp, _vp, _i, _ll, _f, _vp], C.c_int),
+    "storm_sde_prior_rows": ([_vp, _vp, _vp, _vp, _i, _ll, _u64, _u64, _vp], C.c_int),
+    "storm_sde_predictor_step_rows": ([_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _ll, _i, _i, _i, _u64, _u64, _vp], C.c_int),
+    "storm_sde_pf_drift_rows": ([_vp, _vp, _vp, _vp, _vp, _vp, _i, _ll, _vp], C.c_int),
     "storm_rk_combine": ([_vp, _vp, C.POINTER(_vp), C.POINTER(C.c_float), _i, _f, _ll, _vp], C.c_int),
     "storm_rk_scaled_sumsq": ([_vp, _vp, _i, _vp, _vp, C.POINTER(_vp), C.POINTER(C.c_float), _i, _f, _f, _f, _ll, _vp], C.c_int),
     "storm_rk_combine_rows": ([_vp, _vp, _vp, C.POINTER(_vp), C.POINTER(C.c_double), _i, C.POINTER(C.c_double), _i, _ll, _vp], C.c_int),

@@ -201,6 +201,70 @@ __global__ void ouve_pf_drift_g_kernel(float* __restrict__ out, const float* __r
     }
 }
 
+// ---- coefficient-table forms: any SDE  dx = a(t) (y - x) dt + g(t) dw  (OUVPSDE, sdes.py:255-326: a = 1/2 stiffness beta(t),
+// g = sqrt(beta(t))).  The caller hands a(t_b), g(t_b), std(t_b) per row (device fp32 [B]) in the reference's own fp32 torch
+// expressions; the state update is the OUVE kernels' (same op order: SDE.discretize sdes.py:86-90, RSDE.discretize :147-157,
+// rsde_parts :123-145, predictors.py:46-69). -------------------------------------------------------------------------------------
+__global__ void sde_prior_rows_kernel(const float* __restrict__ y, const float* __restrict__ z, float* __restrict__ x,
+                                      const float* __restrict__ std_rows, long long n, uint64_t seed, uint64_t offset) {
+    const int b = blockIdx.y;
+    const float sd = std_rows[b];
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+        const long long k = (long long)b * n + i;
+        const float2 yy = reinterpret_cast<const float2*>(y)[k];
+        const float2 zz = get_noise(z, k, seed, offset);
+        reinterpret_cast<float2*>(x)[k] = make_float2(yy.x + zz.x * sd, yy.y + zz.y * sd);
+    }
+}
+
+__global__ void sde_predictor_rows_kernel(float* __restrict__ x, float* __restrict__ x_mean, const float* __restrict__ score,
+                                          const float* __restrict__ y, const float* __restrict__ z, const float* __restrict__ a_rows,
+                                          const float* __restrict__ g_rows, long long n, int N, int kind, int noise_free,
+                                          uint64_t seed, uint64_t offset) {
+    const int b = blockIdx.y;
+    const float a = a_rows[b], g = g_rows[b];
+    const float dt = (float)(1.0 / N);
+    const float G = g * sqrtf(dt);
+    const float G2 = kind == 0 ? G * G : g * g;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+        const long long k = (long long)b * n + i;
+        const float2 xx = reinterpret_cast<const float2*>(x)[k];
+        const float2 yy = reinterpret_cast<const float2*>(y)[k];
+        const float2 s = reinterpret_cast<const float2*>(score)[k];
+        float2 xm;
+        if (kind == 0) {                      // reverse diffusion: x_mean = x - (a (y - x) dt - G^2 s)
+            const float fx = (a * (yy.x - xx.x)) * dt, fy = (a * (yy.y - xx.y)) * dt;
+            xm = make_float2(xx.x - (fx - G2 * s.x), xx.y - (fy - G2 * s.y));
+        } else {                              // Euler-Maruyama: x_mean = x + (a (y - x) - g^2 s) (-1/N)
+            const float dx = a * (yy.x - xx.x) + (-G2) * s.x, dy = a * (yy.y - xx.y) + (-G2) * s.y;
+            xm = make_float2(xx.x + dx * (-dt), xx.y + dy * (-dt));
+        }
+        if (x_mean) reinterpret_cast<float2*>(x_mean)[k] = xm;
+        if (noise_free) {
+            reinterpret_cast<float2*>(x)[k] = xm;
+        } else {
+            const float2 zz = get_noise(z, k, seed, offset);
+            reinterpret_cast<float2*>(x)[k] = make_float2(xm.x + G * zz.x, xm.y + G * zz.y);
+        }
+    }
+}
+
+// probability-flow drift a_b (y - x) + (-(g_b^2) score) 1/2 in the reference's operation order (sdes.py:129-134)
+__global__ void sde_pf_drift_rows_kernel(float* __restrict__ out, const float* __restrict__ x, const float* __restrict__ y,
+                                         const float* __restrict__ score, const float* __restrict__ a_rows,
+                                         const float* __restrict__ g_rows, long long n) {
+    const int b = blockIdx.y;
+    const float a = a_rows[b], g = g_rows[b];
+    const float g2 = g * g;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+        const long long k = (long long)b * n + i;
+        const float2 xx = reinterpret_cast<const float2*>(x)[k];
+        const float2 yy = reinterpret_cast<const float2*>(y)[k];
+        const float2 s = reinterpret_cast<const float2*>(score)[k];
+        reinterpret_cast<float2*>(out)[k] = make_float2(a * (yy.x - xx.x) + (-g2 * s.x) * 0.5f, a * (yy.y - xx.y) + (-g2 * s.y) * 0.5f);
+    }
+}
+
 // ---- probability-flow ODE (Dormand-Prince RK45, sampling/__init__.py:71-141 runs scipy's on the host) ----------------
 // out = x + h * sum_j coef[j] * K[j]  over n floats (one fused pass per stage instead of one pass per term)
 struct RkTerms { const float* k[7]; float c[7]; int n; };
@@ -507,6 +571,33 @@ extern "C" int storm_ouve_pf_drift_g(float* out, const float* x, const float* y,
                                      long long n, float theta, storm_stream_t s) {
     STORM_CHECK(out && x && y && score && g_rows && B > 0 && n > 0, "storm_ouve_pf_drift_g: bad arguments");
     hipLaunchKernelGGL(ouve_pf_drift_g_kernel, dim3(ew_blocks(n), B), dim3(256), 0, (hipStream_t)s, out, x, y, score, g_rows, n, theta);
+    STORM_LAUNCH_CHECK();
+    return STORM_OK;
+}
+
+extern "C" int storm_sde_prior_rows(const float* y, const float* z, float* x, const float* std_rows, int B, long long n,
+                                    uint64_t seed, uint64_t offset, storm_stream_t s) {
+    STORM_CHECK(y && x && std_rows && B > 0 && n > 0, "storm_sde_prior_rows: bad arguments");
+    hipLaunchKernelGGL(sde_prior_rows_kernel, dim3(ew_blocks(n), B), dim3(256), 0, (hipStream_t)s, y, z, x, std_rows, n, seed, offset);
+    STORM_LAUNCH_CHECK();
+    return STORM_OK;
+}
+
+extern "C" int storm_sde_predictor_step_rows(float* x, float* x_mean, const float* score, const float* y, const float* z,
+                                             const float* a_rows, const float* g_rows, int B, long long n, int N, int kind,
+                                             int noise_free, uint64_t seed, uint64_t offset, storm_stream_t s) {
+    STORM_CHECK(x && score && y && a_rows && g_rows && B > 0 && n > 0 && N > 0, "storm_sde_predictor_step_rows: bad arguments");
+    STORM_CHECK(kind == 0 || kind == 1, "storm_sde_predictor_step_rows: kind=%d", kind);
+    hipLaunchKernelGGL(sde_predictor_rows_kernel, dim3(ew_blocks(n), B), dim3(256), 0, (hipStream_t)s, x, x_mean, score, y, z, a_rows, g_rows, n, N, kind,
+                       noise_free, seed, offset);
+    STORM_LAUNCH_CHECK();
+    return STORM_OK;
+}
+
+extern "C" int storm_sde_pf_drift_rows(float* out, const float* x, const float* y, const float* score, const float* a_rows,
+                                       const float* g_rows, int B, long long n, storm_stream_t s) {
+    STORM_CHECK(out && x && y && score && a_rows && g_rows && B > 0 && n > 0, "storm_sde_pf_drift_rows: bad arguments");
+    hipLaunchKernelGGL(sde_pf_drift_rows_kernel, dim3(ew_blocks(n), B), dim3(256), 0, (hipStream_t)s, out, x, y, score, a_rows, g_rows, n);
     STORM_LAUNCH_CHECK();
     return STORM_OK;
 }

@@ -440,6 +440,40 @@ def ouve_pf_drift_g(sde, x, y, score, g_rows):
     return out
 
 
+def _rows32(v, like):
+    """per-row coefficients as the rows-form kernels read them: device fp32 [B], contiguous"""
+    return v.to(device=like.device, dtype=torch.float32).contiguous()
+
+
+def sde_prior_rows(y, std_rows, z=None, seed=0, offset=0):
+    """y + z * std_b (OUVPSDE.prior_sampling, sdes.py:306-310); z=None draws in-kernel (Philox)."""
+    x = torch.empty_like(y)
+    std_rows = _rows32(std_rows, y)
+    L.check(L.lib().storm_sde_prior_rows(L.ptr(_r(y)), L.ptr(_r(z)), L.ptr(_r(x)), L.ptr(std_rows), y.shape[0], _n_per_batch(y),
+                                         seed, offset, L.stream()), "storm_sde_prior_rows")
+    return x
+
+
+def sde_predictor_step_rows(sde, x, score, y, t, kind=0, z=None, noise_free=False, seed=0, offset=0):
+    """Predictor update for an SDE with drift a(t) (y - x) and diffusion g(t) given by its `drift_rows(t)` / `diffusion(t)`
+    (fp32 [B], the reference's own expressions).  In place on x; returns (x, x_mean)."""
+    xm = torch.empty_like(x)
+    a, g = _rows32(sde.drift_rows(t), x), _rows32(sde.diffusion(t), x)
+    L.check(L.lib().storm_sde_predictor_step_rows(L.ptr(_r(x)), L.ptr(_r(xm)), L.ptr(_r(score)), L.ptr(_r(y)), L.ptr(_r(z)), L.ptr(a),
+                                                  L.ptr(g), x.shape[0], _n_per_batch(x), int(sde.N), kind, int(noise_free), seed,
+                                                  offset, L.stream()), "storm_sde_predictor_step_rows")
+    return x, xm
+
+
+def sde_pf_drift_rows(x, y, score, a_rows, g_rows):
+    """a_b (y - x) - 1/2 g_b^2 score: the probability-flow right-hand side with per-row coefficients (device fp32 [B])"""
+    out = torch.empty_like(x)
+    a, g = _rows32(a_rows, x), _rows32(g_rows, x)
+    L.check(L.lib().storm_sde_pf_drift_rows(L.ptr(_r(out)), L.ptr(_r(x)), L.ptr(_r(y)), L.ptr(_r(score)), L.ptr(a), L.ptr(g),
+                                            x.shape[0], _n_per_batch(x), L.stream()), "storm_sde_pf_drift_rows")
+    return out
+
+
 _rk_scratch = {}
 
 

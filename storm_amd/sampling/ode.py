@@ -80,6 +80,9 @@ def get_ode_sampler(sde, score_fn, y, inverse_scaler=None, denoise=True, rtol=1e
                 if isinstance(sde, OUVESDE):               # fused: theta (y - x) - 1/2 g^2 score in one pass; g(t) for the B
                     score = rsde._score(x, vec_t, (y_c,), dict(conditioning=cond_c))           # rows in the reference's own ops
                     return ops.ouve_pf_drift_g(sde, x, y_c, score.contiguous(), sde.diffusion(t_host))
+                if hasattr(sde, "drift_rows"):             # coefficient-table form (OUVPSDE): a(t_b), g(t_b) per row
+                    score = rsde._score(x, vec_t, (y_c,), dict(conditioning=cond_c))
+                    return ops.sde_pf_drift_rows(x, y_c, score.contiguous(), sde.drift_rows(t_host), sde.diffusion(t_host))
                 return rsde.sde(x, vec_t, y_c, conditioning=cond_c)[0].contiguous()
 
             def norms(sumsq_rows):                            # scipy: ||v|| / sqrt(size) per solver state; ONE host read

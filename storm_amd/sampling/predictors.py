@@ -1,5 +1,5 @@
-"""Predictors of the PC sampler — drop-in for sgmse/sampling/predictors.py.  With an OUVESDE the
-update is one fused HIP kernel (csrc/sde.hip); the score comes from ``score_fn`` (NCSN++ engine)."""
+"""Predictors of the PC sampler — drop-in for sgmse/sampling/predictors.py.  With an OUVESDE (or an SDE that
+gives per-row coefficients: OUVPSDE) the update is one fused HIP kernel (csrc/sde.hip); the score comes from ``score_fn`` (NCSN++ engine)."""
 import abc
 
 from .. import ops
@@ -19,8 +19,9 @@ def _score(score_fn, x, t, args, kwargs):
 class Predictor(abc.ABC):
     def __init__(self, sde, score_fn, probability_flow=False, noise=None):
         super().__init__()
-        if not isinstance(sde, OUVESDE):
-            raise NotImplementedError(f"SDE class {sde.__class__.__name__} not supported by the HIP engine (OUVE only).")
+        if not isinstance(sde, OUVESDE) and not hasattr(sde, "drift_rows"):
+            raise NotImplementedError(f"SDE class {sde.__class__.__name__} not supported by the HIP engine: an SDE either is an OUVESDE or "
+                                      "gives its per-row coefficients (drift_rows(t), diffusion(t)) as OUVPSDE does.")
         self.sde = sde
         self.rsde = sde.reverse(score_fn)           # the reference ignores probability_flow here (predictors.py:18)
         self.score_fn = score_fn
@@ -35,6 +36,9 @@ class Predictor(abc.ABC):
         y = args[0]
         score = _score(self.score_fn, x, t, args, kwargs)
         z, seed, off = (None, 0, 0) if noise_free else self.noise.next(x)
+        if not isinstance(self.sde, OUVESDE):      # coefficient-table form: a(t_b), g(t_b) from the SDE's own fp32 expressions
+            return ops.sde_predictor_step_rows(self.sde, x.contiguous(), score.contiguous(), y.contiguous(), t.contiguous(),
+                                               kind=kind, z=z, noise_free=noise_free, seed=seed, offset=off)
         return ops.ouve_predictor_step(self.sde, x.contiguous(), score.contiguous(), y.contiguous(), t.contiguous(),
                                        kind=kind, z=z, noise_free=noise_free, seed=seed, offset=off)
 

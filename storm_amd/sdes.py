@@ -1,4 +1,4 @@
-"""SDE definitions for the reverse sampler — drop-in for sgmse/sdes.py (OUVESDE, SDERegistry).
+"""SDE definitions for the reverse sampler — drop-in for sgmse/sdes.py (OUVESDE, OUVPSDE, SDERegistry).
 
 The state-sized arithmetic of the hot path (prior sampling, predictor / corrector updates) runs in
 the fused HIP kernels of storm_amd/csrc/sde.hip through ``storm_amd.sampling``; the tensor-level
@@ -16,9 +16,6 @@ from . import ops
 from .util.registry import Registry
 
 SDERegistry = Registry("SDE")
-SDERegistry.declare_out_of_scope("ouvp", "OUVPSDE (sdes.py:255-326) is outside the sampling hot path this engine covers (BASELINE.json names the OUVE "
-                                 "SDE only; upstream's own `ald` corrector rejects it, correctors.py:69)")
-
 
 def _bc(v, x):
     return v.view(*v.size(), *((1,) * (x.ndim - v.ndim))) if v.ndim < x.ndim else v
@@ -153,4 +150,69 @@ class OUVESDE(SDE):
         parser.add_argument("--theta", type=float, default=1.5)
         parser.add_argument("--sigma-min", type=float, default=0.05)
         parser.add_argument("--sigma-max", type=float, default=0.5)
+        return parser
+
+
+@SDERegistry.register("ouvp")
+class OUVPSDE(SDE):
+    """Ornstein-Uhlenbeck variance-preserving SDE  dx = 1/2 beta(t) stiffness (y - x) dt + sqrt(beta(t)) dw,
+    beta(t) = beta_min + t (beta_max - beta_min)  (sdes.py:255-326).
+
+    The samplers reach it through `drift_rows(t)` / `diffusion(t)`: the per-row coefficients a(t_b), g(t_b) in the reference's
+    own fp32 expressions, handed to the coefficient-table kernels (storm_sde_*_rows).  As upstream, the `ald` corrector
+    rejects it (correctors.py:69); `langevin` / `none` and both predictors and the ODE sampler take it."""
+
+    def __init__(self, beta_min, beta_max, stiffness=1, N=1000, **ignored_kwargs):
+        super().__init__(N)
+        self.beta_min, self.beta_max, self.stiffness = beta_min, beta_max, stiffness
+        self.N = N
+
+    def copy(self):
+        return OUVPSDE(self.beta_min, self.beta_max, self.stiffness, N=self.N)
+
+    @property
+    def T(self):
+        return 1
+
+    def _beta(self, t):
+        return self.beta_min + t * (self.beta_max - self.beta_min)
+
+    def drift_rows(self, t):
+        """a(t): the drift is a(t) (y - x)  (sdes.py:294)"""
+        return 0.5 * self.stiffness * self._beta(t)
+
+    def diffusion(self, t):
+        return torch.sqrt(self._beta(t))
+
+    def sde(self, x, t, y):
+        return _bc(self.drift_rows(t), y) * (y - x), self.diffusion(t)
+
+    def _mean(self, x0, t, y):
+        b0, b1, s = self.beta_min, self.beta_max, self.stiffness
+        x0y_fac = torch.exp(-0.25 * s * t * (t * (b1 - b0) + 2 * b0))[:, None, None, None]
+        return y + x0y_fac * (x0 - y)
+
+    def _std(self, t, **kwargs):
+        b0, b1, s = self.beta_min, self.beta_max, self.stiffness
+        return (1 - torch.exp(-0.5 * s * t * (t * (b1 - b0) + 2 * b0))) / s
+
+    def marginal_prob(self, x0, t, y):
+        return self._mean(x0, t, y), self._std(t)
+
+    def prior_sampling(self, shape, y, z=None, seed=0, offset=0):
+        """y + z * std(1)  (sdes.py:306-310) — fused HIP kernel; z=None draws in-kernel (Philox)."""
+        if tuple(shape) != tuple(y.shape):
+            warnings.warn(f"Target shape {shape} does not match shape of y {y.shape}! Ignoring target shape.")
+        std = self._std(torch.ones((y.shape[0],), device=y.device))
+        return ops.sde_prior_rows(y.contiguous(), std, z=z, seed=seed, offset=offset)
+
+    def prior_logp(self, z):
+        raise NotImplementedError("prior_logp for OU SDE not yet implemented!")
+
+    @staticmethod
+    def add_argparse_args(parser):
+        parser.add_argument("--sde-n", type=int, default=1000)
+        parser.add_argument("--beta-min", type=float, required=True)
+        parser.add_argument("--beta-max", type=float, required=True)
+        parser.add_argument("--stiffness", type=float, default=1)
         return parser

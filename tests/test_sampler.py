@@ -59,8 +59,91 @@ def test_registries_and_errors():
     assert "ouve" in SDERegistry.get_all_names()
     with pytest.raises(ValueError):
         SDERegistry.get_by_name("ouvesde")          # the reference's default string is not a registered name either
-    with pytest.raises(ValueError, match="registered upstream but not built here"):
-        SDERegistry.get_by_name("ouvp")             # upstream's second SDE: deliberately out of scope, and the error says so
+    assert set(SDERegistry.get_all_names()) == {"ouve", "ouvp"}            # both SDEs the reference registers (sdes.py:166, 255)
+
+
+@pytest.mark.parametrize("tag", ["a", "b"])
+def test_ouvp_sde_vs_reference_golden(dev, golden, tag):
+    """F18: the reference's second SDE, OUVPSDE (sdes.py:255-326), through the coefficient-table kernels (storm_sde_*_rows):
+    scalars, prior, both predictors' single steps, the probability-flow right-hand side, four pc_sampler runs with the
+    reference's recorded noise and its ODE run; `ald` rejects it as upstream does (correctors.py:69)."""
+    from oracle.make_golden import OUVP_CASES, OUVP_SAMPLERS
+    from storm_amd import ops
+    from storm_amd.sampling import get_ode_sampler, get_pc_sampler
+    from storm_amd.sdes import OUVPSDE, SDERegistry
+    g = golden["f18_ouvp"]
+    b0, b1, st = OUVP_CASES[tag]
+    assert SDERegistry.get_by_name("ouvp") is OUVPSDE
+    sde = OUVPSDE(beta_min=b0, beta_max=b1, stiffness=st, N=30)
+    t, x, y, z = (T(g[f"{tag}_{k}"]) for k in "txyz")
+    assert torch.equal(sde._std(t), T(g[f"{tag}_std"])) and torch.equal(sde._mean(x, t, y), T(g[f"{tag}_mean"]))
+    d, gg = sde.sde(x, t, y)
+    assert torch.equal(d, T(g[f"{tag}_drift"])) and torch.equal(gg, T(g[f"{tag}_diff"]))
+    f, G = sde.discretize(x, t, y)
+    assert torch.equal(f, T(g[f"{tag}_f"])) and torch.equal(G, T(g[f"{tag}_G"]))
+    c = sde.copy()
+    assert (c.beta_min, c.beta_max, c.stiffness, c.N, c.T) == (b0, b1, st, 30, 1)
+    # state-sized work on the device
+    assert rel_l2(sde.prior_sampling(y.shape, y.to(dev), z=z.to(dev)).cpu(), g[f"{tag}_prior"]) < 2e-7
+    osde = SR.OUVP(b0, b1, st, N=30)
+    s = T(g[f"{tag}_mean"])                                       # any complex tensor serves as a score here
+    for kind, fn in ((0, SR.revdiff_step), (1, SR.euler_maruyama_step)):
+        xa, xm = ops.sde_predictor_step_rows(sde, x.clone().to(dev), s.to(dev), y.to(dev), t.to(dev), kind=kind, z=z.to(dev))
+        r, rm = fn(osde, lambda *_: s, x, t, y, z)
+        assert rel_l2(xa.cpu(), r) < 3e-7 and rel_l2(xm.cpu(), rm) < 3e-7
+    xa, xm = ops.sde_predictor_step_rows(sde, x.clone().to(dev), s.to(dev), y.to(dev), t.to(dev), kind=0, noise_free=True)
+    assert torch.equal(xa.cpu(), xm.cpu())
+
+    def score(x, t, y):
+        return -(x - y) / (sde._std(t)[:, None, None, None] ** 2 + 0.1)
+    pf = ops.sde_pf_drift_rows(x.to(dev), y.to(dev), score(x, t, y).to(dev), sde.drift_rows(t), sde.diffusion(t))
+    assert rel_l2(pf.cpu(), g[f"{tag}_pf"]) < 3e-7
+    ysam = T(g[f"{tag}_sam_y"]).to(dev)
+    for stag, (N, pred, corr, steps) in OUVP_SAMPLERS.items():
+        it = iter(T(g[f"{tag}_{stag}_noise"]))
+        out, nfe = get_pc_sampler(pred, corr, sde=OUVPSDE(b0, b1, st, N=N), score_fn=score, y=ysam, eps=0.03, snr=0.5,
+                                  corrector_steps=steps, noise_fn=lambda: next(it))()
+        assert nfe == int(g[f"{tag}_{stag}_nfe"])
+        e = rel_l2(out.cpu(), g[f"{tag}_{stag}_out"])
+        print(f"OUVP {tag} sampler {stag}: rel-L2 vs reference {e:.2e}")
+        assert e < 1e-5
+    with pytest.raises(NotImplementedError):
+        get_pc_sampler("reverse_diffusion", "ald", sde=sde, score_fn=score, y=ysam)
+    zo = T(g[f"{tag}_ode_z"]).to(dev)
+    for per_row in (False, True):
+        sampler = get_ode_sampler(sde, score, y=ysam[:1], eps=0.03, noise_fn=lambda: zo, per_row=per_row)
+        xo, nfe = sampler()
+        want = int(g[f"{tag}_ode_nfe"])
+        assert nfe == want if dev.type == "cpu" else abs(nfe - want) <= 6
+        e = rel_l2(xo.cpu(), g[f"{tag}_ode_out"])
+        print(f"OUVP {tag} ode (per_row={per_row}): nfev {nfe} (reference {want}), rel-L2 vs reference {e:.2e}")
+        assert e < 1e-3
+
+
+@pytest.mark.parametrize("dtype,tol", [(torch.float32, 1e-3), (torch.bfloat16, 5e-2)])
+def test_ouvp_enhance_vs_reference_golden(dev, golden, dtype, tol):
+    """F18 (d): ScoreModel(sde="ouvp").enhance wav -> wav against the reference's own run (tiny NCSN++, reverse_diffusion +
+    langevin, N = 4, recorded noise)"""
+    from oracle.make_golden import OUVP_CASES
+    from storm_amd.data_module import SpecsDataModule
+    from storm_amd.model import ScoreModel
+    from storm_amd.sdes import OUVPSDE
+    g = golden["f18_ouvp"]
+    b0, b1, st = OUVP_CASES["a"]
+    m = ScoreModel(backbone="ncsnpp", sde="ouvp", data_module_cls=SpecsDataModule, beta_min=b0, beta_max=b1, stiffness=st,
+                   spec_factor=0.15, spec_abs_exponent=0.5, nf=8)
+    assert isinstance(m.sde, OUVPSDE)
+    m.dnn.load_state_dict(NR.seeded_state_dict(NR.NCSNppConfig(nf=8, input_channels=4), seed=81))
+    m = m.to(dev)
+    m.dnn.set_compute_dtype(dtype)
+    m.eval(no_ema=True)
+    it = iter(T(g["enh_noise"]))
+    xh, nfe, _ = m.enhance(T(g["enh_wav"]).to(dev), predictor="reverse_diffusion", corrector="langevin", N=4, corrector_steps=1,
+                           snr=0.5, timeit=True, noise_fn=lambda: next(it))
+    assert nfe == int(g["enh_nfe"])
+    e = rel_l2(xh.cpu(), g["enh_out"])
+    print(f"OUVP enhance {dtype}: wav rel-L2 vs reference {e:.2e}")
+    assert e < tol
 
 
 def test_philox_sampler_is_seeded(dev):
