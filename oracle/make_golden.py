@@ -39,6 +39,17 @@ OUVP_SAMPLERS = {"lang": (5, "reverse_diffusion", "langevin", 1), "em": (6, "eul
                  "none": (4, "reverse_diffusion", "none", 1), "lang2": (3, "euler_maruyama", "langevin", 2)}
 
 
+# F19: shapes (B, F, T) of the small variants' forwards; inputs regenerate from a seed on both sides (their SHA-256 is stored)
+F19_SHAPES = dict(small=(1, 32, 64), real=(2, 256, 128))
+
+
+def f19_inputs(name, tag):
+    B, F, T = F19_SHAPES[tag]
+    g = torch.Generator().manual_seed(1919 + 7 * len(name) + B)
+    x = torch.randn(B, 2, F, T, dtype=torch.complex64, generator=g)
+    return x, torch.rand(B, generator=g) * 0.9 + 0.05
+
+
 def sd_hash(sd):
     h = hashlib.sha256()
     for k in sorted(sd):
@@ -652,6 +663,32 @@ def gen_f18(ref):
     np.savez_compressed(os.path.join(OUT, "f18_ouvp.npz"), **f18)
 
 
+def gen_f19(ref):
+    """F19: the two small registered variants of the backbone, `ncsnpp12M` and `ncsnpp6M` (ncsnpp.py:479-513: nf = 96, one ResNet block per
+    level, no attention) - the reference's OWN classes (their hyper-parameters are part of what is pinned), seeded weights, one forward at
+    32 x 64 (simulator-sized) and one at the real 256 x 128 (a 1-s utterance) with a batch of two."""
+    print("F19 ncsnpp12M / ncsnpp6M")
+    f19 = {}
+    for name in ("ncsnpp12M", "ncsnpp6M"):
+        cfg = NR.NCSNppConfig(**NR.NAMED_CONFIGS[name], input_channels=4)
+        sd = NR.seeded_state_dict(cfg, seed=19)
+        net = getattr(ref["ncsnpp"], "NCSNpp12M" if name == "ncsnpp12M" else "NCSNpp6M")(input_channels=4)
+        net.load_state_dict(sd, strict=True)
+        net.eval()
+        nparam = sum(p.numel() for p in net.parameters())
+        print(f"  {name}: {nparam / 1e6:.3f} M params")
+        f19.update({f"{name}_sdhash": np.array(sd_hash(sd)), f"{name}_nparam": np.array(nparam)})
+        for tag, (B, F, T) in F19_SHAPES.items():
+            x, t = f19_inputs(name, tag)
+            with torch.no_grad():
+                y_ref = net(x, t)
+                y_or = NR.ncsnpp_forward(sd, cfg, x, t)
+            check(f"{name} forward {tag}", y_or, y_ref, 5e-5)
+            f19.update({f"{name}_{tag}_xhash": np.array(hashlib.sha256(c2np(x).tobytes()).hexdigest()), f"{name}_{tag}_t": t.numpy(),
+                        f"{name}_{tag}_y": c2np(y_ref)})
+    np.savez_compressed(os.path.join(OUT, "f19_small_nets.npz"), **f19)
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
     if "--only-f9" in sys.argv:
@@ -663,7 +700,7 @@ def main():
     if "--only-f8" in sys.argv:
         gen_f8(import_reference())
         return
-    for flag, fn in (("--only-f10", gen_f10), ("--only-f11", gen_f11), ("--only-f12", gen_f12), ("--only-f13", gen_f13), ("--only-f14", gen_f14), ("--only-f15", gen_f15), ("--only-f16", gen_f16), ("--only-f17", gen_f17), ("--only-f18", gen_f18)):
+    for flag, fn in (("--only-f10", gen_f10), ("--only-f11", gen_f11), ("--only-f12", gen_f12), ("--only-f13", gen_f13), ("--only-f14", gen_f14), ("--only-f15", gen_f15), ("--only-f16", gen_f16), ("--only-f17", gen_f17), ("--only-f18", gen_f18), ("--only-f19", gen_f19)):
         if flag in sys.argv:
             fn(import_reference())
             return
@@ -916,6 +953,7 @@ def main():
     gen_f14(ref)
     gen_f15(ref)
     gen_f17(ref)
+    gen_f19(ref)
     gen_f18(ref)                                 # (F16, the 27.8 M net at 256 x 1280, is generated on request: --only-f16)
     for fn in sorted(os.listdir(OUT)):
         print(f"  {fn}: {os.path.getsize(os.path.join(OUT, fn))/1024:.0f} KiB")
