@@ -57,14 +57,16 @@ class SDE(abc.ABC):
         G = diffusion * torch.sqrt(torch.tensor(dt, device=t.device))
         return f, G
 
-    def reverse(oself, score_model, probability_flow=False):
-        """Reverse-time SDE/ODE (sdes.py:92-159)."""
+    def reverse(oself, score_model, probability_flow=False, diffusion_power_gradient=None):
+        """Reverse-time SDE/ODE (sdes.py:92-159).  diffusion_power_gradient(x, t): subtracted from the total drift when the
+        diffusion depends on the state (sdes.py:98-99, 137-138); None for both registered SDEs."""
         N, T, sde_fn, discretize_fn = oself.N, oself.T, oself.sde, oself.discretize
 
         class RSDE(oself.__class__):
             def __init__(self):
                 self.N = N
                 self.probability_flow = probability_flow
+                self.diffusion_power_gradient = diffusion_power_gradient
 
             @property
             def T(self):
@@ -85,7 +87,10 @@ class SDE(abc.ABC):
                 sde_diffusion = _bc(sde_diffusion, x)
                 score_drift = -sde_diffusion ** 2 * score * (0.5 if self.probability_flow else 1.)
                 diffusion = torch.zeros_like(sde_diffusion) if self.probability_flow else sde_diffusion
-                return {"total_drift": sde_drift + score_drift, "diffusion": diffusion, "sde_drift": sde_drift,
+                total_drift = sde_drift + score_drift
+                if diffusion_power_gradient is not None:
+                    total_drift = total_drift - diffusion_power_gradient(x, t)
+                return {"total_drift": total_drift, "diffusion": diffusion, "sde_drift": sde_drift,
                         "sde_diffusion": sde_diffusion, "score_drift": score_drift, "score": score}
 
             def discretize(self, x, t, *args, **kwargs):

@@ -148,6 +148,25 @@ def test_ouvp_enhance_vs_reference_golden(dev, golden, dtype, tol):
     assert e < tol
 
 
+def test_reverse_sde_surface():
+    """SDE.reverse (sdes.py:92-159): rsde_parts keys, the probability-flow halving / zero diffusion, diffusion_power_gradient"""
+    from storm_amd.sdes import OUVESDE, OUVPSDE
+    g = torch.Generator().manual_seed(4)
+    x, y = (torch.randn(2, 1, 4, 4, dtype=torch.complex64, generator=g) for _ in range(2))
+    t = torch.tensor([0.5, 0.9])
+    score = lambda x, t, y: -(x - y)                                             # noqa: E731
+    for sde, osde in ((OUVESDE(1.5, 0.05, 0.5, N=30), SR.OUVE(1.5, 0.05, 0.5, N=30)), (OUVPSDE(0.1, 2.0, 1, N=30), SR.OUVP(0.1, 2.0, 1, N=30))):
+        parts = sde.reverse(score).rsde_parts(x, t, y)
+        assert set(parts) == {"total_drift", "diffusion", "sde_drift", "sde_diffusion", "score_drift", "score"}
+        pf = sde.reverse(score, probability_flow=True)
+        drift, diff = pf.sde(x, t, y)
+        assert torch.equal(drift, SR.pf_drift(osde, score, x, t, y)) and not diff.any()
+        f, G = pf.discretize(x, t, y)
+        assert not G.any() and f.shape == x.shape
+        shifted = sde.reverse(score, diffusion_power_gradient=lambda x, t: torch.ones_like(x)).sde(x, t, y)[0]
+        assert torch.allclose(shifted, parts["total_drift"] - 1)
+
+
 def test_philox_sampler_is_seeded(dev):
     """production path: noise generated in-kernel; same seed -> same sample, different seed -> different"""
     from storm_amd.sampling import get_pc_sampler
