@@ -12,6 +12,12 @@ GOLDEN = os.path.join(ROOT, "tests", "golden")
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    # an xdist worker keeps to its share of the cores: four workers with torch's default of one OpenMP thread per core each spend their
+    # time waiting for one another (single tests ran up to 3 x slower depending on what ran beside them)
+    wi = getattr(config, "workerinput", None)
+    if wi is not None:
+        import torch
+        torch.set_num_threads(max(1, (os.cpu_count() or 1) // max(1, int(wi.get("workercount", 1)))))
 
 
 # ---- the CPU suite on several workers by default -------------------------------------------------------------------------------
