@@ -15,17 +15,22 @@ N_FFT = 510
 HOP = 128
 
 
-def window(n_fft=N_FFT):
-    return torch.hann_window(n_fft, periodic=True)                   # data_module.py:22-23
+def window(n_fft=N_FFT, kind="hann"):
+    w = torch.hann_window(n_fft, periodic=True)                      # data_module.py:19-25
+    if kind == "sqrthann":
+        return torch.sqrt(w)
+    if kind != "hann":
+        raise NotImplementedError(f"Window type {kind} not implemented!")
+    return w
 
 
-def stft(sig, n_fft=N_FFT, hop=HOP):
-    return torch.stft(sig, n_fft=n_fft, hop_length=hop, window=window(n_fft),
+def stft(sig, n_fft=N_FFT, hop=HOP, kind="hann"):
+    return torch.stft(sig, n_fft=n_fft, hop_length=hop, window=window(n_fft, kind),
                       center=True, return_complex=True)               # data_module.py:217-219
 
 
-def istft(spec, length=None, n_fft=N_FFT, hop=HOP):
-    return torch.istft(spec, n_fft=n_fft, hop_length=hop, window=window(n_fft),
+def istft(spec, length=None, n_fft=N_FFT, hop=HOP, kind="hann"):
+    return torch.istft(spec, n_fft=n_fft, hop_length=hop, window=window(n_fft, kind),
                        center=True, length=length)                    # data_module.py:221-223
 
 

@@ -39,6 +39,11 @@ OUVP_SAMPLERS = {"lang": (5, "reverse_diffusion", "langevin", 1), "em": (6, "eul
                  "none": (4, "reverse_diffusion", "none", 1), "lang2": (3, "euler_maruyama", "langevin", 2)}
 
 
+# F20: data-module settings beside the defaults (window, n_fft, hop_length, spec_factor, spec_abs_exponent)
+F20_CASES = {"sqrthann": dict(window="sqrthann"), "lin": dict(spec_abs_exponent=1.0, spec_factor=0.33),
+             "sq667": dict(window="sqrthann", spec_abs_exponent=0.667, spec_factor=0.065), "n254": dict(n_fft=254, hop_length=64),
+             "hop256": dict(hop_length=256)}
+
 # F19: shapes (B, F, T) of the small variants' forwards; inputs regenerate from a seed on both sides (their SHA-256 is stored)
 F19_SHAPES = dict(small=(1, 32, 64), real=(2, 256, 128))
 
@@ -689,6 +694,26 @@ def gen_f19(ref):
     np.savez_compressed(os.path.join(OUT, "f19_small_nets.npz"), **f19)
 
 
+def gen_f20(ref):
+    """F20: the data module's other settings (data_module.py:19-25, 142-148, 182-223; CLI --window / --n_fft / --hop_length / --spec_factor /
+    --spec_abs_exponent): sqrt-Hann window, no magnitude compression (exponent 1), another exponent / factor, a 254-point and a
+    256-hop transform - spec_fwd(stft(y)) and istft(spec_back(.)) of the reference's SpecsDataModule on one 3000-sample signal."""
+    print("F20 data-module settings")
+    DM = ref["data_module"].SpecsDataModule
+    y = torch.randn(1, 3000, generator=torch.Generator().manual_seed(2020)) * 0.1
+    f20 = dict(y=y.numpy())
+    for tag, kw in F20_CASES.items():
+        dm = DM(gpu=False, **kw)
+        Y = dm.spec_fwd(dm.stft(y))
+        w = dm.istft(dm.spec_back(Y), 3000)
+        k = dict(n_fft=kw.get("n_fft", 510), hop=kw.get("hop_length", 128), kind=kw.get("window", "hann"))
+        fac, e = kw.get("spec_factor", 0.15), kw.get("spec_abs_exponent", 0.5)
+        Yo = FR.spec_fwd(FR.stft(y, **k), fac, e)
+        assert torch.equal(Yo, Y) and torch.equal(FR.istft(FR.spec_back(Yo, fac, e), 3000, **k), w), tag
+        f20.update({f"{tag}_Y": c2np(Y), f"{tag}_wav": w.numpy()})
+    np.savez_compressed(os.path.join(OUT, "f20_data_module.npz"), **f20)
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
     if "--only-f9" in sys.argv:
@@ -700,7 +725,7 @@ def main():
     if "--only-f8" in sys.argv:
         gen_f8(import_reference())
         return
-    for flag, fn in (("--only-f10", gen_f10), ("--only-f11", gen_f11), ("--only-f12", gen_f12), ("--only-f13", gen_f13), ("--only-f14", gen_f14), ("--only-f15", gen_f15), ("--only-f16", gen_f16), ("--only-f17", gen_f17), ("--only-f18", gen_f18), ("--only-f19", gen_f19)):
+    for flag, fn in (("--only-f10", gen_f10), ("--only-f11", gen_f11), ("--only-f12", gen_f12), ("--only-f13", gen_f13), ("--only-f14", gen_f14), ("--only-f15", gen_f15), ("--only-f16", gen_f16), ("--only-f17", gen_f17), ("--only-f18", gen_f18), ("--only-f19", gen_f19), ("--only-f20", gen_f20)):
         if flag in sys.argv:
             fn(import_reference())
             return
@@ -954,6 +979,7 @@ def main():
     gen_f15(ref)
     gen_f17(ref)
     gen_f19(ref)
+    gen_f20(ref)
     gen_f18(ref)                                 # (F16, the 27.8 M net at 256 x 1280, is generated on request: --only-f16)
     for fn in sorted(os.listdir(OUT)):
         print(f"  {fn}: {os.path.getsize(os.path.join(OUT, fn))/1024:.0f} KiB")

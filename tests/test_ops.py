@@ -919,6 +919,26 @@ def test_stft_istft_golden(dev, golden, fac):
     assert rel_l2(w.cpu(), g[f"{key}_wav"]) < 5e-6
 
 
+@pytest.mark.parametrize("tag", ["sqrthann", "lin", "sq667", "n254", "hop256"])
+def test_data_module_settings_vs_reference_golden(dev, golden, tag):
+    """F20: the data module's settings beside the defaults (data_module.py:19-25, 142-148, 182-223; the reference CLI's --window /
+    --n_fft / --hop_length / --spec_factor / --spec_abs_exponent): sqrt-Hann window, exponent 1, another exponent and factor, a 254-point
+    transform, a 256-sample hop - SpecsDataModule.stft / spec_fwd / spec_back / istft against the reference's on the same signal."""
+    from oracle.make_golden import F20_CASES
+    from storm_amd.data_module import SpecsDataModule
+    g = golden["f20_data_module"]
+    dm = SpecsDataModule(gpu=False, **F20_CASES[tag])
+    y = torch.from_numpy(g["y"]).to(dev)
+    Y = dm.spec_fwd(dm.stft(y))
+    want = torch.from_numpy(g[f"{tag}_Y"])
+    assert Y.shape == want.shape
+    e1 = rel_l2(Y.cpu(), want)
+    w = dm.istft(dm.spec_back(want.to(dev)), 3000)
+    e2 = rel_l2(w.cpu(), g[f"{tag}_wav"])
+    print(f"data module {tag}: spec rel-L2 vs reference {e1:.2e}, wav {e2:.2e}")
+    assert e1 < 5e-6 and e2 < 5e-6
+
+
 def test_stft_batched_ragged_vs_oracle(dev):
     """batched front end == per-utterance reference calls; odd length, exponent 1 path"""
     from storm_amd import ops
