@@ -150,6 +150,49 @@ def test_ouvp_enhance_vs_reference_golden(dev, golden, dtype, tol):
     assert e < tol
 
 
+def test_pc_sampler_denoise_false_and_model_minibatch(dev, golden):
+    """the sampler factory's remaining switches: denoise=False returns the last NOISY state instead of the predictor mean
+    (sampling/__init__.py:64-65) - against the oracle under the reference's recorded draws (F4) -, and the model's minibatch= form
+    (model.py:202-222: the batch in slices, samples concatenated, one evaluation count per slice) with a stand-in score function."""
+    from storm_amd.sampling import get_pc_sampler
+    from storm_amd.sdes import OUVESDE
+    g = golden["f4_sampler"]
+    sde = OUVESDE(1.5, 0.05, 0.5, N=7)
+    osde = SR.OUVE(1.5, 0.05, 0.5, N=7)
+
+    def score(x, t, y):
+        return -(x - y) / (sde._std(t)[:, None, None, None] ** 2 + 0.1)
+    y = T(g["sam_y"])
+    outs = {}
+    for denoise in (True, False):
+        it, ito = iter(T(g["ald2_noise"])), iter(T(g["ald2_noise"]))
+        x, nfe = get_pc_sampler("reverse_diffusion", "ald", sde=sde, score_fn=score, y=y.to(dev), eps=0.03, snr=0.5, corrector_steps=2,
+                                denoise=denoise, noise_fn=lambda: next(it))()
+        want, nfe_o = SR.pc_sample(osde, lambda x, t, yy: -(x - yy) / (osde.std(t)[:, None, None, None] ** 2 + 0.1), y, lambda: next(ito),
+                                   corrector="ald", corrector_steps=2, snr=0.5, denoise=denoise)
+        assert nfe == nfe_o == int(g["ald2_nfe"]) and rel_l2(x.cpu(), want) < 1e-5
+        outs[denoise] = x.cpu()
+    assert rel_l2(outs[True], g["ald2_out"]) < 1e-5 and not torch.equal(outs[True], outs[False])
+
+    from storm_amd.model import ScoreModel
+
+    class Stub(ScoreModel):                                   # the model's sampler plumbing without a network
+        def __init__(self):
+            torch.nn.Module.__init__(self)
+            self.sde, self.t_eps = OUVESDE(1.5, 0.05, 0.5, N=30), 0.03
+
+        def forward(self, x, t, y, **kw):
+            return score(x, t, y)
+    m = Stub()
+    noises = T(g["none_noise"])                               # 1 + 4 draws of shape [2, 1, 8, 16]
+    it = iter(noises)
+    whole, n = m.get_pc_sampler("reverse_diffusion", "none", y.to(dev), N=4, noise_fn=lambda: next(it))()
+    assert n == 4 and rel_l2(whole.cpu(), g["none_out"]) < 1e-5
+    rows = iter([z[b:b + 1] for b in range(2) for z in noises])      # slice b consumes its own rows of the same draws
+    parts, ns = m.get_pc_sampler("reverse_diffusion", "none", y.to(dev), N=4, minibatch=1, noise_fn=lambda: next(rows))()
+    assert ns == [4, 4] and parts.shape == whole.shape and rel_l2(parts.cpu(), whole.cpu()) < 1e-6
+
+
 def test_reverse_sde_surface():
     """SDE.reverse (sdes.py:92-159): rsde_parts keys, the probability-flow halving / zero diffusion, diffusion_power_gradient"""
     from storm_amd.sdes import OUVESDE, OUVPSDE
